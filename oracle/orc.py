@@ -1,0 +1,166 @@
+"""ctypes wrapper of the CPU oracle (oracle/resql_oracle.c) and a runner for the compiled
+reference (oracle/_ref/ref_harness).  TEST INFRASTRUCTURE ONLY — see oracle/resql_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import tempfile
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from resql_amd import plan as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libresql_oracle.so")
+REF_HARNESS = os.path.join(_HERE, "_ref", "ref_harness")
+_lib = None
+
+
+def build(force: bool = False) -> None:
+    """compile the C restatement (and, where /root/reference exists, the reference harness)"""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "resql_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(REF_HARNESS)):
+        subprocess.check_call(["make", "-C", _HERE, "-j8", "ref"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_execute.restype = C.c_int
+        L.orc_execute.argtypes = [C.POINTER(P.rsq_plan_desc), C.POINTER(P.rsq_table_desc), C.c_int,
+                                  C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.orc_result_view.restype = C.POINTER(P.rsq_result_view)
+        L.orc_result_view.argtypes = [C.c_void_p]
+        L.orc_result_serialize.restype = C.c_void_p
+        L.orc_result_serialize.argtypes = [C.c_void_p]
+        L.orc_result_agg_slots.restype = C.c_int64
+        L.orc_result_agg_slots.argtypes = [C.c_void_p]
+        L.orc_result_agg_grows.restype = C.c_int64
+        L.orc_result_agg_grows.argtypes = [C.c_void_p]
+        L.orc_result_free.argtypes = [C.c_void_p]
+        L.orc_free_string.argtypes = [C.c_void_p]
+        L.orc_serialize_expr.restype = C.c_void_p
+        L.orc_serialize_expr.argtypes = [C.POINTER(P.rsq_plan_desc), C.c_int, C.c_int,
+                                         C.POINTER(P.rsq_table_desc), C.c_int, C.c_char_p, C.c_size_t]
+        L.orc_eval_scalar.restype = C.c_void_p
+        L.orc_eval_scalar.argtypes = [C.POINTER(P.rsq_plan_desc), C.c_int, C.c_char_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _take_string(ptr) -> str:
+    s = C.string_at(ptr).decode("latin1")
+    lib().orc_free_string(ptr)
+    return s
+
+
+def execute(plan: P.Plan) -> P.Result:
+    """run the plan through the C restatement"""
+    L = lib()
+    keep: list = []
+    d = plan.to_c(keep)
+    tabs = P.tables_to_c(plan.tables, keep)
+    out = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = L.orc_execute(C.byref(d), tabs, len(plan.tables), C.byref(out), err, 512)
+    if rc != 0:
+        raise OracleError(err.value.decode("latin1"))
+    try:
+        res = P.Result.from_view(L.orc_result_view(out).contents)
+        res.agg_slots = L.orc_result_agg_slots(out)
+        res.agg_grows = L.orc_result_agg_grows(out)
+        res.text = _take_string(L.orc_result_serialize(out))
+    finally:
+        L.orc_result_free(out)
+    return res
+
+
+def serialize_expr(plan: P.Plan, expr: int, derive: bool) -> str:
+    L = lib()
+    keep: list = []
+    d = plan.to_c(keep)
+    tabs = P.tables_to_c(plan.tables, keep)
+    err = C.create_string_buffer(512)
+    p = L.orc_serialize_expr(C.byref(d), expr, 1 if derive else 0, tabs, len(plan.tables), err, 512)
+    if not p:
+        raise OracleError(err.value.decode("latin1"))
+    return _take_string(p)
+
+
+def eval_scalar(plan: P.Plan, expr: int) -> str:
+    L = lib()
+    keep: list = []
+    d = plan.to_c(keep)
+    err = C.create_string_buffer(512)
+    p = L.orc_eval_scalar(C.byref(d), expr, err, 512)
+    if not p:
+        raise OracleError(err.value.decode("latin1"))
+    return _take_string(p)
+
+
+# ------------------------------------------------------------------------------------------------
+# the compiled reference
+# ------------------------------------------------------------------------------------------------
+def have_reference() -> bool:
+    return os.path.exists(REF_HARNESS) and os.access(REF_HARNESS, os.X_OK)
+
+
+def write_case(plan: P.Plan, directory: str) -> str:
+    """dump tables as raw column files + the plan text into `directory`; returns the case path"""
+    os.makedirs(directory, exist_ok=True)
+    sources: Dict[str, Dict[str, str]] = {}
+    for t in plan.tables:
+        sources[t.name] = {}
+        for c in t.columns:
+            if c.data is None:
+                continue
+            fn = f"{t.name}.{c.name}.bin"
+            np.ascontiguousarray(c.data).tofile(os.path.join(directory, fn))
+            sources[t.name][c.name] = fn
+    path = os.path.join(directory, "plan.case")
+    with open(path, "w") as f:
+        f.write(plan.to_text(sources))
+    return path
+
+
+def run_reference(plan: P.Plan, threads: int = 1, repeat: int = 1, blocksize: Optional[int] = None,
+                  workdir: Optional[str] = None, quiet: bool = False) -> Tuple[str, Dict[str, list]]:
+    """run the UNMODIFIED reference on the plan; returns (serialised result, timings)"""
+    if not have_reference():
+        raise OracleError("oracle/_ref/ref_harness is not built (needs /root/reference: make -C oracle ref)")
+    own = workdir is None
+    tmp = tempfile.mkdtemp(prefix="resql_ref_") if own else workdir
+    try:
+        case = write_case(plan, tmp)
+        cmd = [REF_HARNESS, case, "--threads", str(threads), "--repeat", str(repeat)]
+        if blocksize:
+            cmd += ["--blocksize", str(blocksize)]
+        if quiet:
+            cmd += ["--quiet"]
+        pr = subprocess.run(cmd, capture_output=True, text=True, errors="replace")
+        if pr.returncode != 0:
+            raise OracleError(f"ref_harness failed ({pr.returncode}): {pr.stderr[-2000:]}")
+        timings: Dict[str, list] = {"compile_ms": [], "exec_ms": [], "load_ms": []}
+        for line in pr.stderr.splitlines():
+            tok = line.split()
+            if tok and tok[0] == "#timing":
+                timings["compile_ms"].append(float(tok[2]))
+                timings["exec_ms"].append(float(tok[4]))
+            elif tok and tok[0] == "#load_ms":
+                timings["load_ms"].append(float(tok[1]))
+        return pr.stdout, timings
+    finally:
+        if own:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)

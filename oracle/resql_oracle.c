@@ -1,0 +1,2000 @@
+/*
+ * resql_oracle.c — CPU ORACLE (test infrastructure only; see resql_oracle.h).
+ *
+ * Plain-C restatement of the reference's algorithm for the operator pipelines
+ * scan -> selection -> hash join -> hash aggregation -> projection -> materialize -> order by.
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference).  Nothing here is shared with the product.
+ *
+ * Structure mirrors the reference's two phases:
+ *   compile phase  = the produce/consume recursion of execute.h:213-229 done for metadata
+ *                    only (expression typing, expression ids/names, symbol table decisions,
+ *                    operator schemas, hash table sizes);
+ *   execute phase  = what the generated code does per tuple, single thread.
+ */
+#define _GNU_SOURCE
+#include "resql_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include <setjmp.h>
+#include <limits.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* error handling: the reference throws ResqlError (util/ResqlError.h) or exit()s               */
+/* (qlib/error.h:29-68); the oracle longjmps out and reports a message                          */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct Ctx Ctx;
+static _Thread_local jmp_buf* g_jmp;
+static _Thread_local char g_err[512];
+
+__attribute__((noreturn, format(printf, 1, 2)))
+static void fail(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    longjmp(*g_jmp, 1);
+}
+
+static void* xmalloc(size_t n) {
+    void* p = calloc(1, n ? n : 1);
+    if (!p) fail("out of memory");
+    return p;
+}
+
+/* simple arena so a failed run frees everything at once */
+typedef struct Chunk { struct Chunk* next; } Chunk;
+typedef struct Arena { Chunk* head; } Arena;
+static void* aalloc(Arena* a, size_t n) {
+    Chunk* c = (Chunk*)calloc(1, sizeof(Chunk) + (n ? n : 1) + 16);
+    if (!c) fail("out of memory");
+    c->next = a->head; a->head = c;
+    return (void*)(((uintptr_t)(c + 1) + 15) & ~(uintptr_t)15);
+}
+static void afree(Arena* a) {
+    Chunk* c = a->head;
+    while (c) { Chunk* n = c->next; free(c); c = n; }
+    a->head = NULL;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* types (types.h)                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+static rsq_type T(int tag) { rsq_type t = {tag, 0, 0, 0}; return t; }
+static rsq_type TDEC(int p, int s) { rsq_type t = {RSQ_DECIMAL, p, s, 0}; return t; }
+
+/* types.h:108-118 */
+static const char* typeTagNames[] = {"VARCHAR", "CHAR", "BOOL", "INT", "BIGINT", "DECIMAL", "FLOAT", "DATE", ""};
+
+/* types.h:121-150 serializeType */
+static void serializeType(rsq_type t, char* out, size_t n) {
+    switch (t.tag) {
+        case RSQ_DECIMAL: snprintf(out, n, "DECIMAL(%d,%d)", t.precision, t.scale); break;
+        case RSQ_CHAR: snprintf(out, n, "CHAR(%d)", t.len); break;
+        case RSQ_VARCHAR: snprintf(out, n, "VARCHAR(%d)", t.len); break;
+        default: snprintf(out, n, "%s", typeTagNames[t.tag]); break;
+    }
+}
+
+/* types.h:153-173 equalTypes */
+static int equalTypes(rsq_type a, rsq_type b) {
+    if (a.tag != b.tag) return 0;
+    if (a.tag == RSQ_DECIMAL) return a.precision == b.precision && a.scale == b.scale;
+    if (a.tag == RSQ_CHAR || a.tag == RSQ_VARCHAR) return a.len == b.len;
+    return 1;
+}
+
+/* types.h:213-261 getSizeInTuple */
+static int getSizeInTuple(rsq_type t, int stringsByVal) {
+    switch (t.tag) {
+        case RSQ_BOOL: return 1;
+        case RSQ_DATE: return 4;
+        case RSQ_DECIMAL: return 8;
+        case RSQ_INT: return 4;
+        case RSQ_BIGINT: return 8;
+        case RSQ_FLOAT: return 8;
+        case RSQ_CHAR:
+            if (t.len == 1) return 2;
+            return stringsByVal ? t.len + 1 : 8;
+        case RSQ_VARCHAR:
+            return stringsByVal ? t.len + 1 : 8;
+        default:
+            fail("getSizeInTuple(..) for undefined type.");
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* values (values.h)                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef union Val {
+    int64_t i;        /* BIGINT / DECIMAL: 64 bit; INT: sign-extended int32; DATE: uint32 value;
+                         BOOL / CHAR(1): 8 bit */
+    const char* s;    /* CHAR(n>1) / VARCHAR: address of NUL-terminated string */
+} Val;
+
+typedef struct StrBuf { char* p; size_t len, cap; } StrBuf;
+static void sb_put(StrBuf* b, const char* s, size_t n) {
+    if (b->len + n + 1 > b->cap) {
+        size_t nc = b->cap ? b->cap * 2 : 256;
+        while (nc < b->len + n + 1) nc *= 2;
+        char* np = (char*)realloc(b->p, nc);
+        if (!np) fail("out of memory");
+        b->p = np; b->cap = nc;
+    }
+    memcpy(b->p + b->len, s, n); b->len += n; b->p[b->len] = 0;
+}
+static void sb_puts(StrBuf* b, const char* s) { sb_put(b, s, strlen(s)); }
+
+static int isString(rsq_type t) { return t.tag == RSQ_VARCHAR || (t.tag == RSQ_CHAR && t.len > 1); }
+
+/* values.h:30-127 serializeSqlValue */
+static void serializeSqlValue(StrBuf* b, Val v, rsq_type t) {
+    char tmp[64];
+    switch (t.tag) {
+        case RSQ_CHAR: {
+            if (t.len > 1) {
+                size_t i = 0;
+                while (v.s[i] != '\0') { sb_put(b, &v.s[i], 1); i++; }
+                for (; i < (size_t)t.len; i++) sb_puts(b, " ");
+            } else {
+                /* CHAR(1) is stored as {char, NUL}; fromAddress hands serializeSqlValue the address */
+                char c = (char)v.i;
+                size_t i = 0;
+                if (c != '\0') { sb_put(b, &c, 1); i = 1; }
+                for (; i < 1; i++) sb_puts(b, " ");
+            }
+            break;
+        }
+        case RSQ_VARCHAR: sb_puts(b, v.s); break;
+        case RSQ_DATE: {
+            unsigned int d = (unsigned int)(uint32_t)v.i;
+            snprintf(tmp, sizeof tmp, "%u/%02u/%02u", d / 10000, d / 100 % 100, d % 100);
+            sb_puts(b, tmp);
+            break;
+        }
+        case RSQ_INT: snprintf(tmp, sizeof tmp, "%d", (int32_t)v.i); sb_puts(b, tmp); break;
+        case RSQ_BIGINT: snprintf(tmp, sizeof tmp, "%lld", (long long)v.i); sb_puts(b, tmp); break;
+        case RSQ_BOOL: sb_puts(b, ((unsigned char)v.i) ? "true" : "false"); break;
+        case RSQ_DECIMAL: {
+            int64_t x = v.i;
+            if (x < 0) { x = (int64_t)((uint64_t)x * (uint64_t)-1); sb_puts(b, "-"); }
+            snprintf(tmp, sizeof tmp, "%lld", (long long)x);
+            size_t len = strlen(tmp);
+            if (len <= (size_t)t.scale) {
+                sb_puts(b, "0.");
+                for (size_t i = len; i < (size_t)t.scale; i++) sb_puts(b, "0");
+                sb_puts(b, tmp);
+            } else if (t.scale > 0) {
+                sb_put(b, tmp, len - t.scale);
+                sb_puts(b, ".");
+                sb_puts(b, tmp + len - t.scale);
+            } else {
+                sb_puts(b, tmp);
+            }
+            break;
+        }
+        default: fail("serializeSqlValue(..) not implemented for datatype.");
+    }
+}
+
+/* values.h:151-198 toAddress / 201-232 fromAddress, for the packed-tuple layout */
+static void storeVal(uint8_t* addr, Val v, rsq_type t, int stringsByVal) {
+    switch (t.tag) {
+        case RSQ_DATE: { uint32_t x = (uint32_t)v.i; memcpy(addr, &x, 4); break; }
+        case RSQ_BOOL: { uint8_t x = (uint8_t)v.i; memcpy(addr, &x, 1); break; }
+        case RSQ_INT: { int32_t x = (int32_t)v.i; memcpy(addr, &x, 4); break; }
+        case RSQ_BIGINT: case RSQ_DECIMAL: memcpy(addr, &v.i, 8); break;
+        case RSQ_CHAR:
+            if (t.len == 1) { uint8_t x = (uint8_t)v.i; memcpy(addr, &x, 1); break; }
+            /* fallthrough */
+        case RSQ_VARCHAR:
+            if (stringsByVal) {
+                /* values.h:136-148 writeString(string, addr, max) */
+                size_t max = (size_t)t.len, i = 0;
+                for (; i < max; i++) { addr[i] = (uint8_t)v.s[i]; if (v.s[i] == '\0') break; }
+                addr[i] = '\0';
+            } else {
+                memcpy(addr, &v.s, 8);
+            }
+            break;
+        default: fail("storeToMem(..) not implemented for datatype");
+    }
+}
+
+static Val loadVal(const uint8_t* addr, rsq_type t, int stringsByVal) {
+    Val v; v.i = 0;
+    switch (t.tag) {
+        case RSQ_DATE: { uint32_t x; memcpy(&x, addr, 4); v.i = (int64_t)x; break; }
+        case RSQ_BOOL: { uint8_t x; memcpy(&x, addr, 1); v.i = x; break; }
+        case RSQ_INT: { int32_t x; memcpy(&x, addr, 4); v.i = x; break; }
+        case RSQ_BIGINT: case RSQ_DECIMAL: memcpy(&v.i, addr, 8); break;
+        case RSQ_CHAR:
+            if (t.len == 1) { uint8_t x; memcpy(&x, addr, 1); v.i = x; break; }
+            /* fallthrough */
+        case RSQ_VARCHAR:
+            if (stringsByVal) v.s = (const char*)addr; else memcpy(&v.s, addr, 8);
+            break;
+        default: fail("loadAttributeToReg(..) not implemented for datatype");
+    }
+    return v;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* schema (schema.h)                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+#define MAX_ATTR 96
+
+typedef struct Attribute { char name[RSQ_SYMBOL_MAX]; rsq_type type; } Attribute;
+typedef struct Schema {
+    Attribute a[MAX_ATTR];
+    int n;
+    int stringsByVal;
+    int tupSize;
+} Schema;
+
+/* schema.h:76-88 */
+static void schemaFinish(Schema* s, int stringsByVal) {
+    s->stringsByVal = stringsByVal;
+    s->tupSize = 0;
+    for (int i = 0; i < s->n; i++) s->tupSize += getSizeInTuple(s->a[i].type, stringsByVal);
+}
+static void schemaAdd(Schema* s, const char* name, rsq_type t) {
+    if (s->n >= MAX_ATTR) fail("schema too wide");
+    snprintf(s->a[s->n].name, RSQ_SYMBOL_MAX, "%s", name);
+    s->a[s->n].type = t;
+    s->n++;
+}
+/* schema.h:94-106 getOffsetInTuple: offset of the FIRST attribute with that name */
+static int getOffsetInTuple(const Schema* s, const char* name) {
+    int off = 0;
+    for (int i = 0; i < s->n; i++) {
+        if (strcmp(s->a[i].name, name) == 0) break;
+        off += getSizeInTuple(s->a[i].type, s->stringsByVal);
+    }
+    if (off >= s->tupSize) fail("The attribute %s was not found in the schema", name);
+    return off;
+}
+static int schemaContains(const Schema* s, const char* name) {
+    for (int i = 0; i < s->n; i++) if (strcmp(s->a[i].name, name) == 0) return 1;
+    return 0;
+}
+/* schema.h:161-169 join */
+static Schema schemaJoin(const Schema* a, const Schema* b) {
+    Schema r; memset(&r, 0, sizeof r);
+    for (int i = 0; i < a->n; i++) schemaAdd(&r, a->a[i].name, a->a[i].type);
+    for (int i = 0; i < b->n; i++) schemaAdd(&r, b->a[i].name, b->a[i].type);
+    r.stringsByVal = a->stringsByVal;
+    r.tupSize = a->tupSize + b->tupSize;
+    return r;
+}
+
+/* symbol sets (schema.h:17-25) */
+#define MAX_SYMS 128
+typedef struct SymSet { char n[MAX_SYMS][RSQ_SYMBOL_MAX]; int cnt; } SymSet;
+static int symHas(const SymSet* s, const char* name) {
+    for (int i = 0; i < s->cnt; i++) if (strcmp(s->n[i], name) == 0) return 1;
+    return 0;
+}
+static void symAdd(SymSet* s, const char* name) {
+    if (symHas(s, name)) return;
+    if (s->cnt >= MAX_SYMS) fail("symbol set overflow");
+    snprintf(s->n[s->cnt++], RSQ_SYMBOL_MAX, "%s", name);
+}
+static void symUnion(SymSet* dst, const SymSet* a) { for (int i = 0; i < a->cnt; i++) symAdd(dst, a->n[i]); }
+
+/* schema.h:128-136 prune */
+static Schema schemaPrune(const Schema* s, const SymSet* req) {
+    Schema r; memset(&r, 0, sizeof r);
+    for (int i = 0; i < s->n; i++) if (symHas(req, s->a[i].name)) schemaAdd(&r, s->a[i].name, s->a[i].type);
+    schemaFinish(&r, 1);   /* Schema(vector) constructor default stringsByVal = true */
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* expressions (expressions.h)                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+enum { S_LITERAL, S_UNARY, S_BINARY, S_TERNARY, S_OTHER };
+
+typedef struct Expr {
+    int tag;
+    int structureTag;
+    char symbol[RSQ_SYMBOL_MAX];
+    struct Expr* next;
+    struct Expr* child;
+    rsq_type type;
+    Val value;
+    size_t id;
+} Expr;
+
+/* expressions.h:93-131 */
+static const char* exprTagNames[] = {
+    "ADD", "SUB", "MUL", "DIV", "AND", "OR", "LT", "LE", "GT", "GE", "EQ", "NEQ", "LIKE",
+    "SUM", "COUNT", "AVG", "MIN", "MAX", "ASC", "DESC", "CASE", "WHENTHEN",
+    "ATTRIBUTE", "TYPECAST", "CONSTANT", "AS", "TYPE", "TABLE", "STAR", "UNDEFINED"};
+
+struct Ctx {
+    Arena arena;
+    /* identTypes of the whole database (planner.h:395-404 mapIdentifierTypes) + AS aliases */
+    struct { char name[RSQ_SYMBOL_MAX]; rsq_type type; } ident[512];
+    int nIdent;
+    int exprIdGen;     /* RelationalContext.h:16: starts with 1, first id handed out is 2 */
+};
+
+static Expr* newExpr(Ctx* c, int tag, int st, const char* symbol) {
+    Expr* e = (Expr*)aalloc(&c->arena, sizeof(Expr));
+    e->tag = tag; e->structureTag = st;
+    snprintf(e->symbol, RSQ_SYMBOL_MAX, "%s", symbol ? symbol : "");
+    e->type = T(RSQ_NT);
+    return e;
+}
+
+static int structureOf(int tag) {
+    switch (tag) {
+        case RSQ_E_ATTRIBUTE: case RSQ_E_CONSTANT: case RSQ_E_STAR: case RSQ_E_TYPE: case RSQ_E_TABLE:
+        case RSQ_E_UNDEFINED: return S_LITERAL;
+        case RSQ_E_SUM: case RSQ_E_COUNT: case RSQ_E_AVG: case RSQ_E_MIN: case RSQ_E_MAX:
+        case RSQ_E_ASC: case RSQ_E_DESC: case RSQ_E_TYPECAST: case RSQ_E_AS: return S_UNARY;
+        case RSQ_E_CASE: return S_OTHER;
+        default: return S_BINARY;
+    }
+}
+
+/* expressions.h:369-467: constant parsing */
+static long long parse_ll(const char* s) {
+    /* std::stoll: skips leading whitespace, optional sign, digits; throws if no digits */
+    char* end = NULL;
+    long long v = strtoll(s, &end, 10);
+    if (end == s) fail("stoll: invalid constant '%s'", s);
+    return v;
+}
+
+static void parseConstant(Ctx* c, Expr* e, int category) {
+    const char* sym = e->symbol;
+    switch (category) {
+        case RSQ_DECIMAL: {   /* expressions.h:443-467 */
+            char buf[RSQ_SYMBOL_MAX]; size_t n = 0; unsigned scale = 0;
+            const char* dot = strchr(sym, '.');
+            if (dot) scale = (unsigned)(strlen(sym) - (size_t)(dot - sym + 1));
+            for (const char* p = sym; *p; p++) { if (p == dot) continue; buf[n++] = *p; }
+            buf[n] = 0;
+            e->value.i = parse_ll(buf);
+            e->type = TDEC((int)(uint8_t)n, (int)(uint8_t)scale);   /* precision = digits incl. sign char */
+            break;
+        }
+        case RSQ_DATE: {      /* expressions.h:413-440 */
+            int y, m, d, ok = 0;
+            if (sscanf(sym, "%4d-%2d-%2d", &y, &m, &d) == 3) ok = 1;
+            if (sscanf(sym, "%4d/%2d/%2d", &y, &m, &d) == 3) ok = 1;
+            if (!ok) fail("Unsupported string type or unsupported date format (formats: \"yyyy/mm/dd\", \"mm/dd/yyyy\")");
+            e->value.i = (int64_t)(uint32_t)(y * 10000 + m * 100 + d);
+            e->type = T(RSQ_DATE);
+            break;
+        }
+        case RSQ_INT: {       /* expressions.h:376-380 (std::stoi) */
+            long long v = parse_ll(sym);
+            if (v > INT_MAX || v < INT_MIN) fail("stoi: out of range");
+            e->value.i = (int32_t)v; e->type = T(RSQ_INT);
+            break;
+        }
+        case RSQ_BIGINT: {    /* expressions.h:369-373: parsed through int32_t */
+            int32_t v = (int32_t)parse_ll(sym);
+            e->value.i = v; e->type = T(RSQ_BIGINT);
+            break;
+        }
+        case RSQ_BOOL: {      /* expressions.h:383-398 */
+            if (strcmp(sym, "true") == 0) e->value.i = 1;
+            else if (strcmp(sym, "false") == 0) e->value.i = 0;
+            else fail("Couldnt parse BOOL constant.");
+            e->type = T(RSQ_BOOL);
+            break;
+        }
+        case RSQ_CHAR: {      /* expressions.h:401-404 */
+            e->type = T(RSQ_CHAR); e->type.len = (int)strlen(sym);
+            if (e->type.len == 1) e->value.i = (uint8_t)sym[0];   /* emitConstantCHAR1: loads the first byte */
+            else e->value.s = e->symbol;
+            break;
+        }
+        case RSQ_VARCHAR: {   /* expressions.h:407-410 */
+            e->type = T(RSQ_VARCHAR); e->type.len = (int)strlen(sym);
+            e->value.s = e->symbol;
+            break;
+        }
+        default: fail("parseConstant(..) not implemented for type.");
+    }
+    (void)c;
+}
+
+/* build the mutable linked Expr structure from the POD description */
+static Expr** buildExprs(Ctx* c, const rsq_plan_desc* p) {
+    Expr** nodes = (Expr**)aalloc(&c->arena, sizeof(Expr*) * (size_t)(p->n_exprs + 1));
+    for (int i = 0; i < p->n_exprs; i++) {
+        const rsq_expr* d = &p->exprs[i];
+        if (d->tag < 0 || d->tag > RSQ_E_UNDEFINED) fail("bad expression tag");
+        nodes[i] = newExpr(c, d->tag, structureOf(d->tag), d->symbol);
+        if (d->tag == RSQ_E_CONSTANT) parseConstant(c, nodes[i], d->const_category);
+    }
+    for (int i = 0; i < p->n_exprs; i++) {
+        const rsq_expr* d = &p->exprs[i];
+        Expr* prev = NULL;
+        for (int k = 0; k < d->n_children; k++) {
+            int ci = d->child[k];
+            if (ci < 0 || ci >= p->n_exprs) fail("bad child index in expr %d", i);
+            Expr* ch = nodes[ci];
+            if (k == 0) nodes[i]->child = ch;
+            else {
+                if (prev->next != NULL && prev->next != ch)
+                    fail("expression node shared as child with different right siblings");
+                prev->next = ch;   /* binaryExpr: left->next = right (expressions.h:302) */
+            }
+            prev = ch;
+        }
+        int st = nodes[i]->structureTag;
+        if (st == S_UNARY && d->n_children != 1) fail("unary expression %d needs one child", i);
+        if (st == S_BINARY && d->n_children != 2) fail("binary expression %d needs two children", i);
+    }
+    return nodes;
+}
+
+/* expressions.h:954-966 getExpressionName */
+static void getExpressionName(const Expr* e, char* out) {
+    if (e->tag == RSQ_E_ATTRIBUTE || e->tag == RSQ_E_AS) snprintf(out, RSQ_SYMBOL_MAX, "%s", e->symbol);
+    else snprintf(out, RSQ_SYMBOL_MAX, "expr%zu", e->id);
+}
+
+/* expressions.h:1354-1358 */
+static void addExpressionIds(Ctx* c, Expr* e) { if (e->id == 0) e->id = (size_t)(++c->exprIdGen); }
+
+/* expressions.h:177-204 serializeExpr */
+static void serializeExpr(StrBuf* b, const Expr* e) {
+    char tb[64];
+    serializeType(e->type, tb, sizeof tb);
+    sb_puts(b, "{"); sb_puts(b, exprTagNames[e->tag]); sb_puts(b, ","); sb_puts(b, tb);
+    if (e->tag == RSQ_E_CONSTANT) { sb_puts(b, ","); serializeSqlValue(b, e->value, e->type); }
+    for (const Expr* ch = e->child; ch; ch = ch->next) { sb_puts(b, ","); serializeExpr(b, ch); }
+    sb_puts(b, "}");
+}
+
+/* ---- type derivation (expressions.h:742-1392) ---- */
+
+static rsq_type* identLookup(Ctx* c, const char* name) {
+    for (int i = 0; i < c->nIdent; i++) if (strcmp(c->ident[i].name, name) == 0) return &c->ident[i].type;
+    return NULL;
+}
+static void identSet(Ctx* c, const char* name, rsq_type t) {
+    rsq_type* p = identLookup(c, name);
+    if (p) { *p = t; return; }
+    if (c->nIdent >= 512) fail("too many identifiers");
+    snprintf(c->ident[c->nIdent].name, RSQ_SYMBOL_MAX, "%s", name);
+    c->ident[c->nIdent].type = t; c->nIdent++;
+}
+
+static void deriveExpressionTypes(Ctx* c, Expr* e);
+
+/* expressions.h:229-255 */
+static void insertUnaryBetweenParentAndChild(Expr* parent, Expr* child, Expr* insert) {
+    if (parent->child == child) {
+        Expr* oldChild = parent->child;
+        parent->child = insert;
+        insert->child = oldChild;
+        insert->next = oldChild->next;
+        child->next = NULL;
+    } else {
+        Expr* prev = parent->child;
+        while (prev->next != child && prev->next != NULL) prev = prev->next;
+        if (prev->next != child) fail("Child in insertUnaryBetweenParentAndChild(..) not found.");
+        prev->next = insert;
+        insert->next = child->next;
+        child->next = NULL;
+        insert->child = child;
+    }
+}
+
+static Expr* mkTypecast(Ctx* c, rsq_type t, Expr* child) {
+    Expr* e = newExpr(c, RSQ_E_TYPECAST, S_UNARY, "typecast");   /* expressions.h:656-660 */
+    e->child = child; e->type = t;
+    return e;
+}
+
+/* expressions.h:742-758 */
+static void insertTypecast(Ctx* c, Expr* e, Expr* child, rsq_type to) {
+    if (to.tag == RSQ_CHAR || to.tag == RSQ_VARCHAR) return;
+    if (to.tag == RSQ_DECIMAL) { to.scale = 0; to.precision = 19; }
+    Expr* tc = mkTypecast(c, to, child);
+    tc->child = NULL;   /* insertUnaryBetweenParentAndChild sets the links */
+    insertUnaryBetweenParentAndChild(e, child, tc);
+}
+
+/* expressions.h:781-796 */
+static void applyPrecedence(Ctx* c, Expr* e, Expr* left, Expr* right) {
+    if (left->type.tag != right->type.tag) {
+        if (left->type.tag > right->type.tag) insertTypecast(c, e, right, left->type);
+        else insertTypecast(c, e, left, right->type);
+    }
+}
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* expressions.h:873-881; DecimalSpec fields are uint8_t */
+static rsq_type scaleToOther(rsq_type spec, rsq_type other) {
+    int difference = other.scale - spec.scale;
+    spec.scale = (uint8_t)(spec.scale + difference);
+    spec.precision = (uint8_t)(spec.precision + difference);
+    if (spec.precision > 19) spec.precision = 19;
+    return spec;
+}
+
+/* expressions.h:884-907 */
+static void typecastDecimalsToSameScale(Ctx* c, Expr* e, Expr* left, Expr* right) {
+    rsq_type ls = left->type, rs = right->type;
+    if (ls.scale < rs.scale) {
+        rsq_type t = scaleToOther(ls, rs); t.tag = RSQ_DECIMAL;
+        if (left->tag == RSQ_E_TYPECAST) left->type = t;
+        else { Expr* tc = mkTypecast(c, t, left); tc->child = NULL; insertUnaryBetweenParentAndChild(e, left, tc); }
+    } else if (ls.scale > rs.scale) {
+        rsq_type t = scaleToOther(rs, ls); t.tag = RSQ_DECIMAL;
+        if (right->tag == RSQ_E_TYPECAST) right->type = t;
+        else { Expr* tc = mkTypecast(c, t, right); tc->child = NULL; insertUnaryBetweenParentAndChild(e, right, tc); }
+    }
+}
+
+/* expressions.h:910-951 */
+static void typecastConfigurableInputTypes(Ctx* c, Expr* e) {
+    Expr* left = e->child;
+    Expr* right = e->child->next;
+    if (left->type.tag != RSQ_DECIMAL) return;
+    switch (e->tag) {
+        case RSQ_E_LT: case RSQ_E_GT: case RSQ_E_LE: case RSQ_E_GE: case RSQ_E_EQ: case RSQ_E_NEQ:
+        case RSQ_E_ADD: case RSQ_E_SUB:
+            typecastDecimalsToSameScale(c, e, left, right);
+            break;
+        case RSQ_E_MUL: break;
+        case RSQ_E_DIV: fail("Decimal division not yet implemented");
+        default: fail("Invalid expression type or type not implemented in typecastDecimalInputs(..)");
+    }
+}
+
+/* expressions.h:799-845 */
+static void configureBinaryArithmeticResultType(Expr* e) {
+    if (e->type.tag != RSQ_DECIMAL) return;
+    rsq_type l = e->child->type, r = e->child->next->type, res = TDEC(0, 0);
+    switch (e->tag) {
+        case RSQ_E_ADD: case RSQ_E_SUB:
+            res.precision = (uint8_t)(imax(l.precision, r.precision) + 1);
+            res.scale = l.scale;
+            break;
+        case RSQ_E_MUL:
+            res.precision = (uint8_t)(l.precision + r.precision);
+            res.scale = (uint8_t)(l.scale + r.scale);
+            break;
+        case RSQ_E_DIV: fail("Decimal division not yet implemented");
+        default: fail("Invalid expression type in getTypeOfDecimalArithmetic(..)");
+    }
+    if (res.precision > 19) res.precision = 19;
+    e->type.precision = res.precision; e->type.scale = res.scale;
+}
+
+/* expressions.h:848-870 */
+static void configureAggregationResultType(Expr* e) {
+    if (e->child->type.tag != RSQ_DECIMAL) return;
+    rsq_type cs = e->child->type;
+    if (e->tag == RSQ_E_SUM) { e->type.scale = cs.scale; e->type.precision = 19; }
+    if (e->tag == RSQ_E_AVG) { e->type.scale = (uint8_t)(cs.scale + 2); e->type.precision = imin(cs.precision + 2, 19); }
+}
+
+static void requireNumericType(const Expr* op, const Expr* e) {
+    int t = e->type.tag;
+    if (t != RSQ_DECIMAL && t != RSQ_BIGINT && t != RSQ_INT && t != RSQ_FLOAT)
+        fail("Incompatible types: %s expression requires a numeric operand", exprTagNames[op->tag]);
+}
+static void requireOrderedType(const Expr* op, const Expr* e) {
+    int t = e->type.tag;
+    if (t != RSQ_DECIMAL && t != RSQ_BIGINT && t != RSQ_INT && t != RSQ_FLOAT && t != RSQ_DATE)
+        fail("Incompatible types: %s expression requires an ordered operand type", exprTagNames[op->tag]);
+}
+static void requireBoolType(const Expr* op, const Expr* e) {
+    if (e->type.tag != RSQ_BOOL) fail("Incompatible types: %s expression requires bool operand", exprTagNames[op->tag]);
+}
+static void requireStringType(const Expr* op, const Expr* e) {
+    if (e->type.tag != RSQ_CHAR && e->type.tag != RSQ_VARCHAR)
+        fail("Incompatible types: %s expression requires a char or varchar operand", exprTagNames[op->tag]);
+}
+
+/* expressions.h:1098-1144 */
+static rsq_type commonSuperType(rsq_type a, rsq_type b) {
+    if (a.tag == b.tag) {
+        if (a.tag == RSQ_DECIMAL) return TDEC(imax(a.precision, b.precision), imax(a.scale, b.scale));
+        if (a.tag == RSQ_VARCHAR || a.tag == RSQ_CHAR) { rsq_type t = a; t.len = imax(a.len, b.len); return t; }
+        return a;
+    } else if (a.tag == RSQ_BIGINT || a.tag == RSQ_INT) {
+        if (b.tag == RSQ_DECIMAL) return b;
+    } else if (b.tag == RSQ_BIGINT || b.tag == RSQ_INT) {
+        if (a.tag == RSQ_DECIMAL) return b;
+    }
+    fail("Incompatible or unimplemented type combination in getCommonSuperType(..)");
+    return a;
+}
+
+/* expressions.h:765-778 */
+static void insertTypecastIfNeeded(Ctx* c, Expr* e, Expr* child, rsq_type from, rsq_type to) {
+    if (equalTypes(from, to)) return;
+    insertTypecast(c, e, child, to);
+}
+
+/* expressions.h:1147-1187 */
+static void deriveCaseExpressionTypes(Ctx* c, Expr* e) {
+    Expr* child = e->child;
+    deriveExpressionTypes(c, child);
+    rsq_type thenType = child->type;
+    child = child->next;
+    while (child != NULL && child->tag == RSQ_E_WHENTHEN) {
+        Expr* when = child->child; Expr* then = when->next;
+        deriveExpressionTypes(c, when);
+        deriveExpressionTypes(c, then);
+        thenType = commonSuperType(thenType, then->type);
+        child = child->next;
+    }
+    if (child != NULL) {
+        deriveExpressionTypes(c, child);
+        thenType = commonSuperType(thenType, child->type);
+    }
+    child = e->child;
+    while (child != NULL && child->tag == RSQ_E_WHENTHEN) {
+        Expr* when = child->child; Expr* then = when->next;
+        insertTypecastIfNeeded(c, child, then, then->type, thenType);
+        deriveExpressionTypes(c, child);
+        child = child->next;
+    }
+    if (child != NULL) insertTypecastIfNeeded(c, e, child, child->type, thenType);
+    e->type = thenType;
+}
+
+static void deriveExpressionTypes(Ctx* c, Expr* e) {
+    switch (e->structureTag) {
+        case S_LITERAL: {   /* expressions.h:1204-1241 */
+            if (e->type.tag != RSQ_NT) {
+                if (e->tag == RSQ_E_ATTRIBUTE) identSet(c, e->symbol, e->type);
+                return;
+            }
+            switch (e->tag) {
+                case RSQ_E_ATTRIBUTE: {
+                    rsq_type* t = identLookup(c, e->symbol);
+                    if (!t) fail("Attribute %s not found.", e->symbol);
+                    e->type = *t;
+                    break;
+                }
+                case RSQ_E_CONSTANT: break;
+                case RSQ_E_STAR: e->type = T(RSQ_BIGINT); break;
+                default: fail("deriveExpressionTypesLiteral(..) not implemented for %s", exprTagNames[e->tag]);
+            }
+            break;
+        }
+        case S_UNARY: {     /* expressions.h:1244-1290 */
+            Expr* child = e->child;
+            deriveExpressionTypes(c, child);
+            switch (e->tag) {
+                case RSQ_E_TYPECAST: break;
+                case RSQ_E_AS: identSet(c, e->symbol, child->type); e->type = child->type; break;
+                case RSQ_E_COUNT: e->type = T(RSQ_BIGINT); break;
+                case RSQ_E_SUM:
+                    requireNumericType(e, child); e->type = child->type; configureAggregationResultType(e); break;
+                case RSQ_E_AVG:
+                    requireNumericType(e, child); e->type = TDEC(19, 2); configureAggregationResultType(e); break;
+                case RSQ_E_MAX: case RSQ_E_MIN:
+                    requireOrderedType(e, child); e->type = child->type; break;
+                case RSQ_E_DESC: case RSQ_E_ASC: e->type = child->type; break;
+                default: fail("deriveExpressionTypesUnary(..) not implemented for %s", exprTagNames[e->tag]);
+            }
+            break;
+        }
+        case S_BINARY: {    /* expressions.h:1293-1351 */
+            Expr* left = e->child;
+            Expr* right = e->child->next;
+            deriveExpressionTypes(c, left);
+            deriveExpressionTypes(c, right);
+            switch (e->tag) {
+                case RSQ_E_ADD: case RSQ_E_SUB: case RSQ_E_MUL: case RSQ_E_DIV:
+                    requireNumericType(e, left); requireNumericType(e, right);
+                    applyPrecedence(c, e, left, right);
+                    e->type = e->child->type;
+                    typecastConfigurableInputTypes(c, e);
+                    configureBinaryArithmeticResultType(e);
+                    break;
+                case RSQ_E_LT: case RSQ_E_LE: case RSQ_E_GT: case RSQ_E_GE:
+                    requireOrderedType(e, left); requireOrderedType(e, right);
+                    /* fallthrough */
+                case RSQ_E_EQ: case RSQ_E_NEQ:
+                    applyPrecedence(c, e, left, right);
+                    typecastConfigurableInputTypes(c, e);
+                    e->type = T(RSQ_BOOL);
+                    break;
+                case RSQ_E_OR: case RSQ_E_AND:
+                    requireBoolType(e, left); requireBoolType(e, right);
+                    e->type = T(RSQ_BOOL);
+                    break;
+                case RSQ_E_LIKE:
+                    requireStringType(e, left); requireStringType(e, right);
+                    e->type = T(RSQ_BOOL);
+                    break;
+                case RSQ_E_WHENTHEN:
+                    requireBoolType(e, left);
+                    e->type = right->type;
+                    break;
+                default: fail("deriveExpressionTypesBinary(..) not implemented for %s", exprTagNames[e->tag]);
+            }
+            break;
+        }
+        case S_OTHER:
+            if (e->tag == RSQ_E_CASE) deriveCaseExpressionTypes(c, e);
+            else fail("deriveExpressionTypesOther(..) not implemented");
+            break;
+        default: fail("deriveExpressionTypes(..)");
+    }
+}
+
+/* expressions.h:1416-1442 extractRequiredAttributes */
+static void extractRequiredAttributes(const Expr* e, SymSet* out) {
+    if (!e) return;
+    if (e->tag == RSQ_E_ATTRIBUTE) { char nm[RSQ_SYMBOL_MAX]; getExpressionName(e, nm); symAdd(out, nm); }
+    for (const Expr* ch = e->child; ch; ch = ch->next) extractRequiredAttributes(ch, out);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* runtime library: hash functions, hash table, string compare (qlib/hash.h, qlib/scalar.h)     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* qlib/hash.h:32-95 */
+static const uint64_t primeHashTableSizes[] = {
+    5ull, 11ull, 23ull, 47ull, 97ull, 199ull, 409ull, 823ull, 1741ull, 3469ull, 6949ull, 14033ull,
+    28411ull, 57557ull, 116731ull, 236897ull, 480881ull, 976369ull, 1982627ull, 4026031ull,
+    8175383ull, 16601593ull, 33712729ull, 68460391ull, 139022417ull, 282312799ull, 573292817ull,
+    1164186217ull, 2364114217ull, 4294967291ull, 8589934583ull, 17179869143ull, 34359738337ull,
+    68719476731ull, 137438953447ull, 274877906899ull, 549755813881ull, 1099511627689ull,
+    2199023255531ull, 4398046511093ull, 8796093022151ull, 17592186044399ull, 35184372088777ull,
+    70368744177643ull, 140737488355213ull, 281474976710597ull, 562949953421231ull,
+    1125899906842597ull, 2251799813685119ull, 4503599627370449ull, 9007199254740881ull,
+    18014398509481951ull, 36028797018963913ull, 72057594037927931ull, 144115188075855859ull,
+    288230376151711717ull, 576460752303423433ull, 1152921504606846883ull, 2305843009213693951ull,
+    4611686018427387847ull, 9223372036854775783ull, 18446744073709551557ull};
+
+#define ENTRY_HDR 9   /* packed {uint8 status; uint64 hash} qlib/hash.h:196-212 */
+
+typedef struct HashTable {
+    uint64_t numEntries;
+    int primeIndex;
+    size_t fullEntrySize, payloadSize;
+    uint8_t* entries;
+    uint8_t* entriesEnd;
+    uint64_t capacityThreshold, numInserts;
+    int64_t grows;
+} HashTable;
+
+/* qlib/hash.h:225-287 allocateHashTable */
+static HashTable* allocateHashTable(uint64_t minSize, size_t payloadSize) {
+    if (minSize < 2) minSize = 2;
+    HashTable* ht = (HashTable*)xmalloc(sizeof(HashTable));
+    /* std::upper_bound over the first 61 entries: first prime > minSize */
+    int idx = 0;
+    while (idx < 61 && !(minSize < primeHashTableSizes[idx])) idx++;
+    ht->primeIndex = idx;
+    ht->numEntries = primeHashTableSizes[idx];
+    ht->payloadSize = payloadSize;
+    ht->fullEntrySize = ENTRY_HDR + payloadSize;
+    size_t bytes = (size_t)ht->numEntries * ht->fullEntrySize;
+    ht->entries = (uint8_t*)malloc(bytes ? bytes : 1);
+    if (!ht->entries) { free(ht); fail("Hash table allocation failed (entries)."); }
+    ht->entriesEnd = ht->entries + bytes;
+    for (uint64_t i = 0; i < ht->numEntries; i++) ht->entries[i * ht->fullEntrySize] = 0;
+    ht->capacityThreshold = ht->numEntries * 6 / 10;
+    ht->numInserts = 0;
+    return ht;
+}
+static void freeHashTable(HashTable* ht) { if (ht) { free(ht->entries); free(ht); } }
+
+static uint8_t* ht_put(HashTable* ht, uint64_t hash);
+
+/* qlib/hash.h:330-365 growHashTable */
+static void growHashTable(HashTable* ht) {
+    HashTable* larger = allocateHashTable(ht->numEntries + 1, ht->payloadSize);
+    for (uint8_t* addr = ht->entries; addr < ht->entriesEnd; addr += ht->fullEntrySize) {
+        if (addr[0] > 0) {
+            uint64_t h; memcpy(&h, addr + 1, 8);
+            uint8_t* nw = ht_put(larger, h);
+            memcpy(nw, addr + ENTRY_HDR, ht->payloadSize);
+        }
+    }
+    int64_t grows = ht->grows + larger->grows + 1;
+    free(ht->entries);
+    memcpy(ht, larger, sizeof(HashTable));
+    ht->grows = grows;
+    free(larger);
+}
+
+/* qlib/hash.h:385-419 ht_put */
+static uint8_t* ht_put(HashTable* ht, uint64_t hash) {
+    ht->numInserts++;
+    if (ht->numInserts > ht->capacityThreshold) growHashTable(ht);
+    uint64_t loc = hash % ht->numEntries;
+    uint64_t nProbes = 0;
+    while (nProbes < ht->numEntries) {
+        uint8_t* entry = &ht->entries[loc * ht->fullEntrySize];
+        if (entry[0] == 0) {
+            entry[0] = 1;
+            memcpy(entry + 1, &hash, 8);
+            return entry + ENTRY_HDR;
+        }
+        loc++;
+        if (loc >= ht->numEntries) loc = 0;
+        nProbes++;
+    }
+    fail("Hash table full");
+    return NULL;
+}
+
+/* qlib/hash.h:427-477 ht_get */
+static uint8_t* ht_get(HashTable* ht, uint64_t hash, uint8_t* dataLoc) {
+    uint8_t* entryLoc;
+    if (dataLoc == NULL) entryLoc = &ht->entries[(hash % ht->numEntries) * ht->fullEntrySize];
+    else entryLoc = dataLoc + ht->payloadSize;
+    /* NB: like the reference, a continued probe that runs off the end is wrapped only inside the
+     * loop body below; dataLoc + payloadSize == entriesEnd is read by the reference out of bounds.
+     * We wrap first — the reference's behaviour there is undefined. */
+    if (entryLoc >= ht->entriesEnd) entryLoc = ht->entries;
+    while (entryLoc[0] != 0) {
+        uint64_t h; memcpy(&h, entryLoc + 1, 8);
+        if (h == hash) return entryLoc + ENTRY_HDR;
+        entryLoc += ht->fullEntrySize;
+        if (entryLoc >= ht->entriesEnd) entryLoc = ht->entries;
+    }
+    return NULL;
+}
+
+/* qlib/hash.h:116-147.  `c * 31636373` is an int multiplication in the reference (signed overflow
+ * for c >= 'D'); clang -O3 on x86-64 evaluates it in 32 bits and sign-extends. */
+static uint64_t hashVarchar(const char* str, uint64_t hash, size_t maxLen) {
+    for (size_t i = 0; i < maxLen && *str != '\0'; i++, str++) {
+        int c = *str;
+        int32_t m = (int32_t)((uint32_t)c * 31636373u);
+        hash = hash + (uint64_t)(int64_t)m + (uint64_t)(int64_t)c;
+    }
+    return hash;
+}
+static uint64_t hashChar(const char* str, uint64_t hash, size_t len) {
+    for (size_t i = 0; i < len; i++) {
+        char c;
+        if (*str != '\0') { c = *str; str++; } else c = ' ';
+        int32_t m = (int32_t)((uint32_t)(int)c * 31636373u);
+        hash = hash + (uint64_t)(int64_t)m + (uint64_t)(int64_t)c;
+    }
+    return hash;
+}
+
+/* qlib/scalar.h:16-24 */
+static int compareVarchar(const char* a, const char* b) {
+    while (*a != '\0' && *b != '\0') { if (*a != *b) return 0; a++; b++; }
+    return *a == *b;
+}
+/* qlib/scalar.h:27-46 */
+static int compareChar(const char* a, const char* b) {
+    while (*a != '\0' && *b != '\0') { if (*a != *b) return 0; a++; b++; }
+    while (*a != '\0') { if (*a != ' ') return 0; a++; }
+    while (*b != '\0') { if (*b != ' ') return 0; b++; }
+    return 1;
+}
+
+/* ValuesJitFlounder.h:65-142 Values::hash for one value */
+static uint64_t hashValue(uint64_t h, Val v, rsq_type t) {
+    switch (t.tag) {
+        case RSQ_BIGINT: case RSQ_DECIMAL:
+            return h + ((uint64_t)v.i * 1710227316115945415ull + 741332713408129251ull);
+        case RSQ_INT:
+            return h + ((uint64_t)(int64_t)(int32_t)v.i + 741332713408129251ull) * 1710227316115945415ull;
+        case RSQ_DATE:   /* movsxd of the 32-bit register */
+            return h + ((uint64_t)(int64_t)(int32_t)(uint32_t)v.i + 741332713408129251ull) * 1710227316115945415ull;
+        case RSQ_BOOL:
+            return ((uint8_t)v.i == 0) ? h + 31636373ull : h;
+        case RSQ_CHAR:
+            if (t.len > 1) return hashChar(v.s, h, (size_t)t.len);
+            h = h + (uint64_t)(uint8_t)v.i;     /* movzx */
+            return h + h;
+        case RSQ_VARCHAR:
+            return hashVarchar(v.s, h, (size_t)t.len);
+        default: fail("Values::hash(..) not implemented for datatype");
+    }
+    return h;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* compiled expressions: emitExpression (ExpressionsJitFlounder.h:1080-1114) resolved at         */
+/* "codegen" time against the symbol table, evaluated per tuple                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct CExpr {
+    int kind;                 /* 0 = read symbol slot, 1 = compute */
+    int slot;
+    int tag;                  /* Expr tag for compute */
+    rsq_type type;            /* result type */
+    rsq_type opType;          /* operationType / child type */
+    Val constant;
+    struct CExpr* kid[RSQ_MAX_CHILDREN];
+    int nKids;
+} CExpr;
+
+#define MAX_SLOTS 256
+typedef struct SymTab {
+    char name[MAX_SLOTS][RSQ_SYMBOL_MAX];
+    rsq_type type[MAX_SLOTS];
+    Val val[MAX_SLOTS];
+    int n;
+} SymTab;
+
+static int symSlot(SymTab* st, const char* name) {
+    for (int i = 0; i < st->n; i++) if (strcmp(st->name[i], name) == 0) return i;
+    return -1;
+}
+/* Values::addSymbols (ValuesJitFlounder.h:57-62) */
+static int symRegister(SymTab* st, const char* name, rsq_type t) {
+    int s = symSlot(st, name);
+    if (s < 0) {
+        if (st->n >= MAX_SLOTS) fail("symbol table overflow");
+        s = st->n++;
+        snprintf(st->name[s], RSQ_SYMBOL_MAX, "%s", name);
+    }
+    st->type[s] = t;
+    return s;
+}
+
+typedef struct Exec Exec;
+
+static CExpr* compileExpr(Exec* x, Expr* e);
+
+/* ExpressionsJitFlounder.h:760 */
+static const int64_t factorsDECIMAL[] = {1, 10, 100, 1000, 10000, 100000, 1000000, 10000000, 100000000};
+
+static int64_t sdiv(int64_t a, int64_t b) {
+    /* cqo; idiv (ExpressionsJitFlounder.h:408-420): traps on /0 and INT64_MIN/-1 */
+    if (b == 0) fail("Division by zero");
+    if (a == INT64_MIN && b == -1) fail("Division overflow (idiv trap)");
+    return a / b;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* operators                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct Relation {           /* row store, packed tuples, strings by value (dbdata.h:105-461) */
+    Schema schema;
+    uint8_t* data;
+    int64_t nTuples, cap;
+} Relation;
+
+typedef struct ValueSet {
+    int n;
+    char name[RSQ_MAX_OP_EXPRS * 2][RSQ_SYMBOL_MAX];
+    rsq_type type[RSQ_MAX_OP_EXPRS * 2];
+} ValueSet;
+
+typedef struct Op {
+    int tag;
+    struct Op* parent;
+    struct Op* child[2];
+    int nChildren;
+    Expr* exprs[RSQ_MAX_OP_EXPRS]; int nExprs;
+    Expr* exprs2[RSQ_MAX_OP_EXPRS]; int nExprs2;
+    int singleMatch;
+    int hasLimit; int64_t limit;
+    Schema schema;                 /* RelOperator::_schema */
+    /* SCAN */
+    Relation* rel;
+    int scanSlots[MAX_ATTR]; int scanOffs[MAX_ATTR]; rsq_type scanTypes[MAX_ATTR]; int nScan;
+    /* SELECTION */
+    SymSet request;
+    CExpr* cCond;
+    /* PROJECTION */
+    CExpr* cProj[RSQ_MAX_OP_EXPRS]; int projSlots[RSQ_MAX_OP_EXPRS];
+    /* HASHJOIN */
+    int nCall;
+    HashTable* ht;
+    Schema schemaBuildKeys;        /* htMatConfig: strings by reference */
+    Schema schemaBuildVals;        /* _lChild->_schema re-laid-out with strings by reference */
+    Schema schemaKeysAndVals;
+    CExpr* cBuildKeys[RSQ_MAX_OP_EXPRS]; CExpr* cProbeKeys[RSQ_MAX_OP_EXPRS]; int nKeys;
+    rsq_type probeKeyTypes[RSQ_MAX_OP_EXPRS];
+    int buildValSlots[MAX_ATTR];   /* symbol slots read at build (Values::get) */
+    int probeValSlots[MAX_ATTR];   /* symbol slots written at probe (addSymbols) */
+    int keyOffs[RSQ_MAX_OP_EXPRS]; int valOffs[MAX_ATTR]; int keysByteSize;
+    /* AGGREGATION */
+    Expr* splitAgg[RSQ_MAX_OP_EXPRS * 2]; int nSplit;
+    CExpr* cGroup[RSQ_MAX_OP_EXPRS]; CExpr* cAgg[RSQ_MAX_OP_EXPRS * 2];
+    Schema entrySchema; int groupOffset;
+    int groupOffs[RSQ_MAX_OP_EXPRS]; int aggOffs[RSQ_MAX_OP_EXPRS * 2];   /* name-based offsets */
+    Schema groupSchema, aggSchema;
+    int outSlots[RSQ_MAX_OP_EXPRS * 2]; int nOut;          /* groupsAndAggregates symbols */
+    /* MATERIALIZE */
+    Relation* relOut;
+    int matSlots[MAX_ATTR]; int matOffs[MAX_ATTR];
+    int64_t count;
+    /* ORDERBY */
+    struct { int offset; rsq_type type; int asc; } order[RSQ_MAX_OP_EXPRS]; int nOrder;
+    int compiled;
+} Op;
+
+struct Exec {
+    Ctx* c;
+    SymTab st;
+    Op* ops; int nOps;
+    Relation* rels; int nRels;
+    int requestAll;
+    int stopPipeline;             /* MaterializeOp LIMIT: jmp _labelExit (materialize.h:199-211) */
+    int64_t aggSlots, aggGrows;
+};
+
+/* ---- expression compile: emitExpression ---- */
+static CExpr* newC(Exec* x) { return (CExpr*)aalloc(&x->c->arena, sizeof(CExpr)); }
+
+static CExpr* compileExpr(Exec* x, Expr* e) {
+    if (e->type.tag == RSQ_NT)
+        fail("Expression type undefined in emitExpression(..). Have you derived the expression types?");
+    char nm[RSQ_SYMBOL_MAX]; getExpressionName(e, nm);
+    int slot = symSlot(&x->st, nm);
+    CExpr* c = newC(x);
+    c->type = e->type;
+    if (slot >= 0) { c->kind = 0; c->slot = slot; return c; }   /* ExpressionsJitFlounder.h:1088-1094 */
+    c->kind = 1; c->tag = e->tag;
+    switch (e->structureTag) {
+        case S_LITERAL:
+            if (e->tag == RSQ_E_ATTRIBUTE) {
+                /* emitAttribute: mov from ctx.symbolTable[symbol]; absent symbol is a null ir_node* */
+                fail("attribute %s is not available in this pipeline", e->symbol);
+            } else if (e->tag == RSQ_E_CONSTANT) {
+                int t = e->type.tag;
+                if (t == RSQ_FLOAT || t == RSQ_NT) fail("Constant code generation not implemented for datatype");
+                c->constant = e->value;
+            } else if (e->tag == RSQ_E_STAR) {
+                c->constant.i = 0;   /* emitExpressionLiteral returns nullptr; never consumed (COUNT ignores its child) */
+            } else fail("emitExpressionLiteral(..) not implemented for expression type %s", exprTagNames[e->tag]);
+            break;
+        case S_UNARY: {
+            if (e->tag == RSQ_E_COUNT && e->child->tag == RSQ_E_STAR) { c->nKids = 0; break; }
+            c->kid[0] = compileExpr(x, e->child); c->nKids = 1;
+            c->opType = e->child->type;
+            switch (e->tag) {
+                case RSQ_E_SUM: case RSQ_E_AVG: case RSQ_E_MIN: case RSQ_E_MAX:
+                    c->type = e->child->type;   /* vregForType(expr->child->type); mov res, child */
+                    break;
+                case RSQ_E_AS: case RSQ_E_COUNT: break;
+                case RSQ_E_TYPECAST: {          /* ExpressionsJitFlounder.h:763-882 */
+                    rsq_type from = e->child->type, to = e->type;
+                    if (to.tag == RSQ_DECIMAL) {
+                        if (from.tag == RSQ_DECIMAL) {
+                            int d = to.scale - from.scale; if (d < 0) d = -d;
+                            if (d > 8) fail("typecast scale difference beyond factorsDECIMAL");
+                        } else if (from.tag == RSQ_BIGINT) {
+                            if (to.scale > 8) fail("typecast scale beyond factorsDECIMAL");
+                        } else fail("emitTypecastToDECIMAL(..) code generation not implemented for datatype");
+                    } else if (to.tag == RSQ_BIGINT) {
+                        if (from.tag != RSQ_INT && from.tag != RSQ_DECIMAL && from.tag != RSQ_BIGINT)
+                            fail("emitTypecastToBIGINT(..) code generation not implemented for datatype");
+                        if (from.tag == RSQ_DECIMAL && from.scale > 8) fail("typecast scale beyond factorsDECIMAL");
+                    } else fail("emitTypecast(..) code generation not implemented for datatype");
+                    break;
+                }
+                default: fail("emitExpression(..) not implemented for expression type %s", exprTagNames[e->tag]);
+            }
+            break;
+        }
+        case S_BINARY: {
+            c->kid[0] = compileExpr(x, e->child);
+            c->kid[1] = compileExpr(x, e->child->next);
+            c->nKids = 2;
+            c->opType = e->child->type;          /* operationType (ExpressionsJitFlounder.h:988) */
+            int tt = e->type.tag, ot = c->opType.tag;
+            switch (e->tag) {
+                case RSQ_E_ADD: case RSQ_E_SUB: case RSQ_E_MUL: case RSQ_E_DIV:
+                    if (tt != RSQ_DECIMAL && tt != RSQ_BIGINT)
+                        fail("%s code generation not implemented for datatype", exprTagNames[e->tag]);
+                    break;
+                case RSQ_E_AND: case RSQ_E_OR: break;
+                case RSQ_E_LT: case RSQ_E_LE: case RSQ_E_GT: case RSQ_E_GE:
+                    if (ot != RSQ_DECIMAL && ot != RSQ_DATE && ot != RSQ_BIGINT)
+                        fail("%s code generation not implemented for datatype", exprTagNames[e->tag]);
+                    break;
+                case RSQ_E_EQ: case RSQ_E_NEQ:
+                    if (ot == RSQ_FLOAT || ot == RSQ_NT) fail("EQUALS code generation not implemented for datatype");
+                    break;
+                case RSQ_E_LIKE: fail("LIKE is outside the oracle's scope");
+                default: fail("emitExpressionBinary(..) not implemented for expression type %s", exprTagNames[e->tag]);
+            }
+            break;
+        }
+        case S_OTHER: {      /* CASE: ExpressionsJitFlounder.h:720-754 */
+            int k = 0;
+            for (Expr* ch = e->child; ch; ch = ch->next) {
+                if (k >= RSQ_MAX_CHILDREN) fail("CASE with too many branches");
+                if (ch->tag == RSQ_E_WHENTHEN) {
+                    CExpr* wt = newC(x); wt->kind = 1; wt->tag = RSQ_E_WHENTHEN; wt->type = ch->type; wt->nKids = 2;
+                    wt->kid[0] = compileExpr(x, ch->child);
+                    wt->kid[1] = compileExpr(x, ch->child->next);
+                    c->kid[k++] = wt;
+                } else c->kid[k++] = compileExpr(x, ch);
+            }
+            c->nKids = k;
+            break;
+        }
+        default: fail("emitExpression(..)");
+    }
+    return c;
+}
+
+/* comparison on the register width of the type (cmp + signed jcc) */
+static int cmpVals(Val a, Val b, rsq_type t) {
+    if (t.tag == RSQ_DATE || t.tag == RSQ_INT) {
+        int32_t x = (int32_t)(uint32_t)a.i, y = (int32_t)(uint32_t)b.i;
+        return (x < y) ? -1 : (x > y);
+    }
+    return (a.i < b.i) ? -1 : (a.i > b.i);
+}
+
+/* emitEquals (ExpressionsJitFlounder.h:657-689) */
+static int equalsVals(Val a, Val b, rsq_type t) {
+    switch (t.tag) {
+        case RSQ_DECIMAL: case RSQ_BIGINT: return a.i == b.i;
+        case RSQ_INT: case RSQ_DATE: return (uint32_t)a.i == (uint32_t)b.i;
+        case RSQ_BOOL: return (uint8_t)a.i == (uint8_t)b.i;
+        case RSQ_CHAR:
+            if (t.len > 1) return compareChar(a.s, b.s);
+            return (uint8_t)a.i == (uint8_t)b.i;
+        case RSQ_VARCHAR: return compareVarchar(a.s, b.s);
+        default: fail("EQUALS code generation not implemented for datatype");
+    }
+    return 0;
+}
+
+static Val evalExpr(Exec* x, const CExpr* c) {
+    if (c->kind == 0) return x->st.val[c->slot];
+    Val r; r.i = 0;
+    switch (c->tag) {
+        case RSQ_E_CONSTANT: case RSQ_E_STAR: return c->constant;
+        case RSQ_E_SUM: case RSQ_E_AVG: case RSQ_E_MIN: case RSQ_E_MAX: case RSQ_E_AS:
+            return evalExpr(x, c->kid[0]);
+        case RSQ_E_COUNT:    /* emitCount: constant BIGINT 1 (ExpressionsJitFlounder.h:710-717) */
+            if (c->nKids) (void)evalExpr(x, c->kid[0]);
+            r.i = 1; return r;
+        case RSQ_E_TYPECAST: {
+            Val v = evalExpr(x, c->kid[0]);
+            rsq_type from = c->opType, to = c->type;
+            if (to.tag == RSQ_DECIMAL) {
+                if (from.tag == RSQ_DECIMAL) {
+                    if (to.scale == from.scale) return v;
+                    if (to.scale >= from.scale) r.i = (int64_t)((uint64_t)v.i * (uint64_t)factorsDECIMAL[to.scale - from.scale]);
+                    else r.i = sdiv(v.i, factorsDECIMAL[from.scale - to.scale]);
+                } else r.i = (int64_t)((uint64_t)v.i * (uint64_t)factorsDECIMAL[to.scale]);
+            } else { /* BIGINT */
+                if (from.tag == RSQ_INT) r.i = (int64_t)(int32_t)v.i;       /* movsx */
+                else if (from.tag == RSQ_DECIMAL) r.i = sdiv(v.i, factorsDECIMAL[from.scale]);
+                else r = v;
+            }
+            return r;
+        }
+        case RSQ_E_CASE: {
+            for (int k = 0; k < c->nKids; k++) {
+                const CExpr* ch = c->kid[k];
+                if (ch->kind == 1 && ch->tag == RSQ_E_WHENTHEN) {
+                    Val w = evalExpr(x, ch->kid[0]);
+                    if ((uint8_t)w.i != 0) return evalExpr(x, ch->kid[1]);
+                } else return evalExpr(x, ch);
+            }
+            return r;   /* no branch taken, no else: register left unassigned in the reference */
+        }
+        default: break;
+    }
+    /* binary: both children are always evaluated (no short circuit, ExpressionsJitFlounder.h:979-980) */
+    Val a = evalExpr(x, c->kid[0]);
+    Val b = evalExpr(x, c->kid[1]);
+    switch (c->tag) {
+        case RSQ_E_ADD: r.i = (int64_t)((uint64_t)a.i + (uint64_t)b.i); break;
+        case RSQ_E_SUB: r.i = (int64_t)((uint64_t)a.i - (uint64_t)b.i); break;
+        case RSQ_E_MUL: r.i = (int64_t)((uint64_t)a.i * (uint64_t)b.i); break;
+        case RSQ_E_DIV: r.i = sdiv(a.i, b.i); break;
+        case RSQ_E_AND: r.i = (uint8_t)a.i & (uint8_t)b.i; break;
+        case RSQ_E_OR: r.i = (uint8_t)a.i | (uint8_t)b.i; break;
+        case RSQ_E_LT: r.i = cmpVals(a, b, c->opType) < 0; break;
+        case RSQ_E_LE: r.i = cmpVals(a, b, c->opType) <= 0; break;
+        case RSQ_E_GT: r.i = cmpVals(a, b, c->opType) > 0; break;
+        case RSQ_E_GE: r.i = cmpVals(a, b, c->opType) >= 0; break;
+        case RSQ_E_EQ: r.i = equalsVals(a, b, c->opType); break;
+        case RSQ_E_NEQ: r.i = (uint8_t)(1 - equalsVals(a, b, c->opType)); break;
+        default: fail("evalExpr: unsupported tag %d", c->tag);
+    }
+    return r;
+}
+
+/* ---- getSize (operators/) ---- */
+static uint64_t getSize(Op* o) {
+    switch (o->tag) {
+        case RSQ_OP_SCAN: return (uint64_t)o->rel->nTuples;                 /* scan.h:216-218 */
+        case RSQ_OP_SELECTION: return getSize(o->child[0]) / 2;              /* selection.h:34-36 */
+        case RSQ_OP_PROJECTION: return getSize(o->child[0]);                 /* projection.h:27-31 */
+        case RSQ_OP_HASHJOIN: return getSize(o->child[0]) + getSize(o->child[1]) / 2;   /* hashjoin.h:93-95 */
+        case RSQ_OP_AGGREGATION: {                                           /* aggregation.h:81-92 */
+            if (o->nExprs2 == 0) return 1;
+            int sizeReduction = 512;
+            for (int i = 1; i < o->nExprs2 && sizeReduction > 2; i++) sizeReduction /= 2;
+            return getSize(o->child[0]) / (uint64_t)sizeReduction;
+        }
+        case RSQ_OP_MATERIALIZE: {                                           /* materialize.h:62-68 */
+            uint64_t s = getSize(o->child[0]);
+            if (o->hasLimit && (uint64_t)o->limit < s) s = (uint64_t)o->limit;
+            return s;
+        }
+        case RSQ_OP_ORDERBY: return getSize(o->child[0]);
+        default: fail("getSize: unsupported operator");
+    }
+    return 0;
+}
+
+/* ---- defineExpressionsForPlan + type derivation (execute.h:222-226) ---- */
+static void deriveList(Ctx* c, Expr** v, int n) { for (int i = 0; i < n; i++) deriveExpressionTypes(c, v[i]); }
+
+static Expr* mkUnary(Ctx* c, int tag, const char* sym, Expr* child) {
+    Expr* e = newExpr(c, tag, S_UNARY, sym); e->child = child; return e;
+}
+
+static void defineAndDerive(Exec* x, Op* o) {
+    /* RelOperator::defineExpressionsForPlan (RelOperator.h:203-208): children first.  Type derivation
+     * happens afterwards in definition order (ExpressionsJitFlounder.h:69-73); deriving right at
+     * definition visits the expressions in the same order. */
+    for (int i = 0; i < o->nChildren; i++) defineAndDerive(x, o->child[i]);
+    Ctx* c = x->c;
+    switch (o->tag) {
+        case RSQ_OP_SCAN: break;   /* scan.h:205-213: typed attribute copies only */
+        case RSQ_OP_SELECTION: case RSQ_OP_PROJECTION: case RSQ_OP_HASHJOIN:
+            deriveList(c, o->exprs, o->nExprs);
+            break;
+        case RSQ_OP_AGGREGATION: {
+            /* aggregation.h:73-78 + splitAverages :167-179 */
+            o->nSplit = 0;
+            for (int i = 0; i < o->nExprs; i++) {
+                Expr* e = o->exprs[i];
+                if (e->tag == RSQ_E_AVG) {
+                    o->splitAgg[o->nSplit++] = mkUnary(c, RSQ_E_SUM, "sum", e->child);
+                    o->splitAgg[o->nSplit++] = mkUnary(c, RSQ_E_COUNT, "count", e->child);
+                } else o->splitAgg[o->nSplit++] = e;
+            }
+            deriveList(c, o->exprs2, o->nExprs2);
+            deriveList(c, o->splitAgg, o->nSplit);
+            deriveList(c, o->exprs, o->nExprs);
+            break;
+        }
+        case RSQ_OP_MATERIALIZE: break;
+        case RSQ_OP_ORDERBY: {     /* orderby.h:48-66 */
+            for (int i = 0; i < o->nExprs; i++) {
+                Expr* e = o->exprs[i];
+                if (e->tag != RSQ_E_ASC && e->tag != RSQ_E_DESC) o->exprs[i] = mkUnary(c, RSQ_E_ASC, "asc", e);
+            }
+            for (int i = 0; i < o->nExprs; i++)
+                if (o->exprs[i]->child->tag != RSQ_E_ATTRIBUTE)
+                    fail("Order by only supports attribute expressions currently.");
+            deriveList(c, o->exprs, o->nExprs);
+            break;
+        }
+        default: fail("unsupported operator in plan");
+    }
+}
+
+/* ---- compile phase: produce/consume for metadata ---- */
+static void compileConsume(Exec* x, Op* o, Op* from);
+
+static void valueSetSchema(Schema* s, const ValueSet* v, int stringsByVal) {
+    memset(s, 0, sizeof *s);
+    for (int i = 0; i < v->n; i++) schemaAdd(s, v->name[i], v->type[i]);
+    schemaFinish(s, stringsByVal);
+}
+
+/* evalExpressions (ValuesJitFlounder.h:471-482): ids, compiled expression, name */
+static void compileExprList(Exec* x, Expr** v, int n, CExpr** out, ValueSet* vs) {
+    for (int i = 0; i < n; i++) {
+        addExpressionIds(x->c, v[i]);
+        out[i] = compileExpr(x, v[i]);
+        getExpressionName(v[i], vs->name[vs->n]);
+        vs->type[vs->n] = v[i]->type;
+        vs->n++;
+    }
+}
+
+static void compileProduce(Exec* x, Op* o, const SymSet* request) {
+    switch (o->tag) {
+        case RSQ_OP_SCAN: {   /* scan.h:221-263 */
+            SymSet req = *request;
+            if (x->requestAll) req.cnt = 0;
+            Schema* rs = &o->rel->schema;
+            o->nScan = 0;
+            memset(&o->schema, 0, sizeof o->schema);
+            for (int i = 0; i < rs->n; i++) {
+                /* Values::dematerialize(..., required): empty request set => all attributes */
+                if (req.cnt == 0 || symHas(&req, rs->a[i].name)) {
+                    o->scanOffs[o->nScan] = getOffsetInTuple(rs, rs->a[i].name);
+                    o->scanTypes[o->nScan] = rs->a[i].type;
+                    o->scanSlots[o->nScan] = symRegister(&x->st, rs->a[i].name, rs->a[i].type);
+                    schemaAdd(&o->schema, rs->a[i].name, rs->a[i].type);
+                    o->nScan++;
+                }
+            }
+            schemaFinish(&o->schema, 1);
+            compileConsume(x, o->parent, o);
+            break;
+        }
+        case RSQ_OP_SELECTION: {   /* selection.h:39-49 */
+            o->request = *request;
+            SymSet r = *request;
+            extractRequiredAttributes(o->exprs[0], &r);
+            compileProduce(x, o->child[0], &r);
+            break;
+        }
+        case RSQ_OP_PROJECTION: {  /* projection.h:40-59 */
+            SymSet r; r.cnt = 0;
+            for (int i = 0; i < o->nExprs; i++) extractRequiredAttributes(o->exprs[i], &r);
+            compileProduce(x, o->child[0], &r);
+            break;
+        }
+        case RSQ_OP_HASHJOIN: {    /* hashjoin.h:98-116 */
+            o->request = *request;
+            SymSet all = *request;
+            for (int i = 0; i < o->nExprs; i++) extractRequiredAttributes(o->exprs[i], &all);
+            compileProduce(x, o->child[0], &all);
+            compileProduce(x, o->child[1], &all);
+            break;
+        }
+        case RSQ_OP_AGGREGATION: { /* aggregation.h:155-164 */
+            SymSet r; r.cnt = 0;
+            for (int i = 0; i < o->nExprs; i++) extractRequiredAttributes(o->exprs[i], &r);
+            for (int i = 0; i < o->nExprs2; i++) extractRequiredAttributes(o->exprs2[i], &r);
+            compileProduce(x, o->child[0], &r);
+            /* consumeAggregateFlounder (aggregation.h:298-343): scan the hash table */
+            Schema* es = &o->entrySchema;
+            ValueSet out; out.n = 0;
+            int firstAgg = o->nExprs2, aggIdx = 0;
+            for (int i = 0; i < es->n; i++) {
+                if (i < firstAgg) {
+                    snprintf(out.name[out.n], RSQ_SYMBOL_MAX, "%s", es->a[i].name); out.type[out.n] = es->a[i].type; out.n++;
+                    continue;
+                }
+                Expr* ag = o->exprs[aggIdx];
+                if (ag->tag == RSQ_E_AVG) {   /* mergeAverages (aggregation.h:207-238) */
+                    addExpressionIds(x->c, ag);
+                    int st = es->a[i].type.tag;
+                    if (st != RSQ_BIGINT && st != RSQ_DECIMAL) fail("getAvgFromSumAndCount(..) not supported for datatype");
+                    i++;
+                    getExpressionName(ag, out.name[out.n]); out.type[out.n] = ag->type; out.n++;
+                } else {
+                    snprintf(out.name[out.n], RSQ_SYMBOL_MAX, "%s", es->a[i].name); out.type[out.n] = es->a[i].type; out.n++;
+                }
+                aggIdx++;
+            }
+            valueSetSchema(&o->schema, &out, 1);
+            o->nOut = out.n;
+            for (int i = 0; i < out.n; i++) o->outSlots[i] = symRegister(&x->st, out.name[i], out.type[i]);
+            compileConsume(x, o->parent, o);
+            break;
+        }
+        case RSQ_OP_MATERIALIZE:   /* materialize.h:69-76 */
+            compileProduce(x, o->child[0], request);
+            break;
+        case RSQ_OP_ORDERBY: {     /* orderby.h:96-136; child is the implicit MaterializeOp (orderby.h:37) */
+            compileProduce(x, o->child[0], request);
+            o->schema = o->child[0]->schema;
+            o->nOrder = 0;
+            for (int i = 0; i < o->nExprs; i++) {
+                Expr* e = o->exprs[i];
+                if (!schemaContains(&o->schema, e->child->symbol)) fail("Order By attribute not found.");
+                int k = 0; while (strcmp(o->schema.a[k].name, e->child->symbol) != 0) k++;
+                o->order[o->nOrder].offset = getOffsetInTuple(&o->schema, e->child->symbol);
+                o->order[o->nOrder].type = o->schema.a[k].type;
+                o->order[o->nOrder].asc = (e->tag != RSQ_E_DESC);
+                o->nOrder++;
+            }
+            break;
+        }
+        default: fail("produce: unsupported operator");
+    }
+}
+
+static void compileConsume(Exec* x, Op* o, Op* from) {
+    if (!o) fail("plan root must be a materializing operator");
+    switch (o->tag) {
+        case RSQ_OP_SELECTION: {   /* selection.h:52-70 */
+            o->schema = o->child[0]->schema;
+            if (!x->requestAll) o->schema = schemaPrune(&o->schema, &o->request);
+            addExpressionIds(x->c, o->exprs[0]);
+            o->cCond = compileExpr(x, o->exprs[0]);
+            compileConsume(x, o->parent, o);
+            break;
+        }
+        case RSQ_OP_PROJECTION: {  /* projection.h:62-72 */
+            ValueSet vs; vs.n = 0;
+            compileExprList(x, o->exprs, o->nExprs, o->cProj, &vs);
+            for (int i = 0; i < vs.n; i++) o->projSlots[i] = symRegister(&x->st, vs.name[i], vs.type[i]);
+            valueSetSchema(&o->schema, &vs, 1);
+            compileConsume(x, o->parent, o);
+            break;
+        }
+        case RSQ_OP_HASHJOIN: {    /* hashjoin.h:217-280 */
+            o->nCall++;
+            if (o->nCall > 2) fail("HashJoin::consumeFlounder(..) called more than 2 times.");
+            if (o->nCall == 1) {
+                Expr* left[RSQ_MAX_OP_EXPRS];
+                for (int i = 0; i < o->nExprs; i++) {
+                    if (o->exprs[i]->tag != RSQ_E_EQ) fail("The elements of the expression list passed to equalitiesLeftSide(..) need the tag Expr::EQ");
+                    left[i] = o->exprs[i]->child;
+                }
+                ValueSet keys; keys.n = 0;
+                compileExprList(x, left, o->nExprs, o->cBuildKeys, &keys);
+                o->nKeys = o->nExprs;
+                valueSetSchema(&o->schemaBuildKeys, &keys, 0);
+                /* buildVals = Values::get(_lChild->_schema): symbols by attribute name */
+                Schema* ls = &o->child[0]->schema;
+                ValueSet vals; vals.n = 0;
+                for (int i = 0; i < ls->n; i++) {
+                    int s = symSlot(&x->st, ls->a[i].name);
+                    if (s < 0) fail("hash join build value %s has no symbol", ls->a[i].name);
+                    o->buildValSlots[i] = s;
+                    snprintf(vals.name[vals.n], RSQ_SYMBOL_MAX, "%s", ls->a[i].name);
+                    vals.type[vals.n] = x->st.type[s]; vals.n++;
+                }
+                valueSetSchema(&o->schemaBuildVals, &vals, 0);
+                o->schemaKeysAndVals = schemaJoin(&o->schemaBuildKeys, &o->schemaBuildVals);
+                o->ht = allocateHashTable(getSize(o->child[0]) * 5 / 3, (size_t)o->schemaKeysAndVals.tupSize);
+                for (int i = 0; i < keys.n; i++) o->keyOffs[i] = getOffsetInTuple(&o->schemaBuildKeys, keys.name[i]);
+                o->keysByteSize = o->schemaBuildKeys.tupSize;
+                for (int i = 0; i < vals.n; i++) o->valOffs[i] = getOffsetInTuple(&o->schemaBuildVals, vals.name[i]);
+            } else {
+                o->schema = schemaJoin(&o->child[0]->schema, &o->child[1]->schema);
+                if (!x->requestAll) o->schema = schemaPrune(&o->schema, &o->request);
+                Expr* right[RSQ_MAX_OP_EXPRS];
+                for (int i = 0; i < o->nExprs; i++) right[i] = o->exprs[i]->child->next;
+                ValueSet keys; keys.n = 0;
+                compileExprList(x, right, o->nExprs, o->cProbeKeys, &keys);
+                for (int i = 0; i < keys.n; i++) o->probeKeyTypes[i] = keys.type[i];
+                /* entry values become symbols (hashjoin.h:146-147 / 204-205) */
+                Schema* ls = &o->schemaBuildVals;
+                for (int i = 0; i < ls->n; i++) o->probeValSlots[i] = symRegister(&x->st, ls->a[i].name, ls->a[i].type);
+                compileConsume(x, o->parent, o);
+            }
+            break;
+        }
+        case RSQ_OP_AGGREGATION: { /* aggregation.h:240-295 */
+            ValueSet gv, av; gv.n = 0; av.n = 0;
+            compileExprList(x, o->exprs2, o->nExprs2, o->cGroup, &gv);
+            compileExprList(x, o->splitAgg, o->nSplit, o->cAgg, &av);
+            /* SUM/MIN/MAX evaluate to the child's type (emitExpressionUnary) but Value.type is expr->type */
+            for (int i = 0; i < o->nSplit; i++) {
+                int t = o->splitAgg[i]->tag, ty = o->splitAgg[i]->type.tag;
+                if (t == RSQ_E_SUM && ty != RSQ_DECIMAL && ty != RSQ_BIGINT) fail("ADD code generation not implemented for datatype");
+                if ((t == RSQ_E_MIN || t == RSQ_E_MAX) && ty != RSQ_DECIMAL && ty != RSQ_DATE && ty != RSQ_BIGINT)
+                    fail("LESS_THAN code generation not implemented for datatype");
+                if (t != RSQ_E_SUM && t != RSQ_E_MIN && t != RSQ_E_MAX && t != RSQ_E_COUNT)
+                    fail("Aggregation type not implemented in updateAggregates(..).");
+            }
+            valueSetSchema(&o->groupSchema, &gv, 0);
+            valueSetSchema(&o->aggSchema, &av, 0);
+            o->entrySchema = schemaJoin(&o->groupSchema, &o->aggSchema);
+            o->groupOffset = o->groupSchema.tupSize;
+            for (int i = 0; i < gv.n; i++) o->groupOffs[i] = getOffsetInTuple(&o->groupSchema, gv.name[i]);
+            for (int i = 0; i < av.n; i++) o->aggOffs[i] = getOffsetInTuple(&o->aggSchema, av.name[i]);
+            o->ht = allocateHashTable(getSize(o), (size_t)o->entrySchema.tupSize);
+            break;   /* pipeline breaker */
+        }
+        case RSQ_OP_MATERIALIZE: { /* materialize.h:78-220 */
+            if (o->compiled) fail("Double consumeFlounder(..) in MaterializeOp.");
+            o->compiled = 1;
+            o->schema = o->child[0]->schema;
+            o->relOut = (Relation*)aalloc(&x->c->arena, sizeof(Relation));
+            o->relOut->schema = o->schema;
+            schemaFinish(&o->relOut->schema, 1);
+            for (int i = 0; i < o->schema.n; i++) {
+                int s = symSlot(&x->st, o->schema.a[i].name);
+                if (s < 0) fail("materialize: symbol %s not found", o->schema.a[i].name);
+                o->matSlots[i] = s;
+                o->matOffs[i] = getOffsetInTuple(&o->relOut->schema, o->schema.a[i].name);
+            }
+            break;
+        }
+        default: fail("consume: unsupported operator");
+    }
+    (void)from;
+}
+
+/* ---- execute phase ---- */
+static void execConsume(Exec* x, Op* o);
+
+static void relAppend(Exec* x, Relation* r, const uint8_t* tuple) {
+    if (r->nTuples >= r->cap) {
+        int64_t nc = r->cap ? r->cap * 2 : 64;
+        uint8_t* nd = (uint8_t*)realloc(r->data, (size_t)nc * (size_t)r->schema.tupSize + 1);
+        if (!nd) fail("out of memory");
+        r->data = nd; r->cap = nc;
+    }
+    memcpy(r->data + (size_t)r->nTuples * (size_t)r->schema.tupSize, tuple, (size_t)r->schema.tupSize);
+    r->nTuples++;
+    (void)x;
+}
+
+static void execProduce(Exec* x, Op* o) {
+    switch (o->tag) {
+        case RSQ_OP_SCAN: {
+            Relation* r = o->rel;
+            size_t step = (size_t)r->schema.tupSize;
+            x->stopPipeline = 0;
+            for (int64_t t = 0; t < r->nTuples && !x->stopPipeline; t++) {
+                const uint8_t* cur = r->data + (size_t)t * step;
+                for (int i = 0; i < o->nScan; i++)
+                    x->st.val[o->scanSlots[i]] = loadVal(cur + o->scanOffs[i], o->scanTypes[i], 1);
+                execConsume(x, o->parent);
+            }
+            x->stopPipeline = 0;
+            break;
+        }
+        case RSQ_OP_SELECTION: case RSQ_OP_PROJECTION: case RSQ_OP_MATERIALIZE:
+            execProduce(x, o->child[0]);
+            break;
+        case RSQ_OP_HASHJOIN:
+            o->nCall = 1;
+            execProduce(x, o->child[0]);      /* build pipeline; then HashJoinState::syncBuild */
+            o->nCall = 2;
+            execProduce(x, o->child[1]);      /* probe pipeline */
+            break;
+        case RSQ_OP_AGGREGATION: {
+            execProduce(x, o->child[0]);
+            HashTable* ht = o->ht;
+            x->aggSlots = (int64_t)ht->numEntries; x->aggGrows = ht->grows;
+            Schema* es = &o->entrySchema;
+            int eoff[MAX_ATTR];
+            for (int i = 0; i < es->n; i++) eoff[i] = getOffsetInTuple(es, es->a[i].name);
+            x->stopPipeline = 0;
+            for (uint8_t* p = ht->entries; p < ht->entriesEnd && !x->stopPipeline; p += ht->fullEntrySize) {
+                if (p[0] == 0) continue;
+                const uint8_t* tup = p + ENTRY_HDR;
+                int firstAgg = o->nExprs2, aggIdx = 0, k = 0;
+                for (int i = 0; i < es->n; i++) {
+                    Val v = loadVal(tup + eoff[i], es->a[i].type, 0);
+                    if (i >= firstAgg) {
+                        if (o->exprs[aggIdx]->tag == RSQ_E_AVG) {
+                            /* getAvgFromSumAndCount (aggregation.h:182-204): (sum * 100) / count */
+                            i++;
+                            Val cnt = loadVal(tup + eoff[i], es->a[i].type, 0);
+                            Val a; a.i = sdiv((int64_t)((uint64_t)v.i * 100ull), cnt.i);
+                            v = a;
+                        }
+                        aggIdx++;
+                    }
+                    x->st.val[o->outSlots[k++]] = v;
+                }
+                execConsume(x, o->parent);
+            }
+            x->stopPipeline = 0;
+            break;
+        }
+        case RSQ_OP_ORDERBY: execProduce(x, o->child[0]); break;
+        default: fail("execProduce: unsupported operator");
+    }
+}
+
+static void execConsume(Exec* x, Op* o) {
+    switch (o->tag) {
+        case RSQ_OP_SELECTION: {
+            Val v = evalExpr(x, o->cCond);
+            if ((uint8_t)v.i == 0) return;        /* je labelNextTuple */
+            execConsume(x, o->parent);
+            break;
+        }
+        case RSQ_OP_PROJECTION: {
+            Val tmp[RSQ_MAX_OP_EXPRS];
+            for (int i = 0; i < o->nExprs; i++) tmp[i] = evalExpr(x, o->cProj[i]);
+            for (int i = 0; i < o->nExprs; i++) x->st.val[o->projSlots[i]] = tmp[i];
+            execConsume(x, o->parent);
+            break;
+        }
+        case RSQ_OP_HASHJOIN: {
+            if (o->nCall == 1) {   /* build: hashjoin.h:226-256 */
+                Val k[RSQ_MAX_OP_EXPRS]; uint64_t h = 0;
+                for (int i = 0; i < o->nKeys; i++) { k[i] = evalExpr(x, o->cBuildKeys[i]); h = hashValue(h, k[i], o->schemaBuildKeys.a[i].type); }
+                uint8_t* e = ht_put(o->ht, h);
+                for (int i = 0; i < o->nKeys; i++) storeVal(e + o->keyOffs[i], k[i], o->schemaBuildKeys.a[i].type, 0);
+                e += o->keysByteSize;
+                for (int i = 0; i < o->schemaBuildVals.n; i++)
+                    storeVal(e + o->valOffs[i], x->st.val[o->buildValSlots[i]], o->schemaBuildVals.a[i].type, 0);
+            } else {               /* probe: hashjoin.h:118-214 */
+                Val k[RSQ_MAX_OP_EXPRS]; uint64_t h = 0;
+                for (int i = 0; i < o->nKeys; i++) { k[i] = evalExpr(x, o->cProbeKeys[i]); h = hashValue(h, k[i], o->probeKeyTypes[i]); }
+                uint8_t* e = NULL;
+                for (;;) {
+                    e = ht_get(o->ht, h, e);
+                    if (e == NULL) break;
+                    int eq = 1;
+                    for (int i = 0; i < o->nKeys && eq; i++) {
+                        Val ev = loadVal(e + o->keyOffs[i], o->schemaBuildKeys.a[i].type, 0);
+                        if (!equalsVals(k[i], ev, o->probeKeyTypes[i])) eq = 0;
+                    }
+                    if (!eq) continue;
+                    const uint8_t* vl = e + o->keysByteSize;
+                    for (int i = 0; i < o->schemaBuildVals.n; i++)
+                        x->st.val[o->probeValSlots[i]] = loadVal(vl + o->valOffs[i], o->schemaBuildVals.a[i].type, 0);
+                    execConsume(x, o->parent);
+                    if (o->singleMatch || x->stopPipeline) break;
+                }
+            }
+            break;
+        }
+        case RSQ_OP_AGGREGATION: {   /* aggregation.h:240-295 */
+            Val g[RSQ_MAX_OP_EXPRS], a[RSQ_MAX_OP_EXPRS * 2]; uint64_t h = 0;
+            for (int i = 0; i < o->nExprs2; i++) { g[i] = evalExpr(x, o->cGroup[i]); }
+            for (int i = 0; i < o->nSplit; i++) a[i] = evalExpr(x, o->cAgg[i]);
+            for (int i = 0; i < o->nExprs2; i++) h = hashValue(h, g[i], o->groupSchema.a[i].type);
+            uint8_t* e = NULL; int found = 0;
+            while (!found) {
+                e = ht_get(o->ht, h, e);
+                if (e == NULL) break;
+                found = 1;
+                for (int i = 0; i < o->nExprs2; i++) {
+                    Val ev = loadVal(e + o->groupOffs[i], o->groupSchema.a[i].type, 0);
+                    if (!equalsVals(g[i], ev, o->groupSchema.a[i].type)) { found = 0; break; }
+                }
+            }
+            if (!found) {
+                e = ht_put(o->ht, h);
+                for (int i = 0; i < o->nExprs2; i++) storeVal(e + o->groupOffs[i], g[i], o->groupSchema.a[i].type, 0);
+                e += o->groupOffset;
+                for (int i = 0; i < o->nSplit; i++) storeVal(e + o->aggOffs[i], a[i], o->aggSchema.a[i].type, 0);
+            } else {
+                e += o->groupOffset;
+                Val acc[RSQ_MAX_OP_EXPRS * 2];
+                for (int i = 0; i < o->nSplit; i++) acc[i] = loadVal(e + o->aggOffs[i], o->aggSchema.a[i].type, 0);
+                for (int i = 0; i < o->nSplit; i++) {   /* updateAggregates (aggregation.h:95-152) */
+                    rsq_type ty = o->aggSchema.a[i].type;
+                    switch (o->splitAgg[i]->tag) {
+                        case RSQ_E_COUNT: acc[i].i = (int64_t)((uint64_t)acc[i].i + 1); break;
+                        case RSQ_E_SUM: acc[i].i = (int64_t)((uint64_t)acc[i].i + (uint64_t)a[i].i); break;
+                        case RSQ_E_MIN: if (cmpVals(a[i], acc[i], ty) < 0) acc[i] = a[i]; break;
+                        case RSQ_E_MAX: if (cmpVals(a[i], acc[i], ty) > 0) acc[i] = a[i]; break;
+                        default: fail("Aggregation type not implemented");
+                    }
+                }
+                for (int i = 0; i < o->nSplit; i++) storeVal(e + o->aggOffs[i], acc[i], o->aggSchema.a[i].type, 0);
+            }
+            break;
+        }
+        case RSQ_OP_MATERIALIZE: {
+            uint8_t buf[4096];
+            Relation* r = o->relOut;
+            if (r->schema.tupSize > (int)sizeof buf) fail("result tuple too wide");
+            memset(buf, 0, (size_t)r->schema.tupSize);
+            for (int i = 0; i < o->schema.n; i++)
+                storeVal(buf + o->matOffs[i], x->st.val[o->matSlots[i]], o->schema.a[i].type, 1);
+            relAppend(x, r, buf);
+            if (o->hasLimit) {   /* materialize.h:197-206 */
+                o->count++;
+                if (o->count >= o->limit) x->stopPipeline = 1;
+            }
+            break;
+        }
+        default: fail("execConsume: unsupported operator");
+    }
+}
+
+/* ---- sort (qlib/sort.h) ---- */
+typedef struct Sorter { Op* o; uint8_t* data; size_t ts; uint8_t* tmp; } Sorter;
+
+/* types.h:264-353 compare<> per type, as used by Quicksorter::compare (qlib/sort.h:138-160) */
+static int typedCompare(rsq_type t, const uint8_t* l, const uint8_t* r) {
+    switch (t.tag) {
+        case RSQ_BIGINT: case RSQ_DECIMAL: { int64_t a, b; memcpy(&a, l, 8); memcpy(&b, r, 8); return (a < b) ? -1 : (a > b); }
+        case RSQ_INT: case RSQ_DATE: { int32_t a, b; memcpy(&a, l, 4); memcpy(&b, r, 4); return (a < b) ? -1 : (a > b); }
+        case RSQ_BOOL: { uint8_t a = l[0] != 0, b = r[0] != 0; return (a < b) ? -1 : (a > b); }
+        case RSQ_CHAR: case RSQ_VARCHAR: { int c = strcmp((const char*)l, (const char*)r); return (int)(int8_t)c; }
+        default: return 0;
+    }
+}
+/* qlib/sort.h:101-136: true when first should be ordered BEFORE second */
+static int sortBefore(Sorter* s, const uint8_t* first, const uint8_t* second) {
+    for (int i = 0; i < s->o->nOrder; i++) {
+        int c = typedCompare(s->o->order[i].type, first + s->o->order[i].offset, second + s->o->order[i].offset);
+        if (s->o->order[i].asc) { if (c < 0) return 1; if (c > 0) return 0; }
+        else { if (c > 0) return 1; if (c < 0) return 0; }
+    }
+    return 0;
+}
+static void sortSwap(Sorter* s, int64_t i, int64_t j) {
+    if (i == j) return;
+    memcpy(s->tmp, s->data + (size_t)i * s->ts, s->ts);
+    memcpy(s->data + (size_t)i * s->ts, s->data + (size_t)j * s->ts, s->ts);
+    memcpy(s->data + (size_t)j * s->ts, s->tmp, s->ts);
+}
+/* qlib/sort.h:40-92: recursive Lomuto quicksort, pivot = last element.  The recursion is kept
+ * (explicit stack to survive adversarial inputs) with the same partition order. */
+static void quicksort(Sorter* s, int64_t low, int64_t high) {
+    typedef struct { int64_t lo, hi; } Range;
+    size_t cap = 1024, n = 0;
+    Range* st = (Range*)malloc(cap * sizeof(Range));
+    if (!st) fail("out of memory");
+    st[n].lo = low; st[n].hi = high; n++;
+    while (n > 0) {
+        Range r = st[--n];
+        if (!(r.lo < r.hi)) continue;
+        const uint8_t* pivot = s->data + (size_t)r.hi * s->ts;
+        int64_t i = r.lo;
+        for (int64_t j = r.lo; j < r.hi; ++j) {
+            if (sortBefore(s, s->data + (size_t)j * s->ts, pivot)) { sortSwap(s, i, j); ++i; }
+        }
+        sortSwap(s, i, r.hi);
+        if (n + 2 > cap) { cap *= 2; Range* ns = (Range*)realloc(st, cap * sizeof(Range)); if (!ns) { free(st); fail("out of memory"); } st = ns; }
+        /* the two sub-ranges are independent, so the order in which they are processed does not
+         * change the result */
+        st[n].lo = i + 1; st[n].hi = r.hi; n++;
+        st[n].lo = r.lo; st[n].hi = i - 1; n++;
+    }
+    free(st);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* driver                                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+struct orc_result {
+    rsq_result_view view;
+    char (*names)[RSQ_SYMBOL_MAX];
+    rsq_type* types;
+    int32_t* offsets;
+    uint8_t* tuples;
+    int64_t aggSlots, aggGrows;
+};
+
+static size_t colWidth(rsq_type t) {
+    switch (t.tag) {
+        case RSQ_INT: case RSQ_DATE: return 4;
+        case RSQ_BIGINT: case RSQ_DECIMAL: return 8;
+        case RSQ_BOOL: return 1;
+        case RSQ_CHAR: case RSQ_VARCHAR: return (size_t)t.len;
+        default: fail("unsupported column type");
+    }
+    return 0;
+}
+
+/* Build the row store the reference scans (dbdata.h:23-102, 217-301): packed tuples in schema
+ * order, strings by value with a terminating NUL.  Columns handed over with data == NULL keep
+ * their place in the identifier map but are not stored (no plan may touch them). */
+static void buildRelation(Exec* x, Relation* r, const rsq_table_desc* td) {
+    memset(r, 0, sizeof *r);
+    int map[MAX_ATTR], m = 0;
+    for (int i = 0; i < td->n_cols; i++) {
+        identSet(x->c, td->cols[i].name, td->cols[i].type);
+        if (td->cols[i].data != NULL) { schemaAdd(&r->schema, td->cols[i].name, td->cols[i].type); map[m++] = i; }
+    }
+    schemaFinish(&r->schema, 1);
+    r->nTuples = td->n_rows; r->cap = td->n_rows;
+    size_t ts = (size_t)r->schema.tupSize;
+    r->data = (uint8_t*)aalloc(&x->c->arena, ts * (size_t)td->n_rows + 1);
+    int off = 0;
+    for (int k = 0; k < m; k++) {
+        const rsq_column* col = &td->cols[map[k]];
+        size_t w = colWidth(col->type);
+        const uint8_t* src = (const uint8_t*)col->data;
+        uint8_t* dst = r->data + off;
+        for (int64_t t = 0; t < td->n_rows; t++) memcpy(dst + (size_t)t * ts, src + (size_t)t * w, w);
+        /* the byte after a CHAR/VARCHAR is its NUL terminator (arena memory is zeroed) */
+        off += getSizeInTuple(col->type, 1);
+    }
+}
+
+static Op* buildOps(Exec* x, const rsq_plan_desc* p, Expr** nodes) {
+    /* ORDERBY wraps its child into a MaterializeOp (orderby.h:32-38): reserve room for those */
+    int extra = 0;
+    for (int i = 0; i < p->n_ops; i++) if (p->ops[i].tag == RSQ_OP_ORDERBY) extra++;
+    Op* ops = (Op*)aalloc(&x->c->arena, sizeof(Op) * (size_t)(p->n_ops + extra + 1));
+    x->ops = ops; x->nOps = p->n_ops + extra;
+    int nextExtra = p->n_ops;
+    for (int i = 0; i < p->n_ops; i++) {
+        const rsq_op* d = &p->ops[i];
+        Op* o = &ops[i];
+        o->tag = d->tag;
+        if (d->n_exprs > RSQ_MAX_OP_EXPRS || d->n_exprs2 > RSQ_MAX_OP_EXPRS) fail("too many expressions");
+        for (int k = 0; k < d->n_exprs; k++) { if (d->exprs[k] < 0 || d->exprs[k] >= p->n_exprs) fail("bad expr index"); o->exprs[k] = nodes[d->exprs[k]]; }
+        o->nExprs = d->n_exprs;
+        for (int k = 0; k < d->n_exprs2; k++) { if (d->exprs2[k] < 0 || d->exprs2[k] >= p->n_exprs) fail("bad expr index"); o->exprs2[k] = nodes[d->exprs2[k]]; }
+        o->nExprs2 = d->n_exprs2;
+        o->singleMatch = d->single_match;
+        switch (d->tag) {
+            case RSQ_OP_SCAN:
+                if (d->table < 0 || d->table >= x->nRels) fail("bad table index");
+                o->rel = &x->rels[d->table]; o->nChildren = 0; break;
+            case RSQ_OP_HASHJOIN: o->nChildren = 2; break;
+            case RSQ_OP_SELECTION:
+                if (d->n_exprs != 1) fail("selection needs one condition");
+                o->nChildren = 1; break;
+            case RSQ_OP_PROJECTION: case RSQ_OP_AGGREGATION: case RSQ_OP_MATERIALIZE: case RSQ_OP_ORDERBY:
+                o->nChildren = 1; break;
+            case RSQ_OP_NESTEDLOOPSJOIN: fail("NestedLoopsJoin is outside the hot path (SURVEY §2)");
+            default: fail("unsupported operator tag %d", d->tag);
+        }
+        for (int k = 0; k < o->nChildren; k++) {
+            int ci = d->child[k];
+            if (ci < 0 || ci >= p->n_ops || ci == i) fail("bad child operator index");
+            o->child[k] = &ops[ci];
+        }
+        if (d->tag == RSQ_OP_ORDERBY) {
+            Op* m = &ops[nextExtra++];
+            m->tag = RSQ_OP_MATERIALIZE; m->nChildren = 1; m->child[0] = o->child[0];
+            o->child[0] = m;
+        }
+    }
+    for (int i = 0; i < x->nOps; i++)
+        for (int k = 0; k < ops[i].nChildren; k++) {
+            if (ops[i].child[k]->parent && ops[i].child[k]->parent != &ops[i]) fail("operator has two parents");
+            ops[i].child[k]->parent = &ops[i];
+        }
+    return ops;
+}
+
+static void cleanupTables(Exec* x) {
+    for (int i = 0; i < x->nOps; i++) {
+        if (x->ops[i].ht) { freeHashTable(x->ops[i].ht); x->ops[i].ht = NULL; }
+        if (x->ops[i].relOut && x->ops[i].relOut->data) { free(x->ops[i].relOut->data); x->ops[i].relOut->data = NULL; }
+    }
+}
+
+int orc_execute(const rsq_plan_desc* plan, const rsq_table_desc* tables, int n_tables,
+                orc_result** out, char* err, size_t errlen) {
+    Ctx* c = (Ctx*)calloc(1, sizeof(Ctx));
+    Exec* x = (Exec*)calloc(1, sizeof(Exec));
+    if (!c || !x) { free(c); free(x); if (err) snprintf(err, errlen, "out of memory"); return 1; }
+    c->exprIdGen = 1;
+    x->c = c;
+    jmp_buf jb; g_jmp = &jb;
+    if (setjmp(jb)) {
+        if (err) snprintf(err, errlen, "%s", g_err);
+        cleanupTables(x);
+        afree(&c->arena); free(c); free(x);
+        return 1;
+    }
+    x->requestAll = plan->request_all;
+    x->nRels = n_tables;
+    x->rels = (Relation*)aalloc(&c->arena, sizeof(Relation) * (size_t)(n_tables + 1));
+    for (int i = 0; i < n_tables; i++) buildRelation(x, &x->rels[i], &tables[i]);
+
+    Expr** nodes = buildExprs(c, plan);
+    Op* ops = buildOps(x, plan, nodes);
+    if (plan->root < 0 || plan->root >= plan->n_ops) fail("bad root");
+    Op* root = &ops[plan->root];
+    if (root->tag != RSQ_OP_MATERIALIZE && root->tag != RSQ_OP_ORDERBY)
+        fail("Calling retrieveResult on non-materialized operator");
+    if (plan->has_limit) { root->hasLimit = 1; root->limit = plan->limit; }   /* addLimit */
+
+    defineAndDerive(x, root);
+    SymSet empty; empty.cnt = 0;
+    compileProduce(x, root, &empty);
+    execProduce(x, root);
+
+    Relation* res;
+    if (root->tag == RSQ_OP_ORDERBY) {
+        res = root->child[0]->relOut;
+        if (!res) fail("order by child did not materialize");
+        Sorter s; s.o = root; s.data = res->data; s.ts = (size_t)res->schema.tupSize;
+        s.tmp = (uint8_t*)aalloc(&c->arena, s.ts + 1);
+        quicksort(&s, 0, res->nTuples - 1);
+        if (root->hasLimit && res->nTuples > root->limit) res->nTuples = root->limit;   /* applyLimit, dbdata.h:407-425 */
+    } else {
+        res = root->relOut;
+        if (!res) fail("plan produced no result relation");
+    }
+
+    orc_result* r = (orc_result*)calloc(1, sizeof(orc_result));
+    int n = res->schema.n;
+    r->names = calloc((size_t)n + 1, RSQ_SYMBOL_MAX);
+    r->types = calloc((size_t)n + 1, sizeof(rsq_type));
+    r->offsets = calloc((size_t)n + 1, sizeof(int32_t));
+    size_t bytes = (size_t)res->nTuples * (size_t)res->schema.tupSize;
+    r->tuples = malloc(bytes ? bytes : 1);
+    if (!r->names || !r->types || !r->offsets || !r->tuples) fail("out of memory");
+    int off = 0;
+    for (int i = 0; i < n; i++) {
+        memcpy(r->names[i], res->schema.a[i].name, RSQ_SYMBOL_MAX);
+        r->types[i] = res->schema.a[i].type;
+        r->offsets[i] = off;
+        off += getSizeInTuple(res->schema.a[i].type, 1);
+    }
+    if (bytes) memcpy(r->tuples, res->data, bytes);
+    r->view.n_cols = n; r->view.names = (const char(*)[RSQ_SYMBOL_MAX])r->names; r->view.types = r->types;
+    r->view.offsets = r->offsets; r->view.tuple_size = res->schema.tupSize; r->view.n_rows = res->nTuples;
+    r->view.tuples = r->tuples;
+    r->aggSlots = x->aggSlots; r->aggGrows = x->aggGrows;
+
+    cleanupTables(x);
+    afree(&c->arena); free(c); free(x);
+    *out = r;
+    return 0;
+}
+
+const rsq_result_view* orc_result_view(const orc_result* r) { return &r->view; }
+int64_t orc_result_agg_slots(const orc_result* r) { return r->aggSlots; }
+int64_t orc_result_agg_grows(const orc_result* r) { return r->aggGrows; }
+
+void orc_result_free(orc_result* r) {
+    if (!r) return;
+    free(r->names); free(r->types); free(r->offsets); free(r->tuples); free(r);
+}
+void orc_free_string(char* s) { free(s); }
+
+char* orc_result_serialize(const orc_result* r) {
+    jmp_buf jb; g_jmp = &jb;
+    StrBuf b = {0, 0, 0};
+    if (setjmp(jb)) { free(b.p); return NULL; }
+    char tb[64];
+    sb_puts(&b, "#schema ");
+    for (int i = 0; i < r->view.n_cols; i++) {
+        serializeType(r->types[i], tb, sizeof tb);
+        sb_puts(&b, r->names[i]); sb_puts(&b, ":"); sb_puts(&b, tb); sb_puts(&b, "|");
+    }
+    sb_puts(&b, "\n");
+    for (int64_t t = 0; t < r->view.n_rows; t++) {
+        const uint8_t* tup = r->tuples + (size_t)t * (size_t)r->view.tuple_size;
+        for (int i = 0; i < r->view.n_cols; i++) {
+            Val v = loadVal(tup + r->offsets[i], r->types[i], 1);
+            serializeSqlValue(&b, v, r->types[i]);
+            sb_puts(&b, "|");
+        }
+        sb_puts(&b, "\n");
+    }
+    return b.p;
+}
+
+char* orc_serialize_expr(const rsq_plan_desc* plan, int expr, int derive,
+                         const rsq_table_desc* tables, int n_tables, char* err, size_t errlen) {
+    Ctx* c = (Ctx*)calloc(1, sizeof(Ctx));
+    if (!c) return NULL;
+    c->exprIdGen = 1;
+    jmp_buf jb; g_jmp = &jb;
+    StrBuf b = {0, 0, 0};
+    if (setjmp(jb)) {
+        if (err) snprintf(err, errlen, "%s", g_err);
+        free(b.p); afree(&c->arena); free(c);
+        return NULL;
+    }
+    for (int t = 0; t < n_tables; t++)
+        for (int i = 0; i < tables[t].n_cols; i++) identSet(c, tables[t].cols[i].name, tables[t].cols[i].type);
+    Expr** nodes = buildExprs(c, plan);
+    if (expr < 0 || expr >= plan->n_exprs) fail("bad expression index");
+    if (derive) deriveExpressionTypes(c, nodes[expr]);
+    serializeExpr(&b, nodes[expr]);
+    afree(&c->arena); free(c);
+    return b.p;
+}
+
+char* orc_eval_scalar(const rsq_plan_desc* plan, int expr, char* err, size_t errlen) {
+    Ctx* c = (Ctx*)calloc(1, sizeof(Ctx));
+    Exec* x = (Exec*)calloc(1, sizeof(Exec));
+    if (!c || !x) { free(c); free(x); return NULL; }
+    c->exprIdGen = 1; x->c = c;
+    jmp_buf jb; g_jmp = &jb;
+    StrBuf b = {0, 0, 0};
+    if (setjmp(jb)) {
+        if (err) snprintf(err, errlen, "%s", g_err);
+        free(b.p); afree(&c->arena); free(c); free(x);
+        return NULL;
+    }
+    Expr** nodes = buildExprs(c, plan);
+    if (expr < 0 || expr >= plan->n_exprs) fail("bad expression index");
+    Expr* e = nodes[expr];
+    deriveExpressionTypes(c, e);            /* executeAndCheckExpression, test_common.h:85-89 */
+    CExpr* ce = compileExpr(x, e);
+    Val v = evalExpr(x, ce);
+    serializeSqlValue(&b, v, e->type);
+    afree(&c->arena); free(c); free(x);
+    return b.p;
+}
