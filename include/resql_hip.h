@@ -1,0 +1,146 @@
+/*
+ * resql_hip.h — C ABI of the MI355X-native execution engine for ReSQL operator pipelines.
+ *
+ * This library takes the place of ReSQL's JIT context: where the reference's
+ * `executeSelectPlan` (reference src/execute.h:213-247) does
+ *
+ *     JitContextFlounder ctx ( config.jit );            // src/JitContextFlounder.h:228
+ *     root->produceFlounder ( ctx, {} );                // operators emit Flounder IR
+ *     ctx.compile();                                    // src/JitContextFlounder.h:410-456
+ *     ctx.execute();                                    // src/JitContextFlounder.h:459-487
+ *     rel = root->retrieveResult();                     // operators/materialize.h:48, orderby.h:87
+ *
+ * a host links this library and does
+ *
+ *     rsq_ctx_create      -> one engine context per GPU (replaces the JitContextFlounder ctor)
+ *     rsq_table_create*   -> columns resident in HBM (replaces Relation / DataBlock row store,
+ *                            src/dbdata.h:23-461, as the scan source; scan.h:85-166)
+ *     rsq_query_compile   -> describe + compile: type derivation, pipeline extraction, HIP kernel
+ *                            specialisation (replaces produceFlounder + ctx.compile())
+ *     rsq_query_execute   -> launch the pipelines' kernels, synchronise (replaces ctx.execute())
+ *     rsq_query_result    -> packed result tuples in ReSQL's own layout (replaces retrieveResult())
+ *
+ * Everything is plain C: opaque handles, plain pointers and sizes, int status codes.  No
+ * exceptions cross the boundary and the library never calls exit() (the reference's
+ * query_error() does, src/qlib/error.h:29-68): errors come back as a status code plus
+ * rsq_last_error().
+ *
+ * The plan / table / result structs are in resql_plan.h.
+ */
+#ifndef RESQL_HIP_H
+#define RESQL_HIP_H
+
+#include "resql_plan.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rsq_ctx   rsq_ctx;
+typedef struct rsq_table rsq_table;
+typedef struct rsq_query rsq_query;
+
+enum rsq_status {
+    RSQ_OK = 0,
+    RSQ_ERR_INVALID = 1,        /* malformed plan / arguments */
+    RSQ_ERR_TYPE = 2,           /* what the reference reports as ResqlError during type derivation / codegen */
+    RSQ_ERR_UNSUPPORTED = 3,    /* valid ReSQL plan, pipeline shape not implemented by this engine */
+    RSQ_ERR_DEVICE = 4,         /* HIP runtime / compiler failure, no usable GPU */
+    RSQ_ERR_RUNTIME = 5,        /* query-time error (division by zero, hash table full, ...) */
+    RSQ_ERR_NOMEM = 6
+};
+
+/* Mirrors JitConfig (reference src/JitContextFlounder.h:86-109) field for field, plus the device. */
+typedef struct rsq_config {
+    int32_t print_assembly;      /* JitConfig::printAssembly  -> dump generated HIP source */
+    int32_t print_flounder;      /* JitConfig::printFlounder  -> dump the pipeline description */
+    int32_t print_performance;   /* JitConfig::printPerformance */
+    int32_t num_threads;         /* JitConfig::numThreads: host threads of the CPU path; unused by the GPU engine */
+    int32_t emit_machine_code;   /* JitConfig::emitMachineCode: ignored (always in-process code objects) */
+    int32_t optimize;            /* JitConfig::optimizeFlounder: ignored */
+    int32_t device;              /* HIP device ordinal this context drives (one context per GPU / process) */
+    const char* kernel_cache_dir;/* directory with pre-built code objects (NULL: <library dir>/../_kcache) */
+} rsq_config;
+
+/* Mirrors JitExecutionReport (reference src/JitContextFlounder.h:114-129), times in ms, plus the
+ * GPU-side figures SURVEY.md §8(b) asks for. */
+typedef struct rsq_report {
+    double   compilation_time_ms;    /* describe + kernel specialisation (JIT or cache hit) */
+    double   execution_time_ms;      /* host wall time of rsq_query_execute, launches to final sync */
+    double   kernel_time_ms;         /* sum of device kernel durations (HIP events on the engine's stream) */
+    double   finalize_time_ms;       /* host-side AVG / projection / order-by / limit over the group rows */
+    uint64_t num_kernels;            /* launches issued by the last execute (cf. numMachineInstructions) */
+    uint64_t bytes_read;             /* ALGORITHMIC bytes: column bytes the pipelines must read once */
+    double   hbm_gbps;               /* bytes_read / kernel_time */
+    int32_t  jit_cache_hits;         /* pipelines served from the code-object cache */
+    int32_t  jit_compiles;           /* pipelines compiled with hiprtc in this call */
+} rsq_report;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int  rsq_ctx_create(const rsq_config* cfg, rsq_ctx** out);
+void rsq_ctx_destroy(rsq_ctx* ctx);
+/* Message of the last failing call on this context (or of rsq_ctx_create when ctx == NULL). */
+const char* rsq_last_error(const rsq_ctx* ctx);
+
+/* ---- tables ------------------------------------------------------------------------------ */
+/* Copy host columns to the device (H2D is outside every timed region). Column statistics the
+ * planner uses (row count as Relation::tupleNum(), min/max, byte-value sets) are gathered here. */
+int  rsq_table_create(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out);
+/* Adopt columns that already live in this GPU's memory (e.g. torch tensors): `data` pointers are
+ * device pointers, not copied, and must outlive the table. */
+int  rsq_table_create_device(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out);
+/* Transpose a ReSQL row store (reference src/dbdata.h: DataBlocks of packed tuples, strings by
+ * value) into device columns: the bridge for a host that keeps ReSQL's own Relation objects. */
+int  rsq_table_from_rowstore(rsq_ctx* ctx, const rsq_table_desc* schema /* data pointers ignored */,
+                             const uint8_t* const* blocks, const size_t* content_size, int32_t n_blocks,
+                             rsq_table** out);
+/* Fill a lineitem / orders / customer / synthetic table on the device with the deterministic
+ * generator of resql_amd/datagen.py (same bits), rows [row0, row0 + n_rows).  kind: 0 lineitem,
+ * 1 orders, 2 customer, 3 synthetic 4 x int64 (param = number of groups). */
+int  rsq_table_generate(rsq_ctx* ctx, int32_t kind, int64_t row0, int64_t n_rows, double scale_factor,
+                        int64_t param, uint64_t seed, rsq_table** out);
+int64_t rsq_table_rows(const rsq_table* t);
+/* Copy one device column back (tests). */
+int  rsq_table_read_column(rsq_ctx* ctx, const rsq_table* t, const char* name, void* host_dst, size_t bytes);
+void rsq_table_destroy(rsq_table* t);
+
+/* ---- queries ----------------------------------------------------------------------------- */
+/* tables[i] is the table SCAN operators refer to by index i. */
+int  rsq_query_compile(rsq_ctx* ctx, const rsq_plan_desc* plan, rsq_table* const* tables, int32_t n_tables,
+                       rsq_query** out);
+/* Run all pipelines and finalise the result.  Blocking, like JitContextFlounder::execute(). */
+int  rsq_query_execute(rsq_query* q);
+/* Multi-GPU (row-range sharded scans): run the pipelines up to the aggregation and stop.  The
+ * dense partial aggregate table then sits in device memory at *dev_ptr as int64 words laid out
+ * [ n_min_words | n_max_words | n_sum_words ]: the first segment merges with MIN (first-row
+ * trackers, MIN aggregates), the second with MAX, the third with SUM (sums, counts) — one RCCL
+ * all-reduce per non-empty segment, issued by the host (one process per GPU).
+ * rsq_query_finalize then produces the result from the reduced table. */
+int  rsq_query_execute_partial(rsq_query* q, void** dev_ptr, int64_t* n_min_words, int64_t* n_max_words,
+                               int64_t* n_sum_words);
+int  rsq_query_finalize(rsq_query* q);
+int  rsq_query_result(rsq_query* q, rsq_result_view* out);
+int  rsq_query_report(const rsq_query* q, rsq_report* out);
+/* Generated HIP source and pipeline description of the compiled query (debugging). */
+const char* rsq_query_source(const rsq_query* q);
+const char* rsq_query_explain(const rsq_query* q);
+void rsq_query_destroy(rsq_query* q);
+
+/* ---- host-side helpers that mirror reference free functions ------------------------------ */
+/* serializeExpr after deriveExpressionTypes (reference src/expressions.h:177-204, 1367-1392): lets a
+ * host check the engine's typing against the reference's (test/test_datatypes.h).  Returns a
+ * malloc'ed string (free with rsq_free) or NULL. */
+char* rsq_serialize_expr(rsq_ctx* ctx, const rsq_plan_desc* plan, int32_t expr, int32_t derive,
+                         rsq_table* const* tables, int32_t n_tables);
+/* serializeRelation (reference src/dbdata.h:688-701) of a result view. */
+char* rsq_result_serialize(const rsq_result_view* view);
+void  rsq_free(void* p);
+
+/* Sustained read-only streaming bandwidth of this GPU (grid-stride int64 sum over `bytes` of
+ * resident memory): the measured roofline SURVEY.md §8(d) quotes fractions against. */
+int  rsq_measure_read_bandwidth(rsq_ctx* ctx, size_t bytes, int32_t iters, double* gb_per_s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESQL_HIP_H */

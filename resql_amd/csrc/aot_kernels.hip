@@ -1,0 +1,313 @@
+// aot_kernels.hip — hand-written gfx950 kernels that do not depend on the query:
+//   * column statistics (min / max, byte-value sets) gathered when a table is created
+//   * the deterministic TPC-H-shaped generator (bit-identical to resql_amd/datagen.py)
+//   * the read-only streaming bandwidth probe (the measured roofline of SURVEY.md §8d)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+
+#include "engine.h"
+
+namespace rsq {
+
+typedef long long i64;
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------------------------------
+// statistics
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_minmax(const T* __restrict__ p, i64 n, i64* out /* [min,max] */) {
+    i64 mn = 0x7fffffffffffffffll, mx = (i64)0x8000000000000000ull;
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        i64 v = (i64)p[i];
+        mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        i64 a = __shfl_xor(mn, m, 64), b = __shfl_xor(mx, m, 64);
+        mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); }
+}
+
+__global__ void __launch_bounds__(256) k_byteset(const unsigned char* __restrict__ p, i64 n, unsigned* out /* 8 words */) {
+    __shared__ unsigned s[8];
+    if (threadIdx.x < 8) s[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        unsigned v = p[i];
+#pragma unroll
+        for (int w = 0; w < 8; w++) loc[w] |= ((v >> 5) == (unsigned)w) ? (1u << (v & 31)) : 0u;
+    }
+#pragma unroll
+    for (int w = 0; w < 8; w++) if (loc[w]) atomicOr(&s[w], loc[w]);
+    __syncthreads();
+    if (threadIdx.x < 8 && s[threadIdx.x]) atomicOr(&out[threadIdx.x], s[threadIdx.x]);
+}
+
+static void hostStats(Table& t) {
+    for (auto& c : t.cols) {
+        if (!c.dptr || t.nRows == 0) continue;
+        int w = columnWidth(c.type);
+        if (c.type.tag == RSQ_BOOL || (c.type.tag == RSQ_CHAR && c.type.len == 1)) {
+            bool seen[256] = {false};
+            const unsigned char* p = (const unsigned char*)c.dptr;
+            for (int64_t i = 0; i < t.nRows; i++) seen[p[i]] = true;
+            for (int v = 0; v < 256; v++) if (seen[v]) c.stats.distinctBytes.push_back((uint8_t)v);
+            c.stats.min = c.stats.distinctBytes.front(); c.stats.max = c.stats.distinctBytes.back();
+            c.stats.valid = true;
+        } else if (w == 4 || w == 8) {
+            if (c.type.isString()) continue;
+            int64_t mn = INT64_MAX, mx = INT64_MIN;
+            for (int64_t i = 0; i < t.nRows; i++) {
+                int64_t v = (w == 8) ? ((const int64_t*)c.dptr)[i]
+                          : (c.type.tag == RSQ_DATE ? (int64_t)((const uint32_t*)c.dptr)[i] : (int64_t)((const int32_t*)c.dptr)[i]);
+                mn = std::min(mn, v); mx = std::max(mx, v);
+            }
+            c.stats.min = mn; c.stats.max = mx; c.stats.valid = true;
+        }
+    }
+}
+
+void computeColumnStats(Context& ctx, Table& t) {
+    if (ctx.device < 0) { hostStats(t); return; }
+    if (t.nRows == 0) return;
+    RSQ_HIP(hipSetDevice(ctx.device));
+    i64* dmm = (i64*)ctx.alloc(2 * sizeof(i64));
+    unsigned* dset = (unsigned*)ctx.alloc(8 * sizeof(unsigned));
+    const unsigned grid = 1024;
+    for (auto& c : t.cols) {
+        if (!c.dptr) continue;
+        if (c.type.tag == RSQ_BOOL || (c.type.tag == RSQ_CHAR && c.type.len == 1)) {
+            RSQ_HIP(hipMemsetAsync(dset, 0, 32, ctx.stream));
+            hipLaunchKernelGGL(k_byteset, dim3(grid), dim3(256), 0, ctx.stream, (const unsigned char*)c.dptr, (i64)t.nRows, dset);
+            unsigned h[8];
+            RSQ_HIP(hipMemcpyAsync(h, dset, 32, hipMemcpyDeviceToHost, ctx.stream));
+            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            for (int v = 0; v < 256; v++) if (h[v >> 5] & (1u << (v & 31))) c.stats.distinctBytes.push_back((uint8_t)v);
+            if (!c.stats.distinctBytes.empty()) { c.stats.min = c.stats.distinctBytes.front(); c.stats.max = c.stats.distinctBytes.back(); c.stats.valid = true; }
+        } else if (!c.type.isString()) {
+            i64 init[2] = {0x7fffffffffffffffll, (i64)0x8000000000000000ull};
+            RSQ_HIP(hipMemcpyAsync(dmm, init, 16, hipMemcpyHostToDevice, ctx.stream));
+            if (c.type.tag == RSQ_INT) hipLaunchKernelGGL(k_minmax<int>, dim3(grid), dim3(256), 0, ctx.stream, (const int*)c.dptr, (i64)t.nRows, dmm);
+            else if (c.type.tag == RSQ_DATE) hipLaunchKernelGGL(k_minmax<unsigned>, dim3(grid), dim3(256), 0, ctx.stream, (const unsigned*)c.dptr, (i64)t.nRows, dmm);
+            else hipLaunchKernelGGL(k_minmax<i64>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)c.dptr, (i64)t.nRows, dmm);
+            i64 h[2];
+            RSQ_HIP(hipMemcpyAsync(h, dmm, 16, hipMemcpyDeviceToHost, ctx.stream));
+            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            c.stats.min = h[0]; c.stats.max = h[1]; c.stats.valid = true;
+        }
+    }
+    ctx.free(dmm); ctx.free(dset);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generator (mirror of resql_amd/datagen.py; keep the two in lock step)
+// ------------------------------------------------------------------------------------------------
+enum { S_QTY = 1, S_PKEY, S_DISC, S_TAX, S_SHIP, S_RCPT, S_RFLG, S_ODATE, S_OCUST, S_PERM, S_CSEG,
+       S_A = 21, S_B, S_C, S_D };
+
+__host__ __device__ inline u64 g_mix(u64 seed, u64 stream, u64 idx) {
+    u64 z = seed + stream * 0x9E3779B97F4A7C15ull + idx * 0xD1342543DE82EF95ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline i64 g_uniform(u64 seed, u64 stream, u64 idx, u64 n) {
+    return (i64)(((g_mix(seed, stream, idx) >> 32) * n) >> 32);
+}
+__host__ __device__ inline unsigned g_yyyymmdd(i64 daysSince1992) {
+    i64 z = daysSince1992 + 8035 + 719468;
+    i64 era = z / 146097;
+    i64 doe = z - era * 146097;
+    i64 yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    i64 y = yoe + era * 400;
+    i64 doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    i64 mp = (5 * doy + 2) / 153;
+    i64 d = doy - (153 * mp + 2) / 5 + 1;
+    i64 m = mp < 10 ? mp + 3 : mp - 9;
+    if (m <= 2) y += 1;
+    return (unsigned)(y * 10000 + m * 100 + d);
+}
+
+struct GenTables { signed char orderOf[14][28]; };
+
+static GenTables makeGenTables() {
+    GenTables g;
+    const int base[7] = {4, 1, 7, 3, 5, 2, 6};
+    for (int p = 0; p < 14; p++) {
+        int counts[7];
+        for (int i = 0; i < 7; i++) {
+            int k = p % 7;
+            counts[i] = (p < 7) ? base[(i + k) % 7] : base[6 - ((i + k) % 7)];
+        }
+        int pos = 0;
+        for (int j = 0; j < 7; j++) for (int l = 0; l < counts[j]; l++) g.orderOf[p][pos++] = (signed char)j;
+    }
+    return g;
+}
+
+struct LineitemCols {
+    int* l_orderkey; i64* l_quantity; i64* l_extendedprice; i64* l_discount; i64* l_tax;
+    unsigned char* l_returnflag; unsigned char* l_linestatus; unsigned* l_shipdate;
+};
+
+__global__ void __launch_bounds__(256) k_gen_lineitem(LineitemCols c, GenTables gt, i64 row0, i64 n, u64 seed, u64 nPart) {
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        u64 r = (u64)(row0 + i);
+        u64 block = r / 28; int off = (int)(r % 28);
+        int pat = (int)g_uniform(seed, S_PERM, block, 14);
+        u64 o = block * 7 + (u64)gt.orderOf[pat][off];
+        i64 qty = 1 + g_uniform(seed, S_QTY, r, 50);
+        i64 pk = 1 + g_uniform(seed, S_PKEY, r, nPart);
+        i64 retail = 90000 + ((pk / 10) % 20001) + 100 * (pk % 1000);
+        i64 ship = g_uniform(seed, S_ODATE, o, 2406) + 1 + g_uniform(seed, S_SHIP, r, 121);
+        i64 rcpt = ship + 1 + g_uniform(seed, S_RCPT, r, 30);
+        if (c.l_orderkey) c.l_orderkey[i] = (int)((o / 8) * 32 + (o % 8) + 1);
+        c.l_quantity[i] = qty;
+        c.l_extendedprice[i] = qty * retail;
+        c.l_discount[i] = g_uniform(seed, S_DISC, r, 11);
+        c.l_tax[i] = g_uniform(seed, S_TAX, r, 9);
+        c.l_shipdate[i] = g_yyyymmdd(ship);
+        unsigned char ra = g_uniform(seed, S_RFLG, r, 2) == 0 ? 'R' : 'A';
+        c.l_returnflag[i] = rcpt <= 1263 ? ra : 'N';
+        c.l_linestatus[i] = ship > 1263 ? 'O' : 'F';
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gen_orders(int* okey, int* ckey, unsigned* odate, int* prio, i64 o0, i64 n, u64 seed, u64 nCust) {
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        u64 o = (u64)(o0 + i);
+        i64 k = 1 + g_uniform(seed, S_OCUST, o, nCust);
+        if (k % 3 == 0) k -= 1;
+        if (k < 1) k = 1;
+        okey[i] = (int)((o / 8) * 32 + (o % 8) + 1);
+        ckey[i] = (int)k;
+        odate[i] = g_yyyymmdd(g_uniform(seed, S_ODATE, o, 2406));
+        prio[i] = 0;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gen_customer(int* ckey, char* seg /* 10 B per row */, i64 c0, i64 n, u64 seed) {
+    const char names[5][11] = {"AUTOMOBILE", "BUILDING\0\0", "FURNITURE\0", "MACHINERY\0", "HOUSEHOLD\0"};
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        u64 c = (u64)(c0 + i);
+        int s = (int)g_uniform(seed, S_CSEG, c, 5);
+        ckey[i] = (int)(c + 1);
+        for (int b = 0; b < 10; b++) seg[i * 10 + b] = names[s][b];
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gen_synth(i64* a, i64* b, i64* c, i64* d, i64 row0, i64 n, u64 seed, u64 groups) {
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        u64 r = (u64)(row0 + i);
+        a[i] = g_uniform(seed, S_A, r, 1ull << 31);
+        b[i] = g_uniform(seed, S_B, r, groups);
+        c[i] = g_uniform(seed, S_C, r, 1ull << 20);
+        d[i] = g_uniform(seed, S_D, r, 1ull << 20);
+    }
+}
+
+static void addCol(Context& ctx, Table& t, const char* name, Type type, bool withData) {
+    TableColumn c; c.name = name; c.type = type;
+    if (withData) { c.dptr = ctx.alloc((size_t)t.nRows * (size_t)columnWidth(type)); c.owned = true; }
+    t.cols.push_back(c);
+}
+static void* colPtr(Table& t, const char* n) { int i = t.findCol(n); return i < 0 ? nullptr : t.cols[i].dptr; }
+
+void generateTable(Context& ctx, Table& t, int kind, int64_t row0, int64_t nRows, double sf, int64_t param, uint64_t seed) {
+    if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "rsq_table_generate needs a device context");
+    RSQ_HIP(hipSetDevice(ctx.device));
+    t.ctx = &ctx; t.nRows = nRows; t.row0 = row0;
+    Type dec0 = Type::decimal(12, 0), dec2 = Type::decimal(12, 2);
+    auto CH = [](int n) { Type x(RSQ_CHAR); x.len = n; return x; };
+    auto VC = [](int n) { Type x(RSQ_VARCHAR); x.len = n; return x; };
+    const unsigned grid = 2048;
+    if (kind == 0) {
+        t.name = "lineitem";
+        bool withKey = param != 0;
+        addCol(ctx, t, "l_orderkey", Type(RSQ_INT), withKey);
+        addCol(ctx, t, "l_partkey", Type(RSQ_INT), false); addCol(ctx, t, "l_suppkey", Type(RSQ_INT), false);
+        addCol(ctx, t, "l_linenumber", Type(RSQ_INT), false);
+        addCol(ctx, t, "l_quantity", dec0, true); addCol(ctx, t, "l_extendedprice", dec2, true);
+        addCol(ctx, t, "l_discount", dec2, true); addCol(ctx, t, "l_tax", dec2, true);
+        addCol(ctx, t, "l_returnflag", CH(1), true); addCol(ctx, t, "l_linestatus", CH(1), true);
+        addCol(ctx, t, "l_shipdate", Type(RSQ_DATE), true);
+        addCol(ctx, t, "l_commitdate", Type(RSQ_DATE), false); addCol(ctx, t, "l_receiptdate", Type(RSQ_DATE), false);
+        addCol(ctx, t, "l_shipinstruct", CH(25), false); addCol(ctx, t, "l_shipmode", CH(10), false);
+        addCol(ctx, t, "l_comment", VC(44), false);
+        LineitemCols c{(int*)colPtr(t, "l_orderkey"), (i64*)colPtr(t, "l_quantity"), (i64*)colPtr(t, "l_extendedprice"),
+                       (i64*)colPtr(t, "l_discount"), (i64*)colPtr(t, "l_tax"), (unsigned char*)colPtr(t, "l_returnflag"),
+                       (unsigned char*)colPtr(t, "l_linestatus"), (unsigned*)colPtr(t, "l_shipdate")};
+        u64 nPart = (u64)std::max<int64_t>(1, (int64_t)(200000.0 * sf + 0.5));
+        hipLaunchKernelGGL(k_gen_lineitem, dim3(grid), dim3(256), 0, ctx.stream, c, makeGenTables(), (i64)row0, (i64)nRows, (u64)seed, nPart);
+    } else if (kind == 1) {
+        t.name = "orders";
+        addCol(ctx, t, "o_orderkey", Type(RSQ_INT), true); addCol(ctx, t, "o_custkey", Type(RSQ_INT), true);
+        addCol(ctx, t, "o_orderstatus", CH(1), false); addCol(ctx, t, "o_totalprice", dec2, false);
+        addCol(ctx, t, "o_orderdate", Type(RSQ_DATE), true); addCol(ctx, t, "o_orderpriority", CH(15), false);
+        addCol(ctx, t, "o_clerk", CH(15), false); addCol(ctx, t, "o_shippriority", Type(RSQ_INT), true);
+        addCol(ctx, t, "o_comment", VC(79), false);
+        u64 nCust = (u64)std::max<int64_t>(3, (int64_t)(150000.0 * sf + 0.5));
+        hipLaunchKernelGGL(k_gen_orders, dim3(grid), dim3(256), 0, ctx.stream, (int*)colPtr(t, "o_orderkey"), (int*)colPtr(t, "o_custkey"),
+                           (unsigned*)colPtr(t, "o_orderdate"), (int*)colPtr(t, "o_shippriority"), (i64)row0, (i64)nRows, (u64)seed, nCust);
+    } else if (kind == 2) {
+        t.name = "customer";
+        addCol(ctx, t, "c_custkey", Type(RSQ_INT), true); addCol(ctx, t, "c_name", VC(25), false);
+        addCol(ctx, t, "c_address", VC(40), false); addCol(ctx, t, "c_nationkey", Type(RSQ_INT), false);
+        addCol(ctx, t, "c_phone", CH(15), false); addCol(ctx, t, "c_acctbal", dec2, false);
+        addCol(ctx, t, "c_mktsegment", CH(10), true); addCol(ctx, t, "c_comment", VC(117), false);
+        hipLaunchKernelGGL(k_gen_customer, dim3(grid), dim3(256), 0, ctx.stream, (int*)colPtr(t, "c_custkey"), (char*)colPtr(t, "c_mktsegment"),
+                           (i64)row0, (i64)nRows, (u64)seed);
+    } else if (kind == 3) {
+        t.name = "t";
+        for (const char* n : {"a", "b", "c", "d"}) addCol(ctx, t, n, Type(RSQ_BIGINT), true);
+        hipLaunchKernelGGL(k_gen_synth, dim3(grid), dim3(256), 0, ctx.stream, (i64*)colPtr(t, "a"), (i64*)colPtr(t, "b"), (i64*)colPtr(t, "c"),
+                           (i64*)colPtr(t, "d"), (i64)row0, (i64)nRows, (u64)seed, (u64)std::max<int64_t>(1, param));
+    } else throw Error(RSQ_ERR_INVALID, "unknown table kind");
+    RSQ_HIP(hipGetLastError());
+    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    computeColumnStats(ctx, t);
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming read bandwidth probe
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) ll2 { i64 x, y; };
+
+__global__ void __launch_bounds__(256) k_read_sum(const ll2* __restrict__ p, i64 n2, u64* out) {
+    u64 s = 0;
+    i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        ll2 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        s += (u64)a.x + (u64)a.y + (u64)b.x + (u64)b.y + (u64)c.x + (u64)c.y + (u64)d.x + (u64)d.y;
+    }
+    for (; i < n2; i += stride) { ll2 a = p[i]; s += (u64)a.x + (u64)a.y; }
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 63) == 0 && s != 0x1234567) atomicAdd(out, s);
+}
+
+double measureReadBandwidth(Context& ctx, size_t bytes, int iters) {
+    if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "bandwidth probe needs a device context");
+    RSQ_HIP(hipSetDevice(ctx.device));
+    bytes &= ~(size_t)1023;
+    void* buf = ctx.alloc(bytes);
+    u64* out = (u64*)ctx.alloc(8);
+    RSQ_HIP(hipMemsetAsync(buf, 1, bytes, ctx.stream));
+    RSQ_HIP(hipMemsetAsync(out, 0, 8, ctx.stream));
+    const unsigned grid = 256 * 8;
+    hipLaunchKernelGGL(k_read_sum, dim3(grid), dim3(256), 0, ctx.stream, (const ll2*)buf, (i64)(bytes / 16), out);   // warm-up
+    RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+    for (int i = 0; i < iters; i++)
+        hipLaunchKernelGGL(k_read_sum, dim3(grid), dim3(256), 0, ctx.stream, (const ll2*)buf, (i64)(bytes / 16), out);
+    RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+    RSQ_HIP(hipEventSynchronize(ctx.ev1));
+    float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+    ctx.free(buf); ctx.free(out);
+    return (double)bytes * iters / (ms * 1e-3) / 1e9;
+}
+
+}  // namespace rsq

@@ -1,0 +1,229 @@
+// api.cpp — the extern "C" surface of include/resql_hip.h.  No exception crosses it.
+#include <cstdlib>
+#include <cstring>
+
+#include "engine.h"
+#include "hostref.h"
+
+using namespace rsq;
+
+namespace {
+thread_local std::string g_createError;
+
+template <typename F>
+int guarded(Context* ctx, F&& f) {
+    try { f(); return RSQ_OK; }
+    catch (const Error& e) { if (ctx) ctx->lastError = e.what(); else g_createError = e.what(); return e.status; }
+    catch (const std::bad_alloc&) { if (ctx) ctx->lastError = "out of host memory"; return RSQ_ERR_NOMEM; }
+    catch (const std::exception& e) { if (ctx) ctx->lastError = e.what(); else g_createError = e.what(); return RSQ_ERR_INVALID; }
+}
+
+Context* C(rsq_ctx* c) { return reinterpret_cast<Context*>(c); }
+Table* T(rsq_table* t) { return reinterpret_cast<Table*>(t); }
+Query* Q(rsq_query* q) { return reinterpret_cast<Query*>(q); }
+
+struct QueryHandle { Context* ctx; Query* q; };
+
+Table* makeTable(Context& ctx, const rsq_table_desc& d, bool adopt) {
+    std::unique_ptr<Table> t(new Table());
+    t->ctx = &ctx;
+    t->name = std::string(d.name, strnlen(d.name, RSQ_SYMBOL_MAX));
+    t->nRows = d.n_rows;
+    if (d.n_rows < 0 || d.n_cols < 0) failInvalid("negative table size");
+    for (int i = 0; i < d.n_cols; i++) {
+        const rsq_column& c = d.cols[i];
+        TableColumn tc;
+        tc.name = std::string(c.name, strnlen(c.name, RSQ_SYMBOL_MAX));
+        tc.type = Type::fromC(c.type);
+        size_t bytes = (size_t)d.n_rows * (size_t)columnWidth(tc.type);
+        if (c.data) {
+            if (adopt) { tc.dptr = const_cast<void*>(c.data); tc.owned = false; }
+            else if (ctx.device >= 0) {
+                tc.dptr = ctx.alloc(bytes); tc.owned = true;
+                if (bytes) RSQ_HIP(hipMemcpy(tc.dptr, c.data, bytes, hipMemcpyHostToDevice));
+            } else {   // compile-only context: keep a host copy for the statistics
+                tc.dptr = malloc(bytes ? bytes : 1); tc.owned = true;
+                if (!tc.dptr) throw std::bad_alloc();
+                memcpy(tc.dptr, c.data, bytes);
+            }
+        }
+        t->cols.push_back(tc);
+    }
+    computeColumnStats(ctx, *t);
+    return t.release();
+}
+}  // namespace
+
+extern "C" {
+
+int rsq_ctx_create(const rsq_config* cfg, rsq_ctx** out) {
+    if (!out) return RSQ_ERR_INVALID;
+    *out = nullptr;
+    rsq_config c{};
+    if (cfg) c = *cfg;
+    return guarded(nullptr, [&] { *out = reinterpret_cast<rsq_ctx*>(new Context(c)); });
+}
+
+void rsq_ctx_destroy(rsq_ctx* ctx) { delete C(ctx); }
+
+const char* rsq_last_error(const rsq_ctx* ctx) {
+    if (!ctx) return g_createError.c_str();
+    return reinterpret_cast<const Context*>(ctx)->lastError.c_str();
+}
+
+int rsq_table_create(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out) {
+    if (!ctx || !desc || !out) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] { *out = reinterpret_cast<rsq_table*>(makeTable(*C(ctx), *desc, false)); });
+}
+
+int rsq_table_create_device(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out) {
+    if (!ctx || !desc || !out) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] {
+        if (C(ctx)->device < 0) throw Error(RSQ_ERR_DEVICE, "rsq_table_create_device needs a device context");
+        *out = reinterpret_cast<rsq_table*>(makeTable(*C(ctx), *desc, true));
+    });
+}
+
+int rsq_table_from_rowstore(rsq_ctx* ctx, const rsq_table_desc* schema, const uint8_t* const* blocks,
+                            const size_t* content_size, int32_t n_blocks, rsq_table** out) {
+    if (!ctx || !schema || !out || n_blocks < 0) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] {
+        // transpose packed ReSQL tuples (strings by value, schema.h:76-106 offsets) into columns on the host,
+        // then upload: the bridge is ingest, not the hot path
+        std::vector<Type> types; std::vector<int> offs; int ts = 0;
+        for (int i = 0; i < schema->n_cols; i++) {
+            Type t = Type::fromC(schema->cols[i].type);
+            types.push_back(t); offs.push_back(ts); ts += sizeInTuple(t, true);
+        }
+        int64_t n = 0;
+        for (int b = 0; b < n_blocks; b++) n += (int64_t)(content_size[b] / (size_t)ts);
+        std::vector<std::vector<uint8_t>> cols((size_t)schema->n_cols);
+        for (int i = 0; i < schema->n_cols; i++) cols[(size_t)i].assign((size_t)n * (size_t)columnWidth(types[(size_t)i]), 0);
+        int64_t r = 0;
+        for (int b = 0; b < n_blocks; b++) {
+            size_t cnt = content_size[b] / (size_t)ts;
+            for (size_t k = 0; k < cnt; k++, r++) {
+                const uint8_t* tup = blocks[b] + k * (size_t)ts;
+                for (int i = 0; i < schema->n_cols; i++) {
+                    int w = columnWidth(types[(size_t)i]);
+                    uint8_t* dst = &cols[(size_t)i][(size_t)r * (size_t)w];
+                    if (types[(size_t)i].tag == RSQ_CHAR || types[(size_t)i].tag == RSQ_VARCHAR) {
+                        const uint8_t* s = tup + offs[(size_t)i];
+                        for (int c = 0; c < w && s[c]; c++) dst[c] = s[c];
+                    } else memcpy(dst, tup + offs[(size_t)i], (size_t)w);
+                }
+            }
+        }
+        std::vector<rsq_column> cd((size_t)schema->n_cols);
+        for (int i = 0; i < schema->n_cols; i++) { cd[(size_t)i] = schema->cols[i]; cd[(size_t)i].data = cols[(size_t)i].data(); }
+        rsq_table_desc d = *schema; d.n_rows = n; d.cols = cd.data();
+        *out = reinterpret_cast<rsq_table*>(makeTable(*C(ctx), d, false));
+    });
+}
+
+int rsq_table_generate(rsq_ctx* ctx, int32_t kind, int64_t row0, int64_t n_rows, double scale_factor,
+                       int64_t param, uint64_t seed, rsq_table** out) {
+    if (!ctx || !out || n_rows < 0) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] {
+        std::unique_ptr<Table> t(new Table());
+        generateTable(*C(ctx), *t, kind, row0, n_rows, scale_factor, param, seed);
+        *out = reinterpret_cast<rsq_table*>(t.release());
+    });
+}
+
+int64_t rsq_table_rows(const rsq_table* t) { return t ? reinterpret_cast<const Table*>(t)->nRows : -1; }
+
+int rsq_table_read_column(rsq_ctx* ctx, const rsq_table* t, const char* name, void* host_dst, size_t bytes) {
+    if (!ctx || !t || !name || !host_dst) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] {
+        const Table* tb = reinterpret_cast<const Table*>(t);
+        int ci = tb->findCol(name);
+        if (ci < 0 || !tb->cols[(size_t)ci].dptr) failInvalid(std::string("no such column: ") + name);
+        size_t have = (size_t)tb->nRows * (size_t)columnWidth(tb->cols[(size_t)ci].type);
+        if (bytes > have) failInvalid("read beyond the column");
+        if (C(ctx)->device >= 0) RSQ_HIP(hipMemcpy(host_dst, tb->cols[(size_t)ci].dptr, bytes, hipMemcpyDeviceToHost));
+        else memcpy(host_dst, tb->cols[(size_t)ci].dptr, bytes);
+    });
+}
+
+void rsq_table_destroy(rsq_table* t) { delete T(t); }
+
+int rsq_query_compile(rsq_ctx* ctx, const rsq_plan_desc* plan, rsq_table* const* tables, int32_t n_tables, rsq_query** out) {
+    if (!ctx || !plan || !out || n_tables < 0) return RSQ_ERR_INVALID;
+    *out = nullptr;
+    return guarded(C(ctx), [&] {
+        std::unique_ptr<QueryHandle> h(new QueryHandle{C(ctx), nullptr});
+        h->q = compileQuery(*C(ctx), *plan, tables, n_tables);
+        *out = reinterpret_cast<rsq_query*>(h.release());
+    });
+}
+
+#define QH(q) reinterpret_cast<QueryHandle*>(q)
+
+int rsq_query_execute(rsq_query* q) {
+    if (!q) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] { executeQuery(*QH(q)->q, false); });
+}
+
+int rsq_query_execute_partial(rsq_query* q, void** dev_ptr, int64_t* n_min_words, int64_t* n_max_words, int64_t* n_sum_words) {
+    if (!q || !dev_ptr || !n_min_words || !n_max_words || !n_sum_words) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] {
+        executeQuery(*QH(q)->q, true);
+        partialBuffer(*QH(q)->q, dev_ptr, n_min_words, n_max_words, n_sum_words);
+    });
+}
+
+int rsq_query_finalize(rsq_query* q) {
+    if (!q) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] { finalizeQuery(*QH(q)->q); });
+}
+
+int rsq_query_result(rsq_query* q, rsq_result_view* out) {
+    if (!q || !out) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] { queryResult(*QH(q)->q, out); });
+}
+
+int rsq_query_report(const rsq_query* q, rsq_report* out) {
+    if (!q || !out) return RSQ_ERR_INVALID;
+    queryReport(*reinterpret_cast<const QueryHandle*>(q)->q, out);
+    return RSQ_OK;
+}
+
+const char* rsq_query_source(const rsq_query* q) { return q ? querySource(*reinterpret_cast<const QueryHandle*>(q)->q) : ""; }
+const char* rsq_query_explain(const rsq_query* q) { return q ? queryExplain(*reinterpret_cast<const QueryHandle*>(q)->q) : ""; }
+
+void rsq_query_destroy(rsq_query* q) {
+    if (!q) return;
+    destroyQuery(QH(q)->q);
+    delete QH(q);
+}
+
+char* rsq_serialize_expr(rsq_ctx* ctx, const rsq_plan_desc* plan, int32_t expr, int32_t derive,
+                         rsq_table* const* tables, int32_t n_tables) {
+    if (!ctx || !plan) return nullptr;
+    char* res = nullptr;
+    guarded(C(ctx), [&] {
+        ExprPool pool;
+        for (int i = 0; i < n_tables; i++)
+            for (auto& c : T(tables[i])->cols) pool.identTypes[c.name] = c.type;
+        std::vector<Expr*> v = pool.build(*plan);
+        if (expr < 0 || expr >= (int)v.size()) failInvalid("bad expression index");
+        if (derive) pool.derive(v[(size_t)expr]);
+        res = strdup(serializeExpr(v[(size_t)expr]).c_str());
+    });
+    return res;
+}
+
+char* rsq_result_serialize(const rsq_result_view* view) {
+    if (!view) return nullptr;
+    try { return strdup(serializeResultView(*view).c_str()); } catch (...) { return nullptr; }
+}
+
+void rsq_free(void* p) { free(p); }
+
+int rsq_measure_read_bandwidth(rsq_ctx* ctx, size_t bytes, int32_t iters, double* gb_per_s) {
+    if (!ctx || !gb_per_s || iters <= 0) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] { *gb_per_s = measureReadBandwidth(*C(ctx), bytes, iters); });
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// engine.h — internal structures of the MI355X execution engine behind include/resql_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "expr.h"
+#include "resql_hip.h"
+
+namespace rsq {
+
+#define RSQ_HIP(call)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (call);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            throw ::rsq::Error(RSQ_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+// ---- column statistics gathered when a table is created (planner input, like the reference's
+// Relation::tupleNum(); lets the planner pick dense group ids) -----------------------------------
+struct ColumnStats {
+    bool valid = false;
+    int64_t min = 0, max = 0;                  // numeric / date columns
+    std::vector<uint8_t> distinctBytes;        // 1-byte columns (CHAR(1), BOOL): sorted distinct values
+};
+
+struct TableColumn {
+    std::string name;
+    Type type;
+    void* dptr = nullptr;                      // device pointer, nullptr if the column was declared without data
+    bool owned = false;
+    ColumnStats stats;
+};
+
+struct Context;
+
+struct Table {
+    Context* ctx = nullptr;
+    std::string name;
+    int64_t nRows = 0;
+    int64_t row0 = 0;                          // global index of the first row (row-range shards)
+    std::vector<TableColumn> cols;
+    int findCol(const std::string& n) const {
+        for (size_t i = 0; i < cols.size(); i++) if (cols[i].name == n) return (int)i;
+        return -1;
+    }
+    ~Table();
+};
+
+// ---- JIT: hiprtc + code object cache ----------------------------------------------------------
+struct Kernel {
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    bool fromCache = false;
+};
+
+struct Context {
+    rsq_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string lastError;
+    std::string cacheDir;
+    std::string includeDir;                    // where kernels/rsq_device.h lives
+    std::map<std::string, Kernel> kernels;     // by source hash
+    uint32_t* dErr = nullptr;                  // device error word
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int jitCompiles = 0, jitCacheHits = 0;
+
+    explicit Context(const rsq_config& c);
+    ~Context();
+    Kernel& getKernel(const std::string& source, const std::string& entry);
+    void* alloc(size_t bytes);
+    void free(void* p);
+};
+
+// launch helper: kernel takes one struct of 8-byte slots by value
+void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::vector<uint64_t>& args);
+
+// AOT kernels (aot_kernels.hip)
+void computeColumnStats(Context& ctx, Table& t);
+void generateTable(Context& ctx, Table& t, int kind, int64_t row0, int64_t nRows, double sf, int64_t param, uint64_t seed);
+double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
+void fillU64(Context& ctx, uint64_t* dptr, const std::vector<uint64_t>& hostValues);
+
+// ---- query ------------------------------------------------------------------------------------
+struct Query;
+Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables);
+void executeQuery(Query& q, bool partialOnly);
+void finalizeQuery(Query& q);
+void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum);
+void queryResult(Query& q, rsq_result_view* out);
+void queryReport(const Query& q, rsq_report* out);
+const char* querySource(const Query& q);
+const char* queryExplain(const Query& q);
+void destroyQuery(Query* q);
+
+std::string serializeResultView(const rsq_result_view& v);
+
+}  // namespace rsq

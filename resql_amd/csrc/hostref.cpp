@@ -1,0 +1,170 @@
+// hostref.cpp — see hostref.h.
+#include "hostref.h"
+
+#include <algorithm>
+
+namespace rsq {
+
+static const uint64_t kPrimes[] = {
+    5ull, 11ull, 23ull, 47ull, 97ull, 199ull, 409ull, 823ull, 1741ull, 3469ull, 6949ull, 14033ull,
+    28411ull, 57557ull, 116731ull, 236897ull, 480881ull, 976369ull, 1982627ull, 4026031ull,
+    8175383ull, 16601593ull, 33712729ull, 68460391ull, 139022417ull, 282312799ull, 573292817ull,
+    1164186217ull, 2364114217ull, 4294967291ull, 8589934583ull, 17179869143ull, 34359738337ull,
+    68719476731ull, 137438953447ull, 274877906899ull, 549755813881ull, 1099511627689ull,
+    2199023255531ull, 4398046511093ull, 8796093022151ull, 17592186044399ull, 35184372088777ull,
+    70368744177643ull, 140737488355213ull, 281474976710597ull, 562949953421231ull,
+    1125899906842597ull, 2251799813685119ull, 4503599627370449ull, 9007199254740881ull,
+    18014398509481951ull, 36028797018963913ull, 72057594037927931ull, 144115188075855859ull,
+    288230376151711717ull, 576460752303423433ull, 1152921504606846883ull, 2305843009213693951ull,
+    4611686018427387847ull, 9223372036854775783ull};   // the 61 sizes the reference's upper_bound searches
+
+static uint64_t primeAbove(uint64_t minSize) {
+    if (minSize < 2) minSize = 2;
+    for (uint64_t p : kPrimes) if (minSize < p) return p;
+    return 18446744073709551557ull;
+}
+
+uint64_t refHashValue(uint64_t h, Val v, const Type& t) {
+    const uint64_t A = 1710227316115945415ull, B = 741332713408129251ull;
+    switch (t.tag) {
+        case RSQ_BIGINT: case RSQ_DECIMAL: return h + ((uint64_t)v.i * A + B);
+        case RSQ_INT: return h + ((uint64_t)(int64_t)(int32_t)v.i + B) * A;
+        case RSQ_DATE: return h + ((uint64_t)(int64_t)(int32_t)(uint32_t)v.i + B) * A;
+        case RSQ_BOOL: return ((uint8_t)v.i == 0) ? h + 31636373ull : h;
+        case RSQ_CHAR:
+            if (t.len == 1) { h += (uint64_t)(uint8_t)v.i; return h + h; }
+            {   // hashChar: fixed length, missing characters count as ' '
+                const char* s = v.s;
+                for (int i = 0; i < t.len; i++) {
+                    char c; if (*s != '\0') { c = *s; s++; } else c = ' ';
+                    int32_t m = (int32_t)((uint32_t)(int)c * 31636373u);
+                    h = h + (uint64_t)(int64_t)m + (uint64_t)(int64_t)c;
+                }
+                return h;
+            }
+        case RSQ_VARCHAR: {
+            const char* s = v.s;
+            for (int i = 0; i < t.len && *s != '\0'; i++, s++) {
+                int c = *s;
+                int32_t m = (int32_t)((uint32_t)c * 31636373u);
+                h = h + (uint64_t)(int64_t)m + (uint64_t)(int64_t)c;
+            }
+            return h;
+        }
+        default: failType("Values::hash(..) not implemented for datatype");
+    }
+}
+
+namespace {
+struct Sim {
+    uint64_t numEntries, threshold, numInserts = 0;
+    std::vector<uint8_t> used;
+    std::vector<uint64_t> hash;
+    std::vector<size_t> who;
+    explicit Sim(uint64_t minSize) {
+        numEntries = primeAbove(minSize);
+        threshold = numEntries * 6 / 10;
+        used.assign(numEntries, 0); hash.assign(numEntries, 0); who.assign(numEntries, 0);
+    }
+    void put(uint64_t h, size_t id) {
+        numInserts++;
+        if (numInserts > threshold) grow();
+        uint64_t loc = h % numEntries;
+        for (uint64_t n = 0; n < numEntries; n++) {
+            if (!used[loc]) { used[loc] = 1; hash[loc] = h; who[loc] = id; return; }
+            if (++loc >= numEntries) loc = 0;
+        }
+        failRuntime("Hash table full");
+    }
+    void grow() {
+        Sim bigger(numEntries + 1);
+        for (uint64_t i = 0; i < numEntries; i++) if (used[i]) bigger.put(hash[i], who[i]);
+        *this = std::move(bigger);
+    }
+};
+}  // namespace
+
+std::vector<size_t> refEmissionOrder(const std::vector<uint64_t>& hashes, uint64_t minSize) {
+    Sim sim(minSize);
+    for (size_t i = 0; i < hashes.size(); i++) sim.put(hashes[i], i);
+    std::vector<size_t> order;
+    order.reserve(hashes.size());
+    for (uint64_t s = 0; s < sim.numEntries; s++) if (sim.used[s]) order.push_back(sim.who[s]);
+    return order;
+}
+
+void storeValue(uint8_t* addr, Val v, const Type& t) {
+    switch (t.tag) {
+        case RSQ_DATE: { uint32_t x = (uint32_t)v.i; memcpy(addr, &x, 4); break; }
+        case RSQ_BOOL: { uint8_t x = (uint8_t)v.i; memcpy(addr, &x, 1); break; }
+        case RSQ_INT: { int32_t x = (int32_t)v.i; memcpy(addr, &x, 4); break; }
+        case RSQ_BIGINT: case RSQ_DECIMAL: memcpy(addr, &v.i, 8); break;
+        case RSQ_CHAR:
+            if (t.len == 1) { addr[0] = (uint8_t)v.i; break; }
+            [[fallthrough]];
+        case RSQ_VARCHAR: {
+            size_t i = 0, max = (size_t)t.len;
+            for (; i < max; i++) { addr[i] = (uint8_t)v.s[i]; if (v.s[i] == '\0') break; }
+            addr[i] = '\0';
+            break;
+        }
+        default: failType("storeToMem(..) not implemented for datatype");
+    }
+}
+
+Val loadValue(const uint8_t* addr, const Type& t) {
+    Val v; v.i = 0;
+    switch (t.tag) {
+        case RSQ_DATE: { uint32_t x; memcpy(&x, addr, 4); v.i = x; break; }
+        case RSQ_BOOL: v.i = addr[0]; break;
+        case RSQ_INT: { int32_t x; memcpy(&x, addr, 4); v.i = x; break; }
+        case RSQ_BIGINT: case RSQ_DECIMAL: memcpy(&v.i, addr, 8); break;
+        case RSQ_CHAR: if (t.len == 1) { v.i = addr[0]; break; } [[fallthrough]];
+        case RSQ_VARCHAR: v.s = (const char*)addr; break;
+        default: failType("loadAttributeToReg(..) not implemented for datatype");
+    }
+    return v;
+}
+
+static int typedCompare(const Type& t, const uint8_t* l, const uint8_t* r) {
+    switch (t.tag) {
+        case RSQ_BIGINT: case RSQ_DECIMAL: { int64_t a, b; memcpy(&a, l, 8); memcpy(&b, r, 8); return a < b ? -1 : a > b; }
+        case RSQ_INT: case RSQ_DATE: { int32_t a, b; memcpy(&a, l, 4); memcpy(&b, r, 4); return a < b ? -1 : a > b; }
+        case RSQ_BOOL: { uint8_t a = l[0] != 0, b = r[0] != 0; return a < b ? -1 : a > b; }
+        case RSQ_CHAR: case RSQ_VARCHAR: return (int)(int8_t)strcmp((const char*)l, (const char*)r);
+        default: return 0;
+    }
+}
+
+void refQuicksort(uint8_t* data, int64_t n, size_t ts, const std::vector<OrderRequest>& order) {
+    if (n < 2) return;
+    std::vector<uint8_t> tmp(ts);
+    auto before = [&](const uint8_t* a, const uint8_t* b) {
+        for (const auto& o : order) {
+            int c = typedCompare(o.type, a + o.offset, b + o.offset);
+            if (o.asc) { if (c < 0) return true; if (c > 0) return false; }
+            else { if (c > 0) return true; if (c < 0) return false; }
+        }
+        return false;
+    };
+    auto swp = [&](int64_t i, int64_t j) {
+        if (i == j) return;
+        memcpy(tmp.data(), data + (size_t)i * ts, ts);
+        memcpy(data + (size_t)i * ts, data + (size_t)j * ts, ts);
+        memcpy(data + (size_t)j * ts, tmp.data(), ts);
+    };
+    std::vector<std::pair<int64_t, int64_t>> stack;
+    stack.emplace_back(0, n - 1);
+    while (!stack.empty()) {
+        auto [lo, hi] = stack.back(); stack.pop_back();
+        if (!(lo < hi)) continue;
+        const uint8_t* pivot = data + (size_t)hi * ts;
+        int64_t i = lo;
+        for (int64_t j = lo; j < hi; ++j) if (before(data + (size_t)j * ts, pivot)) { swp(i, j); ++i; }
+        swp(i, hi);
+        stack.emplace_back(i + 1, hi);
+        stack.emplace_back(lo, i - 1);
+    }
+}
+
+}  // namespace rsq

@@ -1,0 +1,39 @@
+// hostref.h — host-side pieces of the result path that run over the (few) group rows after the
+// device pipelines: the reference's group emission order, its quicksort, and scalar evaluation.
+//
+// Why the emission order matters: without ORDER BY the reference emits groups in the slot order of
+// its aggregation hash table, and with ORDER BY its (unstable) quicksort starts from that order,
+// so ties come out in an order that depends on it.  To hand back a result relation that is
+// byte-identical to ReSQL's — not just equal as a multiset — the engine replays the reference's
+// insertion sequence (groups ordered by the first input row that produced them) through the same
+// hash function, prime table sizes, 60 % growth rule and linear probing
+// (reference src/ValuesJitFlounder.h:65-142, src/qlib/hash.h:32-95, 225-287, 330-419).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "expr.h"
+
+namespace rsq {
+
+// Values::hash for one value (reference src/ValuesJitFlounder.h:65-142)
+uint64_t refHashValue(uint64_t h, Val v, const Type& t);
+
+// Slot order of the reference's aggregation hash table after inserting `hashes` in this order into a
+// table allocated for `minSize` (allocateHashTable(getSize(), ..), aggregation.h:253).  Returns, for
+// every slot in ascending slot order, the index into `hashes` of the group stored there.
+std::vector<size_t> refEmissionOrder(const std::vector<uint64_t>& hashes, uint64_t minSize);
+
+// Quicksorter (reference src/qlib/sort.h:21-173): Lomuto partition, pivot = last element, over
+// packed tuples.
+struct OrderRequest { int offset; Type type; bool asc; };
+void refQuicksort(uint8_t* tuples, int64_t n, size_t tupleSize, const std::vector<OrderRequest>& order);
+
+// packed tuple access (reference src/values.h:151-232)
+void storeValue(uint8_t* addr, Val v, const Type& t);      // strings by value, NUL terminated
+Val loadValue(const uint8_t* addr, const Type& t);
+
+}  // namespace rsq

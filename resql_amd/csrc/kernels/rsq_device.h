@@ -1,0 +1,148 @@
+// rsq_device.h — hand-written CDNA4 (gfx950) device-side building blocks of the ReSQL pipelines.
+//
+// Every pipeline kernel the engine launches is this header plus a short query-specific row
+// function emitted by codegen.cpp (the analogue of the reference's operators emitting Flounder IR
+// around a hand-written runtime library, reference src/qlib/*.h).  Compiled with hiprtc (or
+// hipcc --genco at build time) for --offload-arch=gfx950 only; wave size is 64.
+//
+// Contents
+//   * integer arithmetic with the reference's x86 semantics (64-bit wrap-around add/sub/imul,
+//     truncating idiv; reference src/ExpressionsJitFlounder.h:298-440)
+//   * coalesced tile loads: one wave owns a tile of 128 consecutive rows, lane l owns rows
+//     2l and 2l+1, so an 8-byte column is ONE global_load_dwordx4 per lane (1 KiB per wave
+//     instruction, unit stride), a 4-byte column one dwordx2, a 1-byte column one ushort
+//   * wave64 butterfly reductions (DPP/ds_swizzle via __shfl_xor) and the block-level flush of
+//     per-thread accumulators: registers -> wave reduce -> LDS -> one global atomic per value
+//     per block
+//   * fixed-width CHAR(n)/VARCHAR(n) comparison (reference src/qlib/scalar.h:16-46)
+//   * open-addressing hash tables in HBM for join build/probe and large group-by
+#pragma once
+
+typedef long long i64;
+typedef unsigned long long u64;
+typedef int i32;
+typedef unsigned int u32;
+typedef unsigned char u8;
+typedef unsigned short u16;
+
+#define RSQ_WAVE 64
+#define RSQ_TILE_ROWS 128          /* rows per wave tile: 64 lanes x 2 rows */
+#define RSQ_DEV __device__ inline __attribute__((always_inline))
+
+namespace rsq {
+
+// error word bits (set by kernels, read by the host after the final sync)
+enum { ERR_DIV_ZERO = 1, ERR_HT_FULL = 2, ERR_DUP_KEY = 4, ERR_GROUP_OVERFLOW = 8 };
+
+// ---- arithmetic: x86-64 add / sub / imul wrap, cqo+idiv truncates ---------------------------
+RSQ_DEV i64 add(i64 a, i64 b) { return (i64)((u64)a + (u64)b); }
+RSQ_DEV i64 sub(i64 a, i64 b) { return (i64)((u64)a - (u64)b); }
+RSQ_DEV i64 mul(i64 a, i64 b) { return (i64)((u64)a * (u64)b); }
+RSQ_DEV i64 div(i64 a, i64 b, u32* err) {
+    // the reference's generated code traps (SIGFPE) on /0 and INT64_MIN / -1; we flag and carry on
+    if (b == 0 || (a == (i64)0x8000000000000000ull && b == -1)) { atomicOr(err, (u32)ERR_DIV_ZERO); return 0; }
+    return a / b;
+}
+
+// ---- tile loads -----------------------------------------------------------------------------
+struct __attribute__((aligned(16))) i64x2 { i64 x, y; };
+struct __attribute__((aligned(8))) i32x2 { i32 x, y; };
+struct __attribute__((aligned(2))) u8x2 { u8 x, y; };
+
+// `p` points at the first of this lane's two consecutive rows; 16 / 8 / 2 byte aligned because
+// tiles start at multiples of 128 rows and column bases are 256-byte aligned.
+RSQ_DEV void ld2(const i64* p, i64 (&v)[2]) { i64x2 t = *reinterpret_cast<const i64x2*>(p); v[0] = t.x; v[1] = t.y; }
+RSQ_DEV void ld2(const i32* p, i32 (&v)[2]) { i32x2 t = *reinterpret_cast<const i32x2*>(p); v[0] = t.x; v[1] = t.y; }
+RSQ_DEV void ld2(const u8* p, u8 (&v)[2]) { u8x2 t = *reinterpret_cast<const u8x2*>(p); v[0] = t.x; v[1] = t.y; }
+
+// ---- wave64 reductions ----------------------------------------------------------------------
+RSQ_DEV u64 shfl_xor_u64(u64 v, int mask) {
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = (u32)__shfl_xor((int)lo, mask, 64);
+    hi = (u32)__shfl_xor((int)hi, mask, 64);
+    return ((u64)hi << 32) | lo;
+}
+RSQ_DEV u64 wave_sum(u64 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+    return v;
+}
+RSQ_DEV u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { u64 o = shfl_xor_u64(v, m); v = o < v ? o : v; }
+    return v;
+}
+RSQ_DEV i64 wave_min_i64(i64 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { i64 o = (i64)shfl_xor_u64((u64)v, m); v = o < v ? o : v; }
+    return v;
+}
+RSQ_DEV i64 wave_max_i64(i64 v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { i64 o = (i64)shfl_xor_u64((u64)v, m); v = o > v ? o : v; }
+    return v;
+}
+
+// Flush of one per-thread accumulator: wave butterfly, then lane 0 of every wave merges into the
+// block's LDS slot, later one lane per slot issues the global atomic (flush_block).
+enum Merge { M_SUM = 0, M_MIN_U64 = 1, M_MIN_I64 = 2, M_MAX_I64 = 3 };
+
+template <int OP>
+RSQ_DEV void lds_merge(u64* slot, u64 v) {
+    if (OP == M_SUM) atomicAdd(slot, v);
+    else if (OP == M_MIN_U64) atomicMin(slot, v);
+    else if (OP == M_MIN_I64) atomicMin(reinterpret_cast<i64*>(slot), (i64)v);
+    else atomicMax(reinterpret_cast<i64*>(slot), (i64)v);
+}
+template <int OP>
+RSQ_DEV void wave_to_lds(u64* slot, u64 v) {
+    u64 r;
+    if (OP == M_SUM) r = wave_sum(v);
+    else if (OP == M_MIN_U64) r = wave_min_u64(v);
+    else if (OP == M_MIN_I64) r = (u64)wave_min_i64((i64)v);
+    else r = (u64)wave_max_i64((i64)v);
+    if ((threadIdx.x & 63) == 0) lds_merge<OP>(slot, r);
+}
+template <int OP>
+RSQ_DEV void global_merge(u64* dst, u64 v) {
+    if (OP == M_SUM) { if (v != 0) atomicAdd(dst, v); }
+    else if (OP == M_MIN_U64) { if (v != ~0ull) atomicMin(dst, v); }
+    else if (OP == M_MIN_I64) atomicMin(reinterpret_cast<i64*>(dst), (i64)v);
+    else atomicMax(reinterpret_cast<i64*>(dst), (i64)v);
+}
+RSQ_DEV u64 merge_identity(int op) {
+    return op == M_SUM ? 0ull : op == M_MIN_U64 ? ~0ull : op == M_MIN_I64 ? 0x7fffffffffffffffull : 0x8000000000000000ull;
+}
+
+// ---- strings: columns hold CHAR(n)/VARCHAR(n) as n bytes per row, NUL padded ------------------
+struct Str { const char* p; int cap; };   // at most `cap` bytes, ends at the first NUL if any
+RSQ_DEV Str str(const char* p, int cap) { Str s; s.p = p; s.cap = cap; return s; }
+RSQ_DEV char str_at(const Str& s, int i) { return i < s.cap ? s.p[i] : '\0'; }
+
+// compareChar (reference src/qlib/scalar.h:27-46): equal up to trailing spaces
+RSQ_DEV u8 compare_char(const Str& a, const Str& b) {
+    int i = 0;
+    while (str_at(a, i) != '\0' && str_at(b, i) != '\0') { if (str_at(a, i) != str_at(b, i)) return 0; i++; }
+    for (int j = i; str_at(a, j) != '\0'; j++) if (str_at(a, j) != ' ') return 0;
+    for (int j = i; str_at(b, j) != '\0'; j++) if (str_at(b, j) != ' ') return 0;
+    return 1;
+}
+// compareVarchar (reference src/qlib/scalar.h:16-24): exact
+RSQ_DEV u8 compare_varchar(const Str& a, const Str& b) {
+    int i = 0;
+    while (str_at(a, i) != '\0' && str_at(b, i) != '\0') { if (str_at(a, i) != str_at(b, i)) return 0; i++; }
+    return str_at(a, i) == str_at(b, i);
+}
+
+// ---- hash tables in HBM ----------------------------------------------------------------------
+// Open addressing, linear probing, capacity a power of two.  Slot state lives in `state`
+// (0 empty, 1 being written, 2 ready); keys and payload are struct-of-arrays beside it, so a
+// probe touches one 4-byte state word and one key word per step.
+RSQ_DEV u64 hash64(u64 x) {     // splitmix64 finaliser; the engine's own table layout, not the reference's
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+}  // namespace rsq

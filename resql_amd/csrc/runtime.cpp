@@ -1,0 +1,152 @@
+// runtime.cpp — engine context: device, stream, code-object cache (hiprtc JIT), device tables.
+//
+// "Compilation" in the reference is Flounder IR -> x86 via asmjit, in process
+// (reference src/JitContextFlounder.h:410-456).  Here it is pipeline -> HIP source -> gfx950 code
+// object via hiprtc, in process, with an on-disk cache so that a pipeline shape is compiled once
+// (the cache is pre-populated at build time, __graft_entry__.build()).
+#include "engine.h"
+
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace rsq {
+
+static std::string libraryDir() {
+    Dl_info info;
+    if (dladdr((void*)&libraryDir, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t s = p.find_last_of('/');
+        return s == std::string::npos ? "." : p.substr(0, s);
+    }
+    return ".";
+}
+
+static uint64_t fnv1a(const std::string& s) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+Context::Context(const rsq_config& c) : cfg(c), device(c.device) {
+    std::string lib = libraryDir();
+    includeDir = lib + "/csrc/kernels";
+    struct stat st;
+    if (stat((includeDir + "/rsq_device.h").c_str(), &st) != 0) includeDir = lib + "/kernels";
+    cacheDir = c.kernel_cache_dir ? std::string(c.kernel_cache_dir) : lib + "/_kcache";
+    mkdir(cacheDir.c_str(), 0755);
+    if (device >= 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n == 0)
+            throw Error(RSQ_ERR_DEVICE, "no HIP device available (the engine has no CPU fallback)");
+        if (device >= n) throw Error(RSQ_ERR_DEVICE, "device ordinal out of range");
+        RSQ_HIP(hipSetDevice(device));
+        RSQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        RSQ_HIP(hipMalloc((void**)&dErr, sizeof(uint32_t)));
+        RSQ_HIP(hipMemset(dErr, 0, sizeof(uint32_t)));
+        RSQ_HIP(hipEventCreate(&ev0));
+        RSQ_HIP(hipEventCreate(&ev1));
+    }
+}
+
+Context::~Context() {
+    if (device >= 0) {
+        (void)hipSetDevice(device);
+        for (auto& kv : kernels) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
+        if (dErr) (void)hipFree(dErr);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+}
+
+void* Context::alloc(size_t bytes) {
+    void* p = nullptr;
+    RSQ_HIP(hipSetDevice(device));
+    RSQ_HIP(hipMalloc(&p, bytes ? bytes : 256));
+    return p;
+}
+void Context::free(void* p) { if (p) (void)hipFree(p); }
+
+Table::~Table() {
+    if (ctx && ctx->device >= 0) {
+        for (auto& c : cols) if (c.owned && c.dptr) (void)hipFree(c.dptr);
+    } else {
+        for (auto& c : cols) if (c.owned && c.dptr) ::free(c.dptr);
+    }
+}
+
+static bool readFile(const std::string& path, std::string& out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return false;
+    std::ostringstream ss; ss << f.rdbuf();
+    out = ss.str();
+    return true;
+}
+
+static std::string compileWithHiprtc(Context& ctx, const std::string& source) {
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, source.c_str(), "rsq_pipeline.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        throw Error(RSQ_ERR_DEVICE, "hiprtcCreateProgram failed");
+    std::string inc = "-I" + ctx.includeDir;
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+    hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        throw Error(RSQ_ERR_DEVICE, "hiprtc compilation failed:\n" + log);
+    }
+    size_t n = 0; hiprtcGetCodeSize(prog, &n);
+    std::string code(n, '\0');
+    hiprtcGetCode(prog, &code[0]);
+    hiprtcDestroyProgram(&prog);
+    return code;
+}
+
+Kernel& Context::getKernel(const std::string& source, const std::string& entry) {
+    char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(source));
+    std::string key(hex);
+    auto it = kernels.find(key);
+    if (it != kernels.end()) return it->second;
+
+    std::string path = cacheDir + "/" + key + ".hsaco";
+    std::string code;
+    Kernel k;
+    if (readFile(path, code) && !code.empty()) {
+        k.fromCache = true;
+        jitCacheHits++;
+    } else {
+        code = compileWithHiprtc(*this, source);
+        jitCompiles++;
+        std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        std::ofstream f(tmp, std::ios::binary);
+        if (f.is_open()) { f.write(code.data(), (std::streamsize)code.size()); f.close(); rename(tmp.c_str(), path.c_str()); }
+        std::ofstream fs(cacheDir + "/" + key + ".hip");
+        if (fs.is_open()) fs << source;
+    }
+    if (device >= 0) {
+        RSQ_HIP(hipSetDevice(device));
+        RSQ_HIP(hipModuleLoadData(&k.module, code.data()));
+        RSQ_HIP(hipModuleGetFunction(&k.fn, k.module, entry.c_str()));
+    }
+    return kernels.emplace(key, k).first->second;
+}
+
+void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::vector<uint64_t>& args) {
+    if (!k.fn) throw Error(RSQ_ERR_DEVICE, "kernel not loaded (context without device)");
+    size_t size = args.size() * sizeof(uint64_t);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)args.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
+                      HIP_LAUNCH_PARAM_END};
+    RSQ_HIP(hipModuleLaunchKernel(k.fn, grid, 1, 1, block, 1, 1, 0, ctx.stream, nullptr, config));
+}
+
+}  // namespace rsq

@@ -1,0 +1,256 @@
+"""ctypes binding of the engine's C ABI (include/resql_hip.h -> resql_amd/libresql_hip.so).
+
+This is the whole Python side of the product: load the library, hand plans and columns across the
+C ABI, read results back.  There is no Python or CPU implementation of any operator here — if the
+library is missing the import fails, and on a machine without a GPU only compile-only contexts
+(device = -1) can be created.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import plan as P
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libresql_hip.so")
+
+STATUS = {0: "OK", 1: "INVALID", 2: "TYPE", 3: "UNSUPPORTED", 4: "DEVICE", 5: "RUNTIME", 6: "NOMEM"}
+
+
+class rsq_config(C.Structure):
+    _fields_ = [("print_assembly", C.c_int32), ("print_flounder", C.c_int32), ("print_performance", C.c_int32),
+                ("num_threads", C.c_int32), ("emit_machine_code", C.c_int32), ("optimize", C.c_int32),
+                ("device", C.c_int32), ("kernel_cache_dir", C.c_char_p)]
+
+
+class rsq_report(C.Structure):
+    _fields_ = [("compilation_time_ms", C.c_double), ("execution_time_ms", C.c_double),
+                ("kernel_time_ms", C.c_double), ("finalize_time_ms", C.c_double),
+                ("num_kernels", C.c_uint64), ("bytes_read", C.c_uint64), ("hbm_gbps", C.c_double),
+                ("jit_cache_hits", C.c_int32), ("jit_compiles", C.c_int32)]
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[{STATUS.get(status, status)}] {message}")
+        self.status = status
+        self.message = message
+
+
+_lib = None
+
+
+def lib():
+    """load libresql_hip.so; raises if it has not been built (no fallback)"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C resql_amd/csrc` "
+                              f"(or __graft_entry__.build()); the engine has no Python/CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+        L.rsq_ctx_create.argtypes = [C.POINTER(rsq_config), C.POINTER(vp)]
+        L.rsq_ctx_destroy.argtypes = [vp]
+        L.rsq_last_error.restype = C.c_char_p
+        L.rsq_last_error.argtypes = [vp]
+        L.rsq_table_create.argtypes = [vp, C.POINTER(P.rsq_table_desc), C.POINTER(vp)]
+        L.rsq_table_create_device.argtypes = [vp, C.POINTER(P.rsq_table_desc), C.POINTER(vp)]
+        L.rsq_table_from_rowstore.argtypes = [vp, C.POINTER(P.rsq_table_desc), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_size_t), i32, C.POINTER(vp)]
+        L.rsq_table_generate.argtypes = [vp, i32, i64, i64, C.c_double, i64, C.c_uint64, C.POINTER(vp)]
+        L.rsq_table_rows.restype = i64
+        L.rsq_table_rows.argtypes = [vp]
+        L.rsq_table_read_column.argtypes = [vp, vp, C.c_char_p, vp, C.c_size_t]
+        L.rsq_table_destroy.argtypes = [vp]
+        L.rsq_query_compile.argtypes = [vp, C.POINTER(P.rsq_plan_desc), C.POINTER(vp), i32, C.POINTER(vp)]
+        L.rsq_query_execute.argtypes = [vp]
+        L.rsq_query_execute_partial.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.rsq_query_finalize.argtypes = [vp]
+        L.rsq_query_result.argtypes = [vp, C.POINTER(P.rsq_result_view)]
+        L.rsq_query_report.argtypes = [vp, C.POINTER(rsq_report)]
+        L.rsq_query_source.restype = C.c_char_p
+        L.rsq_query_source.argtypes = [vp]
+        L.rsq_query_explain.restype = C.c_char_p
+        L.rsq_query_explain.argtypes = [vp]
+        L.rsq_query_destroy.argtypes = [vp]
+        L.rsq_serialize_expr.restype = vp
+        L.rsq_serialize_expr.argtypes = [vp, C.POINTER(P.rsq_plan_desc), i32, i32, C.POINTER(vp), i32]
+        L.rsq_result_serialize.restype = vp
+        L.rsq_result_serialize.argtypes = [C.POINTER(P.rsq_result_view)]
+        L.rsq_free.argtypes = [vp]
+        L.rsq_measure_read_bandwidth.argtypes = [vp, C.c_size_t, i32, C.POINTER(C.c_double)]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
+    "rsq_table_from_rowstore", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
+    "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_execute_partial",
+    "rsq_query_finalize", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
+    "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
+    "rsq_measure_read_bandwidth",
+]
+
+GEN_LINEITEM, GEN_ORDERS, GEN_CUSTOMER, GEN_SYNTHETIC = 0, 1, 2, 3
+
+
+class Context:
+    """one engine context per GPU (device=-1: compile-only, no GPU needed)"""
+
+    def __init__(self, device: int = 0, cache_dir: Optional[str] = None, print_source: bool = False):
+        self._L = lib()
+        self._cache = cache_dir.encode() if cache_dir else None
+        cfg = rsq_config(1 if print_source else 0, 0, 0, 1, 1, 0, device, self._cache)
+        h = C.c_void_p()
+        rc = self._L.rsq_ctx_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, self._L.rsq_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(rc, self._L.rsq_last_error(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.rsq_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables ----
+    def table(self, t: P.Table) -> "DeviceTable":
+        keep: list = []
+        d = t.to_c(keep)
+        h = C.c_void_p()
+        self._check(self._L.rsq_table_create(self.h, C.byref(d), C.byref(h)))
+        return DeviceTable(self, h, t.name)
+
+    def table_from_device(self, name: str, n_rows: int, columns) -> "DeviceTable":
+        """columns: list of (name, SqlType, device_pointer_or_None); pointers stay owned by the caller"""
+        cols = (P.rsq_column * len(columns))()
+        for i, (cn, ct, ptr) in enumerate(columns):
+            cols[i].name = cn.encode(); cols[i].type = ct.c(); cols[i].data = ptr
+        d = P.rsq_table_desc(); d.name = name.encode(); d.n_rows = n_rows; d.n_cols = len(columns); d.cols = cols
+        h = C.c_void_p()
+        self._check(self._L.rsq_table_create_device(self.h, C.byref(d), C.byref(h)))
+        return DeviceTable(self, h, name)
+
+    def generate(self, kind: int, n_rows: int, sf: float, row0: int = 0, param: int = 0,
+                 seed: int = 20240613) -> "DeviceTable":
+        h = C.c_void_p()
+        self._check(self._L.rsq_table_generate(self.h, kind, row0, n_rows, sf, param, seed, C.byref(h)))
+        return DeviceTable(self, h, ["lineitem", "orders", "customer", "t"][kind])
+
+    # ---- queries ----
+    def compile(self, plan: P.Plan, tables: Sequence["DeviceTable"]) -> "Query":
+        keep: list = []
+        d = plan.to_c(keep)
+        arr = (C.c_void_p * max(1, len(tables)))(*[t.h for t in tables])
+        h = C.c_void_p()
+        self._check(self._L.rsq_query_compile(self.h, C.byref(d), arr, len(tables), C.byref(h)))
+        return Query(self, h)
+
+    def run(self, plan: P.Plan, tables: Optional[Sequence["DeviceTable"]] = None) -> P.Result:
+        """upload plan.tables (unless device tables are given), compile, execute, fetch the result"""
+        own = tables is None
+        tabs = [self.table(t) for t in plan.tables] if own else list(tables)
+        try:
+            q = self.compile(plan, tabs)
+            try:
+                q.execute()
+                return q.result()
+            finally:
+                q.close()
+        finally:
+            if own:
+                for t in tabs:
+                    t.close()
+
+    def serialize_expr(self, plan: P.Plan, expr: int, derive: bool, tables: Sequence["DeviceTable"] = ()) -> str:
+        keep: list = []
+        d = plan.to_c(keep)
+        arr = (C.c_void_p * max(1, len(tables)))(*[t.h for t in tables])
+        p = self._L.rsq_serialize_expr(self.h, C.byref(d), expr, 1 if derive else 0, arr, len(tables))
+        if not p:
+            raise EngineError(2, self._L.rsq_last_error(self.h).decode())
+        s = C.string_at(p).decode("latin1")
+        self._L.rsq_free(p)
+        return s
+
+    def read_bandwidth(self, nbytes: int = 8 << 30, iters: int = 5) -> float:
+        v = C.c_double()
+        self._check(self._L.rsq_measure_read_bandwidth(self.h, nbytes, iters, C.byref(v)))
+        return v.value
+
+
+class DeviceTable:
+    def __init__(self, ctx: Context, h, name: str):
+        self.ctx, self.h, self.name = ctx, h, name
+
+    @property
+    def n_rows(self) -> int:
+        return self.ctx._L.rsq_table_rows(self.h)
+
+    def read_column(self, name: str, dtype, count: Optional[int] = None) -> np.ndarray:
+        n = self.n_rows if count is None else count
+        out = np.empty(n, dtype=dtype)
+        self.ctx._check(self.ctx._L.rsq_table_read_column(self.ctx.h, self.h, name.encode(), out.ctypes.data, out.nbytes))
+        return out
+
+    def close(self):
+        if self.h:
+            self.ctx._L.rsq_table_destroy(self.h)
+            self.h = None
+
+
+class Query:
+    def __init__(self, ctx: Context, h):
+        self.ctx, self.h = ctx, h
+
+    def execute(self):
+        self.ctx._check(self.ctx._L.rsq_query_execute(self.h))
+
+    def execute_partial(self):
+        """returns (device_pointer, n_min_words, n_max_words, n_sum_words)"""
+        p = C.c_void_p(); a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
+        self.ctx._check(self.ctx._L.rsq_query_execute_partial(self.h, C.byref(p), C.byref(a), C.byref(b), C.byref(c)))
+        return p.value, a.value, b.value, c.value
+
+    def finalize(self):
+        self.ctx._check(self.ctx._L.rsq_query_finalize(self.h))
+
+    def result(self) -> P.Result:
+        v = P.rsq_result_view()
+        self.ctx._check(self.ctx._L.rsq_query_result(self.h, C.byref(v)))
+        res = P.Result.from_view(v)
+        res.text = res.serialize()
+        return res
+
+    def report(self) -> rsq_report:
+        r = rsq_report()
+        self.ctx._check(self.ctx._L.rsq_query_report(self.h, C.byref(r)))
+        return r
+
+    @property
+    def source(self) -> str:
+        return self.ctx._L.rsq_query_source(self.h).decode()
+
+    @property
+    def explain(self) -> str:
+        return self.ctx._L.rsq_query_explain(self.h).decode()
+
+    def close(self):
+        if self.h:
+            self.ctx._L.rsq_query_destroy(self.h)
+            self.h = None
