@@ -119,6 +119,11 @@ int  rsq_query_execute(rsq_query* q);
 int  rsq_query_execute_partial(rsq_query* q, void** dev_ptr, int64_t* n_min_words, int64_t* n_max_words,
                                int64_t* n_sum_words);
 int  rsq_query_finalize(rsq_query* q);
+/* Word counts of the partial aggregate table ([min | max | sum] segments), known after compile. */
+int  rsq_query_partial_layout(const rsq_query* q, int64_t* n_min_words, int64_t* n_max_words, int64_t* n_sum_words);
+/* Make the query keep its partial aggregate table in caller-owned device memory (e.g. a torch
+ * tensor the host hands to RCCL) instead of its own allocation; `bytes` must cover all words. */
+int  rsq_query_bind_partial(rsq_query* q, void* dev_ptr, size_t bytes);
 int  rsq_query_result(rsq_query* q, rsq_result_view* out);
 int  rsq_query_report(const rsq_query* q, rsq_report* out);
 /* Generated HIP source and pipeline description of the compiled query (debugging). */

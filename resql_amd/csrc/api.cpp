@@ -173,6 +173,18 @@ int rsq_query_execute_partial(rsq_query* q, void** dev_ptr, int64_t* n_min_words
     });
 }
 
+int rsq_query_partial_layout(const rsq_query* q, int64_t* n_min_words, int64_t* n_max_words, int64_t* n_sum_words) {
+    if (!q || !n_min_words || !n_max_words || !n_sum_words) return RSQ_ERR_INVALID;
+    void* p = nullptr;
+    partialBuffer(*reinterpret_cast<const QueryHandle*>(q)->q, &p, n_min_words, n_max_words, n_sum_words);
+    return RSQ_OK;
+}
+
+int rsq_query_bind_partial(rsq_query* q, void* dev_ptr, size_t bytes) {
+    if (!q) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] { bindPartial(*QH(q)->q, dev_ptr, bytes); });
+}
+
 int rsq_query_finalize(rsq_query* q) {
     if (!q) return RSQ_ERR_INVALID;
     return guarded(QH(q)->ctx, [&] { finalizeQuery(*QH(q)->q); });

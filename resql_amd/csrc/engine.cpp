@@ -108,6 +108,7 @@ struct Query {
     int unroll = 4;
     std::vector<Accum> accums;             // [0] is the first-row tracker
     std::vector<int> splitToAccum;         // splitAgg index -> accums index
+    bool dAggOwned = true;
     uint64_t* dAgg = nullptr;              // [min words | max words | sum words], each nWords(op) * denseGroups
     std::vector<int> accumSlot;            // accums index -> word-block index in dAgg
     int64_t nMinBlocks = 0, nMaxBlocks = 0, nSumBlocks = 0;
@@ -125,7 +126,7 @@ struct Query {
     std::string allSource, explainText;
 
     explicit Query(Context& c) : ctx(c) {}
-    ~Query() { if (dAgg) ctx.free(dAgg); }
+    ~Query() { if (dAgg && dAggOwned) ctx.free(dAgg); }
 };
 
 namespace {
@@ -965,6 +966,14 @@ void finalizeQuery(Query& q) {
     Tail tail{q, q.agg, {}};
     tail.run();
     q.report.finalize_time_ms = nowMs() - t1;
+}
+
+void bindPartial(Query& q, void* dptr, size_t bytes) {
+    size_t need = q.accums.size() * (size_t)q.denseGroups * 8;
+    if (!dptr || bytes < need) failInvalid("partial buffer too small: need " + std::to_string(need) + " bytes");
+    if (q.dAgg && q.dAggOwned) q.ctx.free(q.dAgg);
+    q.dAgg = (uint64_t*)dptr;
+    q.dAggOwned = false;
 }
 
 void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum) {

@@ -92,6 +92,7 @@ struct Query;
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables);
 void executeQuery(Query& q, bool partialOnly);
 void finalizeQuery(Query& q);
+void bindPartial(Query& q, void* dptr, size_t bytes);
 void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum);
 void queryResult(Query& q, rsq_result_view* out);
 void queryReport(const Query& q, rsq_report* out);

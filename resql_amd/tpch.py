@@ -154,3 +154,14 @@ SYNTH_SCHEMA = [("a", T.BIGINT()), ("b", T.BIGINT()), ("c", T.BIGINT()), ("d", T
 
 def synthetic_table(n: int, groups: int, seed: int = datagen.SEED) -> P.Table:
     return make_table("t", SYNTH_SCHEMA, datagen.synthetic_columns(0, n, groups, seed), n)
+
+
+def standard_plans(sf: float = 0.01):
+    """the plans whose pipeline kernels are pre-compiled at build time (BASELINE.json configs)"""
+    li = lineitem_table(sf, Q1_COLUMNS + ["l_orderkey"])
+    cu, od = customer_table(sf), orders_table(sf)
+    plans = [q1_plan(li), q6_plan(li), q3_plan(cu, od, li)]
+    for groups in (8, 1024, 1 << 20):
+        for thr in (1 << 30,):
+            plans.append(synthetic_plan(synthetic_table(4096, groups), thr))
+    return plans
