@@ -113,6 +113,8 @@ struct Query {
     std::vector<int> accumSlot;            // accums index -> word-block index in dAgg
     int64_t nMinBlocks = 0, nMaxBlocks = 0, nSumBlocks = 0;
     std::vector<uint64_t> hAgg;
+    uint64_t* dAggInit = nullptr;          // identity image, copied over dAgg at the start of every execute
+    uint64_t* hPinned = nullptr;           // pinned read-back buffer: aggregate words + error word
 
     // result
     Schema resultSchema;
@@ -126,7 +128,11 @@ struct Query {
     std::string allSource, explainText;
 
     explicit Query(Context& c) : ctx(c) {}
-    ~Query() { if (dAgg && dAggOwned) ctx.free(dAgg); }
+    ~Query() {
+        if (dAgg && dAggOwned) ctx.free(dAgg);
+        if (dAggInit) ctx.free(dAggInit);
+        if (hPinned) (void)hipHostFree(hPinned);
+    }
 };
 
 namespace {
@@ -485,7 +491,7 @@ uint64_t opSize(OpNode* o) {   // getSize() estimates (operators/*.h)
 const int kRegisterGroupsMax = 8;       // groups whose accumulators live in VGPRs
 int unrollFactor() {                    // tiles in flight per wave (RSQ_UNROLL overrides, for tuning)
     const char* e = getenv("RSQ_UNROLL");
-    int u = e ? atoi(e) : 4;
+    int u = e ? atoi(e) : 2;
     return u < 1 ? 1 : u > 8 ? 8 : u;
 }
 
@@ -871,6 +877,8 @@ OpNode* findAggregation(OpNode* root) {
 // ================================================================================================
 // public (engine.h)
 // ================================================================================================
+static void prepareAggBuffers(Query& q);
+
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables) {
     double t0 = nowMs();
     std::unique_ptr<Query> q(new Query(ctx));
@@ -900,6 +908,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         size_t words = (size_t)q->accums.size() * (size_t)q->denseGroups;
         q->dAgg = (uint64_t*)ctx.alloc(words * 8);
         q->hAgg.assign(words, 0);
+        prepareAggBuffers(*q);
     }
     q->report.compilation_time_ms = nowMs() - t0;
     q->report.jit_cache_hits = ctx.jitCacheHits - hits0;
@@ -909,15 +918,20 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     return q.release();
 }
 
-static void initAggTable(Query& q) {
+// Device-resident identity image of the aggregate table (0 for sums, +/-inf for min/max) and a pinned
+// host buffer for the read-back: one execute is then {D2D init, kernel, D2H} on one stream with a single
+// host synchronisation at the end.
+static void prepareAggBuffers(Query& q) {
     const int64_t D = q.denseGroups;
-    std::vector<uint64_t> init((size_t)q.accums.size() * (size_t)D);
+    const size_t words = q.accums.size() * (size_t)D;
+    std::vector<uint64_t> init(words);
     for (size_t w = 0; w < q.accums.size(); w++) {
         uint64_t idv = q.accums[w].merge == 0 ? 0ull : q.accums[w].merge == 2 ? 0x7fffffffffffffffull : 0x8000000000000000ull;
         for (int64_t g = 0; g < D; g++) init[(size_t)(q.accumSlot[w] * D + g)] = idv;
     }
-    RSQ_HIP(hipMemcpyAsync(q.dAgg, init.data(), init.size() * 8, hipMemcpyHostToDevice, q.ctx.stream));
-    RSQ_HIP(hipStreamSynchronize(q.ctx.stream));   // `init` is a pageable temporary
+    q.dAggInit = (uint64_t*)q.ctx.alloc(words * 8);
+    RSQ_HIP(hipMemcpy(q.dAggInit, init.data(), words * 8, hipMemcpyHostToDevice));
+    RSQ_HIP(hipHostMalloc((void**)&q.hPinned, words * 8 + 8, hipHostMallocDefault));
 }
 
 void executeQuery(Query& q, bool partialOnly) {
@@ -925,7 +939,8 @@ void executeQuery(Query& q, bool partialOnly) {
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(ctx.device));
     double t0 = nowMs();
-    initAggTable(q);
+    const size_t words = q.hAgg.size();
+    RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, words * 8, hipMemcpyDeviceToDevice, ctx.stream));
     RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
     q.report.num_kernels = 0; q.report.bytes_read = 0;
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
@@ -939,17 +954,18 @@ void executeQuery(Query& q, bool partialOnly) {
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
     }
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
-    uint32_t err = 0;
-    RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
-    if (!partialOnly) RSQ_HIP(hipMemcpyAsync(q.hAgg.data(), q.dAgg, q.hAgg.size() * 8, hipMemcpyDeviceToHost, ctx.stream));
+    RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+    if (!partialOnly) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, words * 8, hipMemcpyDeviceToHost, ctx.stream));
     RSQ_HIP(hipStreamSynchronize(ctx.stream));
     float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
     q.report.kernel_time_ms = ms;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
+    uint32_t err = (uint32_t)q.hPinned[words];
     if (err & 1) failRuntime("Division by zero");
     if (err) failRuntime("device error word " + std::to_string(err));
     if (!partialOnly) {
         double t1 = nowMs();
+        memcpy(q.hAgg.data(), q.hPinned, words * 8);
         Tail tail{q, q.agg, {}};
         tail.run();
         q.report.finalize_time_ms = nowMs() - t1;

@@ -2,6 +2,7 @@
 #include "hostref.h"
 
 #include <algorithm>
+#include <map>
 
 namespace rsq {
 
@@ -56,29 +57,29 @@ uint64_t refHashValue(uint64_t h, Val v, const Type& t) {
 }
 
 namespace {
+// The reference's table has numEntries slots, but only the occupied ones matter: keep them in an
+// ordered map (slot -> {hash, group}) so replaying a handful of groups does not touch a table sized
+// for millions of input rows.
 struct Sim {
     uint64_t numEntries, threshold, numInserts = 0;
-    std::vector<uint8_t> used;
-    std::vector<uint64_t> hash;
-    std::vector<size_t> who;
+    std::map<uint64_t, std::pair<uint64_t, size_t>> slots;
     explicit Sim(uint64_t minSize) {
         numEntries = primeAbove(minSize);
         threshold = numEntries * 6 / 10;
-        used.assign(numEntries, 0); hash.assign(numEntries, 0); who.assign(numEntries, 0);
     }
     void put(uint64_t h, size_t id) {
         numInserts++;
         if (numInserts > threshold) grow();
         uint64_t loc = h % numEntries;
         for (uint64_t n = 0; n < numEntries; n++) {
-            if (!used[loc]) { used[loc] = 1; hash[loc] = h; who[loc] = id; return; }
+            if (slots.find(loc) == slots.end()) { slots[loc] = {h, id}; return; }
             if (++loc >= numEntries) loc = 0;
         }
         failRuntime("Hash table full");
     }
     void grow() {
         Sim bigger(numEntries + 1);
-        for (uint64_t i = 0; i < numEntries; i++) if (used[i]) bigger.put(hash[i], who[i]);
+        for (auto& kv : slots) bigger.put(kv.second.first, kv.second.second);   // old table in slot order
         *this = std::move(bigger);
     }
 };
@@ -89,7 +90,7 @@ std::vector<size_t> refEmissionOrder(const std::vector<uint64_t>& hashes, uint64
     for (size_t i = 0; i < hashes.size(); i++) sim.put(hashes[i], i);
     std::vector<size_t> order;
     order.reserve(hashes.size());
-    for (uint64_t s = 0; s < sim.numEntries; s++) if (sim.used[s]) order.push_back(sim.who[s]);
+    for (auto& kv : sim.slots) order.push_back(kv.second.second);
     return order;
 }
 
