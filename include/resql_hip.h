@@ -119,6 +119,10 @@ int  rsq_query_execute(rsq_query* q);
 int  rsq_query_execute_partial(rsq_query* q, void** dev_ptr, int64_t* n_min_words, int64_t* n_max_words,
                                int64_t* n_sum_words);
 int  rsq_query_finalize(rsq_query* q);
+/* Same, from a partial aggregate table that is already in host memory (n_words int64 words in the
+ * layout above).  Needs no device: it is the merge + finalisation step of the multi-GPU path in
+ * isolation, which is how the CPU-only tests cover it (gloo). */
+int  rsq_query_finalize_host(rsq_query* q, const int64_t* words, int64_t n_words);
 /* Word counts of the partial aggregate table ([min | max | sum] segments), known after compile. */
 int  rsq_query_partial_layout(const rsq_query* q, int64_t* n_min_words, int64_t* n_max_words, int64_t* n_sum_words);
 /* Make the query keep its partial aggregate table in caller-owned device memory (e.g. a torch

@@ -273,19 +273,67 @@ void generateTable(Context& ctx, Table& t, int kind, int64_t row0, int64_t nRows
 }
 
 // ------------------------------------------------------------------------------------------------
+// hash-table helpers
+// ------------------------------------------------------------------------------------------------
+struct __attribute__((aligned(16))) u64x2 { u64 x, y; };
+
+__global__ void __launch_bounds__(256) k_fill_u64(u64* __restrict__ p, i64 n, u64 v) {
+    // 16-byte stores where aligned (hipMalloc pointers + even offsets); tail with 8-byte stores
+    i64 n2 = n >> 1;
+    u64x2 vv; vv.x = v; vv.y = v;
+    u64x2* p2 = reinterpret_cast<u64x2*>(p);
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n2; i += (i64)gridDim.x * blockDim.x) p2[i] = vv;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) p[n - 1] = v;
+}
+
+void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value) {
+    if (n == 0) return;
+    if (value == 0) { RSQ_HIP(hipMemsetAsync(dptr, 0, n * 8, ctx.stream)); return; }
+    if (((uintptr_t)dptr & 15) != 0) throw Error(RSQ_ERR_DEVICE, "fillU64Async: unaligned destination");
+    unsigned grid = (unsigned)std::min<size_t>(2048, (n / 2 + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_fill_u64, dim3(grid), dim3(256), 0, ctx.stream, (u64*)dptr, (i64)n, (u64)value);
+    RSQ_HIP(hipGetLastError());
+}
+
+__global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__ first, i64 cap, const i64* __restrict__ words, int nWords,
+                                                         const i64* __restrict__ acc, int nAcc, i64* __restrict__ out, unsigned* count) {
+    const int stride = 1 + nWords + nAcc;
+    for (i64 s = blockIdx.x * (i64)blockDim.x + threadIdx.x; s < cap; s += (i64)gridDim.x * blockDim.x) {
+        const i64 f = first[s];
+        if (f == 0x7fffffffffffffffll) continue;
+        // (the compiler folds the per-thread increments of one wave into one atomic)
+        const unsigned pos = atomicAdd(count, 1u);
+        i64* o = out + (size_t)pos * stride;
+        o[0] = f;
+        for (int w = 0; w < nWords; w++) o[1 + w] = words[(size_t)w * cap + s];
+        for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
+    }
+}
+
+void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,
+                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t* count) {
+    unsigned grid = (unsigned)std::min<int64_t>(2048, (capacity + 255) / 256);
+    hipLaunchKernelGGL(k_compact_entries, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, (const i64*)words, nWords,
+                       (const i64*)acc, nAcc, (i64*)outRows, count);
+    RSQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // streaming read bandwidth probe
 // ------------------------------------------------------------------------------------------------
-struct __attribute__((aligned(16))) ll2 { i64 x, y; };
+typedef i64 ll2 __attribute__((ext_vector_type(2)));
 
+// 16 B per lane, unit stride, non-temporal (the same access form the pipeline kernels use for 8-byte columns)
 __global__ void __launch_bounds__(256) k_read_sum(const ll2* __restrict__ p, i64 n2, u64* out) {
     u64 s = 0;
     i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x;
     const i64 stride = (i64)gridDim.x * blockDim.x;
     for (; i + 3 * stride < n2; i += 4 * stride) {
-        ll2 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        ll2 a = __builtin_nontemporal_load(p + i), b = __builtin_nontemporal_load(p + i + stride);
+        ll2 c = __builtin_nontemporal_load(p + i + 2 * stride), d = __builtin_nontemporal_load(p + i + 3 * stride);
         s += (u64)a.x + (u64)a.y + (u64)b.x + (u64)b.y + (u64)c.x + (u64)c.y + (u64)d.x + (u64)d.y;
     }
-    for (; i < n2; i += stride) { ll2 a = p[i]; s += (u64)a.x + (u64)a.y; }
+    for (; i < n2; i += stride) { ll2 a = __builtin_nontemporal_load(p + i); s += (u64)a.x + (u64)a.y; }
     for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
     if ((threadIdx.x & 63) == 0 && s != 0x1234567) atomicAdd(out, s);
 }
@@ -298,7 +346,7 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters) {
     u64* out = (u64*)ctx.alloc(8);
     RSQ_HIP(hipMemsetAsync(buf, 1, bytes, ctx.stream));
     RSQ_HIP(hipMemsetAsync(out, 0, 8, ctx.stream));
-    const unsigned grid = 256 * 8;
+    const unsigned grid = (unsigned)(2 * ctx.numCUs);     // the geometry the pipeline kernels use
     hipLaunchKernelGGL(k_read_sum, dim3(grid), dim3(256), 0, ctx.stream, (const ll2*)buf, (i64)(bytes / 16), out);   // warm-up
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     for (int i = 0; i < iters; i++)

@@ -1,0 +1,830 @@
+// codegen.cpp — operator tree -> device pipelines (HIP source per pipeline).
+//
+// Mirrors the reference's produce/consume code generation (reference src/operators/*.h driven from
+// src/execute.h:228): produce() walks down to the scans; every scan opens a pipeline (scan.h:227-263)
+// and the operators above it consume() into the body of that pipeline's row function until a
+// pipeline breaker ends it — hash-join build (hashjoin.h:226-256) or aggregation
+// (aggregation.h:240-295).  The hand-written skeleton around the row function (tile loads,
+// reductions, hash-table access) comes from kernels/rsq_device.h.
+#include <algorithm>
+#include <cstring>
+#include <sstream>
+
+#include "engine_internal.h"
+
+namespace rsq {
+
+namespace {
+
+struct Sym { std::string var; Type type; };
+
+int envInt(const char* name, int def, int lo, int hi) {
+    const char* e = getenv(name);
+    int v = e ? atoi(e) : def;
+    return v < lo ? lo : v > hi ? hi : v;
+}
+
+int64_t nextPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
+
+// ================================================================================================
+// expressions -> device code (emitExpression, reference src/ExpressionsJitFlounder.h:1080-1114)
+// ================================================================================================
+struct ExprGen {
+    std::map<std::string, Sym> symbols;     // JitContextFlounder::symbolTable of the current pipeline
+
+    static std::string ctype(const Type& t) {
+        switch (t.tag) {
+            case RSQ_BIGINT: case RSQ_DECIMAL: return "i64";
+            case RSQ_INT: case RSQ_DATE: return "i32";
+            case RSQ_BOOL: return "u8";
+            case RSQ_CHAR: return t.len == 1 ? "u8" : "rsq::Str";
+            case RSQ_VARCHAR: return "rsq::Str";
+            default: failType("no device type for " + serializeType(t));
+        }
+    }
+    static std::string lit64(int64_t v) {
+        if (v == INT64_MIN) return "((i64)0x8000000000000000ull)";
+        return "((i64)" + std::to_string((long long)v) + "ll)";
+    }
+    static std::string cstring(const std::string& s) {
+        std::string o = "\"";
+        for (unsigned char c : s) {
+            char buf[8];
+            if (c == '"' || c == '\\') { o += '\\'; o += (char)c; }
+            else if (c < 32 || c > 126) { snprintf(buf, sizeof buf, "\\%03o", c); o += buf; }
+            else o += (char)c;
+        }
+        return o + "\"";
+    }
+    static int64_t pow10(int n) { int64_t v = 1; while (n-- > 0) v *= 10; return v; }
+
+    std::string constant(const Expr* e) {
+        switch (e->type.tag) {
+            case RSQ_DECIMAL: case RSQ_BIGINT: return lit64(e->ival);
+            case RSQ_INT: case RSQ_DATE: return "((i32)" + std::to_string((long long)(int32_t)e->ival) + ")";
+            case RSQ_BOOL: return "((u8)" + std::to_string((int)(uint8_t)e->ival) + ")";
+            case RSQ_CHAR:
+                if (e->type.len == 1) return "((u8)" + std::to_string((int)(uint8_t)e->ival) + ")";
+                [[fallthrough]];
+            case RSQ_VARCHAR: return "rsq::str(" + cstring(e->symbol) + ", " + std::to_string(e->type.len) + ")";
+            default: failType("Constant code generation not implemented for datatype");
+        }
+    }
+
+    std::string emit(Expr* e) {
+        if (e->type.tag == RSQ_NT) failType("Expression type undefined in emitExpression(..). Have you derived the expression types?");
+        auto it = symbols.find(expressionName(e));
+        if (it != symbols.end()) return it->second.var;          // value already available under this name
+        switch (e->structure) {
+            case LITERAL:
+                if (e->tag == RSQ_E_ATTRIBUTE) failType("attribute " + e->symbol + " is not available in this pipeline");
+                if (e->tag == RSQ_E_CONSTANT) return constant(e);
+                if (e->tag == RSQ_E_STAR) return "((i64)0)";
+                failType(std::string("emitExpressionLiteral(..) not implemented for expression type") + exprTagNames[e->tag]);
+            case UNARY: return emitUnary(e);
+            case BINARY: return emitBinary(e);
+            case OTHER: return emitCase(e);
+            default: failType("emitExpression(..)");
+        }
+    }
+
+    std::string emitUnary(Expr* e) {
+        if (e->tag == RSQ_E_COUNT) return "((i64)1)";           // emitCount: every row counts
+        std::string c = emit(e->child);
+        const Type from = e->child->type, to = e->type;
+        switch (e->tag) {
+            case RSQ_E_SUM: case RSQ_E_AVG: case RSQ_E_MIN: case RSQ_E_MAX: case RSQ_E_AS: return c;
+            case RSQ_E_TYPECAST:
+                if (to.tag == RSQ_DECIMAL) {
+                    if (from.tag == RSQ_DECIMAL) {
+                        if (to.scale == from.scale) return c;
+                        int d = to.scale - from.scale;
+                        if (d > 8 || d < -8) failType("typecast beyond the supported scale difference");
+                        if (d > 0) return "rsq::mul(" + c + ", " + lit64(pow10(d)) + ")";
+                        return "((i64)((" + c + ") / " + lit64(pow10(-d)) + "))";
+                    }
+                    if (from.tag == RSQ_BIGINT) {
+                        if (to.scale > 8) failType("typecast beyond the supported scale");
+                        return "rsq::mul(" + c + ", " + lit64(pow10(to.scale)) + ")";
+                    }
+                    failType("emitTypecastToDECIMAL(..) code generation not implemented for datatype");
+                }
+                if (to.tag == RSQ_BIGINT) {
+                    if (from.tag == RSQ_INT) return "((i64)(" + c + "))";
+                    if (from.tag == RSQ_DECIMAL) {
+                        if (from.scale > 8) failType("typecast beyond the supported scale");
+                        return "((i64)((" + c + ") / " + lit64(pow10(from.scale)) + "))";
+                    }
+                    if (from.tag == RSQ_BIGINT) return c;
+                    failType("emitTypecastToBIGINT(..) code generation not implemented for datatype");
+                }
+                failType("emitTypecast(..) code generation not implemented for datatype");
+            default:
+                failType(std::string("emitExpression(..) not implemented for expression type") + exprTagNames[e->tag]);
+        }
+    }
+
+    std::string emitBinary(Expr* e) {
+        std::string l = emit(e->child), r = emit(e->child->next);
+        const Type res = e->type, op = e->child->type;
+        auto arithOk = [&]() {
+            if (res.tag != RSQ_DECIMAL && res.tag != RSQ_BIGINT)
+                failType(std::string(exprTagNames[e->tag]) + " code generation not implemented for datatype");
+        };
+        auto orderedOk = [&]() {
+            if (op.tag != RSQ_DECIMAL && op.tag != RSQ_DATE && op.tag != RSQ_BIGINT)
+                failType(std::string(exprTagNames[e->tag]) + " code generation not implemented for datatype");
+        };
+        auto equals = [&]() -> std::string {
+            switch (op.tag) {
+                case RSQ_DECIMAL: case RSQ_INT: case RSQ_BIGINT: case RSQ_BOOL: case RSQ_DATE:
+                    return "((u8)((" + l + ") == (" + r + ")))";
+                case RSQ_CHAR:
+                    if (op.len > 1) return "rsq::compare_char(" + l + ", " + r + ")";
+                    return "((u8)((" + l + ") == (" + r + ")))";
+                case RSQ_VARCHAR: return "rsq::compare_varchar(" + l + ", " + r + ")";
+                default: failType("EQUALS code generation not implemented for datatype");
+            }
+        };
+        switch (e->tag) {
+            case RSQ_E_ADD: arithOk(); return "rsq::add(" + l + ", " + r + ")";
+            case RSQ_E_SUB: arithOk(); return "rsq::sub(" + l + ", " + r + ")";
+            case RSQ_E_MUL: arithOk(); return "rsq::mul(" + l + ", " + r + ")";
+            case RSQ_E_DIV: arithOk(); return "rsq::div(" + l + ", " + r + ", a.err)";
+            case RSQ_E_AND: return "((u8)((" + l + ") & (" + r + ")))";      // no short circuit, as in the reference
+            case RSQ_E_OR: return "((u8)((" + l + ") | (" + r + ")))";
+            case RSQ_E_LT: orderedOk(); return "((u8)((" + l + ") < (" + r + ")))";
+            case RSQ_E_LE: orderedOk(); return "((u8)((" + l + ") <= (" + r + ")))";
+            case RSQ_E_GT: orderedOk(); return "((u8)((" + l + ") > (" + r + ")))";
+            case RSQ_E_GE: orderedOk(); return "((u8)((" + l + ") >= (" + r + ")))";
+            case RSQ_E_EQ: return equals();
+            case RSQ_E_NEQ: return "((u8)(1 - " + equals() + "))";
+            case RSQ_E_LIKE: failUnsupported("LIKE is not implemented by the GPU engine (outside the hot path, SURVEY §2)");
+            default: failType(std::string("emitExpressionBinary(..) not implemented for expression type") + exprTagNames[e->tag]);
+        }
+    }
+
+    std::string emitCase(Expr* e) {   // ExpressionsJitFlounder.h:720-754
+        std::string out, close;
+        Expr* c = e->child;
+        for (; c && c->tag == RSQ_E_WHENTHEN; c = c->next) {
+            out += "((" + emit(c->child) + ") ? (" + emit(c->child->next) + ") : ";
+            close += ")";
+        }
+        if (c) out += "(" + emit(c) + ")";
+        else out += (e->type.isString() ? std::string("rsq::str(\"\", 0)") : "((" + ctype(e->type) + ")0)");
+        return out + close;
+    }
+};
+
+// value of a 64-bit table word as a typed device value, and back
+std::string fromWord(const std::string& w, const Type& t) {
+    switch (t.tag) {
+        case RSQ_BIGINT: case RSQ_DECIMAL: return w;
+        case RSQ_INT: case RSQ_DATE: return "((i32)(" + w + "))";
+        case RSQ_BOOL: return "((u8)(" + w + "))";
+        case RSQ_CHAR: if (t.len == 1) return "((u8)(" + w + "))"; [[fallthrough]];
+        default: failUnsupported("string values cannot be carried through a join in this engine version");
+    }
+}
+std::string toWord(const std::string& v, const Type& t) {
+    if (t.isString()) failUnsupported("string values cannot be carried through a join in this engine version");
+    return "((i64)(" + v + "))";
+}
+
+// ================================================================================================
+// the walk
+// ================================================================================================
+struct Walker {
+    Query& q;
+    ExprGen eg;
+
+    // state of the pipeline under construction
+    Pipeline pipe;
+    std::vector<std::string> colTypes;        // device type per scanned (vector-loadable) column
+    std::vector<int> colIsString;
+    std::string rowParams, rowArgsTail;
+    std::string body;                          // row function body
+    std::string closers;                       // closing braces of the open scopes
+    std::string stateDecl, stateInit, prologue, epilogue, fileScope;
+    std::vector<std::string> explainSteps;
+    int indent = 1;
+    int matchSlotTable = -1;                   // innermost single-match probe whose slot variable is in scope
+    std::map<int, std::string> slotVar;        // hash table id -> device variable holding the matched slot
+    std::map<std::string, int> symbolOrigin;   // symbol -> hash table id it was read from (or -1: scan column)
+    std::map<std::string, int> symbolWord;     // symbol -> word index in that table
+    bool multiMatchAbove = false;
+
+    explicit Walker(Query& q_) : q(q_) {}
+
+    void line(const std::string& s) { body += std::string((size_t)indent * 4, ' ') + s + "\n"; }
+    void openScope(const std::string& head) { line(head); indent++; }
+    void closeScope() { indent--; line("}"); }
+    void addArg(const std::string& name, const std::string& ctype, uint64_t v) {
+        for (auto& a : pipe.args) if (a.name == name) return;
+        pipe.args.push_back({name, ctype, v});
+    }
+
+    // -------------------------------------------------------------------------------------------
+    void produce(OpNode* o, std::vector<std::string> request) {
+        switch (o->tag) {
+            case RSQ_OP_SCAN: produceScan(o, request); break;
+            case RSQ_OP_SELECTION: {                    // selection.h:39-49
+                o->schema.clear();
+                std::vector<std::string> r = request;
+                requiredAttributes(o->exprs[0], r);
+                requestOf[o] = request;
+                produce(o->child[0], r);
+                break;
+            }
+            case RSQ_OP_PROJECTION: {                   // projection.h:40-59
+                std::vector<std::string> r;
+                for (Expr* e : o->exprs) requiredAttributes(e, r);
+                produce(o->child[0], r);
+                break;
+            }
+            case RSQ_OP_HASHJOIN: {                     // hashjoin.h:98-116
+                requestOf[o] = request;
+                std::vector<std::string> all = request;
+                for (Expr* e : o->exprs) requiredAttributes(e, all);
+                joinPhase[o] = 1;
+                produce(o->child[0], all);              // build pipeline(s)
+                joinPhase[o] = 2;
+                produce(o->child[1], all);              // probe pipeline(s)
+                break;
+            }
+            case RSQ_OP_AGGREGATION: {                  // aggregation.h:155-164
+                if (q.agg) failUnsupported("more than one aggregation in a plan");
+                q.agg = o;
+                std::vector<std::string> r;
+                for (Expr* e : o->exprs) requiredAttributes(e, r);
+                for (Expr* e : o->exprs2) requiredAttributes(e, r);
+                produce(o->child[0], r);
+                break;                                   // everything above runs on the host (tail.cpp)
+            }
+            case RSQ_OP_MATERIALIZE: case RSQ_OP_ORDERBY:
+                produce(o->child[0], request);
+                break;
+            default: failUnsupported("operator not supported by the GPU engine");
+        }
+    }
+
+    std::map<OpNode*, std::vector<std::string>> requestOf;
+    std::map<OpNode*, int> joinPhase;
+
+    static bool has(const std::vector<std::string>& v, const std::string& s) { return std::find(v.begin(), v.end(), s) != v.end(); }
+
+    Schema prune(const Schema& s, const std::vector<std::string>& req) {
+        Schema r;
+        for (auto& a : s) if (has(req, a.name)) r.push_back(a);
+        return r;
+    }
+
+    // -------------------------------------------------------------------------------------------
+    void produceScan(OpNode* o, std::vector<std::string> request) {     // scan.h:221-263
+        Table* t = o->table;
+        if (q.requestAll) request.clear();
+        pipe = Pipeline();
+        pipe.src = t;
+        // tuned on MI355X with TPC-H Q1 SF10 (profiles/): 1 tile in flight per wave + non-temporal loads
+        // 0.395 ms; 2 tiles 0.42 ms; 4 tiles 0.47 ms (fewer resident waves); without nt loads 0.45-0.47 ms
+        pipe.unroll = envInt("RSQ_UNROLL", 1, 1, 8);
+        // workgroups (of 256 threads) per launch; 0 = 2 per CU.  Measured on MI355X (Q1 SF10): 512 workgroups 0.348 ms,
+        // 768: 0.367, 1024: 0.374, 2048: 0.395, 4096: 0.448 - a streaming kernel wants exactly 2 resident workgroups per CU
+        pipe.maxGrid = (unsigned)envInt("RSQ_MAXGRID", 0, 0, 1 << 20);
+        colTypes.clear(); colIsString.clear(); rowParams.clear(); rowArgsTail.clear();
+        body.clear(); stateDecl.clear(); stateInit.clear(); prologue.clear(); epilogue.clear(); fileScope.clear();
+        explainSteps.clear(); indent = 1; matchSlotTable = -1; slotVar.clear(); symbolOrigin.clear(); symbolWord.clear();
+        multiMatchAbove = false;
+        eg.symbols.clear();
+        o->schema.clear();
+        for (size_t ci = 0; ci < t->cols.size(); ci++) {
+            const TableColumn& c = t->cols[ci];
+            // Values::dematerialize(..., required): an empty request set means all attributes
+            if (!request.empty() && !has(request, c.name)) continue;
+            if (!c.dptr) {
+                if (request.empty()) continue;   // declared without data: cannot be part of `select *`
+                failInvalid("column " + c.name + " is needed by the plan but was declared without data");
+            }
+            int k = (int)pipe.cols.size();
+            pipe.cols.push_back((int)ci);
+            std::string var = "v_" + std::to_string(k);
+            eg.symbols[c.name] = Sym{var, c.type};
+            symbolOrigin[c.name] = -1;
+            o->schema.push_back({c.name, c.type});
+            pipe.bytesPerRow += columnWidth(c.type);
+            if (c.type.isString()) {
+                addArg("c" + std::to_string(k), "const char*", (uint64_t)(uintptr_t)c.dptr);
+                colIsString.push_back(1); colTypes.push_back("");
+                line("const rsq::Str " + var + " = rsq::str(a.c" + std::to_string(k) + " + lr * " + std::to_string(c.type.len) + ", " +
+                     std::to_string(c.type.len) + ");");
+            } else {
+                std::string ct = ExprGen::ctype(c.type);
+                addArg("c" + std::to_string(k), "const " + ct + "*", (uint64_t)(uintptr_t)c.dptr);
+                colIsString.push_back(0); colTypes.push_back(ct);
+                rowParams += ", " + ct + " " + var;
+                rowArgsTail += ", a.c" + std::to_string(k) + "[r]";
+            }
+        }
+        explainSteps.push_back("scan " + t->name + " [" + std::to_string((long long)t->nRows) + " rows, " +
+                               std::to_string((long long)pipe.bytesPerRow) + " B/row]");
+        consume(o->parent, o);
+        finishPipeline();
+    }
+
+    // -------------------------------------------------------------------------------------------
+    void consume(OpNode* o, OpNode* from) {
+        if (!o) failInvalid("plan root must be a materializing operator");
+        switch (o->tag) {
+            case RSQ_OP_SELECTION: {                    // selection.h:52-70
+                o->schema = from->schema;
+                if (!q.requestAll) o->schema = prune(o->schema, requestOf[o]);
+                q.pool.addId(o->exprs[0]);
+                openScope("if (" + eg.emit(o->exprs[0]) + ") {");
+                explainSteps.push_back("selection " + serializeExpr(o->exprs[0]));
+                consume(o->parent, o);
+                closeScope();
+                break;
+            }
+            case RSQ_OP_PROJECTION: {                   // projection.h:62-72
+                Schema s;
+                std::vector<std::pair<std::string, Sym>> defs;
+                openScope("{");
+                int k = 0;
+                for (Expr* e : o->exprs) {
+                    q.pool.addId(e);
+                    std::string var = "p" + std::to_string((int)(size_t)o->exprs.size()) + "_" + std::to_string(k++) + "_" + std::to_string(indent);
+                    line("const " + ExprGen::ctype(e->type) + " " + var + " = " + eg.emit(e) + ";");
+                    defs.push_back({expressionName(e), Sym{var, e->type}});
+                    s.push_back({expressionName(e), e->type});
+                }
+                for (auto& d : defs) { eg.symbols[d.first] = d.second; symbolOrigin[d.first] = -2; }
+                o->schema = s;
+                consume(o->parent, o);
+                closeScope();
+                break;
+            }
+            case RSQ_OP_HASHJOIN:
+                if (joinPhase[o] == 1) consumeBuild(o, from); else consumeProbe(o, from);
+                break;
+            case RSQ_OP_AGGREGATION: consumeAggregation(o, from); break;
+            case RSQ_OP_MATERIALIZE:
+                failUnsupported("plans without an aggregation (device-side materialisation) are not built yet in this engine version");
+            default: failUnsupported("operator not supported by the GPU engine");
+        }
+    }
+
+    // ---- hash join build (hashjoin.h:226-256) ---------------------------------------------------
+    std::string hashOf(const std::vector<std::string>& keyVars) {
+        std::string h = "rsq::hash64((u64)" + keyVars[0] + ")";
+        for (size_t i = 1; i < keyVars.size(); i++) h = "rsq::hash64(" + h + " ^ ((u64)" + keyVars[i] + " * 0x9E3779B97F4A7C15ull))";
+        return h;
+    }
+
+    void consumeBuild(OpNode* o, OpNode* from) {
+        std::unique_ptr<HashTable> ht(new HashTable());
+        ht->id = (int)q.hashTables.size();
+        ht->unique = o->singleMatch;
+        const std::string T = "ht" + std::to_string(ht->id);
+        std::vector<std::string> keyVars;
+        openScope("{");
+        int k = 0;
+        for (Expr* eq : o->exprs) {
+            if (eq->tag != RSQ_E_EQ) failType("The elements of the expression list passed to equalitiesLeftSide(..) need the tag Expr::EQ");
+            Expr* l = eq->child;
+            q.pool.addId(l);
+            std::string kv = T + "_k" + std::to_string(k++);
+            line("const i64 " + kv + " = " + toWord(eg.emit(l), l->type) + ";");
+            keyVars.push_back(kv);
+            ht->keys.push_back({expressionName(l), l->type});
+        }
+        // build payload = the attributes of the left child's schema (Values::get(_lChild->_schema))
+        for (auto& a : from->schema) {
+            auto it = eg.symbols.find(a.name);
+            if (it == eg.symbols.end()) failType("hash join build value " + a.name + " has no symbol");
+            ht->payload.push_back({a.name, it->second.type});
+        }
+        // capacity: the reference sizes its table lChild.getSize() * 5 / 3 and grows it; ours cannot grow
+        // inside a kernel, so it is sized for twice the rows the build pipeline can deliver and re-run
+        // at double size if it still overflows (engine.cpp).
+        ht->capacity = 0;     // decided by the sizing pass at execute time (engine.cpp)
+        addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
+        addArg(T + "_countonly", "u64", 0);
+        // sizing pass: the same pipeline run once with countonly = 1 tells the host how many entries to expect
+        openScope("if (a." + T + "_countonly) { atomicAdd(a." + T + "_count, 1u); } else {");
+        line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
+        line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
+        line("u64 " + T + "_n = 0;");
+        openScope("for (;; " + T + "_n++) {");
+        line("if (" + T + "_n > " + T + "_mask) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
+        line("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) break;");
+        line(T + "_s = (" + T + "_s + 1) & " + T + "_mask;");
+        closeScope();
+        openScope("if (" + T + "_n <= " + T + "_mask) {");
+        int w = 0;
+        for (auto& kv : keyVars) line("a." + T + "_words[" + std::to_string(w++) + " * a." + T + "_cap + " + T + "_s] = " + kv + ";");
+        for (auto& p : ht->payload)
+            line("a." + T + "_words[" + std::to_string(w++) + " * a." + T + "_cap + " + T + "_s] = " + toWord(eg.symbols[p.name].var, p.type) + ";");
+        line("atomicAdd(a." + T + "_count, 1u);");
+        closeScope();
+        closeScope();
+        closeScope();
+        pipe.sink = SinkKind::BUILD;
+        pipe.buildTable = ht->id;
+        o->hashTable = ht->id;
+        explainSteps.push_back("build hash table " + T + " (" + std::to_string(ht->keys.size()) + " key(s), " +
+                               std::to_string(ht->payload.size()) + " payload word(s), sized by a counting pass)");
+        q.hashTables.push_back(std::move(ht));
+    }
+
+    // ---- hash join probe (hashjoin.h:118-214) ---------------------------------------------------
+    void consumeProbe(OpNode* o, OpNode* from) {
+        HashTable& ht = *q.hashTables[(size_t)o->hashTable];
+        const std::string T = "ht" + std::to_string(ht.id);
+        o->schema = o->child[0]->schema;
+        for (auto& a : from->schema) o->schema.push_back(a);
+        if (!q.requestAll) o->schema = prune(o->schema, requestOf[o]);
+        std::vector<std::string> keyVars;
+        openScope("{");
+        int k = 0;
+        std::vector<std::string> probeKeyNames;
+        for (Expr* eq : o->exprs) {
+            Expr* r = eq->child->next;
+            q.pool.addId(r);
+            std::string kv = T + "_p" + std::to_string(k++);
+            line("const i64 " + kv + " = " + toWord(eg.emit(r), r->type) + ";");
+            keyVars.push_back(kv);
+            probeKeyNames.push_back(expressionName(r));
+        }
+        addArg(T + "_state", "const u32*", 0); addArg(T + "_words", "const i64*", 0); addArg(T + "_cap", "u64", 0);
+        line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
+        line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
+        openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
+        line("if (a." + T + "_state[" + T + "_s] == 0u) break;");
+        std::string cond;
+        for (size_t i = 0; i < keyVars.size(); i++)
+            cond += (i ? " && " : "") + std::string("a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s] == " + keyVars[i];
+        openScope("if (" + cond + ") {");
+        // the build side's values become symbols (hashjoin.h:146-147 / 204-205)
+        int w = (int)ht.keys.size();
+        for (auto& p : ht.payload) {
+            std::string var = T + "_v" + std::to_string(w);
+            line("const " + ExprGen::ctype(p.type) + " " + var + " = " + fromWord("a." + T + "_words[" + std::to_string(w) + " * a." + T + "_cap + " + T + "_s]", p.type) + ";");
+            eg.symbols[p.name] = Sym{var, p.type};
+            symbolOrigin[p.name] = ht.id; symbolWord[p.name] = w;
+            w++;
+        }
+        // probe-side key attributes are equal to the build keys of the matched entry
+        for (size_t i = 0; i < probeKeyNames.size(); i++)
+            if (symbolOrigin.count(probeKeyNames[i]) && symbolOrigin[probeKeyNames[i]] == -1) probeKeyOf[probeKeyNames[i]] = {ht.id, (int)i};
+        int prevMatch = matchSlotTable; bool prevMulti = multiMatchAbove;
+        slotVar[ht.id] = T + "_s";
+        if (o->singleMatch) matchSlotTable = ht.id; else { multiMatchAbove = true; }
+        explainSteps.push_back(std::string("probe ") + T + (o->singleMatch ? " (single match)" : " (all matches)"));
+        consume(o->parent, o);
+        matchSlotTable = prevMatch; multiMatchAbove = prevMulti;
+        if (o->singleMatch) line("break;");
+        closeScope();
+        closeScope();
+        closeScope();
+    }
+    std::map<std::string, std::pair<int, int>> probeKeyOf;   // probe-side key symbol -> (table, key word)
+
+    // ---- aggregation (aggregation.h:240-295) ----------------------------------------------------
+    void collectAccumulators(OpNode* o) {
+        for (Expr* g : o->exprs2) q.pool.addId(g);
+        for (Expr* s : o->splitAgg) q.pool.addId(s);
+        q.accums.clear(); q.splitToAccum.clear();
+        // accumulator 0: first input row of the group (drives the reference's emission order)
+        q.accums.push_back(Accum{RSQ_E_MIN, "#firstrow", "row", Type(RSQ_BIGINT), 2});
+        for (Expr* s : o->splitAgg) {
+            Accum ac; ac.kind = s->tag; ac.type = s->type;
+            switch (s->tag) {
+                case RSQ_E_COUNT: ac.key = "COUNT"; ac.input = "((i64)1)"; ac.merge = 0; break;
+                case RSQ_E_SUM:
+                    if (s->type.tag != RSQ_DECIMAL && s->type.tag != RSQ_BIGINT) failType("ADD code generation not implemented for datatype");
+                    ac.key = "SUM" + structuralKey(s->child); ac.input = eg.emit(s); ac.merge = 0; break;
+                case RSQ_E_MIN: case RSQ_E_MAX:
+                    if (s->type.tag != RSQ_DECIMAL && s->type.tag != RSQ_BIGINT && s->type.tag != RSQ_DATE)
+                        failType("LESS_THAN code generation not implemented for datatype");
+                    ac.key = std::string(s->tag == RSQ_E_MIN ? "MIN" : "MAX") + structuralKey(s->child);
+                    ac.input = "((i64)(" + eg.emit(s) + "))"; ac.merge = s->tag == RSQ_E_MIN ? 2 : 3; break;
+                default: failType("Aggregation type not implemented in updateAggregates(..).");
+            }
+            int found = -1;
+            for (size_t i = 1; i < q.accums.size(); i++) if (q.accums[i].key == ac.key) found = (int)i;
+            if (found < 0) { q.accums.push_back(ac); found = (int)q.accums.size() - 1; }
+            q.splitToAccum.push_back(found);
+        }
+        // word blocks ordered [min | max | sum] so that each segment reduces with ONE collective across GPUs
+        q.accumSlot.assign(q.accums.size(), 0);
+        int slot = 0;
+        q.nMinBlocks = q.nMaxBlocks = 0;
+        for (int m : {2, 3, 0}) {
+            for (size_t i = 0; i < q.accums.size(); i++) if (q.accums[i].merge == m) q.accumSlot[i] = slot++;
+            if (m == 2) q.nMinBlocks = slot; else if (m == 3) q.nMaxBlocks = slot - q.nMinBlocks;
+        }
+        q.nSumBlocks = (int64_t)q.accums.size() - q.nMinBlocks - q.nMaxBlocks;
+    }
+
+    bool tryDenseKeys(OpNode* o) {
+        Table* t = pipe.src;
+        q.denseKeys.clear();
+        int64_t total = 1;
+        for (Expr* g : o->exprs2) {
+            if (g->tag != RSQ_E_ATTRIBUTE) return false;
+            auto org = symbolOrigin.find(g->symbol);
+            if (org == symbolOrigin.end() || org->second != -1) return false;      // not a column of this pipeline's scan
+            int ci = t->findCol(g->symbol);
+            if (ci < 0 || !t->cols[(size_t)ci].dptr) return false;
+            const TableColumn& c = t->cols[(size_t)ci];
+            DenseKey k; k.expr = g; k.type = c.type;
+            if (t->nRows == 0) { k.card = 1; k.min = 0; }      // empty input: no row reaches the aggregation
+            else if (!c.stats.valid) return false;
+            else if (!c.stats.distinctBytes.empty()) { k.byteSet = true; k.values = c.stats.distinctBytes; k.card = (int64_t)k.values.size(); }
+            else {
+                if (c.type.isString()) return false;
+                k.min = c.stats.min;
+                unsigned __int128 range = (unsigned __int128)((__int128)c.stats.max - (__int128)c.stats.min) + 1;
+                if (range > (unsigned __int128)(1u << 24)) return false;
+                k.card = (int64_t)range;
+            }
+            if (total > (int64_t)(1 << 24) / k.card) return false;
+            total *= k.card;
+            q.denseKeys.push_back(k);
+        }
+        int64_t stride = 1;
+        for (size_t i = q.denseKeys.size(); i-- > 0;) { q.denseKeys[i].stride = stride; stride *= q.denseKeys[i].card; }
+        q.denseGroups = total;
+        return true;
+    }
+
+    bool tryJoinEntry(OpNode* o) {
+        // Every group-by value is determined by the entry matched by a single-match probe of this pipeline
+        // (a build-side payload value, or the probe key that equals the build key): the group IS the entry,
+        // and the aggregates can live beside it.  (TPC-H Q3: l_orderkey = o_orderkey, o_orderdate,
+        // o_shippriority all hang off the matched orders entry.)
+        if (matchSlotTable < 0 || o->exprs2.empty()) return false;
+        q.groupSource.clear();
+        for (Expr* g : o->exprs2) {
+            if (g->tag != RSQ_E_ATTRIBUTE) return false;
+            auto org = symbolOrigin.find(g->symbol);
+            if (org != symbolOrigin.end() && org->second == matchSlotTable) { q.groupSource.push_back(symbolWord[g->symbol]); continue; }
+            auto pk = probeKeyOf.find(g->symbol);
+            if (pk != probeKeyOf.end() && pk->second.first == matchSlotTable) { q.groupSource.push_back(pk->second.second); continue; }
+            return false;
+        }
+        // a probe key counts only if ALL keys of the table are covered, otherwise two entries could share the group
+        HashTable& ht = *q.hashTables[(size_t)matchSlotTable];
+        for (size_t kw = 0; kw < ht.keys.size(); kw++)
+            if (std::find(q.groupSource.begin(), q.groupSource.end(), (int)kw) == q.groupSource.end()) return false;
+        q.aggTable = matchSlotTable;
+        return true;
+    }
+
+    void consumeAggregation(OpNode* o, OpNode* from) {
+        (void)from;
+        collectAccumulators(o);
+        const int W = (int)q.accums.size();
+        std::string mode;
+        if (tryDenseKeys(o)) {
+            const int64_t D = q.denseGroups, cells = D * W;
+            int forced = envInt("RSQ_AGG_MODE", 0, 0, 4);
+            // measured on MI355X (Q1 SF10, 42 cells): registers 0.47 ms, lane-private LDS 0.71 ms
+            if ((cells <= 64 && forced == 0) || forced == 1) { q.aggMode = AggMode::DENSE_REG; if (cells > 64) failUnsupported("too many groups for register accumulators"); }
+            else if ((cells <= 56 && forced == 0) || forced == 2) { q.aggMode = AggMode::DENSE_LDS_PRIVATE; if (cells > 56) failUnsupported("too many groups for lane-private LDS accumulators"); }
+            else if ((cells <= 6144 && forced == 0) || forced == 3) { q.aggMode = AggMode::DENSE_LDS_SHARED; if (cells > 6144) failUnsupported("too many groups for an LDS table"); }
+            else q.aggMode = AggMode::DENSE_GLOBAL;
+            emitDenseAggregation(o);
+        } else if (tryJoinEntry(o)) {
+            q.aggMode = AggMode::AT_JOIN_ENTRY;
+            emitJoinEntryAggregation(o);
+        } else {
+            failUnsupported("group-by on computed or high-cardinality keys needs the generic hash aggregation, which is not built yet");
+        }
+        pipe.sink = SinkKind::AGGREGATE;
+    }
+
+    std::string groupIdExpr() {
+        std::string gid = "0";
+        for (size_t ki = 0; ki < q.denseKeys.size(); ki++) {
+            DenseKey& k = q.denseKeys[ki];
+            std::string v = eg.emit(k.expr), rank;
+            if (k.byteSet) {
+                rank = "0";
+                for (size_t d = 1; d < k.values.size(); d++) {
+                    std::string an = "k" + std::to_string(ki) + "_" + std::to_string(d);
+                    addArg(an, "u64", k.values[d]);
+                    rank += " + (int)((u8)(" + v + ") >= (u8)a." + an + ")";
+                }
+            } else {
+                std::string an = "k" + std::to_string(ki) + "_min";
+                addArg(an, "i64", (uint64_t)k.min);
+                rank = "(int)((i64)(" + v + ") - a." + an + ")";
+            }
+            gid += " + (" + rank + ") * " + std::to_string((long long)k.stride);
+        }
+        return gid;
+    }
+
+    static const char* identityOf(int merge) { return merge == 0 ? "0ull" : merge == 2 ? "0x7fffffffffffffffull" : "0x8000000000000000ull"; }
+
+    std::string blockIdentityExpr(const std::string& blk) {
+        return blk + " < " + std::to_string((long long)q.nMinBlocks) + " ? 0x7fffffffffffffffull : " + blk + " < " +
+               std::to_string((long long)(q.nMinBlocks + q.nMaxBlocks)) + " ? 0x8000000000000000ull : 0ull";
+    }
+
+    void emitGlobalFlush(std::ostringstream& s, const std::string& count, const std::string& srcExpr, int64_t D) {
+        s << "    for (int i = threadIdx.x; i < " << count << "; i += blockDim.x) {\n";
+        s << "        const int blk = i / " << D << ";\n        const u64 v = " << srcExpr << ";\n";
+        s << "        if (blk < " << q.nMinBlocks << ") rsq::global_merge<2>(a.out + i, v);\n";
+        s << "        else if (blk < " << (q.nMinBlocks + q.nMaxBlocks) << ") rsq::global_merge<3>(a.out + i, v);\n";
+        s << "        else rsq::global_merge<0>(a.out + i, v);\n    }\n";
+    }
+
+    void emitDenseAggregation(OpNode* o) {
+        const int64_t D = q.denseGroups;
+        const int W = (int)q.accums.size();
+        line("const int gid = " + groupIdExpr() + ";");
+        for (int w = 1; w < W; w++) line("const i64 in" + std::to_string(w) + " = " + q.accums[(size_t)w].input + ";");
+        auto inOf = [&](int w) { return w == 0 ? std::string("row") : "in" + std::to_string(w); };
+        addArg("out", "u64*", 0);
+        std::ostringstream ep;
+        if (q.aggMode == AggMode::DENSE_REG) {
+            // accumulators in VGPRs, branch-free per-group update.  (An `if (gid == g) acc_g += x` chain gets its
+            // common tail sunk by the compiler into one store through a selected pointer, which forces every
+            // accumulator into scratch.)
+            for (int w = 0; w < W; w++)
+                for (int64_t g = 0; g < D; g++)
+                    stateDecl += "    i64 acc_" + std::to_string(w) + "_" + std::to_string((long long)g) + " = (i64)" + identityOf(q.accums[(size_t)w].merge) + ";\n";
+            const bool branchy = envInt("RSQ_REG_UPDATE", D > 1 ? 1 : 0, 0, 1) == 1;
+            for (int64_t g = 0; g < D; g++) {
+                if (branchy) {
+                    // EXEC-masked update of one group's accumulators (2 VALU per 64-bit add instead of the
+                    // select form's 4).  The distinct asm comment at the end of every block is load-bearing: without
+                    // it the compiler sinks the identical tails of the blocks into one store through a selected
+                    // pointer, which forces all accumulators into scratch memory.
+                    openScope("if (gid == " + std::to_string((long long)g) + ") {");
+                    for (int w = 0; w < W; w++) {
+                        std::string acc = "st.acc_" + std::to_string(w) + "_" + std::to_string((long long)g), in = inOf(w);
+                        int m = q.accums[(size_t)w].merge;
+                        if (m == 0) line(acc + " = rsq::add(" + acc + ", " + in + ");");
+                        else if (m == 2) line(acc + " = " + in + " < " + acc + " ? " + in + " : " + acc + ";");
+                        else line(acc + " = " + in + " > " + acc + " ? " + in + " : " + acc + ";");
+                    }
+                    line("asm volatile(\"; rsq group " + std::to_string((long long)g) + "\");");
+                    closeScope();
+                    continue;
+                }
+                openScope("{");
+                line("const bool m = gid == " + std::to_string((long long)g) + ";");
+                for (int w = 0; w < W; w++) {
+                    std::string acc = "st.acc_" + std::to_string(w) + "_" + std::to_string((long long)g), in = inOf(w);
+                    int m = q.accums[(size_t)w].merge;
+                    if (m == 0) line(acc + " = rsq::add(" + acc + ", m ? " + in + " : (i64)0);");
+                    else if (m == 2) line(acc + " = (m && " + in + " < " + acc + ") ? " + in + " : " + acc + ";");
+                    else line(acc + " = (m && " + in + " > " + acc + ") ? " + in + " : " + acc + ";");
+                }
+                closeScope();
+            }
+            ep << "    __shared__ u64 s_acc[" << W * D << "];\n";
+            ep << "    for (int i = threadIdx.x; i < " << W * D << "; i += blockDim.x) { const int blk = i / " << D << "; s_acc[i] = " << blockIdentityExpr("blk") << "; }\n";
+            ep << "    __syncthreads();\n";
+            for (int w = 0; w < W; w++)
+                for (int64_t g = 0; g < D; g++)
+                    ep << "    rsq::wave_to_lds<" << q.accums[(size_t)w].merge << ">(&s_acc[" << (q.accumSlot[(size_t)w] * D + g) << "], (u64)st.acc_" << w << "_" << g << ");\n";
+            ep << "    __syncthreads();\n";
+            emitGlobalFlush(ep, std::to_string((long long)(W * D)), "s_acc[i]", D);
+        } else if (q.aggMode == AggMode::DENSE_LDS_PRIVATE) {
+            // one private copy of the [block][group] table per LANE in LDS, laid out [cell][thread] so that a
+            // wave's 64 accesses to one cell are 64 consecutive 8-byte words: conflict-free, no contention,
+            // one ds_add_u64 / ds_min_i64 per accumulator and row instead of a select+add per group.
+            const int64_t cells = W * D;
+            pipe.blockThreads = cells <= 28 ? 256 : 128;
+            const int B = pipe.blockThreads;
+            prologue += "    __shared__ u64 s_priv[" + std::to_string((long long)(cells * B)) + "];\n";
+            prologue += "    for (int i = threadIdx.x; i < " + std::to_string((long long)(cells * B)) + "; i += blockDim.x) { const int blk = (i / " +
+                        std::to_string(B) + ") / " + std::to_string((long long)D) + "; s_priv[i] = " + blockIdentityExpr("blk") + "; }\n";
+            prologue += "    __syncthreads();\n    st.priv = s_priv + threadIdx.x;\n";
+            stateDecl += "    u64* priv;\n";
+            for (int w = 0; w < W; w++) {
+                std::string cell = "st.priv + (" + std::to_string((long long)(q.accumSlot[(size_t)w] * D)) + " + gid) * " + std::to_string(B);
+                int m = q.accums[(size_t)w].merge;
+                if (m == 0) line("rsq::lds_merge<0>(" + cell + ", (u64)" + inOf(w) + ");");
+                else line("rsq::lds_merge<" + std::to_string(m) + ">(" + cell + ", (u64)" + inOf(w) + ");");
+            }
+            // flush: every wave folds whole cells: lanes stride over the B private copies, butterfly, one atomic
+            ep << "    __syncthreads();\n";
+            ep << "    for (int c = (threadIdx.x >> 6); c < " << cells << "; c += (blockDim.x >> 6)) {\n";
+            ep << "        const int blk = c / " << D << ";\n        const int lane = threadIdx.x & 63;\n";
+            ep << "        u64 v = s_priv[c * " << B << " + lane];\n";
+            ep << "        for (int j = lane + 64; j < " << B << "; j += 64) {\n            const u64 o = s_priv[c * " << B << " + j];\n";
+            ep << "            if (blk < " << q.nMinBlocks << ") v = (i64)o < (i64)v ? o : v; else if (blk < " << (q.nMinBlocks + q.nMaxBlocks)
+               << ") v = (i64)o > (i64)v ? o : v; else v += o;\n        }\n";
+            ep << "        if (blk < " << q.nMinBlocks << ") { v = (u64)rsq::wave_min_i64((i64)v); if (lane == 0) rsq::global_merge<2>(a.out + c, v); }\n";
+            ep << "        else if (blk < " << (q.nMinBlocks + q.nMaxBlocks) << ") { v = (u64)rsq::wave_max_i64((i64)v); if (lane == 0) rsq::global_merge<3>(a.out + c, v); }\n";
+            ep << "        else { v = rsq::wave_sum(v); if (lane == 0) rsq::global_merge<0>(a.out + c, v); }\n    }\n";
+        } else if (q.aggMode == AggMode::DENSE_LDS_SHARED) {
+            // one [block][group] table per workgroup in LDS, LDS atomics (many groups => little contention),
+            // flushed once per workgroup with global atomics
+            const int64_t cells = W * D;
+            prologue += "    __shared__ u64 s_tab[" + std::to_string((long long)cells) + "];\n";
+            prologue += "    for (int i = threadIdx.x; i < " + std::to_string((long long)cells) + "; i += blockDim.x) { const int blk = i / " +
+                        std::to_string((long long)D) + "; s_tab[i] = " + blockIdentityExpr("blk") + "; }\n    __syncthreads();\n    st.tab = s_tab;\n";
+            stateDecl += "    u64* tab;\n";
+            for (int w = 0; w < W; w++)
+                line("rsq::lds_merge<" + std::to_string(q.accums[(size_t)w].merge) + ">(st.tab + " + std::to_string((long long)(q.accumSlot[(size_t)w] * D)) +
+                     " + gid, (u64)" + inOf(w) + ");");
+            ep << "    __syncthreads();\n";
+            emitGlobalFlush(ep, std::to_string((long long)cells), "s_tab[i]", D);
+        } else {   // DENSE_GLOBAL: straight to the table in HBM
+            for (int w = 0; w < W; w++)
+                line("rsq::global_merge<" + std::to_string(q.accums[(size_t)w].merge) + ">(a.out + " + std::to_string((long long)(q.accumSlot[(size_t)w] * D)) +
+                     " + gid, (u64)" + inOf(w) + ");");
+        }
+        epilogue += ep.str();
+        static const char* names[] = {"none", "registers", "lane-private LDS", "workgroup LDS table", "HBM table", "join entry", "hash"};
+        explainSteps.push_back("aggregation dense groups=" + std::to_string((long long)D) + " accumulators=" + std::to_string(W - 1) +
+                               " (of " + std::to_string(o->splitAgg.size()) + " in the reference) in " + names[(int)q.aggMode]);
+    }
+
+    void emitJoinEntryAggregation(OpNode* o) {
+        HashTable& ht = *q.hashTables[(size_t)q.aggTable];
+        const std::string T = "ht" + std::to_string(ht.id);
+        const int W = (int)q.accums.size();
+        ht.nAccBlocks = W;
+        addArg(T + "_acc", "u64*", 0);
+        for (int w = 0; w < W; w++) {
+            std::string in = w == 0 ? "row" : q.accums[(size_t)w].input;
+            line("rsq::global_merge_always<" + std::to_string(q.accums[(size_t)w].merge) + ">(a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) +
+                 " * a." + T + "_cap + " + slotVar[ht.id] + ", (u64)(" + in + "));");
+        }
+        explainSteps.push_back("aggregation at the matched entry of " + T + " accumulators=" + std::to_string(W - 1) + " (of " +
+                               std::to_string(o->splitAgg.size()) + " in the reference)");
+    }
+
+    // -------------------------------------------------------------------------------------------
+    void finishPipeline() {
+        while (indent > 1) closeScope();
+        addArg("n_rows", "i64", (uint64_t)pipe.src->nRows);
+        addArg("row0", "i64", (uint64_t)pipe.src->row0);
+        addArg("err", "u32*", (uint64_t)(uintptr_t)q.ctx.dErr);
+        const int U = pipe.unroll;
+        std::ostringstream s;
+        s << "// generated by resql_amd/csrc/codegen.cpp\n//   ";
+        for (size_t i = 0; i < explainSteps.size(); i++) s << (i ? " -> " : "") << explainSteps[i];
+        s << "\n";
+        if (envInt("RSQ_NT", 1, 0, 1)) s << "#define RSQ_NT_LOADS 1\n";
+        s << "#include \"rsq_device.h\"\n";
+        s << fileScope;
+        s << "struct Args {\n";
+        for (auto& a : pipe.args) s << "    " << a.ctype << " " << a.name << ";\n";
+        s << "};\nstruct State {\n" << stateDecl << "};\n";
+        s << "static RSQ_DEV void row_fn(const Args& a, State& st, const i64 lr" << rowParams << ") {\n";
+        s << "    const i64 row = a.row0 + lr;\n" << body << "}\n";
+        s << "extern \"C\" __global__ void __launch_bounds__(" << pipe.blockThreads << ") rsq_pipeline(Args a) {\n";
+        s << "    State st;\n" << prologue;
+        s << "    const int lane = threadIdx.x & 63;\n";
+        s << "    const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n";
+        s << "    const i64 nwaves = (i64)gridDim.x * (blockDim.x >> 6);\n";
+        s << "    const i64 ntiles = a.n_rows >> 7;\n";
+        // main loop, textually unrolled: the loads of U tiles are issued before the first row is processed
+        s << "    for (i64 t = wave; t < ntiles; t += nwaves * " << U << ") {\n";
+        const int ncols = (int)colTypes.size();
+        for (int u = 0; u < U; u++) {
+            s << "        const i64 tt" << u << " = t + " << u << " * nwaves;\n";
+            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2];\n";
+            s << "        if (tt" << u << " < ntiles) {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
+            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "            rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
+            s << "        }\n";
+        }
+        for (int u = 0; u < U; u++) {
+            s << "        if (tt" << u << " < ntiles) {\n";
+            for (int j = 0; j < 2; j++) {
+                s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j;
+                for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
+                s << ");\n";
+            }
+            s << "        }\n";
+        }
+        s << "    }\n";
+        s << "    for (i64 r = (ntiles << 7) + (i64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (i64)gridDim.x * blockDim.x)\n";
+        s << "        row_fn(a, st, r" << rowArgsTail << ");\n";
+        s << epilogue << "}\n";
+        pipe.source = s.str();
+        std::string ex = "pipeline " + std::to_string(q.pipelines.size()) + ": ";
+        for (size_t i = 0; i < explainSteps.size(); i++) ex += (i ? " -> " : "") + explainSteps[i];
+        pipe.explain = ex;
+        q.pipelines.push_back(pipe);
+    }
+};
+
+}  // namespace
+
+void buildPipelines(Query& q) {
+    Walker w(q);
+    w.produce(q.root, {});
+    if (!q.agg) failUnsupported("plans without an aggregation (device-side materialisation) are not built yet in this engine version");
+}
+
+}  // namespace rsq

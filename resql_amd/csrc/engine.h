@@ -62,10 +62,12 @@ struct Kernel {
 struct Context {
     rsq_config cfg{};
     int device = 0;
+    int numCUs = 256;
     hipStream_t stream = nullptr;
     std::string lastError;
     std::string cacheDir;
     std::string includeDir;                    // where kernels/rsq_device.h lives
+    std::string headerText;                    // its content (part of the code-object cache key)
     std::map<std::string, Kernel> kernels;     // by source hash
     uint32_t* dErr = nullptr;                  // device error word
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -85,13 +87,18 @@ void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::v
 void computeColumnStats(Context& ctx, Table& t);
 void generateTable(Context& ctx, Table& t, int kind, int64_t row0, int64_t nRows, double sf, int64_t param, uint64_t seed);
 double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
-void fillU64(Context& ctx, uint64_t* dptr, const std::vector<uint64_t>& hostValues);
+void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
+// gather the occupied entries (first-row word != INT64_MAX) of a hash table that carries aggregates into
+// packed rows [first row | table words | accumulator blocks]; *count receives the number of rows
+void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,
+                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t* count);
 
 // ---- query ------------------------------------------------------------------------------------
 struct Query;
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables);
 void executeQuery(Query& q, bool partialOnly);
 void finalizeQuery(Query& q);
+void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords);
 void bindPartial(Query& q, void* dptr, size_t bytes);
 void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum);
 void queryResult(Query& q, rsq_result_view* out);

@@ -1,0 +1,153 @@
+// engine_internal.h — plan / pipeline structures shared by the planner (engine.cpp), the kernel
+// generator (codegen.cpp) and the host tail (tail.cpp).
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+#include "hostref.h"
+
+namespace rsq {
+
+struct Attr { std::string name; Type type; };
+typedef std::vector<Attr> Schema;
+int schemaTupleSize(const Schema& s);
+int schemaOffset(const Schema& s, const std::string& name);
+
+struct OpNode {
+    int tag = RSQ_OP_UNDEFINED;
+    OpNode* parent = nullptr;
+    OpNode* child[2] = {nullptr, nullptr};
+    int nChildren = 0;
+    std::vector<Expr*> exprs, exprs2;
+    bool singleMatch = false;
+    bool hasLimit = false;
+    int64_t limit = 0;
+    Table* table = nullptr;
+    std::vector<Expr*> splitAgg;     // aggregation.h:167-179
+    Schema schema;                   // RelOperator::_schema
+    int hashTable = -1;              // HASHJOIN: index into Query::hashTables
+};
+
+// ---- device hash table (join build side; optionally carries aggregates "at the entry") ----------
+// Open addressing, linear probing, power-of-two capacity.  Struct of arrays in HBM:
+//   state[cap]            u32   0 = empty, 1 = occupied
+//   words[(k) * cap + s]  i64   key words first, then payload words (every value widened to 8 bytes)
+//   acc[(w) * cap + s]    i64   aggregate words when an aggregation is fused onto the entries
+struct HashTable {
+    int id = 0;
+    std::vector<Attr> keys;          // build-side key values (names of the build key expressions)
+    std::vector<Attr> payload;       // build-side attributes carried to the probe side
+    int64_t capacity = 0;
+    bool unique = false;             // probed single-match
+    uint32_t* dState = nullptr;
+    int64_t* dWords = nullptr;
+    int64_t* dAcc = nullptr;         // [nAccBlocks][capacity] when aggregated at the entry
+    int nAccBlocks = 0;
+    uint32_t* dCount = nullptr;      // number of occupied slots (set by the build kernel)
+};
+
+// one accumulator the aggregation keeps per group
+struct Accum {
+    int kind;            // RSQ_E_SUM / RSQ_E_MIN / RSQ_E_MAX / RSQ_E_COUNT
+    std::string key;     // structural key of (kind, typed input): identical aggregates share an accumulator
+    std::string input;   // device expression of the input value
+    Type type;
+    int merge;           // rsq::Merge on the device: 0 sum, 2 min (i64), 3 max (i64)
+};
+
+struct DenseKey {
+    Expr* expr = nullptr;
+    Type type;
+    bool byteSet = false;
+    std::vector<uint8_t> values;     // byteSet: sorted distinct values
+    int64_t min = 0;
+    int64_t card = 1;
+    int64_t stride = 1;
+};
+
+enum class AggMode { NONE, DENSE_REG, DENSE_LDS_PRIVATE, DENSE_LDS_SHARED, DENSE_GLOBAL, AT_JOIN_ENTRY, HASH };
+enum class SinkKind { AGGREGATE, BUILD, MATERIALIZE };
+
+struct ArgSlot { std::string name; std::string ctype; uint64_t value; };
+
+struct Pipeline {
+    Table* src = nullptr;
+    std::vector<int> cols;           // scanned columns (indices into src->cols)
+    SinkKind sink = SinkKind::AGGREGATE;
+    int buildTable = -1;             // SinkKind::BUILD
+    std::string source;              // generated HIP source
+    std::string entry = "rsq_pipeline";
+    std::vector<ArgSlot> args;
+    Kernel* kernel = nullptr;
+    int64_t bytesPerRow = 0;
+    int blockThreads = 256;
+    int unroll = 2;
+    unsigned maxGrid = 0;            // 256-thread workgroups per launch; 0 = 2 per CU
+    std::string explain;
+};
+
+struct Query {
+    Context& ctx;
+    ExprPool pool;
+    std::vector<Expr*> exprs;
+    std::vector<std::unique_ptr<OpNode>> ops;
+    OpNode* root = nullptr;
+    bool requestAll = false;
+    std::vector<Table*> tables;
+
+    // device side
+    std::vector<Pipeline> pipelines;
+    std::vector<std::unique_ptr<HashTable>> hashTables;
+    OpNode* agg = nullptr;                 // the aggregation whose input pipeline runs on the device (may be null)
+    AggMode aggMode = AggMode::NONE;
+    std::vector<DenseKey> denseKeys;
+    int64_t denseGroups = 1;
+    std::vector<Accum> accums;             // [0] is the first-row tracker
+    std::vector<int> splitToAccum;         // splitAgg index -> accums index
+    std::vector<int> accumSlot;            // accums index -> word-block index: blocks ordered [min | max | sum]
+    int64_t nMinBlocks = 0, nMaxBlocks = 0, nSumBlocks = 0;
+    int aggTable = -1;                     // AT_JOIN_ENTRY: hash table whose entries carry the aggregates
+    std::vector<int> groupSource;          // AT_JOIN_ENTRY: per group expr, word index in the table (keys then payload)
+
+    bool dAggOwned = true;
+    uint64_t* dAgg = nullptr;              // dense modes: [blocks][denseGroups]
+    uint64_t* dAggInit = nullptr;          // identity image copied over dAgg at the start of every execute
+    uint64_t* hPinned = nullptr;           // pinned read-back: aggregate words + error word
+    size_t pinnedWords = 0;
+    std::vector<uint64_t> hAgg;
+
+    // compacted group rows read back from a join-entry aggregation: [nGroups][groupWords]
+    int64_t* dGroupRows = nullptr;
+    uint32_t* dGroupCount = nullptr;
+    std::vector<int64_t> hGroupRows;
+    int64_t nGroupRows = 0;
+    int groupRowWords = 0;
+
+    // result
+    Schema resultSchema;
+    std::vector<uint8_t> resultTuples;
+    int64_t resultRows = 0;
+    std::vector<char> rvNames;
+    std::vector<rsq_type> rvTypes;
+    std::vector<int32_t> rvOffsets;
+
+    rsq_report report{};
+    std::string allSource, explainText;
+
+    explicit Query(Context& c) : ctx(c) {}
+    ~Query();
+};
+
+uint64_t opSize(OpNode* o);      // getSize() estimates of the reference's operators
+
+// codegen.cpp: turns the operator tree below the last pipeline breaker into device pipelines
+void buildPipelines(Query& q);
+
+// tail.cpp: aggregate table / group rows -> result relation (AVG, projection, materialize, order by, limit)
+void runTail(Query& q);
+
+}  // namespace rsq

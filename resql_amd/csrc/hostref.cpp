@@ -127,7 +127,7 @@ Val loadValue(const uint8_t* addr, const Type& t) {
     return v;
 }
 
-static int typedCompare(const Type& t, const uint8_t* l, const uint8_t* r) {
+int compareTyped(const Type& t, const uint8_t* l, const uint8_t* r) {
     switch (t.tag) {
         case RSQ_BIGINT: case RSQ_DECIMAL: { int64_t a, b; memcpy(&a, l, 8); memcpy(&b, r, 8); return a < b ? -1 : a > b; }
         case RSQ_INT: case RSQ_DATE: { int32_t a, b; memcpy(&a, l, 4); memcpy(&b, r, 4); return a < b ? -1 : a > b; }
@@ -142,7 +142,7 @@ void refQuicksort(uint8_t* data, int64_t n, size_t ts, const std::vector<OrderRe
     std::vector<uint8_t> tmp(ts);
     auto before = [&](const uint8_t* a, const uint8_t* b) {
         for (const auto& o : order) {
-            int c = typedCompare(o.type, a + o.offset, b + o.offset);
+            int c = compareTyped(o.type, a + o.offset, b + o.offset);
             if (o.asc) { if (c < 0) return true; if (c > 0) return false; }
             else { if (c > 0) return true; if (c < 0) return false; }
         }

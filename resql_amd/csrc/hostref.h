@@ -30,6 +30,8 @@ std::vector<size_t> refEmissionOrder(const std::vector<uint64_t>& hashes, uint64
 // Quicksorter (reference src/qlib/sort.h:21-173): Lomuto partition, pivot = last element, over
 // packed tuples.
 struct OrderRequest { int offset; Type type; bool asc; };
+// compare<> per type as the Quicksorter uses it (reference src/types.h:264-353, src/qlib/sort.h:138-160)
+int compareTyped(const Type& t, const uint8_t* l, const uint8_t* r);
 void refQuicksort(uint8_t* tuples, int64_t n, size_t tupleSize, const std::vector<OrderRequest>& order);
 
 // packed tuple access (reference src/values.h:151-232)

@@ -51,9 +51,18 @@ struct __attribute__((aligned(2))) u8x2 { u8 x, y; };
 
 // `p` points at the first of this lane's two consecutive rows; 16 / 8 / 2 byte aligned because
 // tiles start at multiples of 128 rows and column bases are 256-byte aligned.
+#ifdef RSQ_NT_LOADS
+// streamed-once data: non-temporal loads (global_load_dwordx4 ... nt) leave the caches to the tables that are re-read
+typedef i64 i64v2 __attribute__((ext_vector_type(2)));
+typedef i32 i32v2 __attribute__((ext_vector_type(2)));
+RSQ_DEV void ld2(const i64* p, i64 (&v)[2]) { i64v2 t = __builtin_nontemporal_load(reinterpret_cast<const i64v2*>(p)); v[0] = t.x; v[1] = t.y; }
+RSQ_DEV void ld2(const i32* p, i32 (&v)[2]) { i32v2 t = __builtin_nontemporal_load(reinterpret_cast<const i32v2*>(p)); v[0] = t.x; v[1] = t.y; }
+RSQ_DEV void ld2(const u8* p, u8 (&v)[2]) { u16 t = __builtin_nontemporal_load(reinterpret_cast<const u16*>(p)); v[0] = (u8)(t & 0xff); v[1] = (u8)(t >> 8); }
+#else
 RSQ_DEV void ld2(const i64* p, i64 (&v)[2]) { i64x2 t = *reinterpret_cast<const i64x2*>(p); v[0] = t.x; v[1] = t.y; }
 RSQ_DEV void ld2(const i32* p, i32 (&v)[2]) { i32x2 t = *reinterpret_cast<const i32x2*>(p); v[0] = t.x; v[1] = t.y; }
 RSQ_DEV void ld2(const u8* p, u8 (&v)[2]) { u8x2 t = *reinterpret_cast<const u8x2*>(p); v[0] = t.x; v[1] = t.y; }
+#endif
 
 // ---- wave64 reductions ----------------------------------------------------------------------
 RSQ_DEV u64 shfl_xor_u64(u64 v, int mask) {
@@ -107,6 +116,14 @@ template <int OP>
 RSQ_DEV void global_merge(u64* dst, u64 v) {
     if (OP == M_SUM) { if (v != 0) atomicAdd(dst, v); }
     else if (OP == M_MIN_U64) { if (v != ~0ull) atomicMin(dst, v); }
+    else if (OP == M_MIN_I64) atomicMin(reinterpret_cast<i64*>(dst), (i64)v);
+    else atomicMax(reinterpret_cast<i64*>(dst), (i64)v);
+}
+// unconditional form (aggregates kept beside a hash-table entry: every matching row updates its entry)
+template <int OP>
+RSQ_DEV void global_merge_always(u64* dst, u64 v) {
+    if (OP == M_SUM) atomicAdd(dst, v);
+    else if (OP == M_MIN_U64) atomicMin(dst, v);
     else if (OP == M_MIN_I64) atomicMin(reinterpret_cast<i64*>(dst), (i64)v);
     else atomicMax(reinterpret_cast<i64*>(dst), (i64)v);
 }

@@ -48,6 +48,9 @@ Context::Context(const rsq_config& c) : cfg(c), device(c.device) {
             throw Error(RSQ_ERR_DEVICE, "no HIP device available (the engine has no CPU fallback)");
         if (device >= n) throw Error(RSQ_ERR_DEVICE, "device ordinal out of range");
         RSQ_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        RSQ_HIP(hipGetDeviceProperties(&prop, device));
+        numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         RSQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         RSQ_HIP(hipMalloc((void**)&dErr, sizeof(uint32_t)));
         RSQ_HIP(hipMemset(dErr, 0, sizeof(uint32_t)));
@@ -113,7 +116,10 @@ static std::string compileWithHiprtc(Context& ctx, const std::string& source) {
 }
 
 Kernel& Context::getKernel(const std::string& source, const std::string& entry) {
-    char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)fnv1a(source));
+    // the key covers the generated source AND the hand-written header it includes
+    if (headerText.empty() && !readFile(includeDir + "/rsq_device.h", headerText))
+        throw Error(RSQ_ERR_DEVICE, "cannot read " + includeDir + "/rsq_device.h");
+    char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)(fnv1a(source) ^ (fnv1a(headerText) * 0x9E3779B97F4A7C15ull)));
     std::string key(hex);
     auto it = kernels.find(key);
     if (it != kernels.end()) return it->second;

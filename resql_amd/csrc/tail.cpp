@@ -1,0 +1,382 @@
+// tail.cpp — from the device's aggregate table to ReSQL's result relation, on the host.
+//
+// What the reference does after its aggregation hash table is complete (reference
+// src/operators/aggregation.h:298-343 consumeAggregateFlounder: scan the table in slot order, AVG =
+// (sum * 100) / count; projection.h:62-72; materialize.h:78-220; orderby.h:87-136 + qlib/sort.h) runs
+// here over the #groups rows the device produced — same values, same types, same order.
+#include <algorithm>
+#include <cstring>
+
+#include "engine_internal.h"
+
+namespace rsq {
+
+int schemaTupleSize(const Schema& s) { int n = 0; for (auto& a : s) n += sizeInTuple(a.type, true); return n; }
+int schemaOffset(const Schema& s, const std::string& name) {
+    int off = 0;
+    for (auto& a : s) { if (a.name == name) return off; off += sizeInTuple(a.type, true); }
+    failType("The attribute " + name + " was not found in the schema");
+}
+
+namespace {
+
+// ---- scalar evaluation with the device code's semantics, symbols resolved to slots once ----------
+struct HostExpr {
+    int kind = 0;              // 0 symbol slot, 1 constant, 2 operator
+    int slot = -1;
+    int tag = 0;
+    Type type, opType;
+    Val constant{};
+    std::vector<HostExpr> kids;
+};
+
+struct HostCompiler {
+    std::vector<std::string> names;      // symbol table: slot -> name
+    std::vector<Type> types;
+
+    int slotOf(const std::string& n) const {
+        for (size_t i = 0; i < names.size(); i++) if (names[i] == n) return (int)i;
+        return -1;
+    }
+    int define(const std::string& n, const Type& t) {
+        int s = slotOf(n);
+        if (s < 0) { names.push_back(n); types.push_back(t); s = (int)names.size() - 1; }
+        else types[(size_t)s] = t;
+        return s;
+    }
+
+    HostExpr compile(Expr* e) {
+        HostExpr h; h.type = e->type;
+        int s = slotOf(expressionName(e));
+        if (s >= 0) { h.kind = 0; h.slot = s; return h; }
+        switch (e->structure) {
+            case LITERAL:
+                if (e->tag == RSQ_E_CONSTANT) {
+                    h.kind = 1;
+                    if (e->type.isString()) h.constant.s = e->symbol.c_str(); else h.constant.i = e->ival;
+                    return h;
+                }
+                if (e->tag == RSQ_E_STAR) { h.kind = 1; h.constant.i = 0; return h; }
+                failType("attribute " + e->symbol + " is not available after the aggregation");
+            case UNARY:
+                h.kind = 2; h.tag = e->tag;
+                if (e->tag == RSQ_E_COUNT) return h;
+                h.opType = e->child->type;
+                h.kids.push_back(compile(e->child));
+                return h;
+            case BINARY:
+                h.kind = 2; h.tag = e->tag; h.opType = e->child->type;
+                if (e->tag == RSQ_E_LIKE) failUnsupported("LIKE is not implemented by the GPU engine");
+                h.kids.push_back(compile(e->child));
+                h.kids.push_back(compile(e->child->next));
+                return h;
+            case OTHER:
+                h.kind = 2; h.tag = RSQ_E_CASE;
+                for (Expr* c = e->child; c; c = c->next) {
+                    if (c->tag == RSQ_E_WHENTHEN) {
+                        HostExpr wt; wt.kind = 2; wt.tag = RSQ_E_WHENTHEN; wt.type = c->type;
+                        wt.kids.push_back(compile(c->child)); wt.kids.push_back(compile(c->child->next));
+                        h.kids.push_back(wt);
+                    } else h.kids.push_back(compile(c));
+                }
+                return h;
+            default: failType("emitExpression(..)");
+        }
+    }
+};
+
+int cmpVal(Val a, Val b, const Type& t) {
+    if (t.tag == RSQ_DATE || t.tag == RSQ_INT) {
+        int32_t x = (int32_t)(uint32_t)a.i, y = (int32_t)(uint32_t)b.i;
+        return x < y ? -1 : x > y;
+    }
+    return a.i < b.i ? -1 : a.i > b.i;
+}
+bool strEqChar(const char* a, const char* b) {
+    while (*a && *b) { if (*a != *b) return false; a++; b++; }
+    while (*a) { if (*a != ' ') return false; a++; }
+    while (*b) { if (*b != ' ') return false; b++; }
+    return true;
+}
+bool strEqVarchar(const char* a, const char* b) {
+    while (*a && *b) { if (*a != *b) return false; a++; b++; }
+    return *a == *b;
+}
+bool equalsVal(Val a, Val b, const Type& t) {
+    switch (t.tag) {
+        case RSQ_DECIMAL: case RSQ_BIGINT: return a.i == b.i;
+        case RSQ_INT: case RSQ_DATE: return (uint32_t)a.i == (uint32_t)b.i;
+        case RSQ_BOOL: return (uint8_t)a.i == (uint8_t)b.i;
+        case RSQ_CHAR: return t.len > 1 ? strEqChar(a.s, b.s) : (uint8_t)a.i == (uint8_t)b.i;
+        case RSQ_VARCHAR: return strEqVarchar(a.s, b.s);
+        default: failType("EQUALS code generation not implemented for datatype");
+    }
+}
+int64_t sdiv(int64_t a, int64_t b) {
+    if (b == 0) failRuntime("Division by zero");
+    if (a == INT64_MIN && b == -1) failRuntime("Division overflow");
+    return a / b;
+}
+int64_t pow10i(int n) { int64_t v = 1; while (n-- > 0) v *= 10; return v; }
+
+Val evalHost(const HostExpr& h, const std::vector<Val>& sym) {
+    if (h.kind == 0) return sym[(size_t)h.slot];
+    if (h.kind == 1) return h.constant;
+    Val r; r.i = 0;
+    switch (h.tag) {
+        case RSQ_E_COUNT: r.i = 1; return r;
+        case RSQ_E_SUM: case RSQ_E_AVG: case RSQ_E_MIN: case RSQ_E_MAX: case RSQ_E_AS: case RSQ_E_ASC: case RSQ_E_DESC:
+            return evalHost(h.kids[0], sym);
+        case RSQ_E_TYPECAST: {
+            Val c = evalHost(h.kids[0], sym);
+            const Type &from = h.opType, &to = h.type;
+            if (to.tag == RSQ_DECIMAL) {
+                if (from.tag == RSQ_DECIMAL) {
+                    if (to.scale == from.scale) return c;
+                    if (to.scale > from.scale) r.i = (int64_t)((uint64_t)c.i * (uint64_t)pow10i(to.scale - from.scale));
+                    else r.i = sdiv(c.i, pow10i(from.scale - to.scale));
+                } else if (from.tag == RSQ_BIGINT) r.i = (int64_t)((uint64_t)c.i * (uint64_t)pow10i(to.scale));
+                else failType("emitTypecastToDECIMAL(..) code generation not implemented for datatype");
+            } else if (to.tag == RSQ_BIGINT) {
+                if (from.tag == RSQ_INT) r.i = (int64_t)(int32_t)c.i;
+                else if (from.tag == RSQ_DECIMAL) r.i = sdiv(c.i, pow10i(from.scale));
+                else r = c;
+            } else failType("emitTypecast(..) code generation not implemented for datatype");
+            return r;
+        }
+        case RSQ_E_CASE:
+            for (const HostExpr& k : h.kids) {
+                if (k.kind == 2 && k.tag == RSQ_E_WHENTHEN) { if ((uint8_t)evalHost(k.kids[0], sym).i) return evalHost(k.kids[1], sym); }
+                else return evalHost(k, sym);
+            }
+            return r;
+        default: break;
+    }
+    Val a = evalHost(h.kids[0], sym), b = evalHost(h.kids[1], sym);
+    switch (h.tag) {
+        case RSQ_E_ADD: r.i = (int64_t)((uint64_t)a.i + (uint64_t)b.i); break;
+        case RSQ_E_SUB: r.i = (int64_t)((uint64_t)a.i - (uint64_t)b.i); break;
+        case RSQ_E_MUL: r.i = (int64_t)((uint64_t)a.i * (uint64_t)b.i); break;
+        case RSQ_E_DIV: r.i = sdiv(a.i, b.i); break;
+        case RSQ_E_AND: r.i = (uint8_t)a.i & (uint8_t)b.i; break;
+        case RSQ_E_OR: r.i = (uint8_t)a.i | (uint8_t)b.i; break;
+        case RSQ_E_LT: r.i = cmpVal(a, b, h.opType) < 0; break;
+        case RSQ_E_LE: r.i = cmpVal(a, b, h.opType) <= 0; break;
+        case RSQ_E_GT: r.i = cmpVal(a, b, h.opType) > 0; break;
+        case RSQ_E_GE: r.i = cmpVal(a, b, h.opType) >= 0; break;
+        case RSQ_E_EQ: r.i = equalsVal(a, b, h.opType); break;
+        case RSQ_E_NEQ: r.i = 1 - (int)equalsVal(a, b, h.opType); break;
+        default: failUnsupported(std::string("host evaluation of ") + exprTagNames[h.tag]);
+    }
+    return r;
+}
+
+// ---- the groups the device produced ---------------------------------------------------------------
+struct Groups {
+    size_t n = 0;
+    std::vector<int64_t> firstRow;                 // [n]
+    std::vector<std::vector<Val>> keys;            // [n][nGroupExprs]
+    std::vector<std::vector<int64_t>> acc;         // [n][accums]  (index = accums index)
+};
+
+Groups groupsFromDense(Query& q) {
+    const int64_t D = q.denseGroups;
+    const size_t W = q.accums.size();
+    auto word = [&](size_t w, int64_t g) { return (int64_t)q.hAgg[(size_t)(q.accumSlot[w] * D + g)]; };
+    Groups G;
+    for (int64_t g = 0; g < D; g++) {
+        if (word(0, g) == INT64_MAX) continue;
+        G.firstRow.push_back(word(0, g));
+        std::vector<Val> k;
+        for (auto& dk : q.denseKeys) {
+            int64_t rank = (g / dk.stride) % dk.card;
+            Val v; v.i = dk.byteSet ? (int64_t)dk.values[(size_t)rank] : dk.min + rank;
+            k.push_back(v);
+        }
+        G.keys.push_back(k);
+        std::vector<int64_t> a(W);
+        for (size_t w = 0; w < W; w++) a[w] = word(w, g);
+        G.acc.push_back(a);
+    }
+    G.n = G.firstRow.size();
+    return G;
+}
+
+Groups groupsFromJoinEntries(Query& q) {
+    // rows compacted on the device: [firstrow | table words (keys, payload) | accumulator blocks]
+    HashTable& ht = *q.hashTables[(size_t)q.aggTable];
+    const size_t W = q.accums.size();
+    const size_t nTabWords = ht.keys.size() + ht.payload.size();
+    const size_t stride = (size_t)q.groupRowWords;
+    Groups G;
+    G.n = (size_t)q.nGroupRows;
+    G.firstRow.resize(G.n); G.keys.resize(G.n); G.acc.resize(G.n);
+    for (size_t i = 0; i < G.n; i++) {
+        const int64_t* r = &q.hGroupRows[i * stride];
+        G.firstRow[i] = r[0];
+        for (int src : q.groupSource) { Val v; v.i = r[1 + (size_t)src]; G.keys[i].push_back(v); }
+        G.acc[i].resize(W);
+        for (size_t w = 0; w < W; w++) G.acc[i][w] = r[1 + nTabWords + (size_t)q.accumSlot[w]];
+        G.acc[i][0] = r[0];
+    }
+    return G;
+}
+
+}  // namespace
+
+void runTail(Query& q) {
+    OpNode* agg = q.agg;
+    Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY) ? groupsFromJoinEntries(q) : groupsFromDense(q);
+
+    // ---- operators above the aggregation (bottom-up) and their schemas ----
+    OpNode* mat = nullptr; OpNode* orderBy = nullptr;
+    std::vector<OpNode*> projections;
+    for (OpNode* o = agg->parent; o; o = o->parent) {
+        if (o->tag == RSQ_OP_PROJECTION) { if (mat) failUnsupported("projection above materialize"); projections.push_back(o); }
+        else if (o->tag == RSQ_OP_MATERIALIZE) { if (mat) failUnsupported("two materializations"); mat = o; }
+        else if (o->tag == RSQ_OP_ORDERBY) orderBy = o;
+        else failUnsupported("operator above an aggregation other than projection / materialize / order by");
+    }
+    if (!mat) failInvalid("plan has no materialization");
+
+    HostCompiler hc;
+    std::vector<int> keySlots, aggSlots;              // symbol slots written per group
+    Schema aggSchema;
+    for (Expr* g : agg->exprs2) { keySlots.push_back(hc.define(expressionName(g), g->type)); aggSchema.push_back({expressionName(g), g->type}); }
+    struct AggOut { bool avg; int sumAcc, cntAcc, slot; };
+    std::vector<AggOut> outs;
+    {
+        size_t si = 0;
+        for (Expr* a : agg->exprs) {
+            if (a->tag == RSQ_E_AVG) {      // mergeAverages (aggregation.h:207-238)
+                q.pool.addId(a);
+                Type st = agg->splitAgg[si]->type;
+                if (st.tag != RSQ_BIGINT && st.tag != RSQ_DECIMAL) failType("getAvgFromSumAndCount(..) not supported for datatype");
+                outs.push_back({true, q.splitToAccum[si], q.splitToAccum[si + 1], hc.define(expressionName(a), a->type)});
+                aggSchema.push_back({expressionName(a), a->type});
+                si += 2;
+            } else {
+                Expr* s = agg->splitAgg[si];
+                outs.push_back({false, q.splitToAccum[si], -1, hc.define(expressionName(s), s->type)});
+                aggSchema.push_back({expressionName(s), s->type});
+                si += 1;
+            }
+        }
+    }
+    agg->schema = aggSchema;
+    Schema cur = aggSchema;
+    struct Proj { std::vector<HostExpr> exprs; std::vector<int> slots; };
+    std::vector<Proj> projs;
+    for (OpNode* p : projections) {
+        Proj pr; Schema s;
+        for (Expr* e : p->exprs) { q.pool.addId(e); pr.exprs.push_back(hc.compile(e)); }
+        for (Expr* e : p->exprs) { pr.slots.push_back(hc.define(expressionName(e), e->type)); s.push_back({expressionName(e), e->type}); }
+        p->schema = s; cur = s;
+        projs.push_back(std::move(pr));
+    }
+    mat->schema = cur;
+    q.resultSchema = cur;
+    const size_t ts = (size_t)schemaTupleSize(cur);
+    std::vector<int> offs, matSlots;
+    for (auto& a : cur) {
+        offs.push_back(schemaOffset(cur, a.name));
+        int s = hc.slotOf(a.name);
+        if (s < 0) failType("materialize: symbol " + a.name + " not found");
+        matSlots.push_back(s);
+    }
+    std::vector<OrderRequest> reqs;
+    if (orderBy)
+        for (Expr* e : orderBy->exprs) {
+            const std::string& n = e->child->symbol;
+            bool found = false;
+            for (auto& a : cur) if (a.name == n) { reqs.push_back({schemaOffset(cur, n), a.type, e->tag != RSQ_E_DESC}); found = true; break; }
+            if (!found) failType("Order By attribute not found.");
+        }
+
+    // ---- per group: dematerialize, AVG, projections, materialize ----
+    std::vector<Val> sym(hc.names.size());
+    auto materializeGroup = [&](size_t gi, uint8_t* dst) {
+        for (size_t k = 0; k < keySlots.size(); k++) sym[(size_t)keySlots[k]] = G.keys[gi][k];
+        for (auto& o : outs) {
+            Val v;
+            if (o.avg) v.i = sdiv((int64_t)((uint64_t)G.acc[gi][(size_t)o.sumAcc] * 100ull), G.acc[gi][(size_t)o.cntAcc]);
+            else v.i = G.acc[gi][(size_t)o.sumAcc];
+            sym[(size_t)o.slot] = v;
+        }
+        for (auto& pr : projs) {
+            Val tmp[RSQ_MAX_OP_EXPRS];
+            for (size_t i = 0; i < pr.exprs.size(); i++) tmp[i] = evalHost(pr.exprs[i], sym);
+            for (size_t i = 0; i < pr.exprs.size(); i++) sym[(size_t)pr.slots[i]] = tmp[i];
+        }
+        memset(dst, 0, ts);
+        for (size_t c = 0; c < cur.size(); c++) storeValue(dst + offs[c], sym[(size_t)matSlots[c]], cur[c].type);
+    };
+
+    // The reference's order of the materialized rows: groups enter its hash table in the order of their first
+    // input row and leave it in slot order.  Only needed when that order is observable.
+    auto emissionOrder = [&]() {
+        std::vector<size_t> byFirst(G.n);
+        for (size_t i = 0; i < G.n; i++) byFirst[i] = i;
+        std::sort(byFirst.begin(), byFirst.end(), [&](size_t a, size_t b) { return G.firstRow[a] < G.firstRow[b]; });
+        std::vector<uint64_t> hashes(G.n);
+        for (size_t i = 0; i < G.n; i++) {
+            uint64_t h = 0;
+            for (size_t k = 0; k < agg->exprs2.size(); k++) h = refHashValue(h, G.keys[byFirst[i]][k], agg->exprs2[k]->type);
+            hashes[i] = h;
+        }
+        std::vector<size_t> slotOrder = refEmissionOrder(hashes, opSize(agg));
+        std::vector<size_t> order(G.n);
+        for (size_t i = 0; i < G.n; i++) order[i] = byFirst[slotOrder[i]];
+        return order;
+    };
+
+    q.resultTuples.clear(); q.resultRows = 0;
+
+    // ---- ORDER BY ... LIMIT k over many groups: the k first rows of the sorted order are determined by the
+    // sort keys alone unless rows tie on ALL of them; select them without sorting (or replaying) everything ----
+    if (orderBy && orderBy->hasLimit && !mat->hasLimit && orderBy->limit >= 0 && (size_t)orderBy->limit * 4 < G.n) {
+        const size_t k = (size_t)orderBy->limit;
+        std::vector<uint8_t> all(G.n * ts);
+        for (size_t i = 0; i < G.n; i++) materializeGroup(i, &all[i * ts]);
+        auto before = [&](const uint8_t* a, const uint8_t* b) {
+            for (const auto& o : reqs) {
+                int c = compareTyped(o.type, a + o.offset, b + o.offset);
+                if (o.asc) { if (c < 0) return true; if (c > 0) return false; }
+                else { if (c > 0) return true; if (c < 0) return false; }
+            }
+            return false;
+        };
+        std::vector<size_t> idx(G.n);
+        for (size_t i = 0; i < G.n; i++) idx[i] = i;
+        std::partial_sort(idx.begin(), idx.begin() + (long)std::min(k + 1, G.n), idx.end(),
+                          [&](size_t a, size_t b) { return before(&all[a * ts], &all[b * ts]); });
+        bool tie = false;
+        for (size_t i = 0; i + 1 < std::min(k + 1, G.n) && !tie; i++)
+            if (!before(&all[idx[i] * ts], &all[idx[i + 1] * ts])) tie = true;     // sorted, so "not before" means equal keys
+        if (!tie) {
+            q.resultTuples.resize(std::min(k, G.n) * ts);
+            for (size_t i = 0; i < std::min(k, G.n); i++) memcpy(&q.resultTuples[i * ts], &all[idx[i] * ts], ts);
+            q.resultRows = (int64_t)std::min(k, G.n);
+            return;
+        }
+        // ties among the leading rows: fall through to the faithful path
+    }
+
+    std::vector<size_t> order = emissionOrder();
+    q.resultTuples.resize(G.n * ts);
+    for (size_t oi : order) {
+        materializeGroup(oi, &q.resultTuples[(size_t)q.resultRows * ts]);
+        q.resultRows++;
+        if (mat->hasLimit && q.resultRows >= mat->limit) break;      // materialize.h:197-206
+    }
+    q.resultTuples.resize((size_t)q.resultRows * ts);
+    if (orderBy) {
+        refQuicksort(q.resultTuples.data(), q.resultRows, ts, reqs);
+        if (orderBy->hasLimit && q.resultRows > orderBy->limit) {      // applyLimit after the sort (orderby.h:87-93)
+            q.resultRows = orderBy->limit;
+            q.resultTuples.resize((size_t)q.resultRows * ts);
+        }
+    }
+}
+
+}  // namespace rsq

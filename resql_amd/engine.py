@@ -71,6 +71,7 @@ def lib():
         L.rsq_query_execute_partial.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.rsq_query_finalize.argtypes = [vp]
         L.rsq_query_bind_partial.argtypes = [vp, vp, C.c_size_t]
+        L.rsq_query_finalize_host.argtypes = [vp, C.POINTER(i64), i64]
         L.rsq_query_partial_layout.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.rsq_query_result.argtypes = [vp, C.POINTER(P.rsq_result_view)]
         L.rsq_query_report.argtypes = [vp, C.POINTER(rsq_report)]
@@ -93,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
     "rsq_table_from_rowstore", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_execute_partial",
-    "rsq_query_finalize", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
+    "rsq_query_finalize", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
     "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
     "rsq_measure_read_bandwidth",
 ]
@@ -228,6 +229,11 @@ class Query:
         p = C.c_void_p(); a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
         self.ctx._check(self.ctx._L.rsq_query_execute_partial(self.h, C.byref(p), C.byref(a), C.byref(b), C.byref(c)))
         return p.value, a.value, b.value, c.value
+
+    def finalize_host(self, words: np.ndarray):
+        """finalise from a partial aggregate table held in host memory (int64 words)"""
+        w = np.ascontiguousarray(words, dtype=np.int64)
+        self.ctx._check(self.ctx._L.rsq_query_finalize_host(self.h, w.ctypes.data_as(C.POINTER(C.c_int64)), w.size))
 
     def bind_partial(self, dev_ptr: int, nbytes: int):
         self.ctx._check(self.ctx._L.rsq_query_bind_partial(self.h, dev_ptr, nbytes))

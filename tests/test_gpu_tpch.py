@@ -35,3 +35,34 @@ def test_q1_ragged_row_counts(gpu_ctx):
         got = gpu_ctx.run(plan)
         want = orc.execute(plan)
         assert got.text == want.text, n
+
+
+@pytest.mark.parametrize("sf", [0.01, 0.2])
+def test_q3_matches_oracle(gpu_ctx, sf):
+    li = tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+    plan = tpch.q3_plan(tpch.customer_table(sf), tpch.orders_table(sf), li)
+    got = gpu_ctx.run(plan)
+    want = orc.execute(plan)
+    assert got.text == want.text
+    assert got.tuples == want.tuples
+
+
+def test_q3_without_limit_full_order(gpu_ctx):
+    """no LIMIT: every group is materialised, in the reference's quicksort order (ties included)"""
+    sf = 0.05
+    li = tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+    plan = tpch.q3_plan(tpch.customer_table(sf), tpch.orders_table(sf), li, limit=None)
+    got = gpu_ctx.run(plan)
+    want = orc.execute(plan)
+    assert got.n_rows == want.n_rows and got.n_rows > 100
+    assert got.text == want.text
+
+
+@pytest.mark.parametrize("groups", [8, 1024, 1 << 16])
+@pytest.mark.parametrize("selectivity", [0.01, 0.5])
+def test_synthetic_filter_aggregate(gpu_ctx, groups, selectivity):
+    t = tpch.synthetic_table(300_000, groups)
+    plan = tpch.synthetic_plan(t, int(selectivity * (1 << 31)))
+    got = gpu_ctx.run(plan)
+    want = orc.execute(plan)
+    assert got.text == want.text
