@@ -86,11 +86,9 @@ def main():
     device = torch.device("cuda", local_rank if world > 1 else 0)
 
     # ---- data: this rank's row range of the SF table, generated in HBM ----
+    from resql_amd.dist import allreduce_partial, shard_rows
     n_total = datagen.n_lineitem(args.sf)
-    tile = 128 * world
-    per = (n_total // tile) * 128                     # shard boundaries on 128-row tiles
-    row0 = rank * per
-    n_rows = per if rank < world - 1 else n_total - per * (world - 1)
+    row0, n_rows = shard_rows(n_total, world, rank)   # shard boundaries on 128-row tiles
     ctx = engine.Context(device=local_rank if world > 1 else 0)
     table = ctx.generate(engine.GEN_LINEITEM, n_rows, args.sf, row0=row0)
     schema_only = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
@@ -105,11 +103,7 @@ def main():
             q.execute()
             return
         q.execute_partial()                           # blocks until the kernel has finished
-        if n_min:
-            dist.all_reduce(partial[:n_min], op=dist.ReduceOp.MIN)
-        if n_max:
-            dist.all_reduce(partial[n_min:n_min + n_max], op=dist.ReduceOp.MAX)
-        dist.all_reduce(partial[n_min + n_max:], op=dist.ReduceOp.SUM)
+        allreduce_partial(dist, partial, n_min, n_max, n_sum)      # the one exchange step: RCCL over xGMI
         torch.cuda.current_stream().synchronize()
         if rank == 0:
             q.finalize()
@@ -136,6 +130,17 @@ def main():
 
     if rank == 0:
         result = q.result()
+        # HBM traffic of this kernel from the PMC pass committed under profiles/ (FETCH_SIZE, collected in its own
+        # rocprofv3 --pmc run and corrected x2 as MI355X_MICROARCH.md prescribes for gfx950); only quoted for the
+        # configuration it was measured on
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_q1_sf10_pmc.json")) as f:
+                pmc = json.load(f)
+            if world == 1 and pmc.get("algorithmic_bytes_per_launch") == tpch.Q1_BYTES_PER_ROW * n_rows:
+                traffic = pmc["hbm_read_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = tpch.Q1_BYTES_PER_ROW * n_rows / (avg_kernel_ms * 1e-3) / 1e9
         out = {
@@ -157,7 +162,7 @@ def main():
                        "parallelism": f"row-range shards x{world}, RCCL int64 all-reduce of the partial group table"
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "rsq_pipeline (scan+filter+dense aggregation)", "kernel_ms": avg_kernel_ms,
                          "bytes_per_launch": tpch.Q1_BYTES_PER_ROW * n_rows},
         }

@@ -172,6 +172,24 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         q->allSource += p.source + "\n";
         q->explainText += p.explain + "\n";
     }
+    if (denseMode(*q)) {
+        // layout of the (partial) aggregate table, for hosts that merge it across GPUs
+        std::ostringstream d;
+        d << "partial table: groups=" << q->denseGroups << " keys=[";
+        for (size_t i = 0; i < q->denseKeys.size(); i++) {
+            const DenseKey& k = q->denseKeys[i];
+            d << (i ? " x " : "") << k.expr->symbol;
+            if (k.byteSet) { d << "{"; for (size_t v = 0; v < k.values.size(); v++) d << (v ? "," : "") << (int)k.values[v]; d << "}"; }
+            else d << "[" << k.min << ".." << (k.min + k.card - 1) << "]";
+        }
+        d << "] blocks=[";
+        std::vector<std::string> names(q->accums.size());
+        for (size_t w = 0; w < q->accums.size(); w++)
+            names[(size_t)q->accumSlot[w]] = std::string(q->accums[w].merge == 0 ? "sum:" : q->accums[w].merge == 2 ? "min:" : "max:") + q->accums[w].key;
+        for (size_t b = 0; b < names.size(); b++) d << (b ? " | " : "") << names[b];
+        d << "] (word = block * groups + group)";
+        q->explainText += d.str() + "\n";
+    }
     if (ctx.device >= 0) {
         if (denseMode(*q)) prepareDenseBuffers(*q);
         for (auto& h : q->hashTables) {
