@@ -1,0 +1,209 @@
+// resql_hip_binding.h — the ReSQL-side binding of the MI355X engine (include/resql_hip.h).
+//
+// This is the file a ReSQL maintainer adds to ReSQL's src/ to run SELECT plans on the GPU: it walks ReSQL's OWN
+// operator tree (src/operators/*.h) and expression trees (src/expressions.h), describes them as the plain-C
+// rsq_plan_desc of include/resql_plan.h, hands ReSQL's row-store Relations (src/dbdata.h) to the engine, and turns
+// the result back into a ReSQL Relation — so that executeSelectPlanHip() is a drop-in for executeSelectPlan()
+// (src/execute.h:213-247).  It contains no engine logic: everything it calls is the C ABI.
+//
+// It is compiled against the reference's headers where they live (it must be included AFTER
+// "operators/JitOperators.h"); oracle/Makefile builds it into oracle/_ref/ref_harness (`--engine hip`), which is how
+// the drop-in is exercised with the reference's real classes on the GPU box.
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include <cstring>
+
+#include "resql_hip.h"
+
+namespace resql_hip {
+
+struct HipError : public ResqlError {
+    int status;
+    HipError(int st, const std::string& m) : ResqlError(m), status(st) {}
+};
+
+inline rsq_type toRsqType(SqlType t) {
+    rsq_type r{(int32_t)t.tag, 0, 0, 0};     // SqlType::Tag == rsq_type_tag by construction
+    if (t.tag == SqlType::DECIMAL) { r.precision = t.decimalSpec().precision; r.scale = t.decimalSpec().scale; }
+    if (t.tag == SqlType::CHAR) r.len = (int32_t)t.charSpec().num;
+    if (t.tag == SqlType::VARCHAR) r.len = (int32_t)t.varcharSpec().num;
+    return r;
+}
+
+inline SqlType fromRsqType(const rsq_type& t) {
+    switch (t.tag) {
+        case RSQ_DECIMAL: return TypeInit::DECIMAL((uint8_t)t.precision, (uint8_t)t.scale);
+        case RSQ_CHAR: return TypeInit::CHAR((size_t)t.len);
+        case RSQ_VARCHAR: return TypeInit::VARCHAR((size_t)t.len);
+        case RSQ_INT: return TypeInit::INT();
+        case RSQ_BIGINT: return TypeInit::BIGINT();
+        case RSQ_DATE: return TypeInit::DATE();
+        case RSQ_BOOL: return TypeInit::BOOL();
+        default: throw ResqlError("result type not representable");
+    }
+}
+
+// Describes a ReSQL plan (RelOperator tree + Expr trees) as rsq_plan_desc.
+class PlanDescriber {
+public:
+    std::vector<rsq_expr> exprs;
+    std::vector<rsq_op> ops;
+    std::vector<Relation*> tables;
+    std::vector<std::string> tableNames;
+
+    int expr(Expr* e) {
+        // a TYPECAST that ReSQL's own type derivation already inserted is skipped: the engine derives types itself
+        if (e->tag == Expr::TYPECAST) return expr(e->child);
+        auto it = exprIds_.find(e);
+        if (it != exprIds_.end()) return it->second;           // shared Expr* => shared node (planner.h:90-99, :430)
+        rsq_expr d{};
+        d.tag = (int32_t)e->tag;                                 // Expr::Tag == rsq_expr_tag by construction
+        std::vector<int> kids;
+        for (Expr* c = e->child; c != nullptr; c = c->next) kids.push_back(expr(c));
+        if (kids.size() > RSQ_MAX_CHILDREN) throw ResqlError("expression with too many children");
+        d.n_children = (int32_t)kids.size();
+        for (size_t i = 0; i < kids.size(); i++) d.child[i] = kids[i];
+        d.const_category = (e->tag == Expr::CONSTANT) ? (int32_t)e->type.tag : RSQ_NT;
+        if (e->symbol.size() >= RSQ_SYMBOL_MAX) throw ResqlError("symbol too long: " + e->symbol);
+        std::strncpy(d.symbol, e->symbol.c_str(), RSQ_SYMBOL_MAX - 1);
+        exprs.push_back(d);
+        exprIds_[e] = (int)exprs.size() - 1;
+        return (int)exprs.size() - 1;
+    }
+
+    int table(Relation* rel, const std::string& name) {
+        for (size_t i = 0; i < tables.size(); i++) if (tables[i] == rel) return (int)i;
+        tables.push_back(rel);
+        tableNames.push_back(name.empty() ? "rel" + std::to_string(tables.size()) : name);
+        return (int)tables.size() - 1;
+    }
+
+    int op(RelOperator* o, bool* hasLimit = nullptr, int64_t* limit = nullptr) {
+        rsq_op d{};
+        d.child[0] = d.child[1] = -1; d.table = -1;
+        auto list = [&](std::vector<Expr*>& v, int32_t& n, int32_t* dst) {
+            if (v.size() > RSQ_MAX_OP_EXPRS) throw ResqlError("too many expressions on one operator");
+            n = (int32_t)v.size();
+            for (size_t i = 0; i < v.size(); i++) dst[i] = expr(v[i]);
+        };
+        if (auto* s = dynamic_cast<ScanOp*>(o)) {
+            d.tag = RSQ_OP_SCAN; d.table = table(s->_rel, s->relationName);
+        } else if (auto* s = dynamic_cast<SelectionOp*>(o)) {
+            d.tag = RSQ_OP_SELECTION; d.child[0] = op(s->_child);
+            d.n_exprs = 1; d.exprs[0] = expr(s->_condition);
+        } else if (auto* p = dynamic_cast<ProjectionOp*>(o)) {
+            if (p->_child == nullptr) throw ResqlError("leaf projections are not supported by the HIP engine");
+            d.tag = RSQ_OP_PROJECTION; d.child[0] = op(p->_child); list(p->_expr, d.n_exprs, d.exprs);
+        } else if (auto* h = dynamic_cast<HashJoinOp*>(o)) {
+            d.tag = RSQ_OP_HASHJOIN; d.child[0] = op(h->_lChild); d.child[1] = op(h->_rChild);
+            list(h->_equalities, d.n_exprs, d.exprs); d.single_match = h->_singleMatch ? 1 : 0;
+        } else if (auto* a = dynamic_cast<AggregationOp*>(o)) {
+            d.tag = RSQ_OP_AGGREGATION; d.child[0] = op(a->_child);
+            list(a->_aggExpr, d.n_exprs, d.exprs); list(a->_groupExpr, d.n_exprs2, d.exprs2);
+        } else if (auto* ob = dynamic_cast<OrderByOp*>(o)) {
+            // OrderByOp owns a MaterializeOp child (orderby.h:32-38); the engine re-creates it
+            d.tag = RSQ_OP_ORDERBY; d.child[0] = op(ob->_child->_child);
+            list(ob->_orderExpressions, d.n_exprs, d.exprs);
+            if (hasLimit && ob->_hasLimitClause) { *hasLimit = true; *limit = (int64_t)ob->_limit; }
+        } else if (auto* m = dynamic_cast<MaterializeOp*>(o)) {
+            d.tag = RSQ_OP_MATERIALIZE; d.child[0] = op(m->_child);
+            if (hasLimit && m->_hasLimitClause) { *hasLimit = true; *limit = (int64_t)m->_limit; }
+        } else {
+            throw ResqlError("operator " + o->name() + " is not supported by the HIP engine");
+        }
+        ops.push_back(d);
+        return (int)ops.size() - 1;
+    }
+
+private:
+    std::map<Expr*, int> exprIds_;
+};
+
+// One engine context + the device copies of the Relations it has seen.
+class JitContextHip {
+public:
+    explicit JitContextHip(const JitConfig& cfg, int device = 0) {
+        rsq_config c{};
+        c.print_assembly = cfg.printAssembly; c.print_flounder = cfg.printFlounder; c.print_performance = cfg.printPerformance;
+        c.num_threads = cfg.numThreads; c.emit_machine_code = cfg.emitMachineCode; c.optimize = cfg.optimizeFlounder;
+        c.device = device;
+        int rc = rsq_ctx_create(&c, &ctx_);
+        if (rc != RSQ_OK) throw HipError(rc, rsq_last_error(nullptr));
+        report.config = cfg;
+    }
+    ~JitContextHip() {
+        for (auto& kv : tables_) rsq_table_destroy(kv.second);
+        if (ctx_) rsq_ctx_destroy(ctx_);
+    }
+
+    // Relation (row store of 2 MiB DataBlocks, dbdata.h:23-102) -> device columns, once per Relation
+    rsq_table* deviceTable(Relation* rel, const std::string& name) {
+        auto it = tables_.find(rel);
+        if (it != tables_.end()) return it->second;
+        std::vector<rsq_column> cols;
+        for (auto& a : rel->_schema._attribs) {
+            rsq_column c{};
+            std::strncpy(c.name, a.name.c_str(), RSQ_SYMBOL_MAX - 1);
+            c.type = toRsqType(a.type);
+            cols.push_back(c);
+        }
+        rsq_table_desc d{};
+        std::strncpy(d.name, name.c_str(), RSQ_SYMBOL_MAX - 1);
+        d.n_cols = (int32_t)cols.size(); d.cols = cols.data();
+        std::vector<const uint8_t*> blocks; std::vector<size_t> sizes;
+        for (auto& b : rel->_dataBlocks) { blocks.push_back(b->begin()); sizes.push_back(b->_contentSize); }
+        rsq_table* t = nullptr;
+        check(rsq_table_from_rowstore(ctx_, &d, blocks.data(), sizes.data(), (int32_t)blocks.size(), &t));
+        tables_[rel] = t;
+        return t;
+    }
+
+    // describe + compile + execute + retrieve: the body of executeSelectPlan (execute.h:213-247)
+    std::unique_ptr<Relation> run(RelOperator* root, bool requestAll) {
+        PlanDescriber pd;
+        bool hasLimit = false; int64_t limit = 0;
+        int rootIdx = pd.op(root, &hasLimit, &limit);
+        rsq_plan_desc plan{};
+        plan.exprs = pd.exprs.data(); plan.n_exprs = (int32_t)pd.exprs.size();
+        plan.ops = pd.ops.data(); plan.n_ops = (int32_t)pd.ops.size();
+        plan.root = rootIdx; plan.request_all = requestAll ? 1 : 0;
+        plan.has_limit = hasLimit ? 1 : 0; plan.limit = limit;
+        std::vector<rsq_table*> tabs;
+        for (size_t i = 0; i < pd.tables.size(); i++) tabs.push_back(deviceTable(pd.tables[i], pd.tableNames[i]));
+        rsq_query* q = nullptr;
+        check(rsq_query_compile(ctx_, &plan, tabs.data(), (int32_t)tabs.size(), &q));
+        struct Guard { rsq_query* q; ~Guard() { rsq_query_destroy(q); } } guard{q};
+        check(rsq_query_execute(q));
+        rsq_report r{};
+        rsq_query_report(q, &r);
+        report.compilationTime = r.compilation_time_ms;
+        report.executionTime = r.execution_time_ms;
+        report.numMachineInstructions = r.num_kernels;
+        kernelTimeMs = r.kernel_time_ms; hbmGBps = r.hbm_gbps;
+        rsq_result_view v{};
+        check(rsq_query_result(q, &v));
+        // packed tuples have ReSQL's own layout (schema.h:76-106): copy them into a Relation block by block
+        std::vector<Attribute> atts;
+        for (int i = 0; i < v.n_cols; i++) atts.push_back({std::string(v.names[i]), fromRsqType(v.types[i])});
+        auto rel = std::make_unique<Relation>(Schema(atts));
+        if ((size_t)v.tuple_size != rel->_schema._tupSize) throw ResqlError("result tuple layout mismatch");
+        Relation::AppendIterator app(rel.get());
+        for (int64_t t = 0; t < v.n_rows; t++)
+            std::memcpy(app.get(), v.tuples + (size_t)t * (size_t)v.tuple_size, (size_t)v.tuple_size);
+        return rel;
+    }
+
+    JitExecutionReport report;
+    double kernelTimeMs = 0, hbmGBps = 0;
+
+private:
+    void check(int rc) { if (rc != RSQ_OK) throw HipError(rc, rsq_last_error(ctx_)); }
+    rsq_ctx* ctx_ = nullptr;
+    std::map<Relation*, rsq_table*> tables_;
+};
+
+}  // namespace resql_hip

@@ -135,8 +135,11 @@ def write_case(plan: P.Plan, directory: str) -> str:
 
 
 def run_reference(plan: P.Plan, threads: int = 1, repeat: int = 1, blocksize: Optional[int] = None,
-                  workdir: Optional[str] = None, quiet: bool = False) -> Tuple[str, Dict[str, list]]:
-    """run the UNMODIFIED reference on the plan; returns (serialised result, timings)"""
+                  workdir: Optional[str] = None, quiet: bool = False, engine: str = "flounder",
+                  device: int = 0) -> Tuple[str, Dict[str, list]]:
+    """run the UNMODIFIED reference on the plan; returns (serialised result, timings).
+    engine="hip": same harness, same ReSQL plan objects, but executed through integration/resql_hip_binding.h
+    (the drop-in), i.e. ReSQL's operator tree -> C ABI -> HIP engine."""
     if not have_reference():
         raise OracleError("oracle/_ref/ref_harness is not built (needs /root/reference: make -C oracle ref)")
     own = workdir is None
@@ -144,11 +147,17 @@ def run_reference(plan: P.Plan, threads: int = 1, repeat: int = 1, blocksize: Op
     try:
         case = write_case(plan, tmp)
         cmd = [REF_HARNESS, case, "--threads", str(threads), "--repeat", str(repeat)]
+        if engine != "flounder":
+            cmd += ["--engine", engine, "--device", str(device)]
         if blocksize:
             cmd += ["--blocksize", str(blocksize)]
         if quiet:
             cmd += ["--quiet"]
         pr = subprocess.run(cmd, capture_output=True, text=True, errors="replace")
+        if pr.returncode < 0 and os.environ.get("RESQL_HARNESS_DEBUGGER"):
+            dbg = os.environ["RESQL_HARNESS_DEBUGGER"].split() + cmd
+            pd = subprocess.run(dbg, capture_output=True, text=True, errors="replace")
+            raise OracleError(f"ref_harness crashed ({pr.returncode}); under the debugger:\n{pd.stdout[-6000:]}\n{pd.stderr[-3000:]}")
         if pr.returncode != 0:
             raise OracleError(f"ref_harness failed ({pr.returncode}): {pr.stderr[-2000:]}")
         timings: Dict[str, list] = {"compile_ms": [], "exec_ms": [], "load_ms": []}

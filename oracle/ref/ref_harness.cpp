@@ -21,6 +21,10 @@
 #include "schema.h"
 #include "JitContextFlounder.h"
 
+#ifdef RSQ_WITH_HIP_BINDING
+#include "resql_hip_binding.h"     // integration/: ReSQL operator tree -> include/resql_hip.h
+#endif
+
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -350,6 +354,7 @@ int main(int argc, char** argv) {
     if (argc < 2) die("usage: ref_harness CASEFILE [--threads N] [--blocksize B] [--repeat K] [--out FILE] [--quiet]");
     std::string casePath = argv[1];
     int threads = 1, repeat = 1; bool quiet = false; std::string outPath;
+    std::string engine = "flounder"; int device = 0;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--threads") threads = atoi(argv[++i]);
@@ -357,6 +362,8 @@ int main(int argc, char** argv) {
         else if (a == "--repeat") repeat = atoi(argv[++i]);
         else if (a == "--out") outPath = argv[++i];
         else if (a == "--quiet") quiet = true;
+        else if (a == "--engine") engine = argv[++i];        // "flounder" (the reference's own JIT) | "hip"
+        else if (a == "--device") device = atoi(argv[++i]);
         else die("unknown option " + a);
     }
 
@@ -367,12 +374,35 @@ int main(int argc, char** argv) {
     std::cerr << "#load_ms " << tLoad.get() << std::endl;
 
     std::unique_ptr<Relation> result;
+#ifdef RSQ_WITH_HIP_BINDING
+    std::unique_ptr<resql_hip::JitContextHip> hip;
+    if (engine == "hip") {
+        JitConfig jc; jc.numThreads = threads;
+        try { hip = std::make_unique<resql_hip::JitContextHip>(jc, device); }
+        catch (ResqlError& err) { std::cerr << "ResqlError: " << err.message(); return 3; }
+    }
+#else
+    if (engine == "hip") die("built without the HIP binding");
+#endif
     for (int rep = 0; rep < repeat; rep++) {
         // plans are single use (operators own iterators / hash tables): rebuild per repetition
         PlanBuilder pb{c, db, {}, {}};
         RelOperator* root = pb.op(c.root);
         if (c.hasLimit) root->addLimit(c.limit);
 
+#ifdef RSQ_WITH_HIP_BINDING
+        if (hip) {
+            // the drop-in: same plan objects, the HIP engine instead of produceFlounder/compile/execute
+            try { result = hip->run(root, c.requestAll); }
+            catch (ResqlError& err) { std::cerr << "ResqlError: " << err.message(); return 3; }
+            // NOT root->deletePlan(): HashJoinOp::~HashJoinOp (hashjoin.h:83-85) frees _ht unconditionally and
+            // crashes when produceFlounder never allocated it (AggregationOp's destructor has the null check,
+            // aggregation.h:66-70).  A ReSQL-side integration adds the same check; the harness leaks the plan.
+            std::cerr << "#timing compile_ms " << hip->report.compilationTime << " exec_ms " << hip->report.executionTime
+                      << " instrs " << hip->report.numMachineInstructions << " kernel_ms " << hip->kernelTimeMs << std::endl;
+            continue;
+        }
+#endif
         // the reference's executeSelectPlan call sequence (execute.h:213-247)
         ExpressionContext exprCtx;
         root->defineExpressionsForPlan(exprCtx);
