@@ -3,6 +3,7 @@
 //   * the deterministic TPC-H-shaped generator (bit-identical to resql_amd/datagen.py)
 //   * the read-only streaming bandwidth probe (the measured roofline of SURVEY.md §8d)
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -316,6 +317,25 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
     hipLaunchKernelGGL(k_compact_entries, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, (const i64*)words, nWords,
                        (const i64*)acc, nAcc, (i64*)outRows, count);
     RSQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of per-slot tuple counts (u32) into output offsets (u64); `n` includes one trailing zero
+// slot so that offs[n - 1] is the total (rocPRIM device scan through hipCUB)
+// ------------------------------------------------------------------------------------------------
+struct CastU64 { __host__ __device__ u64 operator()(const unsigned& v) const { return (u64)v; } };
+
+size_t scanTempBytes(int64_t n) {
+    size_t bytes = 0;
+    hipcub::TransformInputIterator<u64, CastU64, const unsigned*> in((const unsigned*)nullptr, CastU64());
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, (u64*)nullptr, (int)n, (hipStream_t)0);
+    return bytes;
+}
+
+void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes) {
+    if (n > 0x7fffffff) throw Error(RSQ_ERR_UNSUPPORTED, "materialisation of more than 2^31 lane slots");
+    hipcub::TransformInputIterator<u64, CastU64, const unsigned*> in((const unsigned*)counts, CastU64());
+    RSQ_HIP(hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, in, (u64*)offs, (int)n, ctx.stream));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -368,8 +368,7 @@ struct Walker {
                 if (joinPhase[o] == 1) consumeBuild(o, from); else consumeProbe(o, from);
                 break;
             case RSQ_OP_AGGREGATION: consumeAggregation(o, from); break;
-            case RSQ_OP_MATERIALIZE:
-                failUnsupported("plans without an aggregation (device-side materialisation) are not built yet in this engine version");
+            case RSQ_OP_MATERIALIZE: consumeMaterialize(o, from); break;
             default: failUnsupported("operator not supported by the GPU engine");
         }
     }
@@ -600,9 +599,73 @@ struct Walker {
             q.aggMode = AggMode::AT_JOIN_ENTRY;
             emitJoinEntryAggregation(o);
         } else {
-            failUnsupported("group-by on computed or high-cardinality keys needs the generic hash aggregation, which is not built yet");
+            q.aggMode = AggMode::HASH;
+            emitHashAggregation(o);
         }
         pipe.sink = SinkKind::AGGREGATE;
+    }
+
+    // Generic hash aggregation (computed keys, wide domains): an open-addressing table in HBM keyed by the group
+    // values, insert-or-find inside the kernel, aggregates beside the entries.  Slot protocol: state 0 empty ->
+    // CAS to 1 (being written) -> keys stored -> fence -> 2 (ready); a lane that loses the CAS or meets state 1
+    // simply looks at the slot again in its next loop iteration (no inner spin, so lanes of one wave cannot
+    // dead-lock each other).
+    void emitHashAggregation(OpNode* o) {
+        std::unique_ptr<HashTable> ht(new HashTable());
+        ht->id = (int)q.hashTables.size();
+        const std::string T = "ht" + std::to_string(ht->id);
+        const int W = (int)q.accums.size();
+        ht->nAccBlocks = W;
+        std::vector<std::string> keyVars;
+        openScope("{");
+        int k = 0;
+        q.groupSource.clear();
+        for (Expr* g : o->exprs2) {
+            std::string kv = T + "_g" + std::to_string(k);
+            line("const i64 " + kv + " = " + toWord(eg.emit(g), g->type) + ";");
+            keyVars.push_back(kv);
+            ht->keys.push_back({expressionName(g), g->type});
+            q.groupSource.push_back(k++);
+        }
+        if (keyVars.empty()) failUnsupported("hash aggregation without group keys");
+        for (int w = 1; w < W; w++) line("const i64 in" + std::to_string(w) + " = " + q.accums[(size_t)w].input + ";");
+        addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
+        addArg(T + "_acc", "u64*", 0);
+        line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
+        line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
+        openScope("for (u64 " + T + "_n = 0;; " + T + "_n++) {");
+        line("if (" + T + "_n > 4 * " + T + "_mask + 4096) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
+        line("const u32 stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);");
+        line("bool hit = false;");
+        openScope("if (stt == 2u) {");
+        std::string cond;
+        for (size_t i = 0; i < keyVars.size(); i++)
+            cond += (i ? " && " : "") + std::string("rsq::ld_agent(&a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s]) == " + keyVars[i];
+        line("if (" + cond + ") hit = true; else { " + T + "_s = (" + T + "_s + 1) & " + T + "_mask; continue; }");
+        closeScope();
+        openScope("else if (stt == 0u) {");
+        openScope("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) {");
+        for (size_t i = 0; i < keyVars.size(); i++)
+            line("rsq::st_agent(&a." + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s], " + keyVars[i] + ");");
+        line("__threadfence();");
+        line("rsq::st_agent(&a." + T + "_state[" + T + "_s], 2u);");
+        line("atomicAdd(a." + T + "_count, 1u);");
+        line("hit = true;");
+        closeScope();
+        closeScope();
+        line("if (!hit) continue;       // lost the race or the slot is being written: look at it again");
+        for (int w = 0; w < W; w++) {
+            std::string in = w == 0 ? "row" : "in" + std::to_string(w);
+            line("rsq::global_merge_always<" + std::to_string(q.accums[(size_t)w].merge) + ">(a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) +
+                 " * a." + T + "_cap + " + T + "_s, (u64)(" + in + "));");
+        }
+        line("break;");
+        closeScope();
+        closeScope();
+        q.aggTable = ht->id;
+        explainSteps.push_back("hash aggregation in " + T + " (" + std::to_string(ht->keys.size()) + " key word(s)) accumulators=" +
+                               std::to_string(W - 1) + " (of " + std::to_string(o->splitAgg.size()) + " in the reference)");
+        q.hashTables.push_back(std::move(ht));
     }
 
     std::string groupIdExpr() {
@@ -763,6 +826,46 @@ struct Walker {
                                std::to_string(o->splitAgg.size()) + " in the reference)");
     }
 
+    // ---- materialisation of a pipeline without aggregation (materialize.h:78-220) ----------------
+    // The reference appends tuples in scan order.  On the device the same order is kept with two passes of the
+    // same pipeline: pass 1 counts the tuples every lane emits per 128-row tile, an exclusive scan turns the counts
+    // into output offsets, pass 2 writes each tuple to its final position (struct of arrays; the host packs
+    // ReSQL tuples from them).
+    void consumeMaterialize(OpNode* o, OpNode* from) {
+        if (q.agg) failUnsupported("materialize inside an aggregation input");
+        if (q.matOp) failUnsupported("more than one materialisation on the device");
+        o->schema = from->schema;
+        q.matOp = o;
+        q.matSchema = o->schema;
+        openScope("{");
+        line("#if RSQ_PASS == 1");
+        line("st.cnt++;");
+        line("#else");
+        line("const u64 pos = st.pos++;");
+        openScope("if (pos < a.out_limit) {");
+        int k = 0;
+        for (auto& a : o->schema) {
+            auto it = eg.symbols.find(a.name);
+            if (it == eg.symbols.end()) failType("materialize: symbol " + a.name + " not found");
+            const Type& t = it->second.type;
+            std::string on = "o" + std::to_string(k++);
+            if (t.isString()) {
+                addArg(on, "char*", 0);
+                line("for (int i = 0; i < " + std::to_string(t.len) + "; i++) a." + on + "[pos * " + std::to_string(t.len) + " + i] = rsq::str_at(" + it->second.var + ", i);");
+            } else {
+                addArg(on, ExprGen::ctype(t) + "*", 0);
+                line("a." + on + "[pos] = " + it->second.var + ";");
+            }
+        }
+        closeScope();
+        line("#endif");
+        closeScope();
+        addArg("cnt", "u32*", 0); addArg("offs", "const u64*", 0); addArg("out_limit", "u64", 0);
+        stateDecl += "    u32 cnt = 0;\n    u64 pos = 0;\n";
+        pipe.sink = SinkKind::MATERIALIZE;
+        explainSteps.push_back("materialize " + std::to_string(o->schema.size()) + " column(s) in scan order (count / scan / write)");
+    }
+
     // -------------------------------------------------------------------------------------------
     void finishPipeline() {
         while (indent > 1) closeScope();
@@ -770,6 +873,7 @@ struct Walker {
         addArg("row0", "i64", (uint64_t)pipe.src->row0);
         addArg("err", "u32*", (uint64_t)(uintptr_t)q.ctx.dErr);
         const int U = pipe.unroll;
+        const bool mat = pipe.sink == SinkKind::MATERIALIZE;
         std::ostringstream s;
         s << "// generated by resql_amd/csrc/codegen.cpp\n//   ";
         for (size_t i = 0; i < explainSteps.size(); i++) s << (i ? " -> " : "") << explainSteps[i];
@@ -800,18 +904,27 @@ struct Walker {
         }
         for (int u = 0; u < U; u++) {
             s << "        if (tt" << u << " < ntiles) {\n";
+            if (mat) s << "            const i64 slot = tt" << u << " * 64 + lane;\n#if RSQ_PASS == 2\n            st.pos = a.offs[slot];\n#endif\n";
             for (int j = 0; j < 2; j++) {
                 s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j;
                 for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
                 s << ");\n";
             }
+            if (mat) s << "#if RSQ_PASS == 1\n            a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
             s << "        }\n";
         }
         s << "    }\n";
-        s << "    for (i64 r = (ntiles << 7) + (i64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (i64)gridDim.x * blockDim.x)\n";
+        s << "    for (i64 r = (ntiles << 7) + (i64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (i64)gridDim.x * blockDim.x) {\n";
+        if (mat) s << "        const i64 slot = ntiles * 64 + (r - (ntiles << 7));\n#if RSQ_PASS == 2\n        st.pos = a.offs[slot];\n#endif\n";
         s << "        row_fn(a, st, r" << rowArgsTail << ");\n";
+        if (mat) s << "#if RSQ_PASS == 1\n        a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
+        s << "    }\n";
         s << epilogue << "}\n";
         pipe.source = s.str();
+        if (mat) {   // two code objects from one source
+            pipe.sourcePass1 = "#define RSQ_PASS 1\n" + pipe.source;
+            pipe.source = "#define RSQ_PASS 2\n" + pipe.source;
+        }
         std::string ex = "pipeline " + std::to_string(q.pipelines.size()) + ": ";
         for (size_t i = 0; i < explainSteps.size(); i++) ex += (i ? " -> " : "") + explainSteps[i];
         pipe.explain = ex;
@@ -824,7 +937,7 @@ struct Walker {
 void buildPipelines(Query& q) {
     Walker w(q);
     w.produce(q.root, {});
-    if (!q.agg) failUnsupported("plans without an aggregation (device-side materialisation) are not built yet in this engine version");
+    if (!q.agg && !q.matOp) failInvalid("plan has neither an aggregation nor a materialisation");
 }
 
 }  // namespace rsq

@@ -116,6 +116,10 @@ Query::~Query() {
     if (dAgg && dAggOwned) ctx.free(dAgg);
     if (dAggInit) ctx.free(dAggInit);
     if (hPinned) (void)hipHostFree(hPinned);
+    if (dMatCnt) ctx.free(dMatCnt);
+    if (dMatOffs) ctx.free(dMatOffs);
+    if (dScanTemp) ctx.free(dScanTemp);
+    for (void* p : dMatCols) if (p) ctx.free(p);
     if (dGroupRows) ctx.free(dGroupRows);
     if (dGroupCount) ctx.free(dGroupCount);
     for (auto& h : hashTables) {
@@ -168,6 +172,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     defineAndDerive(*q, q->root);
     buildPipelines(*q);
     for (auto& p : q->pipelines) {
+        if (!p.sourcePass1.empty()) p.kernelPass1 = &ctx.getKernel(p.sourcePass1, p.entry);
         p.kernel = &ctx.getKernel(p.source, p.entry);
         q->allSource += p.source + "\n";
         q->explainText += p.explain + "\n";
@@ -195,7 +200,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         for (auto& h : q->hashTables) {
             h->dCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
         }
-        if (q->aggMode == AggMode::AT_JOIN_ENTRY) q->dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
+        if (q->aggMode == AggMode::AT_JOIN_ENTRY || q->aggMode == AggMode::HASH) q->dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
         size_t pw = q->pinnedWords + 8;
         RSQ_HIP(hipHostMalloc((void**)&q->hPinned, pw * 8, hipHostMallocDefault));
     }
@@ -212,6 +217,13 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
 // ================================================================================================
 static uint64_t argValue(Query& q, const ArgSlot& a, int countOnlyTable) {
     if (a.name == "out") return (uint64_t)(uintptr_t)q.dAgg;
+    if (a.name == "cnt") return (uint64_t)(uintptr_t)q.dMatCnt;
+    if (a.name == "offs") return (uint64_t)(uintptr_t)q.dMatOffs;
+    if (a.name == "out_limit") return (uint64_t)q.matLimit;
+    if (a.name.size() >= 2 && a.name[0] == 'o' && isdigit((unsigned char)a.name[1])) {
+        size_t k = (size_t)atoi(a.name.c_str() + 1);
+        return k < q.dMatCols.size() ? (uint64_t)(uintptr_t)q.dMatCols[k] : 0;
+    }
     if (a.name.compare(0, 2, "ht") == 0) {
         size_t us = a.name.find('_');
         int id = atoi(a.name.substr(2, us - 2).c_str());
@@ -227,7 +239,7 @@ static uint64_t argValue(Query& q, const ArgSlot& a, int countOnlyTable) {
     return a.value;
 }
 
-static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable) {
+static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
     std::vector<uint64_t> args;
     for (auto& a : p.args) args.push_back(argValue(q, a, countOnlyTable));
     const int64_t tiles = p.src->nRows >> 7;
@@ -235,8 +247,46 @@ static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable) {
     int64_t want = (tiles + (int64_t)wavesPerBlock * p.unroll - 1) / ((int64_t)wavesPerBlock * p.unroll);
     const int64_t maxGrid = p.maxGrid ? (int64_t)p.maxGrid : 2 * (int64_t)q.ctx.numCUs;
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(maxGrid * 256 / p.blockThreads, want));
-    launch(q.ctx, *p.kernel, grid, (unsigned)p.blockThreads, args);
+    launch(q.ctx, pass1 ? *p.kernelPass1 : *p.kernel, grid, (unsigned)p.blockThreads, args);
     q.report.num_kernels++;
+}
+
+// count / scan / write (see consumeMaterialize in codegen.cpp)
+static void materializePipeline(Query& q, Pipeline& p) {
+    Context& ctx = q.ctx;
+    const int64_t n = p.src->nRows;
+    const int64_t slots = (n >> 7) * 64 + (n & 127) + 1;          // + one trailing zero slot: its offset is the total
+    if (q.matSlots < slots) {
+        if (q.dMatCnt) ctx.free(q.dMatCnt);
+        if (q.dMatOffs) ctx.free(q.dMatOffs);
+        if (q.dScanTemp) ctx.free(q.dScanTemp);
+        q.dMatCnt = (uint32_t*)ctx.alloc((size_t)slots * 4);
+        q.dMatOffs = (uint64_t*)ctx.alloc((size_t)slots * 8);
+        q.scanTempBytes = scanTempBytes(slots);
+        q.dScanTemp = ctx.alloc(q.scanTempBytes);
+        q.matSlots = slots;
+    }
+    RSQ_HIP(hipMemsetAsync(q.dMatCnt, 0, (size_t)slots * 4, ctx.stream));
+    q.matLimit = 0;
+    launchPipeline(q, p, -1, true);
+    exclusiveScanCounts(ctx, q.dMatCnt, q.dMatOffs, slots, q.dScanTemp, q.scanTempBytes);
+    q.report.num_kernels++;
+    uint64_t total = 0;
+    RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + (slots - 1), 8, hipMemcpyDeviceToHost, ctx.stream));
+    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    // MaterializeOp with a LIMIT leaves the pipeline once count >= limit, i.e. after max(limit, 1) tuples (materialize.h:197-206)
+    uint64_t keep = total;
+    if (q.matOp->hasLimit) keep = std::min<uint64_t>(total, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));
+    q.matRows = (int64_t)keep;
+    if ((int64_t)keep > q.matCapacity || q.dMatCols.empty()) {
+        for (void* c : q.dMatCols) if (c) ctx.free(c);
+        q.dMatCols.clear();
+        q.matCapacity = std::max<int64_t>((int64_t)keep, 1);
+        for (auto& a : q.matSchema) q.dMatCols.push_back(ctx.alloc((size_t)q.matCapacity * (size_t)columnWidth(a.type)));
+    }
+    q.matLimit = keep;
+    launchPipeline(q, p, -1, false);
+    q.report.bytes_read += 2 * (uint64_t)(p.bytesPerRow * p.src->nRows);
 }
 
 // size (by a counting pass of the same pipeline), allocate and clear a join hash table, then build it
@@ -279,18 +329,48 @@ void executeQuery(Query& q, bool partialOnly) {
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     for (auto& p : q.pipelines) {
         if (p.sink == SinkKind::BUILD) { buildHashTable(q, p); continue; }
-        if (q.aggMode == AggMode::AT_JOIN_ENTRY) {
-            HashTable& h = *q.hashTables[(size_t)q.aggTable];
+        if (p.sink == SinkKind::MATERIALIZE) { materializePipeline(q, p); continue; }
+        auto resetAccumulators = [&](HashTable& h) {
             // aggregate words beside the entries: first-row / min blocks to +inf, max blocks to -inf, sums to 0
             for (int b = 0; b < h.nAccBlocks; b++) {
                 uint64_t idv = b < q.nMinBlocks ? 0x7fffffffffffffffull : b < q.nMinBlocks + q.nMaxBlocks ? 0x8000000000000000ull : 0ull;
                 fillU64Async(ctx, (uint64_t*)h.dAcc + (size_t)b * (size_t)h.capacity, (size_t)h.capacity, idv);
             }
+        };
+        if (q.aggMode == AggMode::AT_JOIN_ENTRY) resetAccumulators(*q.hashTables[(size_t)q.aggTable]);
+        if (q.aggMode == AggMode::HASH) {
+            // The number of groups is not known before the scan: start from the reference's own estimate
+            // (AggregationOp::getSize, aggregation.h:81-92) and re-run the pipeline with a 4x larger table while
+            // the kernel reports a full table.
+            HashTable& h = *q.hashTables[(size_t)q.aggTable];
+            if (h.capacity == 0) h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)opSize(q.agg)));
+            for (;;) {
+                if (!h.dState) {
+                    h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
+                    h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * h.keys.size());
+                    h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
+                }
+                RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
+                RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
+                resetAccumulators(h);
+                launchPipeline(q, p, -1);
+                uint32_t err = 0;
+                RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+                RSQ_HIP(hipStreamSynchronize(ctx.stream));
+                if (!(err & 2)) break;
+                if (h.capacity >= ((int64_t)1 << 31)) failRuntime("Hash table full");
+                ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc);
+                h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
+                h.capacity *= 4;
+                RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+            }
+            q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
+            continue;
         }
         launchPipeline(q, p, -1);
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
     }
-    if (q.aggMode == AggMode::AT_JOIN_ENTRY && !partialOnly) {
+    if ((q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) && !partialOnly) {
         HashTable& h = *q.hashTables[(size_t)q.aggTable];
         const int nTab = (int)(h.keys.size() + h.payload.size());
         q.groupRowWords = 1 + nTab + h.nAccBlocks;
@@ -311,7 +391,7 @@ void executeQuery(Query& q, bool partialOnly) {
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
     if (!partialOnly && denseMode(q)) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, words * 8, hipMemcpyDeviceToHost, ctx.stream));
-    if (!partialOnly && q.aggMode == AggMode::AT_JOIN_ENTRY)
+    if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH))
         RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
     RSQ_HIP(hipStreamSynchronize(ctx.stream));
     float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
@@ -321,7 +401,14 @@ void executeQuery(Query& q, bool partialOnly) {
     if (!partialOnly) {
         double t1 = nowMs();
         if (denseMode(q)) memcpy(q.hAgg.data(), q.hPinned, words * 8);
-        else {
+        else if (q.matOp && !q.agg) {
+            q.hMatCols.resize(q.matSchema.size());
+            for (size_t c = 0; c < q.matSchema.size(); c++) {
+                size_t bytes = (size_t)q.matRows * (size_t)columnWidth(q.matSchema[c].type);
+                q.hMatCols[c].resize(bytes);
+                if (bytes) RSQ_HIP(hipMemcpy(q.hMatCols[c].data(), q.dMatCols[c], bytes, hipMemcpyDeviceToHost));
+            }
+        } else {
             q.nGroupRows = (int64_t)(uint32_t)q.hPinned[words + 1];
             if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows.data(), q.dGroupRows, (size_t)q.nGroupRows * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost));
         }

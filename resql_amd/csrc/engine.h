@@ -87,6 +87,8 @@ void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::v
 void computeColumnStats(Context& ctx, Table& t);
 void generateTable(Context& ctx, Table& t, int kind, int64_t row0, int64_t nRows, double sf, int64_t param, uint64_t seed);
 double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
+size_t scanTempBytes(int64_t n);
+void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
 // gather the occupied entries (first-row word != INT64_MAX) of a hash table that carries aggregates into
 // packed rows [first row | table words | accumulator blocks]; *count receives the number of rows

@@ -80,6 +80,8 @@ struct Pipeline {
     SinkKind sink = SinkKind::AGGREGATE;
     int buildTable = -1;             // SinkKind::BUILD
     std::string source;              // generated HIP source
+    std::string sourcePass1;         // SinkKind::MATERIALIZE: the counting pass of the same pipeline
+    Kernel* kernelPass1 = nullptr;
     std::string entry = "rsq_pipeline";
     std::vector<ArgSlot> args;
     Kernel* kernel = nullptr;
@@ -119,6 +121,19 @@ struct Query {
     uint64_t* hPinned = nullptr;           // pinned read-back: aggregate words + error word
     size_t pinnedWords = 0;
     std::vector<uint64_t> hAgg;
+
+    // device-side materialisation (plans without aggregation)
+    OpNode* matOp = nullptr;
+    Schema matSchema;
+    uint32_t* dMatCnt = nullptr;           // per lane-tile slot: tuples emitted
+    uint64_t* dMatOffs = nullptr;          // exclusive scan of dMatCnt (+ total at the end)
+    void* dScanTemp = nullptr; size_t scanTempBytes = 0;
+    int64_t matSlots = 0;
+    std::vector<void*> dMatCols;           // output columns (struct of arrays)
+    int64_t matCapacity = 0;               // rows the output columns can hold
+    uint64_t matLimit = 0;                 // rows pass 2 may write
+    int64_t matRows = 0;
+    std::vector<std::vector<uint8_t>> hMatCols;
 
     // compacted group rows read back from a join-entry aggregation: [nGroups][groupWords]
     int64_t* dGroupRows = nullptr;

@@ -155,6 +155,15 @@ RSQ_DEV u8 compare_varchar(const Str& a, const Str& b) {
 // Open addressing, linear probing, capacity a power of two.  Slot state lives in `state`
 // (0 empty, 1 being written, 2 ready); keys and payload are struct-of-arrays beside it, so a
 // probe touches one 4-byte state word and one key word per step.
+// Slots that are inserted AND looked up inside one launch (hash aggregation) are published with agent-scope
+// accesses: a CU's vector L1 is never refreshed by another CU's stores, so plain loads of a freshly written key
+// could be stale (MI355X_MICROARCH.md, inter-workgroup visibility).  Writer: key stores (sc1, write-through) ->
+// __threadfence() -> state = 2.  Reader: state load (sc1) == 2 -> key loads (sc1).
+RSQ_DEV u32 ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RSQ_DEV i64 ld_agent(const i64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RSQ_DEV void st_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+RSQ_DEV void st_agent(i64* p, i64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 RSQ_DEV u64 hash64(u64 x) {     // splitmix64 finaliser; the engine's own table layout, not the reference's
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
     x ^= x >> 27; x *= 0x94d049bb133111ebull;

@@ -224,9 +224,57 @@ Groups groupsFromJoinEntries(Query& q) {
 
 }  // namespace
 
+// plans without aggregation: the device delivered the materialised columns in scan order; pack ReSQL tuples and
+// apply ORDER BY / LIMIT of an OrderByOp above (orderby.h:87-136)
+static void runMaterializeTail(Query& q) {
+    const Schema& cur = q.matSchema;
+    q.resultSchema = cur;
+    const size_t ts = (size_t)schemaTupleSize(cur);
+    const size_t n = (size_t)q.matRows;
+    q.resultTuples.assign(n * ts, 0);
+    q.resultRows = (int64_t)n;
+    int off = 0;
+    std::vector<char> strbuf;
+    for (size_t c = 0; c < cur.size(); c++) {
+        const Type& t = cur[c].type;
+        const size_t w = (size_t)columnWidth(t);
+        const uint8_t* src = q.hMatCols[c].data();
+        if (t.isString()) strbuf.assign(w + 1, 0);
+        for (size_t r = 0; r < n; r++) {
+            uint8_t* dst = &q.resultTuples[r * ts + (size_t)off];
+            if (t.isString()) {
+                memcpy(strbuf.data(), src + r * w, w); strbuf[w] = 0;
+                Val v; v.s = strbuf.data();
+                storeValue(dst, v, t);
+            } else memcpy(dst, src + r * w, w);      // same little-endian value widths as the packed tuple
+        }
+        off += sizeInTuple(t, true);
+    }
+    OpNode* orderBy = nullptr;
+    for (OpNode* o = q.matOp->parent; o; o = o->parent) {
+        if (o->tag == RSQ_OP_ORDERBY) orderBy = o;
+        else failUnsupported("operator above a materialisation other than order by");
+    }
+    if (orderBy) {
+        std::vector<OrderRequest> reqs;
+        for (Expr* e : orderBy->exprs) {
+            const std::string& nm = e->child->symbol;
+            bool found = false;
+            for (auto& a : cur) if (a.name == nm) { reqs.push_back({schemaOffset(cur, nm), a.type, e->tag != RSQ_E_DESC}); found = true; break; }
+            if (!found) failType("Order By attribute not found.");
+        }
+        refQuicksort(q.resultTuples.data(), q.resultRows, ts, reqs);
+        if (orderBy->hasLimit && q.resultRows > orderBy->limit) {
+            q.resultRows = orderBy->limit;
+            q.resultTuples.resize((size_t)q.resultRows * ts);
+        }
+    }
+}
+
 void runTail(Query& q) {
+    if (!q.agg) { runMaterializeTail(q); return; }
     OpNode* agg = q.agg;
-    Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY) ? groupsFromJoinEntries(q) : groupsFromDense(q);
+    Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) ? groupsFromJoinEntries(q) : groupsFromDense(q);
 
     // ---- operators above the aggregation (bottom-up) and their schemas ----
     OpNode* mat = nullptr; OpNode* orderBy = nullptr;
