@@ -245,7 +245,7 @@ static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1
     const int64_t tiles = p.src->nRows >> 7;
     const int wavesPerBlock = p.blockThreads / 64;
     int64_t want = (tiles + (int64_t)wavesPerBlock * p.unroll - 1) / ((int64_t)wavesPerBlock * p.unroll);
-    const int64_t maxGrid = p.maxGrid ? (int64_t)p.maxGrid : 2 * (int64_t)q.ctx.numCUs;
+    const int64_t maxGrid = p.maxGrid ? (int64_t)p.maxGrid : (int64_t)p.gridPerCU * (int64_t)q.ctx.numCUs;
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(maxGrid * 256 / p.blockThreads, want));
     launch(q.ctx, pass1 ? *p.kernelPass1 : *p.kernel, grid, (unsigned)p.blockThreads, args);
     q.report.num_kernels++;
@@ -327,9 +327,24 @@ void executeQuery(Query& q, bool partialOnly) {
     if (denseMode(q)) RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, words * 8, hipMemcpyDeviceToDevice, ctx.stream));
     RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+    const bool trace = getenv("RSQ_TRACE") != nullptr;      // per-pipeline wall time (synchronises after each one)
+    double tPipe = nowMs();
+    auto tracePoint = [&](const Pipeline& p) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx.stream);
+        double t = nowMs();
+        fprintf(stderr, "[rsq trace] %.3f ms  %s\n", t - tPipe, p.explain.c_str());
+        if (p.sink == SinkKind::BUILD) {
+            HashTable& h = *q.hashTables[(size_t)p.buildTable];
+            uint32_t n = 0;
+            (void)hipMemcpy(&n, h.dCount, 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[rsq trace]     ht%d: %u entries in %lld slots\n", h.id, n, (long long)h.capacity);
+        }
+        tPipe = nowMs();
+    };
     for (auto& p : q.pipelines) {
-        if (p.sink == SinkKind::BUILD) { buildHashTable(q, p); continue; }
-        if (p.sink == SinkKind::MATERIALIZE) { materializePipeline(q, p); continue; }
+        if (p.sink == SinkKind::BUILD) { buildHashTable(q, p); tracePoint(p); continue; }
+        if (p.sink == SinkKind::MATERIALIZE) { materializePipeline(q, p); tracePoint(p); continue; }
         auto resetAccumulators = [&](HashTable& h) {
             // aggregate words beside the entries: first-row / min blocks to +inf, max blocks to -inf, sums to 0
             for (int b = 0; b < h.nAccBlocks; b++) {
@@ -369,6 +384,7 @@ void executeQuery(Query& q, bool partialOnly) {
         }
         launchPipeline(q, p, -1);
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
+        tracePoint(p);
     }
     if ((q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) && !partialOnly) {
         HashTable& h = *q.hashTables[(size_t)q.aggTable];

@@ -88,7 +88,9 @@ struct Pipeline {
     int64_t bytesPerRow = 0;
     int blockThreads = 256;
     int unroll = 2;
-    unsigned maxGrid = 0;            // 256-thread workgroups per launch; 0 = 2 per CU
+    unsigned maxGrid = 0;            // 256-thread workgroups per launch; 0 = gridPerCU per CU
+    int gridPerCU = 2;               // 2 for pure streaming pipelines (measured optimum), 8 when the row path
+                                     // does dependent random accesses (hash tables, HBM atomics): latency wants waves
     std::string explain;
 };
 

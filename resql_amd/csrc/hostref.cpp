@@ -85,7 +85,46 @@ struct Sim {
 };
 }  // namespace
 
+namespace {
+// Same replay with the table held as arrays: used when there are many groups (an ordered map of a million slots
+// costs far more than the arrays of the table it simulates).
+struct DenseSim {
+    uint64_t numEntries, threshold, numInserts = 0;
+    std::vector<uint8_t> used;
+    std::vector<uint64_t> hash;
+    std::vector<uint32_t> who;
+    explicit DenseSim(uint64_t minSize) {
+        numEntries = primeAbove(minSize);
+        threshold = numEntries * 6 / 10;
+        used.assign(numEntries, 0); hash.resize(numEntries); who.resize(numEntries);
+    }
+    void put(uint64_t h, uint32_t id) {
+        numInserts++;
+        if (numInserts > threshold) grow();
+        uint64_t loc = h % numEntries;
+        for (uint64_t n = 0; n < numEntries; n++) {
+            if (!used[loc]) { used[loc] = 1; hash[loc] = h; who[loc] = id; return; }
+            if (++loc >= numEntries) loc = 0;
+        }
+        failRuntime("Hash table full");
+    }
+    void grow() {
+        DenseSim bigger(numEntries + 1);
+        for (uint64_t i = 0; i < numEntries; i++) if (used[i]) bigger.put(hash[i], who[i]);
+        *this = std::move(bigger);
+    }
+};
+}  // namespace
+
 std::vector<size_t> refEmissionOrder(const std::vector<uint64_t>& hashes, uint64_t minSize) {
+    if (hashes.size() >= 2048 && hashes.size() < 0xffffffffull && primeAbove(minSize) <= (1ull << 28)) {
+        DenseSim sim(minSize);
+        for (size_t i = 0; i < hashes.size(); i++) sim.put(hashes[i], (uint32_t)i);
+        std::vector<size_t> order;
+        order.reserve(hashes.size());
+        for (uint64_t s = 0; s < sim.numEntries; s++) if (sim.used[s]) order.push_back(sim.who[s]);
+        return order;
+    }
     Sim sim(minSize);
     for (size_t i = 0; i < hashes.size(); i++) sim.put(hashes[i], i);
     std::vector<size_t> order;

@@ -173,10 +173,12 @@ Val evalHost(const HostExpr& h, const std::vector<Val>& sym) {
 
 // ---- the groups the device produced ---------------------------------------------------------------
 struct Groups {
-    size_t n = 0;
+    size_t n = 0, nKeys = 0, nAcc = 0;
     std::vector<int64_t> firstRow;                 // [n]
-    std::vector<std::vector<Val>> keys;            // [n][nGroupExprs]
-    std::vector<std::vector<int64_t>> acc;         // [n][accums]  (index = accums index)
+    std::vector<Val> keyData;                      // [n][nKeys], flat
+    std::vector<int64_t> accData;                  // [n][nAcc], flat (index = accums index)
+    const Val* keys(size_t i) const { return keyData.data() + i * nKeys; }
+    const int64_t* acc(size_t i) const { return accData.data() + i * nAcc; }
 };
 
 Groups groupsFromDense(Query& q) {
@@ -184,21 +186,21 @@ Groups groupsFromDense(Query& q) {
     const size_t W = q.accums.size();
     auto word = [&](size_t w, int64_t g) { return (int64_t)q.hAgg[(size_t)(q.accumSlot[w] * D + g)]; };
     Groups G;
+    G.nKeys = q.denseKeys.size(); G.nAcc = W;
+    size_t present = 0;
+    for (int64_t g = 0; g < D; g++) if (word(0, g) != INT64_MAX) present++;
+    G.n = present;
+    G.firstRow.reserve(present); G.keyData.reserve(present * G.nKeys); G.accData.reserve(present * W);
     for (int64_t g = 0; g < D; g++) {
         if (word(0, g) == INT64_MAX) continue;
         G.firstRow.push_back(word(0, g));
-        std::vector<Val> k;
         for (auto& dk : q.denseKeys) {
             int64_t rank = (g / dk.stride) % dk.card;
             Val v; v.i = dk.byteSet ? (int64_t)dk.values[(size_t)rank] : dk.min + rank;
-            k.push_back(v);
+            G.keyData.push_back(v);
         }
-        G.keys.push_back(k);
-        std::vector<int64_t> a(W);
-        for (size_t w = 0; w < W; w++) a[w] = word(w, g);
-        G.acc.push_back(a);
+        for (size_t w = 0; w < W; w++) G.accData.push_back(word(w, g));
     }
-    G.n = G.firstRow.size();
     return G;
 }
 
@@ -209,15 +211,14 @@ Groups groupsFromJoinEntries(Query& q) {
     const size_t nTabWords = ht.keys.size() + ht.payload.size();
     const size_t stride = (size_t)q.groupRowWords;
     Groups G;
-    G.n = (size_t)q.nGroupRows;
-    G.firstRow.resize(G.n); G.keys.resize(G.n); G.acc.resize(G.n);
+    G.n = (size_t)q.nGroupRows; G.nKeys = q.groupSource.size(); G.nAcc = W;
+    G.firstRow.resize(G.n); G.keyData.resize(G.n * G.nKeys); G.accData.resize(G.n * W);
     for (size_t i = 0; i < G.n; i++) {
         const int64_t* r = &q.hGroupRows[i * stride];
         G.firstRow[i] = r[0];
-        for (int src : q.groupSource) { Val v; v.i = r[1 + (size_t)src]; G.keys[i].push_back(v); }
-        G.acc[i].resize(W);
-        for (size_t w = 0; w < W; w++) G.acc[i][w] = r[1 + nTabWords + (size_t)q.accumSlot[w]];
-        G.acc[i][0] = r[0];
+        for (size_t k = 0; k < G.nKeys; k++) G.keyData[i * G.nKeys + k].i = r[1 + (size_t)q.groupSource[k]];
+        for (size_t w = 0; w < W; w++) G.accData[i * W + w] = r[1 + nTabWords + (size_t)q.accumSlot[w]];
+        G.accData[i * W] = r[0];
     }
     return G;
 }
@@ -344,11 +345,13 @@ void runTail(Query& q) {
     // ---- per group: dematerialize, AVG, projections, materialize ----
     std::vector<Val> sym(hc.names.size());
     auto materializeGroup = [&](size_t gi, uint8_t* dst) {
-        for (size_t k = 0; k < keySlots.size(); k++) sym[(size_t)keySlots[k]] = G.keys[gi][k];
+        const Val* gk = G.keys(gi);
+        const int64_t* ga = G.acc(gi);
+        for (size_t k = 0; k < keySlots.size(); k++) sym[(size_t)keySlots[k]] = gk[k];
         for (auto& o : outs) {
             Val v;
-            if (o.avg) v.i = sdiv((int64_t)((uint64_t)G.acc[gi][(size_t)o.sumAcc] * 100ull), G.acc[gi][(size_t)o.cntAcc]);
-            else v.i = G.acc[gi][(size_t)o.sumAcc];
+            if (o.avg) v.i = sdiv((int64_t)((uint64_t)ga[(size_t)o.sumAcc] * 100ull), ga[(size_t)o.cntAcc]);
+            else v.i = ga[(size_t)o.sumAcc];
             sym[(size_t)o.slot] = v;
         }
         for (auto& pr : projs) {
@@ -369,7 +372,8 @@ void runTail(Query& q) {
         std::vector<uint64_t> hashes(G.n);
         for (size_t i = 0; i < G.n; i++) {
             uint64_t h = 0;
-            for (size_t k = 0; k < agg->exprs2.size(); k++) h = refHashValue(h, G.keys[byFirst[i]][k], agg->exprs2[k]->type);
+            const Val* gk = G.keys(byFirst[i]);
+            for (size_t k = 0; k < agg->exprs2.size(); k++) h = refHashValue(h, gk[k], agg->exprs2[k]->type);
             hashes[i] = h;
         }
         std::vector<size_t> slotOrder = refEmissionOrder(hashes, opSize(agg));
