@@ -44,6 +44,8 @@ def lib():
         L.orc_result_agg_slots.argtypes = [C.c_void_p]
         L.orc_result_agg_grows.restype = C.c_int64
         L.orc_result_agg_grows.argtypes = [C.c_void_p]
+        L.orc_result_ref_oob_probes.restype = C.c_int64
+        L.orc_result_ref_oob_probes.argtypes = [C.c_void_p]
         L.orc_result_free.argtypes = [C.c_void_p]
         L.orc_free_string.argtypes = [C.c_void_p]
         L.orc_serialize_expr.restype = C.c_void_p
@@ -80,6 +82,7 @@ def execute(plan: P.Plan) -> P.Result:
         res = P.Result.from_view(L.orc_result_view(out).contents)
         res.agg_slots = L.orc_result_agg_slots(out)
         res.agg_grows = L.orc_result_agg_grows(out)
+        res.ref_oob_probes = L.orc_result_ref_oob_probes(out)
         res.text = _take_string(L.orc_result_serialize(out))
     finally:
         L.orc_result_free(out)
@@ -160,6 +163,11 @@ def run_reference(plan: P.Plan, threads: int = 1, repeat: int = 1, blocksize: Op
             raise OracleError(f"ref_harness crashed ({pr.returncode}); under the debugger:\n{pd.stdout[-6000:]}\n{pd.stderr[-3000:]}")
         if pr.returncode != 0:
             raise OracleError(f"ref_harness failed ({pr.returncode}): {pr.stderr[-2000:]}")
+        if "#timing" not in pr.stderr:
+            # error_msg() in the reference prints "Error: ..." and calls exit(0) (reference src/qlib/error.h:66-84):
+            # a refused plan ends the process with status 0 and no result
+            msg = [l for l in pr.stderr.splitlines() if l.startswith("Error: ")]
+            raise OracleError("reference refused the plan: " + (msg[0][7:] if msg else pr.stderr[-500:]))
         timings: Dict[str, list] = {"compile_ms": [], "exec_ms": [], "load_ms": []}
         for line in pr.stderr.splitlines():
             tok = line.split()

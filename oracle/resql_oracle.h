@@ -43,6 +43,9 @@ char* orc_result_serialize(const orc_result* r);
  * tests that pin the hash-table restatement: number of slots and number of grow events. */
 int64_t orc_result_agg_slots(const orc_result* r);
 int64_t orc_result_agg_grows(const orc_result* r);
+/* number of probes for which the reference itself reads one byte past its hash table (qlib/hash.h:441-451, a continued
+ * probe after the last slot): when > 0 the reference's result for this input depends on heap contents */
+int64_t orc_result_ref_oob_probes(const orc_result* r);
 
 void orc_result_free(orc_result* r);
 void orc_free_string(char* s);

@@ -89,7 +89,13 @@ struct ExprGen {
     }
 
     std::string emitUnary(Expr* e) {
-        if (e->tag == RSQ_E_COUNT) return "((i64)1)";           // emitCount: every row counts
+        if (e->tag == RSQ_E_COUNT) {
+            // emitCount: every row counts.  The reference still emits the argument first (emitExpressionUnary,
+            // ExpressionsJitFlounder.h:925-928), so an argument it cannot compile refuses the whole plan: emit it for
+            // its checks and drop the text.
+            if (e->child && e->child->tag != RSQ_E_STAR) (void)emit(e->child);
+            return "((i64)1)";
+        }
         std::string c = emit(e->child);
         const Type from = e->child->type, to = e->type;
         switch (e->tag) {
@@ -511,7 +517,7 @@ struct Walker {
         for (Expr* s : o->splitAgg) {
             Accum ac; ac.kind = s->tag; ac.type = s->type;
             switch (s->tag) {
-                case RSQ_E_COUNT: ac.key = "COUNT"; ac.input = "((i64)1)"; ac.merge = 0; break;
+                case RSQ_E_COUNT: ac.key = "COUNT"; ac.input = eg.emit(s); ac.merge = 0; break;
                 case RSQ_E_SUM:
                     if (s->type.tag != RSQ_DECIMAL && s->type.tag != RSQ_BIGINT) failType("ADD code generation not implemented for datatype");
                     ac.key = "SUM" + structuralKey(s->child); ac.input = eg.emit(s); ac.merge = 0; break;
@@ -598,16 +604,16 @@ struct Walker {
         collectAccumulators(o);
         const int W = (int)q.accums.size();
         std::string mode;
-        if (tryDenseKeys(o)) {
+        const int forced = envInt("RSQ_AGG_MODE", 0, 0, 5);     // 5 = generic hash aggregation even where a dense id exists (tests)
+        if (!(forced == 5 && !o->exprs2.empty()) && tryDenseKeys(o)) {
             const int64_t D = q.denseGroups, cells = D * W;
-            int forced = envInt("RSQ_AGG_MODE", 0, 0, 4);
             // measured on MI355X (Q1 SF10, 42 cells): registers 0.47 ms, lane-private LDS 0.71 ms
             if ((cells <= 64 && forced == 0) || forced == 1) { q.aggMode = AggMode::DENSE_REG; if (cells > 64) failUnsupported("too many groups for register accumulators"); }
             else if ((cells <= 56 && forced == 0) || forced == 2) { q.aggMode = AggMode::DENSE_LDS_PRIVATE; if (cells > 56) failUnsupported("too many groups for lane-private LDS accumulators"); }
             else if ((cells <= 6144 && forced == 0) || forced == 3) { q.aggMode = AggMode::DENSE_LDS_SHARED; if (cells > 6144) failUnsupported("too many groups for an LDS table"); }
             else q.aggMode = AggMode::DENSE_GLOBAL;
             emitDenseAggregation(o);
-        } else if (tryJoinEntry(o)) {
+        } else if (forced != 5 && tryJoinEntry(o)) {
             q.aggMode = AggMode::AT_JOIN_ENTRY;
             emitJoinEntryAggregation(o);
         } else {
@@ -620,8 +626,7 @@ struct Walker {
     // Generic hash aggregation (computed keys, wide domains): an open-addressing table in HBM keyed by the group
     // values, insert-or-find inside the kernel, aggregates beside the entries.  Slot protocol: state 0 empty ->
     // CAS to 1 (being written) -> keys stored -> fence -> 2 (ready); a lane that loses the CAS or meets state 1
-    // simply looks at the slot again in its next loop iteration (no inner spin, so lanes of one wave cannot
-    // dead-lock each other).
+    // looks at the slot again (see the note at the loop about keeping this safe inside one wave).
     void emitHashAggregation(OpNode* o) {
         pipe.gridPerCU = 8;
         std::unique_ptr<HashTable> ht(new HashTable());
@@ -647,33 +652,40 @@ struct Walker {
         countPerThread(T);
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
         line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
-        openScope("for (u64 " + T + "_n = 0;; " + T + "_n++) {");
-        line("if (" + T + "_n > 4 * " + T + "_mask + 4096) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
-        line("const u32 stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);");
-        line("bool hit = false;");
-        openScope("if (stt == 2u) {");
-        std::string cond;
-        for (size_t i = 0; i < keyVars.size(); i++)
-            cond += (i ? " && " : "") + std::string("rsq::ld_agent(&a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s]) == " + keyVars[i];
-        line("if (" + cond + ") hit = true; else { " + T + "_s = (" + T + "_s + 1) & " + T + "_mask; continue; }");
-        closeScope();
-        openScope("else if (stt == 0u) {");
+        // Insert-or-find, written so that it cannot deadlock inside a wave: the lane that wins the CAS writes the keys and
+        // publishes state 2 in a plain if-block that is followed by code every lane runs (the reload), so the publish
+        // stays inside the loop body.  (With `if (won) {publish; hit} if (!hit) continue; ...; break;` the compiler threads
+        // the winner straight to the loop exit, the structurizer parks it there until the whole wave has left the loop,
+        // and the losers of the same wave spin on a slot that is never published.)
+        line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0;");
+        openScope("for (;;) {");
+        line("u32 stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);");
+        openScope("if (stt == 0u) {");
         openScope("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) {");
         for (size_t i = 0; i < keyVars.size(); i++)
             line("rsq::st_agent(&a." + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s], " + keyVars[i] + ");");
         line("__threadfence();");
         line("rsq::st_agent(&a." + T + "_state[" + T + "_s], 2u);");
         line("st.n_" + T + "++;");
-        line("hit = true;");
         closeScope();
+        line("stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);      // our own publish, or whoever won the slot");
         closeScope();
-        line("if (!hit) continue;       // lost the race or the slot is being written: look at it again");
+        openScope("if (stt == 2u) {");
+        std::string cond;
+        for (size_t i = 0; i < keyVars.size(); i++)
+            cond += (i ? " && " : "") + std::string("rsq::ld_agent(&a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s]) == " + keyVars[i];
+        openScope("if (" + cond + ") {");
         for (int w = 0; w < W; w++) {
             std::string in = w == 0 ? "row" : "in" + std::to_string(w);
             line("rsq::global_merge_always<" + std::to_string(q.accums[(size_t)w].merge) + ">(a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) +
                  " * a." + T + "_cap + " + T + "_s, (u64)(" + in + "));");
         }
         line("break;");
+        closeScope();
+        line(T + "_s = (" + T + "_s + 1) & " + T + "_mask;");
+        line("if (++" + T + "_adv > " + T + "_mask) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
+        closeScope();
+        line("else if (++" + T + "_spin > (1u << 22)) { atomicOr(a.err, (u32)rsq::ERR_STUCK); break; }   // a slot another wave is writing");
         closeScope();
         closeScope();
         q.aggTable = ht->id;

@@ -314,6 +314,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
 static void checkDeviceError(uint32_t err) {
     if (err & 1) failRuntime("Division by zero");
     if (err & 2) failRuntime("Hash table full");
+    if (err & 16) failRuntime("internal error: a hash-table slot stayed in the 'being written' state");
     if (err) failRuntime("device error word " + std::to_string(err));
 }
 
