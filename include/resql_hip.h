@@ -118,6 +118,15 @@ int  rsq_query_execute(rsq_query* q);
  * rsq_query_finalize then produces the result from the reduced table. */
 int  rsq_query_execute_partial(rsq_query* q, void** dev_ptr, int64_t* n_min_words, int64_t* n_max_words,
                                int64_t* n_sum_words);
+/* Same step without the host synchronisation: the pipelines are enqueued on the context's stream and the call
+ * returns.  Work the caller enqueues on that stream afterwards (the merge collective over the bound partial table,
+ * rsq_query_bind_partial) is ordered behind the kernels; rsq_query_finalize() synchronises once, checks the device
+ * error word and fills the report.  Dense aggregations without join build pipelines only (everything else needs the
+ * host between kernels); pair it with rsq_ctx_set_stream so that the caller's collectives share the stream. */
+int  rsq_query_execute_partial_async(rsq_query* q);
+/* Make the context launch on the caller's HIP stream (use_callers_stream != 0; hip_stream may be the null stream) or go
+ * back to its own non-blocking stream (use_callers_stream == 0).  Synchronises the stream it leaves. */
+int  rsq_ctx_set_stream(rsq_ctx* ctx, void* hip_stream, int32_t use_callers_stream);
 int  rsq_query_finalize(rsq_query* q);
 /* Same, from a partial aggregate table that is already in host memory (n_words int64 words in the
  * layout above).  Needs no device: it is the merge + finalisation step of the multi-GPU path in

@@ -173,6 +173,16 @@ int rsq_query_execute_partial(rsq_query* q, void** dev_ptr, int64_t* n_min_words
     });
 }
 
+int rsq_query_execute_partial_async(rsq_query* q) {
+    if (!q) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] { executeQuery(*QH(q)->q, true, true); });
+}
+
+int rsq_ctx_set_stream(rsq_ctx* ctx, void* hip_stream, int32_t use_callers_stream) {
+    if (!ctx) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] { C(ctx)->setStream((hipStream_t)hip_stream, use_callers_stream != 0); });
+}
+
 int rsq_query_partial_layout(const rsq_query* q, int64_t* n_min_words, int64_t* n_max_words, int64_t* n_sum_words) {
     if (!q || !n_min_words || !n_max_words || !n_sum_words) return RSQ_ERR_INVALID;
     void* p = nullptr;

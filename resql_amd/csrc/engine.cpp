@@ -11,11 +11,6 @@ namespace rsq {
 
 namespace {
 
-double nowMs() {
-    using namespace std::chrono;
-    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
 int64_t nextPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 
 // ================================================================================================
@@ -256,6 +251,7 @@ static void materializePipeline(Query& q, Pipeline& p) {
     Context& ctx = q.ctx;
     const int64_t n = p.src->nRows;
     const int64_t slots = (n >> 7) * 64 + (n & 127) + 1;          // + one trailing zero slot: its offset is the total
+    if (slots > 0x7fffffff) failUnsupported("materialisation over more than 4 G rows in one table (the offset scan is 32-bit)");
     if (q.matSlots < slots) {
         if (q.dMatCnt) ctx.free(q.dMatCnt);
         if (q.dMatOffs) ctx.free(q.dMatOffs);
@@ -318,10 +314,15 @@ static void checkDeviceError(uint32_t err) {
     if (err) failRuntime("device error word " + std::to_string(err));
 }
 
-void executeQuery(Query& q, bool partialOnly) {
+void executeQuery(Query& q, bool partialOnly, bool async) {
     Context& ctx = q.ctx;
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(ctx.device));
+    if (async) {
+        if (!partialOnly || !denseMode(q)) failUnsupported("asynchronous execution is available for dense partial aggregation only");
+        for (auto& p : q.pipelines)
+            if (p.sink != SinkKind::AGGREGATE) failUnsupported("asynchronous execution needs a plan without join / materialize pipelines");
+    }
     double t0 = nowMs();
     const size_t words = q.pinnedWords;
     q.report.num_kernels = 0; q.report.bytes_read = 0;
@@ -410,6 +411,13 @@ void executeQuery(Query& q, bool partialOnly) {
     if (!partialOnly && denseMode(q)) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, words * 8, hipMemcpyDeviceToHost, ctx.stream));
     if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH))
         RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+    if (async && partialOnly) {
+        // everything is enqueued; the caller orders its own work (the group-by merge collective) behind it on the same
+        // stream and finalizeQuery() does the one host synchronisation of the step
+        q.pendingAsync = true;
+        q.report.execution_time_ms = nowMs() - t0;
+        return;
+    }
     RSQ_HIP(hipStreamSynchronize(ctx.stream));
     float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
     q.report.kernel_time_ms = ms;
@@ -442,6 +450,13 @@ void finalizeQuery(Query& q) {
     double t1 = nowMs();
     RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.pinnedWords * 8, hipMemcpyDeviceToHost, ctx.stream));
     RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    if (q.pendingAsync) {         // the step was enqueued by rsq_query_execute_partial_async: account for it now
+        q.pendingAsync = false;
+        float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+        q.report.kernel_time_ms = ms;
+        q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
+        checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
+    }
     memcpy(q.hAgg.data(), q.hPinned, q.pinnedWords * 8);
     runTail(q);
     q.report.finalize_time_ms = nowMs() - t1;

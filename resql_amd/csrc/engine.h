@@ -63,7 +63,8 @@ struct Context {
     rsq_config cfg{};
     int device = 0;
     int numCUs = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;              // the stream every launch / copy of this context goes to
+    hipStream_t ownStream = nullptr;           // created by the context; `stream` is a caller's stream after setStream()
     std::string lastError;
     std::string cacheDir;
     std::string includeDir;                    // where kernels/rsq_device.h lives
@@ -78,6 +79,7 @@ struct Context {
     Kernel& getKernel(const std::string& source, const std::string& entry);
     void* alloc(size_t bytes);
     void free(void* p);
+    void setStream(hipStream_t s, bool callers);   // callers == false: back to the context's own stream
 };
 
 // launch helper: kernel takes one struct of 8-byte slots by value
@@ -98,7 +100,7 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
 // ---- query ------------------------------------------------------------------------------------
 struct Query;
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables);
-void executeQuery(Query& q, bool partialOnly);
+void executeQuery(Query& q, bool partialOnly, bool async = false);
 void finalizeQuery(Query& q);
 void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords);
 void bindPartial(Query& q, void* dptr, size_t bytes);

@@ -2,6 +2,7 @@
 // generator (codegen.cpp) and the host tail (tail.cpp).
 #pragma once
 
+#include <chrono>
 #include <map>
 #include <memory>
 #include <string>
@@ -153,6 +154,7 @@ struct Query {
     std::vector<int32_t> rvOffsets;
 
     rsq_report report{};
+    bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
     std::string allSource, explainText;
 
     explicit Query(Context& c) : ctx(c) {}
@@ -160,6 +162,11 @@ struct Query {
 };
 
 uint64_t opSize(OpNode* o);      // getSize() estimates of the reference's operators
+
+inline double nowMs() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
 
 // codegen.cpp: turns the operator tree below the last pipeline breaker into device pipelines
 void buildPipelines(Query& q);

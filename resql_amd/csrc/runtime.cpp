@@ -51,7 +51,8 @@ Context::Context(const rsq_config& c) : cfg(c), device(c.device) {
         hipDeviceProp_t prop;
         RSQ_HIP(hipGetDeviceProperties(&prop, device));
         numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        RSQ_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        RSQ_HIP(hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking));
+        stream = ownStream;
         RSQ_HIP(hipMalloc((void**)&dErr, sizeof(uint32_t)));
         RSQ_HIP(hipMemset(dErr, 0, sizeof(uint32_t)));
         RSQ_HIP(hipEventCreate(&ev0));
@@ -66,8 +67,15 @@ Context::~Context() {
         if (dErr) (void)hipFree(dErr);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (ownStream) (void)hipStreamDestroy(ownStream);
     }
+}
+
+void Context::setStream(hipStream_t s, bool callers) {
+    if (device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
+    RSQ_HIP(hipSetDevice(device));
+    RSQ_HIP(hipStreamSynchronize(stream));     // nothing of ours may still be in flight on the stream we leave
+    stream = callers ? s : ownStream;          // a caller's stream may be the null stream (0)
 }
 
 void* Context::alloc(size_t bytes) {

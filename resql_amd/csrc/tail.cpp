@@ -275,7 +275,16 @@ static void runMaterializeTail(Query& q) {
 void runTail(Query& q) {
     if (!q.agg) { runMaterializeTail(q); return; }
     OpNode* agg = q.agg;
+    const bool trace = getenv("RSQ_TRACE") != nullptr;
+    double tPhase = nowMs();
+    auto phase = [&](const char* what) {
+        if (!trace) return;
+        double t = nowMs();
+        fprintf(stderr, "[rsq trace]     tail: %.3f ms  %s\n", t - tPhase, what);
+        tPhase = t;
+    };
     Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) ? groupsFromJoinEntries(q) : groupsFromDense(q);
+    phase("groups from the device tables");
 
     // ---- operators above the aggregation (bottom-up) and their schemas ----
     OpNode* mat = nullptr; OpNode* orderBy = nullptr;
@@ -369,6 +378,7 @@ void runTail(Query& q) {
         std::vector<size_t> byFirst(G.n);
         for (size_t i = 0; i < G.n; i++) byFirst[i] = i;
         std::sort(byFirst.begin(), byFirst.end(), [&](size_t a, size_t b) { return G.firstRow[a] < G.firstRow[b]; });
+        phase("sort groups by first row");
         std::vector<uint64_t> hashes(G.n);
         for (size_t i = 0; i < G.n; i++) {
             uint64_t h = 0;
@@ -376,9 +386,11 @@ void runTail(Query& q) {
             for (size_t k = 0; k < agg->exprs2.size(); k++) h = refHashValue(h, gk[k], agg->exprs2[k]->type);
             hashes[i] = h;
         }
+        phase("reference hashes");
         std::vector<size_t> slotOrder = refEmissionOrder(hashes, opSize(agg));
         std::vector<size_t> order(G.n);
         for (size_t i = 0; i < G.n; i++) order[i] = byFirst[slotOrder[i]];
+        phase("replay of the reference's hash table (slot order)");
         return order;
     };
 
@@ -405,6 +417,7 @@ void runTail(Query& q) {
         bool tie = false;
         for (size_t i = 0; i + 1 < std::min(k + 1, G.n) && !tie; i++)
             if (!before(&all[idx[i] * ts], &all[idx[i + 1] * ts])) tie = true;     // sorted, so "not before" means equal keys
+        phase("top-k selection");
         if (!tie) {
             q.resultTuples.resize(std::min(k, G.n) * ts);
             for (size_t i = 0; i < std::min(k, G.n); i++) memcpy(&q.resultTuples[i * ts], &all[idx[i] * ts], ts);
@@ -422,8 +435,10 @@ void runTail(Query& q) {
         if (mat->hasLimit && q.resultRows >= mat->limit) break;      // materialize.h:197-206
     }
     q.resultTuples.resize((size_t)q.resultRows * ts);
+    phase("AVG / projections / materialize");
     if (orderBy) {
         refQuicksort(q.resultTuples.data(), q.resultRows, ts, reqs);
+        phase("order by (the reference's quicksort)");
         if (orderBy->hasLimit && q.resultRows > orderBy->limit) {      // applyLimit after the sort (orderby.h:87-93)
             q.resultRows = orderBy->limit;
             q.resultTuples.resize((size_t)q.resultRows * ts);

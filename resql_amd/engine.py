@@ -69,6 +69,8 @@ def lib():
         L.rsq_query_compile.argtypes = [vp, C.POINTER(P.rsq_plan_desc), C.POINTER(vp), i32, C.POINTER(vp)]
         L.rsq_query_execute.argtypes = [vp]
         L.rsq_query_execute_partial.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.rsq_query_execute_partial_async.argtypes = [vp]
+        L.rsq_ctx_set_stream.argtypes = [vp, vp, i32]
         L.rsq_query_finalize.argtypes = [vp]
         L.rsq_query_bind_partial.argtypes = [vp, vp, C.c_size_t]
         L.rsq_query_finalize_host.argtypes = [vp, C.POINTER(i64), i64]
@@ -94,6 +96,7 @@ EXPORTED_SYMBOLS = [
     "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
     "rsq_table_from_rowstore", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_execute_partial",
+    "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
     "rsq_query_finalize", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
     "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
     "rsq_measure_read_bandwidth",
@@ -119,6 +122,11 @@ class Context:
     def _check(self, rc: int):
         if rc != 0:
             raise EngineError(rc, self._L.rsq_last_error(self.h).decode())
+
+    def set_stream(self, hip_stream: Optional[int]):
+        """launch on the caller's HIP stream (an integer handle, 0 = the null stream; e.g.
+        torch.cuda.current_stream().cuda_stream), or None to go back to the context's own stream"""
+        self._check(self._L.rsq_ctx_set_stream(self.h, hip_stream or None, 0 if hip_stream is None else 1))
 
     def close(self):
         if getattr(self, "h", None):
@@ -229,6 +237,10 @@ class Query:
         p = C.c_void_p(); a = C.c_int64(); b = C.c_int64(); c = C.c_int64()
         self.ctx._check(self.ctx._L.rsq_query_execute_partial(self.h, C.byref(p), C.byref(a), C.byref(b), C.byref(c)))
         return p.value, a.value, b.value, c.value
+
+    def execute_partial_async(self):
+        """enqueue the pipelines on the context's stream and return; finalize() synchronises (see resql_hip.h)"""
+        self.ctx._check(self.ctx._L.rsq_query_execute_partial_async(self.h))
 
     def finalize_host(self, words: np.ndarray):
         """finalise from a partial aggregate table held in host memory (int64 words)"""

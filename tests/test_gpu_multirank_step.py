@@ -1,0 +1,93 @@
+"""The multi-rank step of bench.py on one GPU: two row-range shards of lineitem are scanned one after the other by the
+same device ("rank 0" and "rank 1" of a 2-way sharding), each with the asynchronous partial execution on torch's stream,
+the partial tables are merged with resql_amd.dist.PartialMerger over an RCCL (nccl) process group of world size 1 whose
+collective is forced to run, and the merged table is finalised.  Result == the oracle on the unsharded table.
+(The 2-process merge itself is covered on CPU over gloo in tests/test_distributed_merge.py.)"""
+import os
+import socket
+
+import pytest
+
+from resql_amd import datagen, engine, tpch
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("plan_of", [tpch.q1_plan, tpch.q6_plan])
+def test_async_partial_merge_finalize(nccl_world1, plan_of):
+    import torch
+    from resql_amd.dist import PartialMerger, shard_rows
+    dist = nccl_world1
+    sf, world = 0.05, 2
+    cols = tpch.Q1_COLUMNS if plan_of is tpch.q1_plan else tpch.Q6_COLUMNS
+    n_total = datagen.n_lineitem(sf)
+    dev = torch.device("cuda", 0)
+    ctx = engine.Context(device=0)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        ctx.set_stream(stream.cuda_stream)
+        schema_only = tpch.lineitem_table(0.001, cols, n_rows=0)
+        merged = None
+        for rank in range(world):
+            row0, n = shard_rows(n_total, world, rank)
+            table = ctx.generate(engine.GEN_LINEITEM, n, sf, row0=row0)
+            q = ctx.compile(plan_of(schema_only), [table])
+            n_min, n_max, n_sum = q.partial_layout()
+            partial = torch.zeros(n_min + n_max + n_sum, dtype=torch.int64, device=dev)
+            q.bind_partial(partial.data_ptr(), partial.numel() * 8)
+            merger = PartialMerger(dist, partial, n_min, n_max, n_sum, 1, always_collective=True)
+            assert merger.gather
+            for _ in range(3):                         # steps queue up behind each other without host syncs
+                q.execute_partial_async()
+                merger.merge()
+            if merged is None:
+                merged = partial.clone()
+            else:                                      # what the all-gather + segment reductions do across real ranks
+                a, b = n_min, n_min + n_max
+                merged[:a] = torch.minimum(merged[:a], partial[:a])
+                merged[a:b] = torch.maximum(merged[a:b], partial[a:b])
+                merged[b:] += partial[b:]
+                partial.copy_(merged)
+                q.finalize()
+                got = q.result()
+                assert q.report().kernel_time_ms > 0
+            if rank < world - 1:
+                q.finalize()                           # accounts for the enqueued steps, checks the device error word
+            q.close(); table.close()
+    ctx.set_stream(None)
+    ctx.close()
+    want = orc.execute(plan_of(tpch.lineitem_table(sf, cols)))
+    assert got.text == want.text
+
+
+def test_async_needs_a_plain_dense_plan(gpu_ctx):
+    sf = 0.01
+    li = tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+    cu, od = tpch.customer_table(sf), tpch.orders_table(sf)
+    tabs = [gpu_ctx.table(t) for t in (cu, od, li)]
+    q = gpu_ctx.compile(tpch.q3_plan(cu, od, li), tabs)
+    with pytest.raises(engine.EngineError) as e:
+        q.execute_partial_async()
+    assert e.value.status == 3
+    q.close()
+    for t in tabs:
+        t.close()
