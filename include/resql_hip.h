@@ -94,6 +94,14 @@ int  rsq_table_create_device(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table
 int  rsq_table_from_rowstore(rsq_ctx* ctx, const rsq_table_desc* schema /* data pointers ignored */,
                              const uint8_t* const* blocks, const size_t* content_size, int32_t n_blocks,
                              rsq_table** out);
+/* BULK INSERT: load a '.tbl' text file (one tuple per line, fields ended by `field_terminator`, dbgen style with or
+ * without the trailing terminator) straight into device columns, with the parsing rules of the reference's
+ * executeBulkInsert / parseConstant (reference src/execute.h:332-388, src/expressions.h:369-515): see
+ * resql_amd/csrc/tbl.cpp for the rules that matter (DECIMAL = digits with the point removed, BIGINT through int32,
+ * dates as yyyy-mm-dd or yyyy/mm/dd).  `schema` gives names and types (data pointers ignored).
+ * n_threads <= 0: all host threads.  Malformed lines give RSQ_ERR_INVALID with the line number. */
+int  rsq_table_load_tbl(rsq_ctx* ctx, const rsq_table_desc* schema, const char* path, char field_terminator,
+                        int32_t n_threads, rsq_table** out);
 /* Fill a lineitem / orders / customer / synthetic table on the device with the deterministic
  * generator of resql_amd/datagen.py (same bits), rows [row0, row0 + n_rows).  kind: 0 lineitem,
  * 1 orders, 2 customer, 3 synthetic 4 x int64 (param = number of groups). */

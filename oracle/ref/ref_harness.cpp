@@ -198,8 +198,7 @@ void loadTable(const CaseSpec& c, const TableSpec& ts, Database& db) {
         if (!f.is_open()) die("cannot open " + ts.tblPath);
         std::string line;
         while (std::getline(f, line)) {
-            if (line.empty()) continue;
-            Data* t = app.get();
+            Data* t = app.get();     // an empty line has no fields: "missing attributes", as in the reference
             std::istringstream ls(line);
             std::string tok; size_t a = 0;
             while (std::getline(ls, tok, '|')) {

@@ -895,6 +895,45 @@ static int compareChar(const char* a, const char* b) {
     return 1;
 }
 
+/* qlib/scalar.h:49-118 stringLikeCheck ('%' any run, '_' any one character), restated with indices instead of the
+ * reference's pointers.  The quirks are the reference's and are kept: the prefix and the suffix of the pattern are
+ * matched independently and may overlap in the string ("ab" LIKE "abab" is true), and infixes are searched greedily
+ * left to right.  at(i) returns the terminating NUL for i == length, which is the one place the reference reads it. */
+static int cmpLike(char c, char l) { return c == l || l == '_'; }
+static int stringLikeCheck(const char* string, const char* like) {
+    long sn = (long)strlen(string), ln = (long)strlen(like);
+    long sPos = 0, lPos = 0, sTrace, lTrace;
+    long lInStart = 0, lInEnd = ln, sInStart = 0, sInEnd = sn;
+    /* prefix */
+    if (like[0] != '%') {
+        for (; lPos < ln && sPos < sn && like[lPos] != '%'; ++lPos, ++sPos)
+            if (!cmpLike(string[sPos], like[lPos])) return 0;
+        lInStart = lPos; sInStart = sPos;
+    }
+    if (lInStart == ln) return sInStart == sn;          /* no '%' left */
+    /* suffix */
+    if (like[ln - 1] != '%') {
+        sPos = sn - 1; lPos = ln - 1;
+        for (; lPos >= 0 && sPos >= 0 && like[lPos] != '%'; --lPos, --sPos)
+            if (!cmpLike(string[sPos], like[lPos])) return 0;
+        lInEnd = lPos; sInEnd = sPos + 1;
+    }
+    /* infixes */
+    if (lInStart < lInEnd) {
+        lPos = lInStart + 1; sPos = sInStart;
+        while (sPos < sInEnd && lPos < lInEnd) {
+            lTrace = lPos; sTrace = sPos;
+            while (cmpLike(string[sTrace], like[lTrace]) && sTrace < sInEnd) {
+                ++lTrace;
+                if (like[lTrace] == '%') { lPos = ++lTrace; sPos = sTrace; break; }
+                ++sTrace;
+            }
+            ++sPos;
+        }
+    }
+    return lPos >= lInEnd;
+}
+
 /* ValuesJitFlounder.h:65-142 Values::hash for one value */
 static uint64_t hashValue(uint64_t h, Val v, rsq_type t) {
     switch (t.tag) {
@@ -1115,7 +1154,12 @@ static CExpr* compileExpr(Exec* x, Expr* e) {
                 case RSQ_E_EQ: case RSQ_E_NEQ:
                     if (ot == RSQ_FLOAT || ot == RSQ_NT) fail("EQUALS code generation not implemented for datatype");
                     break;
-                case RSQ_E_LIKE: fail("LIKE is outside the oracle's scope");
+                case RSQ_E_LIKE:
+                    /* emitLike hands both operand registers to stringLikeCheck as char* (ExpressionsJitFlounder.h:695-705);
+                     * a CHAR(1) value lives in a byte register, so the reference would dereference a character: undefined */
+                    if ((ot == RSQ_CHAR && c->opType.len == 1) || (e->child->next->type.tag == RSQ_CHAR && e->child->next->type.len == 1))
+                        fail("LIKE on a CHAR(1) operand is undefined in the reference");
+                    break;
                 default: fail("emitExpressionBinary(..) not implemented for expression type %s", exprTagNames[e->tag]);
             }
             break;
@@ -1217,6 +1261,7 @@ static Val evalExpr(Exec* x, const CExpr* c) {
         case RSQ_E_GE: r.i = cmpVals(a, b, c->opType) >= 0; break;
         case RSQ_E_EQ: r.i = equalsVals(a, b, c->opType); break;
         case RSQ_E_NEQ: r.i = (uint8_t)(1 - equalsVals(a, b, c->opType)); break;
+        case RSQ_E_LIKE: r.i = stringLikeCheck(a.s, b.s); break;
         default: fail("evalExpr: unsupported tag %d", c->tag);
     }
     return r;

@@ -1,6 +1,7 @@
 // api.cpp — the extern "C" surface of include/resql_hip.h.  No exception crosses it.
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 #include "engine.h"
 #include "hostref.h"
@@ -116,6 +117,27 @@ int rsq_table_from_rowstore(rsq_ctx* ctx, const rsq_table_desc* schema, const ui
         }
         std::vector<rsq_column> cd((size_t)schema->n_cols);
         for (int i = 0; i < schema->n_cols; i++) { cd[(size_t)i] = schema->cols[i]; cd[(size_t)i].data = cols[(size_t)i].data(); }
+        rsq_table_desc d = *schema; d.n_rows = n; d.cols = cd.data();
+        *out = reinterpret_cast<rsq_table*>(makeTable(*C(ctx), d, false));
+    });
+}
+
+int rsq_table_load_tbl(rsq_ctx* ctx, const rsq_table_desc* schema, const char* path, char field_terminator,
+                       int32_t n_threads, rsq_table** out) {
+    if (!ctx || !schema || !path || !out || schema->n_cols < 0) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] {
+        std::vector<Type> types;
+        for (int i = 0; i < schema->n_cols; i++) types.push_back(Type::fromC(schema->cols[i].type));
+        std::vector<std::vector<uint8_t>> cols;
+        int64_t n = 0;
+        int threads = n_threads > 0 ? n_threads : (int)std::max(1u, std::thread::hardware_concurrency());
+        parseTblFile(path, types, field_terminator, threads, cols, n);
+        static const uint8_t kEmpty[16] = {0};       // an empty file still gives columns WITH data (of zero rows)
+        std::vector<rsq_column> cd((size_t)schema->n_cols);
+        for (int i = 0; i < schema->n_cols; i++) {
+            cd[(size_t)i] = schema->cols[i];
+            cd[(size_t)i].data = cols[(size_t)i].empty() ? (const void*)kEmpty : (const void*)cols[(size_t)i].data();
+        }
         rsq_table_desc d = *schema; d.n_rows = n; d.cols = cd.data();
         *out = reinterpret_cast<rsq_table*>(makeTable(*C(ctx), d, false));
     });

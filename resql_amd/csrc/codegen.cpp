@@ -165,7 +165,13 @@ struct ExprGen {
             case RSQ_E_GE: orderedOk(); return "((u8)((" + l + ") >= (" + r + ")))";
             case RSQ_E_EQ: return equals();
             case RSQ_E_NEQ: return "((u8)(1 - " + equals() + "))";
-            case RSQ_E_LIKE: failUnsupported("LIKE is not implemented by the GPU engine (outside the hot path, SURVEY §2)");
+            case RSQ_E_LIKE: {
+                // emitLike passes both operands to stringLikeCheck as char* (ExpressionsJitFlounder.h:695-705): a CHAR(1)
+                // operand is a byte there, not a pointer — undefined in the reference, refused here
+                const Type rt = e->child->next->type;
+                if (!op.isString() || !rt.isString()) failType("LIKE on a CHAR(1) operand is undefined in the reference");
+                return "rsq::like(" + l + ", " + r + ")";
+            }
             default: failType(std::string("emitExpressionBinary(..) not implemented for expression type") + exprTagNames[e->tag]);
         }
     }

@@ -97,6 +97,10 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t* count);
 
+// tbl.cpp: '.tbl' text -> columns with the reference's BULK INSERT semantics (execute.h:332-388)
+void parseTblFile(const std::string& path, const std::vector<Type>& types, char terminator, int nThreads,
+                  std::vector<std::vector<uint8_t>>& cols, int64_t& nRows);
+
 // ---- query ------------------------------------------------------------------------------------
 struct Query;
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables);

@@ -151,6 +151,43 @@ RSQ_DEV u8 compare_varchar(const Str& a, const Str& b) {
     return str_at(a, i) == str_at(b, i);
 }
 
+// stringLikeCheck (reference src/qlib/scalar.h:49-118): '%' any run, '_' any one character.  Restated with indices;
+// the reference's behaviour is kept where it is peculiar (prefix and suffix of the pattern are matched independently
+// and may overlap in the string; infixes are searched greedily left to right).  str_at() yields the NUL the reference
+// reads at index == length.
+RSQ_DEV int str_len(const Str& s) { int n = 0; while (n < s.cap && s.p[n] != '\0') n++; return n; }
+RSQ_DEV bool like_char(char c, char l) { return c == l || l == '_'; }
+RSQ_DEV u8 like(const Str& S, const Str& L) {
+    const int sn = str_len(S), ln = str_len(L);
+    int sPos = 0, lPos = 0;
+    int lInStart = 0, lInEnd = ln, sInStart = 0, sInEnd = sn;
+    if (str_at(L, 0) != '%') {                                   // prefix
+        for (; lPos < ln && sPos < sn && str_at(L, lPos) != '%'; ++lPos, ++sPos)
+            if (!like_char(str_at(S, sPos), str_at(L, lPos))) return 0;
+        lInStart = lPos; sInStart = sPos;
+    }
+    if (lInStart == ln) return (u8)(sInStart == sn);            // no '%' left
+    if (str_at(L, ln - 1) != '%') {                              // suffix
+        sPos = sn - 1; lPos = ln - 1;
+        for (; lPos >= 0 && sPos >= 0 && str_at(L, lPos) != '%'; --lPos, --sPos)
+            if (!like_char(str_at(S, sPos), str_at(L, lPos))) return 0;
+        lInEnd = lPos; sInEnd = sPos + 1;
+    }
+    if (lInStart < lInEnd) {                                     // infixes
+        lPos = lInStart + 1; sPos = sInStart;
+        while (sPos < sInEnd && lPos < lInEnd) {
+            int lTrace = lPos, sTrace = sPos;
+            while (like_char(sTrace < sn ? str_at(S, sTrace) : '\0', lTrace < ln ? str_at(L, lTrace) : '\0') && sTrace < sInEnd) {
+                ++lTrace;
+                if ((lTrace < ln ? str_at(L, lTrace) : '\0') == '%') { lPos = ++lTrace; sPos = sTrace; break; }
+                ++sTrace;
+            }
+            ++sPos;
+        }
+    }
+    return (u8)(lPos >= lInEnd);
+}
+
 // ---- hash tables in HBM ----------------------------------------------------------------------
 // Open addressing, linear probing, capacity a power of two.  Slot state lives in `state`
 // (0 empty, 1 being written, 2 ready); keys and payload are struct-of-arrays beside it, so a

@@ -62,6 +62,7 @@ def lib():
         L.rsq_table_from_rowstore.argtypes = [vp, C.POINTER(P.rsq_table_desc), C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_size_t), i32, C.POINTER(vp)]
         L.rsq_table_generate.argtypes = [vp, i32, i64, i64, C.c_double, i64, C.c_uint64, C.POINTER(vp)]
+        L.rsq_table_load_tbl.argtypes = [vp, C.POINTER(P.rsq_table_desc), C.c_char_p, C.c_char, i32, C.POINTER(vp)]
         L.rsq_table_rows.restype = i64
         L.rsq_table_rows.argtypes = [vp]
         L.rsq_table_read_column.argtypes = [vp, vp, C.c_char_p, vp, C.c_size_t]
@@ -94,7 +95,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
-    "rsq_table_from_rowstore", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
+    "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
     "rsq_query_finalize", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
@@ -156,6 +157,15 @@ class Context:
         h = C.c_void_p()
         self._check(self._L.rsq_table_create_device(self.h, C.byref(d), C.byref(h)))
         return DeviceTable(self, h, name)
+
+    def load_tbl(self, schema: P.Table, path: str, terminator: str = "|", threads: int = 0) -> "DeviceTable":
+        """BULK INSERT of a '.tbl' text file into a table with `schema`'s column names and types"""
+        keep: list = []
+        bare = P.Table(schema.name, [P.Column(c.name, c.type) for c in schema.columns], 0)
+        d = bare.to_c(keep)
+        h = C.c_void_p()
+        self._check(self._L.rsq_table_load_tbl(self.h, C.byref(d), path.encode(), terminator.encode()[:1], threads, C.byref(h)))
+        return DeviceTable(self, h, schema.name)
 
     def generate(self, kind: int, n_rows: int, sf: float, row0: int = 0, param: int = 0,
                  seed: int = 20240613) -> "DeviceTable":

@@ -279,6 +279,7 @@ class Plan:
     def ge(self, l, r): return self._e("GE", [l, r])
     def eq(self, l, r): return self._e("EQ", [l, r])
     def neq(self, l, r): return self._e("NEQ", [l, r])
+    def like(self, l, r): return self._e("LIKE", [l, r])
     def sum(self, c): return self._e("SUM", [c])
     def count(self, c): return self._e("COUNT", [c])
     def avg(self, c): return self._e("AVG", [c])

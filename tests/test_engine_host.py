@@ -97,10 +97,15 @@ def test_error_codes(compile_ctx):
     with pytest.raises(engine.EngineError) as e:
         compile_ctx.compile(p, [dt])
     assert e.value.status == 1
-    # LIKE: valid ReSQL, outside this engine's scope
+    # LIKE between strings compiles (resql_amd/csrc/kernels/rsq_device.h: rsq::like)
     p = P.Plan([t])
-    cond = p._e("LIKE", [p.constant("ab", P.VARCHAR), p.constant("a%", P.VARCHAR)])
+    cond = p.like(p.constant("ab", P.VARCHAR), p.constant("a%", P.VARCHAR))
     p.set_root(p.materialize(p.aggregation([p.count(p.star())], [], p.selection(cond, p.scan("rel")))))
+    compile_ctx.compile(p, [dt]).close()
+    # a nested-loops join is valid ReSQL but outside this engine's scope: refused, never emulated
+    p = P.Plan([t])
+    nl = p._o(P.OpNode("NESTEDLOOPSJOIN", [p.scan("rel"), p.scan("rel")], exprs=[p.eq(p.attr("a"), p.attr("a"))]))
+    p.set_root(p.materialize(nl), request_all=True)
     with pytest.raises(engine.EngineError) as e:
         compile_ctx.compile(p, [dt])
     assert e.value.status == 3
