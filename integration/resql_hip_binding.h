@@ -162,6 +162,26 @@ public:
         return t;
     }
 
+    // BULK INSERT (execute.h:332-388) straight into device columns: the Relation object stays the table's identity
+    // (plans scan it), its rows live on the GPU only.  Same field rules as the reference's loop (csrc/tbl.cpp).
+    int64_t bulkInsert(Relation* rel, const std::string& name, const std::string& fileName, char fieldTerminator) {
+        if (tables_.count(rel)) throw ResqlError("Table " + name + " is already resident on the device.");
+        std::vector<rsq_column> cols;
+        for (auto& a : rel->_schema._attribs) {
+            rsq_column c{};
+            std::strncpy(c.name, a.name.c_str(), RSQ_SYMBOL_MAX - 1);
+            c.type = toRsqType(a.type);
+            cols.push_back(c);
+        }
+        rsq_table_desc d{};
+        std::strncpy(d.name, name.c_str(), RSQ_SYMBOL_MAX - 1);
+        d.n_cols = (int32_t)cols.size(); d.cols = cols.data();
+        rsq_table* t = nullptr;
+        check(rsq_table_load_tbl(ctx_, &d, fileName.c_str(), fieldTerminator, 0, &t));
+        tables_[rel] = t;
+        return rsq_table_rows(t);
+    }
+
     // describe + compile + execute + retrieve: the body of executeSelectPlan (execute.h:213-247)
     std::unique_ptr<Relation> run(RelOperator* root, bool requestAll) {
         PlanDescriber pd;

@@ -183,7 +183,7 @@ size_t fileWidth(SqlType t) {
     }
 }
 
-void loadTable(const CaseSpec& c, const TableSpec& ts, Database& db) {
+void loadTable(const CaseSpec& c, const TableSpec& ts, Database& db, bool tblOnDevice) {
     std::vector<Attribute> atts;
     for (auto& cs : ts.cols) atts.push_back({cs.name, cs.type});
     Schema schema(atts);
@@ -192,6 +192,7 @@ void loadTable(const CaseSpec& c, const TableSpec& ts, Database& db) {
     auto its = AttributeIterator::getAll(rel._schema);
     Relation::AppendIterator app(&rel);
 
+    if (!ts.tblPath.empty() && tblOnDevice) return;      // --engine hip: BULK INSERT goes straight to device columns
     if (!ts.tblPath.empty()) {
         // text rows, parsed with the reference's own constant parser (as execute.h:332-388 does)
         std::ifstream f(resolve(c, ts.tblPath));
@@ -369,7 +370,7 @@ int main(int argc, char** argv) {
     CaseSpec c = parseCase(casePath);
     Database db;
     Timer tLoad;
-    for (auto& t : c.tables) loadTable(c, t, db);
+    for (auto& t : c.tables) loadTable(c, t, db, engine == "hip");
     std::cerr << "#load_ms " << tLoad.get() << std::endl;
 
     std::unique_ptr<Relation> result;
@@ -377,7 +378,11 @@ int main(int argc, char** argv) {
     std::unique_ptr<resql_hip::JitContextHip> hip;
     if (engine == "hip") {
         JitConfig jc; jc.numThreads = threads;
-        try { hip = std::make_unique<resql_hip::JitContextHip>(jc, device); }
+        try {
+            hip = std::make_unique<resql_hip::JitContextHip>(jc, device);
+            for (auto& t : c.tables)
+                if (!t.tblPath.empty()) hip->bulkInsert(&db.relations[t.name], t.name, resolve(c, t.tblPath), '|');
+        }
         catch (ResqlError& err) { std::cerr << "ResqlError: " << err.message(); return 3; }
     }
 #else

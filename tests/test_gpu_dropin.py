@@ -32,3 +32,21 @@ def test_tpch_through_resql_objects(sf):
 def test_reference_operator_cases_through_resql_objects(case):
     ref, hip = both(refcases.CASES[case]())
     assert hip == ref
+
+
+@pytest.mark.parametrize("name", ["orders_by_status", "building_orders", "scan_customer"])
+def test_bulk_insert_through_the_binding(tmp_path, name):
+    """`tbl` tables: the Flounder run loads them with the reference's own field parser into Relations, the HIP run with
+    JitContextHip::bulkInsert (rsq_table_load_tbl) straight into device columns; same ReSQL plan objects on both."""
+    import subprocess
+    import tblcases
+    needed, make = tblcases.QUERIES[name]
+    plan = make({t: tblcases.schema_table(t) for t in needed})
+    case = tmp_path / "plan.case"
+    case.write_text(plan.to_text(tbl_files={t: tblcases.FILES[t] for t in needed}))
+    outs = []
+    for extra in ([], ["--engine", "hip", "--device", "0"]):
+        pr = subprocess.run([orc.REF_HARNESS, str(case)] + extra, capture_output=True)
+        assert pr.returncode == 0 and b"#timing" in pr.stderr, pr.stderr[-600:]
+        outs.append(pr.stdout)
+    assert outs[0] == outs[1] and len(outs[0]) > 50
