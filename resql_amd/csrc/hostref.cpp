@@ -89,28 +89,46 @@ namespace {
 // Same replay with the table held as arrays: used when there are many groups (an ordered map of a million slots
 // costs far more than the arrays of the table it simulates).
 struct DenseSim {
-    uint64_t numEntries, threshold, numInserts = 0;
-    std::vector<uint8_t> used;
-    std::vector<uint64_t> hash;
-    std::vector<uint32_t> who;
+    struct Slot { uint64_t hash; uint32_t who; uint32_t used; };     // one cache line touch per probe step
+    uint64_t numEntries, threshold, numInserts = 0, magic = 0;
+    std::vector<Slot> slots;
     explicit DenseSim(uint64_t minSize) {
         numEntries = primeAbove(minSize);
         threshold = numEntries * 6 / 10;
-        used.assign(numEntries, 0); hash.resize(numEntries); who.resize(numEntries);
+        magic = (uint64_t)((((__uint128_t)1) << 64) / numEntries);      // floor(2^64 / d), d >= 5
+        slots.assign(numEntries, Slot{0, 0, 0});
+    }
+    // h % numEntries without the 64-bit divide (≈35 cycles, and there are two per insert): the quotient estimate
+    // floor(h * floor(2^64/d) / 2^64) is at most 1 short, fixed by the conditional subtractions
+    uint64_t mod(uint64_t h) const {
+        uint64_t q = (uint64_t)(((__uint128_t)h * magic) >> 64);
+        uint64_t r = h - q * numEntries;
+        while (r >= numEntries) r -= numEntries;
+        return r;
     }
     void put(uint64_t h, uint32_t id) {
         numInserts++;
         if (numInserts > threshold) grow();
-        uint64_t loc = h % numEntries;
+        uint64_t loc = mod(h);
         for (uint64_t n = 0; n < numEntries; n++) {
-            if (!used[loc]) { used[loc] = 1; hash[loc] = h; who[loc] = id; return; }
+            Slot& s = slots[loc];
+            if (!s.used) { s.used = 1; s.hash = h; s.who = id; return; }
             if (++loc >= numEntries) loc = 0;
         }
         failRuntime("Hash table full");
     }
+    void prefetch(uint64_t h) const { __builtin_prefetch(&slots[mod(h)], 1, 1); }
     void grow() {
         DenseSim bigger(numEntries + 1);
-        for (uint64_t i = 0; i < numEntries; i++) if (used[i]) bigger.put(hash[i], who[i]);
+        // old table in slot order (growHashTable, qlib/hash.h:330-365); the occupied slots are gathered first so that
+        // the target slot of an insert can be prefetched a few inserts ahead (the table is far larger than the caches)
+        std::vector<Slot> live;
+        live.reserve(numInserts);
+        for (uint64_t i = 0; i < numEntries; i++) if (slots[i].used) live.push_back(slots[i]);
+        for (size_t i = 0; i < live.size(); i++) {
+            if (i + 12 < live.size()) bigger.prefetch(live[i + 12].hash);
+            bigger.put(live[i].hash, live[i].who);
+        }
         *this = std::move(bigger);
     }
 };
@@ -119,10 +137,13 @@ struct DenseSim {
 std::vector<size_t> refEmissionOrder(const std::vector<uint64_t>& hashes, uint64_t minSize) {
     if (hashes.size() >= 2048 && hashes.size() < 0xffffffffull && primeAbove(minSize) <= (1ull << 28)) {
         DenseSim sim(minSize);
-        for (size_t i = 0; i < hashes.size(); i++) sim.put(hashes[i], (uint32_t)i);
+        for (size_t i = 0; i < hashes.size(); i++) {
+            if (i + 12 < hashes.size()) sim.prefetch(hashes[i + 12]);
+            sim.put(hashes[i], (uint32_t)i);
+        }
         std::vector<size_t> order;
         order.reserve(hashes.size());
-        for (uint64_t s = 0; s < sim.numEntries; s++) if (sim.used[s]) order.push_back(sim.who[s]);
+        for (uint64_t s = 0; s < sim.numEntries; s++) if (sim.slots[s].used) order.push_back(sim.slots[s].who);
         return order;
     }
     Sim sim(minSize);

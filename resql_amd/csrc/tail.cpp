@@ -6,10 +6,34 @@
 // here over the #groups rows the device produced — same values, same types, same order.
 #include <algorithm>
 #include <cstring>
+#include <functional>
+#include <thread>
 
 #include "engine_internal.h"
 
 namespace rsq {
+
+// Run fn(begin, end, part) over [0, n) on up to 16 host threads; small ranges stay on the calling thread.
+// An exception in any part (e.g. a division by zero in a projection) is re-thrown on the calling thread.
+static int tailThreads(size_t n) {
+    if (n < 65536) return 1;
+    unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+}
+static void parallelFor(size_t n, int parts, const std::function<void(size_t, size_t, int)>& fn) {
+    if (parts <= 1) { fn(0, n, 0); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> errs((size_t)parts);
+    const size_t per = (n + (size_t)parts - 1) / (size_t)parts;
+    for (int p = 0; p < parts; p++) {
+        size_t b = std::min(n, per * (size_t)p), e = std::min(n, b + per);
+        th.emplace_back([&fn, &errs, b, e, p] {
+            try { fn(b, e, p); } catch (...) { errs[(size_t)p] = std::current_exception(); }
+        });
+    }
+    for (auto& t : th) t.join();
+    for (auto& e : errs) if (e) std::rethrow_exception(e);
+}
 
 int schemaTupleSize(const Schema& s) { int n = 0; for (auto& a : s) n += sizeInTuple(a.type, true); return n; }
 int schemaOffset(const Schema& s, const std::string& name) {
@@ -187,20 +211,35 @@ Groups groupsFromDense(Query& q) {
     auto word = [&](size_t w, int64_t g) { return (int64_t)q.hAgg[(size_t)(q.accumSlot[w] * D + g)]; };
     Groups G;
     G.nKeys = q.denseKeys.size(); G.nAcc = W;
-    size_t present = 0;
-    for (int64_t g = 0; g < D; g++) if (word(0, g) != INT64_MAX) present++;
+    // two passes over the dense table, both split over the host threads: count the groups present per part, then
+    // fill each part's slice (group order = dense id order, as before)
+    const int parts = tailThreads((size_t)D);
+    std::vector<size_t> cnt((size_t)parts + 1, 0);
+    parallelFor((size_t)D, parts, [&](size_t b, size_t e, int p) {
+        size_t c = 0;
+        for (size_t g = b; g < e; g++) if (word(0, (int64_t)g) != INT64_MAX) c++;
+        cnt[(size_t)p + 1] = c;
+    });
+    for (int p = 0; p < parts; p++) cnt[(size_t)p + 1] += cnt[(size_t)p];
+    const size_t present = cnt[(size_t)parts];
     G.n = present;
-    G.firstRow.reserve(present); G.keyData.reserve(present * G.nKeys); G.accData.reserve(present * W);
-    for (int64_t g = 0; g < D; g++) {
-        if (word(0, g) == INT64_MAX) continue;
-        G.firstRow.push_back(word(0, g));
-        for (auto& dk : q.denseKeys) {
-            int64_t rank = (g / dk.stride) % dk.card;
-            Val v; v.i = dk.byteSet ? (int64_t)dk.values[(size_t)rank] : dk.min + rank;
-            G.keyData.push_back(v);
+    G.firstRow.resize(present); G.keyData.resize(present * G.nKeys); G.accData.resize(present * W);
+    parallelFor((size_t)D, parts, [&](size_t b, size_t e, int p) {
+        size_t o = cnt[(size_t)p];
+        for (size_t gi = b; gi < e; gi++) {
+            const int64_t g = (int64_t)gi;
+            if (word(0, g) == INT64_MAX) continue;
+            G.firstRow[o] = word(0, g);
+            size_t k = 0;
+            for (auto& dk : q.denseKeys) {
+                int64_t rank = (g / dk.stride) % dk.card;
+                Val v; v.i = dk.byteSet ? (int64_t)dk.values[(size_t)rank] : dk.min + rank;
+                G.keyData[o * G.nKeys + k++] = v;
+            }
+            for (size_t w = 0; w < W; w++) G.accData[o * W + w] = word(w, g);
+            o++;
         }
-        for (size_t w = 0; w < W; w++) G.accData.push_back(word(w, g));
-    }
+    });
     return G;
 }
 
@@ -352,8 +391,7 @@ void runTail(Query& q) {
         }
 
     // ---- per group: dematerialize, AVG, projections, materialize ----
-    std::vector<Val> sym(hc.names.size());
-    auto materializeGroup = [&](size_t gi, uint8_t* dst) {
+    auto materializeGroupWith = [&](size_t gi, uint8_t* dst, std::vector<Val>& sym) {
         const Val* gk = G.keys(gi);
         const int64_t* ga = G.acc(gi);
         for (size_t k = 0; k < keySlots.size(); k++) sym[(size_t)keySlots[k]] = gk[k];
@@ -371,21 +409,47 @@ void runTail(Query& q) {
         memset(dst, 0, ts);
         for (size_t c = 0; c < cur.size(); c++) storeValue(dst + offs[c], sym[(size_t)matSlots[c]], cur[c].type);
     };
+    // many groups: every output row is independent, so the rows are split over the host threads
+    auto materializeMany = [&](size_t count, const std::function<size_t(size_t)>& groupOf, uint8_t* base) {
+        parallelFor(count, tailThreads(count), [&](size_t lo, size_t hi, int) {
+            std::vector<Val> sym(hc.names.size());
+            for (size_t i = lo; i < hi; i++) materializeGroupWith(groupOf(i), base + i * ts, sym);
+        });
+    };
 
     // The reference's order of the materialized rows: groups enter its hash table in the order of their first
     // input row and leave it in slot order.  Only needed when that order is observable.
     auto emissionOrder = [&]() {
         std::vector<size_t> byFirst(G.n);
-        for (size_t i = 0; i < G.n; i++) byFirst[i] = i;
-        std::sort(byFirst.begin(), byFirst.end(), [&](size_t a, size_t b) { return G.firstRow[a] < G.firstRow[b]; });
+        if (G.n < 4096) {
+            for (size_t i = 0; i < G.n; i++) byFirst[i] = i;
+            std::sort(byFirst.begin(), byFirst.end(), [&](size_t a, size_t b) { return G.firstRow[a] < G.firstRow[b]; });
+        } else {
+            // LSD radix sort of (first row, group) pairs, 11 bits per pass over the bits the rows actually use (stable,
+            // so groups that share a first row — matches of one probe row — keep their order)
+            struct KI { uint64_t key; uint32_t idx; };
+            std::vector<KI> a(G.n), b(G.n);
+            uint64_t maxKey = 0;
+            for (size_t i = 0; i < G.n; i++) { a[i].key = (uint64_t)G.firstRow[i]; a[i].idx = (uint32_t)i; maxKey = std::max(maxKey, a[i].key); }
+            for (int shift = 0; shift < 64 && (maxKey >> shift) != 0; shift += 11) {
+                size_t hist[2049] = {0};
+                for (size_t i = 0; i < G.n; i++) hist[((a[i].key >> shift) & 2047) + 1]++;
+                for (int d = 0; d < 2048; d++) hist[d + 1] += hist[d];
+                for (size_t i = 0; i < G.n; i++) b[hist[(a[i].key >> shift) & 2047]++] = a[i];
+                a.swap(b);
+            }
+            for (size_t i = 0; i < G.n; i++) byFirst[i] = a[i].idx;
+        }
         phase("sort groups by first row");
         std::vector<uint64_t> hashes(G.n);
-        for (size_t i = 0; i < G.n; i++) {
-            uint64_t h = 0;
-            const Val* gk = G.keys(byFirst[i]);
-            for (size_t k = 0; k < agg->exprs2.size(); k++) h = refHashValue(h, gk[k], agg->exprs2[k]->type);
-            hashes[i] = h;
-        }
+        parallelFor(G.n, tailThreads(G.n), [&](size_t lo, size_t hi, int) {
+            for (size_t i = lo; i < hi; i++) {
+                uint64_t h = 0;
+                const Val* gk = G.keys(byFirst[i]);
+                for (size_t k = 0; k < agg->exprs2.size(); k++) h = refHashValue(h, gk[k], agg->exprs2[k]->type);
+                hashes[i] = h;
+            }
+        });
         phase("reference hashes");
         std::vector<size_t> slotOrder = refEmissionOrder(hashes, opSize(agg));
         std::vector<size_t> order(G.n);
@@ -401,7 +465,7 @@ void runTail(Query& q) {
     if (orderBy && orderBy->hasLimit && !mat->hasLimit && orderBy->limit >= 0 && (size_t)orderBy->limit * 4 < G.n) {
         const size_t k = (size_t)orderBy->limit;
         std::vector<uint8_t> all(G.n * ts);
-        for (size_t i = 0; i < G.n; i++) materializeGroup(i, &all[i * ts]);
+        materializeMany(G.n, [](size_t i) { return i; }, all.data());
         auto before = [&](const uint8_t* a, const uint8_t* b) {
             for (const auto& o : reqs) {
                 int c = compareTyped(o.type, a + o.offset, b + o.offset);
@@ -428,13 +492,12 @@ void runTail(Query& q) {
     }
 
     std::vector<size_t> order = emissionOrder();
-    q.resultTuples.resize(G.n * ts);
-    for (size_t oi : order) {
-        materializeGroup(oi, &q.resultTuples[(size_t)q.resultRows * ts]);
-        q.resultRows++;
-        if (mat->hasLimit && q.resultRows >= mat->limit) break;      // materialize.h:197-206
-    }
-    q.resultTuples.resize((size_t)q.resultRows * ts);
+    // materialize.h:197-206: with a LIMIT the pipeline is left once count >= limit, i.e. after max(limit, 1) tuples
+    size_t emit = order.size();
+    if (mat->hasLimit) emit = std::min(emit, (size_t)std::max<int64_t>(mat->limit, 1));
+    q.resultTuples.resize(emit * ts);
+    materializeMany(emit, [&order](size_t i) { return order[i]; }, q.resultTuples.data());
+    q.resultRows = (int64_t)emit;
     phase("AVG / projections / materialize");
     if (orderBy) {
         refQuicksort(q.resultTuples.data(), q.resultRows, ts, reqs);

@@ -66,3 +66,33 @@ def test_synthetic_filter_aggregate(gpu_ctx, groups, selectivity):
     got = gpu_ctx.run(plan)
     want = orc.execute(plan)
     assert got.text == want.text
+
+
+@pytest.mark.parametrize("groups", [1024, 1 << 16])
+def test_repeated_execution_gives_the_same_answer(gpu_ctx, groups):
+    """a compiled query is executed again and again (bench.py does): aggregate tables are re-initialised per execution and
+    nothing cached from the previous run (L2 lines read by the min/max pre-check of the HBM-table modes) may leak in"""
+    t = tpch.synthetic_table(200_000, groups)
+    plan = tpch.synthetic_plan(t, 1 << 30)
+    want = orc.execute(plan).text
+    tabs = [gpu_ctx.table(t)]
+    q = gpu_ctx.compile(plan, tabs)
+    for _ in range(4):
+        q.execute()
+        assert q.result().text == want
+    q.close(); tabs[0].close()
+
+
+def test_repeated_execution_q3(gpu_ctx):
+    sf = 0.05
+    cu, od, li = tpch.customer_table(sf), tpch.orders_table(sf), tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+    plan = tpch.q3_plan(cu, od, li)
+    want = orc.execute(plan).text
+    tabs = [gpu_ctx.table(t) for t in (cu, od, li)]
+    q = gpu_ctx.compile(plan, tabs)
+    for _ in range(3):
+        q.execute()
+        assert q.result().text == want
+    q.close()
+    for t in tabs:
+        t.close()
