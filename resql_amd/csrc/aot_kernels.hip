@@ -320,6 +320,61 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// partitioned aggregation: per-(workgroup, partition) record counts -> record positions.
+// m[wg][p] becomes the position of workgroup wg's first record of partition p when partitions are laid out one after
+// the other and, inside a partition, workgroups in order; partStart[p] / partStart[P] are the partition bounds.
+// One workgroup: the matrix is small (workgroups x partitions words) and every column walk is coalesced across threads.
+// ------------------------------------------------------------------------------------------------
+// step 1, one workgroup per partition p: exclusive prefix of column p over the workgroups (block scan in LDS, chunks of
+// 1024 workgroups with a carry), the column total goes to totals[p]
+__global__ void __launch_bounds__(1024) k_part_within(unsigned* __restrict__ m, int nWG, int P, u64* __restrict__ totals) {
+    __shared__ u64 s[1024];          // 64-bit: the host rejects totals >= 2^32 and must see them unwrapped
+    __shared__ u64 carry;
+    const int p = blockIdx.x, t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nWG; base += 1024) {
+        const int wg = base + t;
+        const u64 c = wg < nWG ? (u64)m[(size_t)wg * P + p] : 0ull;
+        s[t] = c;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {                  // Hillis-Steele inclusive scan
+            const u64 v = t >= d ? s[t - d] : 0ull;
+            __syncthreads();
+            s[t] += v;
+            __syncthreads();
+        }
+        const u64 before = carry;
+        if (wg < nWG) m[(size_t)wg * P + p] = (unsigned)(before + s[t] - c);
+        __syncthreads();
+        if (t == 1023) carry = before + s[1023];
+        __syncthreads();
+    }
+    if (t == 0) totals[p] = carry;
+}
+// step 2, one workgroup: exclusive scan of the partition totals -> partStart[0..P], grand total
+__global__ void __launch_bounds__(1024) k_part_starts(const u64* __restrict__ totals, int P, unsigned* __restrict__ partStart, u64* total) {
+    __shared__ u64 s_tot[4097];
+    for (int p = threadIdx.x; p < P; p += blockDim.x) s_tot[p] = totals[p];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 acc = 0;
+        for (int p = 0; p < P; p++) { const u64 v = s_tot[p]; s_tot[p] = acc; acc += v; }
+        s_tot[P] = acc;
+        *total = acc;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p <= P; p += blockDim.x) partStart[p] = (unsigned)s_tot[p];
+}
+
+void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPartitions, uint64_t* totals, uint32_t* partStart, uint64_t* total) {
+    if (nPartitions > 4096) throw Error(RSQ_ERR_UNSUPPORTED, "more than 4096 aggregation partitions");
+    hipLaunchKernelGGL(k_part_within, dim3((unsigned)nPartitions), dim3(1024), 0, ctx.stream, (unsigned*)counts, nWorkgroups, nPartitions, (u64*)totals);
+    hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(1024), 0, ctx.stream, (const u64*)totals, nPartitions, (unsigned*)partStart, (u64*)total);
+    RSQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // exclusive scan of per-slot tuple counts (u32) into output offsets (u64); `n` includes one trailing zero
 // slot so that offs[n - 1] is the total (rocPRIM device scan through hipCUB)
 // ------------------------------------------------------------------------------------------------

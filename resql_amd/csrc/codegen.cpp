@@ -832,16 +832,104 @@ struct Walker {
                      " + gid, (u64)" + inOf(w) + ");");
             ep << "    __syncthreads();\n";
             emitGlobalFlush(ep, std::to_string((long long)cells), "s_tab[i]", D);
-        } else {   // DENSE_GLOBAL: straight to the table in HBM
+        } else {   // DENSE_GLOBAL: the table lives in HBM
+            // Three forms of the same pipeline, one source (RSQ_AGG_VARIANT):
+            //  0 direct     every passing row merges into the table with HBM atomics.  Those execute at the memory side,
+            //               ≈25 G requests/s chip-wide, so this form is atomic-bound once many rows pass the filter.
+            //  1 count      per (workgroup, partition) row counts in LDS (partition = group id / groups-per-partition);
+            //               with a.tile_step > 1 it samples every n-th tile: the engine's selectivity estimate.
+            //  2 scatter    each passing row becomes a record (group-in-partition, row, accumulator inputs) written to
+            //               its partition's region at a position taken from a workgroup-local LDS cursor that starts
+            //               at the exclusive prefix of the counts: no HBM atomics at all.
+            // A fourth kernel (rsq_part_agg, emitted below) aggregates each partition in an LDS table and stores the
+            // finished groups with plain stores.  The engine picks direct or partitioned per execution from the counts.
             pipe.gridPerCU = 8;
-            for (int w = 0; w < W; w++)
+            int gpp = 1;
+            while ((int64_t)gpp * 2 * W * 8 <= 128 * 1024 && gpp * 2 <= (1 << 20)) gpp *= 2;
+            const int64_t P = (D + gpp - 1) / gpp;
+            int shift = 0; while ((1 << shift) < gpp) shift++;
+            const bool part = P >= 2 && P <= 4096 && envInt("RSQ_PARTITION", 1, 0, 2) != 0;
+            if (part) {
+                pipe.partitioned = true; pipe.partCount = (int)P; pipe.partGroups = gpp;
+                line("#if RSQ_AGG_VARIANT == 1");
+                line("atomicAdd(&st.part[gid >> " + std::to_string(shift) + "], 1u);");
+                line("#elif RSQ_AGG_VARIANT == 2");
+                openScope("{");
+                // records are arrays of R words, stored whole (array of structures): a workgroup then streams into ONE
+                // address range per partition, and with one 1024-thread workgroup per CU the partially written lines of
+                // all its partitions stay in the XCD's L2 until they are full.  (Struct of arrays with 8 workgroups per
+                // CU measured 4.4 ms for 100 M records — every 8-byte store left L2 as its own partial write.)
+                for (int w = 1; w < W; w++)
+                    if (q.accums[(size_t)w].input != "((i64)1)") pipe.partRecordInputs.push_back(w);   // COUNT's input is the constant 1
+                const std::string R = std::to_string(1 + pipe.partRecordInputs.size());
+                line("const u32 pos = atomicAdd(&st.part[gid >> " + std::to_string(shift) + "], 1u);");
+                line("u64* rec = a.rec + (u64)pos * " + R + ";");
+                line("rec[0] = ((u64)(gid & " + std::to_string(gpp - 1) + ") << 40) | (u64)(row - a.row0);");
+                addArg("rec", "u64*", 0);
+                for (size_t j = 0; j < pipe.partRecordInputs.size(); j++)
+                    line("rec[" + std::to_string(j + 1) + "] = (u64)in" + std::to_string(pipe.partRecordInputs[j]) + ";");
+                closeScope();
+                line("#else");
+            }
+            pipe.partAtomicsPerRow = 0;
+            for (int w = 0; w < W; w++) {
+                if (q.accums[(size_t)w].merge == 0) pipe.partAtomicsPerRow++;
                 line("rsq::global_merge<" + std::to_string(q.accums[(size_t)w].merge) + ">(a.out + " + std::to_string((long long)(q.accumSlot[(size_t)w] * D)) +
                      " + gid, (u64)" + inOf(w) + ");");
+            }
+            if (part) {
+                line("#endif");
+                addArg("part_counts", "u32*", 0); addArg("part_start", "const u32*", 0); addArg("tile_step", "i64", 1);
+                stateDecl += "    u32* part;\n";
+                const std::string Ps = std::to_string((long long)P);
+                prologue += "#if RSQ_AGG_VARIANT != 0\n    __shared__ u32 s_part[" + Ps + "];\n";
+                prologue += "    for (int i = threadIdx.x; i < " + Ps + "; i += blockDim.x)\n";
+                prologue += "        s_part[i] = RSQ_AGG_VARIANT == 2 ? a.part_start[i] + a.part_counts[(u64)blockIdx.x * " + Ps + " + i] : 0u;\n";
+                prologue += "    __syncthreads();\n    st.part = s_part;\n#endif\n";
+                ep << "#if RSQ_AGG_VARIANT == 1\n    __syncthreads();\n";
+                ep << "    for (int i = threadIdx.x; i < " << P << "; i += blockDim.x) a.part_counts[(u64)blockIdx.x * " << P << " + i] = s_part[i];\n#endif\n";
+                // ---- the per-partition aggregation kernel ----
+                std::ostringstream k;
+                auto& A2 = pipe.argsPartAgg;
+                A2.push_back({"rec", "const u64*", 0});
+                A2.push_back({"part_start", "const u32*", 0});
+                A2.push_back({"out", "u64*", 0});
+                A2.push_back({"row0", "i64", (uint64_t)pipe.src->row0});
+                k << "// generated by resql_amd/csrc/codegen.cpp: aggregation of one partition of records in an LDS table\n";
+                k << "#include \"rsq_device.h\"\nstruct Args {\n";
+                for (auto& a : A2) k << "    " << a.ctype << " " << a.name << ";\n";
+                k << "};\nextern \"C\" __global__ void __launch_bounds__(1024) rsq_part_agg(Args a) {\n";
+                k << "    __shared__ u64 s_tab[" << (int64_t)W * gpp << "];\n";
+                k << "    for (int i = threadIdx.x; i < " << (int64_t)W * gpp << "; i += blockDim.x) { const int blk = i >> " << shift << "; s_tab[i] = " << blockIdentityExpr("blk") << "; }\n";
+                k << "    __syncthreads();\n";
+                k << "    const u32 b = a.part_start[blockIdx.x], e = a.part_start[blockIdx.x + 1];\n";
+                k << "    for (u32 i = b + threadIdx.x; i < e; i += blockDim.x) {\n";
+                const size_t RW = 1 + pipe.partRecordInputs.size();
+                k << "        const u64* rec = a.rec + (u64)i * " << RW << ";\n";
+                k << "        const u64 key = rec[0];\n        const int g = (int)(key >> 40);\n";
+                k << "        const i64 row = a.row0 + (i64)(key & ((1ull << 40) - 1));\n";
+                for (int w = 0; w < W; w++) {
+                    std::string in = "row";
+                    if (w > 0) {
+                        in = "(i64)1";
+                        for (size_t j = 0; j < pipe.partRecordInputs.size(); j++)
+                            if (pipe.partRecordInputs[j] == w) in = "rec[" + std::to_string(j + 1) + "]";
+                    }
+                    k << "        rsq::lds_merge<" << q.accums[(size_t)w].merge << ">(&s_tab[" << (int64_t)q.accumSlot[(size_t)w] * gpp << " + g], (u64)(" << in << "));\n";
+                }
+                k << "    }\n    __syncthreads();\n";
+                k << "    for (int i = threadIdx.x; i < " << (int64_t)W * gpp << "; i += blockDim.x) {\n";
+                k << "        const i64 g = (i64)blockIdx.x * " << gpp << " + (i & " << (gpp - 1) << ");\n";
+                k << "        if (g < " << D << ") a.out[(i64)(i >> " << shift << ") * " << D << " + g] = s_tab[i];\n    }\n}\n";
+                pipe.sourcePartAgg = k.str();
+            }
         }
         epilogue += ep.str();
         static const char* names[] = {"none", "registers", "lane-private LDS", "workgroup LDS table", "HBM table", "join entry", "hash"};
         explainSteps.push_back("aggregation dense groups=" + std::to_string((long long)D) + " accumulators=" + std::to_string(W - 1) +
-                               " (of " + std::to_string(o->splitAgg.size()) + " in the reference) in " + names[(int)q.aggMode]);
+                               " (of " + std::to_string(o->splitAgg.size()) + " in the reference) in " + names[(int)q.aggMode] +
+                               (pipe.partitioned ? " (atomics, or " + std::to_string(pipe.partCount) + " partitions x " + std::to_string(pipe.partGroups) +
+                                                   " groups aggregated in LDS when many rows pass)" : ""));
     }
 
     void emitJoinEntryAggregation(OpNode* o) {
@@ -919,17 +1007,20 @@ struct Walker {
         s << "};\nstruct State {\n" << stateDecl << "};\n";
         s << "static RSQ_DEV void row_fn(const Args& a, State& st, const i64 lr" << rowParams << ") {\n";
         s << "    const i64 row = a.row0 + lr;\n" << body << "}\n";
-        s << "extern \"C\" __global__ void __launch_bounds__(" << pipe.blockThreads << ") rsq_pipeline(Args a) {\n";
+        s << "#ifndef RSQ_BLOCK_THREADS\n#define RSQ_BLOCK_THREADS " << pipe.blockThreads << "\n#endif\n";
+        s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) rsq_pipeline(Args a) {\n";
         s << "    State st;\n" << prologue;
         s << "    const int lane = threadIdx.x & 63;\n";
         s << "    const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n";
         s << "    const i64 nwaves = (i64)gridDim.x * (blockDim.x >> 6);\n";
         s << "    const i64 ntiles = a.n_rows >> 7;\n";
+        if (pipe.partitioned) s << "#if RSQ_AGG_VARIANT == 1\n    const i64 tstep = a.tile_step;      // > 1: sample every n-th tile\n#else\n    const i64 tstep = 1;\n#endif\n";
+        else s << "    const i64 tstep = 1;\n";
         // main loop, textually unrolled: the loads of U tiles are issued before the first row is processed
-        s << "    for (i64 t = wave; t < ntiles; t += nwaves * " << U << ") {\n";
+        s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
         const int ncols = (int)colTypes.size();
         for (int u = 0; u < U; u++) {
-            s << "        const i64 tt" << u << " = t + " << u << " * nwaves;\n";
+            s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2];\n";
             s << "        if (tt" << u << " < ntiles) {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "            rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
@@ -957,6 +1048,12 @@ struct Walker {
         if (mat) {   // two code objects from one source
             pipe.sourcePass1 = "#define RSQ_PASS 1\n" + pipe.source;
             pipe.source = "#define RSQ_PASS 2\n" + pipe.source;
+        }
+        if (pipe.partitioned) {   // three code objects from one source (see emitDenseAggregation)
+            // count and scatter run as ONE 1024-thread workgroup per CU (see the note at the record stores)
+            pipe.sourcePartCount = "#define RSQ_AGG_VARIANT 1\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
+            pipe.sourcePartScatter = "#define RSQ_AGG_VARIANT 2\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
+            pipe.source = "#define RSQ_AGG_VARIANT 0\n" + pipe.source;
         }
         std::string ex = "pipeline " + std::to_string(q.pipelines.size()) + ": ";
         for (size_t i = 0; i < explainSteps.size(); i++) ex += (i ? " -> " : "") + explainSteps[i];

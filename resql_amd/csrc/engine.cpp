@@ -117,6 +117,10 @@ Query::~Query() {
     for (void* p : dMatCols) if (p) ctx.free(p);
     if (dGroupRows) ctx.free(dGroupRows);
     if (dGroupCount) ctx.free(dGroupCount);
+    if (dPartCounts) ctx.free(dPartCounts);
+    if (dPartStart) ctx.free(dPartStart);
+    if (dPartTotals) ctx.free(dPartTotals);
+    for (void* r : dPartRecords) if (r) ctx.scratchFree(r);
     for (auto& h : hashTables) {
         if (h->dState) ctx.free(h->dState);
         if (h->dWords) ctx.free(h->dWords);
@@ -168,6 +172,11 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     buildPipelines(*q);
     for (auto& p : q->pipelines) {
         if (!p.sourcePass1.empty()) p.kernelPass1 = &ctx.getKernel(p.sourcePass1, p.entry);
+        if (p.partitioned) {
+            p.kernelPartCount = &ctx.getKernel(p.sourcePartCount, p.entry);
+            p.kernelPartScatter = &ctx.getKernel(p.sourcePartScatter, p.entry);
+            p.kernelPartAgg = &ctx.getKernel(p.sourcePartAgg, "rsq_part_agg");
+        }
         p.kernel = &ctx.getKernel(p.source, p.entry);
         q->allSource += p.source + "\n";
         q->explainText += p.explain + "\n";
@@ -210,8 +219,13 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
 // ================================================================================================
 // execute
 // ================================================================================================
-static uint64_t argValue(Query& q, const ArgSlot& a, int countOnlyTable) {
+static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTable) {
     if (a.name == "out") return (uint64_t)(uintptr_t)q.dAgg;
+    if (a.name == "part_counts") return (uint64_t)(uintptr_t)q.dPartCounts;
+    if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
+    if (a.name == "tile_step") return (uint64_t)q.partTileStep;
+    if (a.name == "rec") return q.dPartRecords.empty() ? 0 : (uint64_t)(uintptr_t)q.dPartRecords[0];
+    (void)p;
     if (a.name == "cnt") return (uint64_t)(uintptr_t)q.dMatCnt;
     if (a.name == "offs") return (uint64_t)(uintptr_t)q.dMatOffs;
     if (a.name == "out_limit") return (uint64_t)q.matLimit;
@@ -234,15 +248,86 @@ static uint64_t argValue(Query& q, const ArgSlot& a, int countOnlyTable) {
     return a.value;
 }
 
-static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
-    std::vector<uint64_t> args;
-    for (auto& a : p.args) args.push_back(argValue(q, a, countOnlyTable));
+static unsigned pipelineGrid(const Query& q, const Pipeline& p) {
     const int64_t tiles = p.src->nRows >> 7;
     const int wavesPerBlock = p.blockThreads / 64;
     int64_t want = (tiles + (int64_t)wavesPerBlock * p.unroll - 1) / ((int64_t)wavesPerBlock * p.unroll);
     const int64_t maxGrid = p.maxGrid ? (int64_t)p.maxGrid : (int64_t)p.gridPerCU * (int64_t)q.ctx.numCUs;
-    unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(maxGrid * 256 / p.blockThreads, want));
-    launch(q.ctx, pass1 ? *p.kernelPass1 : *p.kernel, grid, (unsigned)p.blockThreads, args);
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(maxGrid * 256 / p.blockThreads, want));
+}
+
+static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnlyTable, unsigned grid = 0, unsigned block = 0) {
+    std::vector<uint64_t> args;
+    for (auto& a : p.args) args.push_back(argValue(q, p, a, countOnlyTable));
+    launch(q.ctx, k, grid ? grid : pipelineGrid(q, p), block ? block : (unsigned)p.blockThreads, args);
+    q.report.num_kernels++;
+}
+
+static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
+    launchPipelineKernel(q, p, pass1 ? *p.kernelPass1 : *p.kernel, countOnlyTable);
+}
+
+// Aggregation into a large dense table (see emitDenseAggregation, DENSE_GLOBAL): pick, per execution, between HBM
+// atomics (few rows pass the filter) and count -> scatter -> per-partition LDS aggregation (many rows pass).
+// RSQ_PARTITION=0 never partitions (decided at compile time), 2 always does (tests), 1 / unset decides from a sample.
+static void runLargeDenseAggregation(Query& q, Pipeline& p) {
+    Context& ctx = q.ctx;
+    const int P = p.partCount;
+    // count and scatter: ONE 1024-thread workgroup per CU (codegen.cpp explains why), the same grid for both passes —
+    // the scatter positions are the prefix sums of exactly these workgroups' counts
+    const unsigned block = 1024;
+    const int64_t tiles = p.src->nRows >> 7;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx.numCUs, (tiles + 15) / 16));
+    const int64_t rows = p.src->nRows;
+    const char* forceEnv = getenv("RSQ_PARTITION");
+    const bool force = forceEnv && atoi(forceEnv) == 2;
+    const bool trace = getenv("RSQ_TRACE") != nullptr;
+    if (!force && rows < (4 << 20)) { launchPipeline(q, p, -1); return; }       // small inputs: the extra passes cost more than they save
+    const size_t words = (size_t)grid * (size_t)P;
+    if (q.partCountsWords < words) {
+        if (q.dPartCounts) ctx.free(q.dPartCounts);
+        q.dPartCounts = (uint32_t*)ctx.alloc(words * 4);
+        q.partCountsWords = words;
+    }
+    if (!q.dPartStart) {
+        q.dPartStart = (uint32_t*)ctx.alloc(((size_t)P + 1) * 4);
+        q.dPartTotals = (uint64_t*)ctx.alloc(((size_t)P + 1) * 8);       // [P] column totals, [P] = grand total
+    }
+    auto countPass = [&](int64_t step) -> uint64_t {
+        q.partTileStep = step;
+        RSQ_HIP(hipMemsetAsync(q.dPartCounts, 0, words * 4, ctx.stream));
+        launchPipelineKernel(q, p, *p.kernelPartCount, -1, grid, block);
+        partitionOffsets(ctx, q.dPartCounts, (int)grid, P, q.dPartTotals, q.dPartStart, q.dPartTotals + P);
+        q.report.num_kernels += 2;
+        uint64_t total = 0;
+        RSQ_HIP(hipMemcpyAsync(&total, q.dPartTotals + P, 8, hipMemcpyDeviceToHost, ctx.stream));
+        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        q.partTileStep = 1;
+        return total;
+    };
+    const size_t recBytes = 8 * (1 + p.partRecordInputs.size());
+    if (!force) {
+        const int64_t step = 32;
+        const double passing = (double)countPass(step) * (double)step;
+        const double direct = passing * (double)std::max(1, p.partAtomicsPerRow) / 25e9;
+        const double parted = ((double)rows * 16.0 + (double)rows * (double)p.bytesPerRow) / 6e12 + passing * (double)recBytes * 2.0 / 4e12 + 60e-6;
+        if (trace) fprintf(stderr, "[rsq trace]     large dense aggregation: ~%.0f of %lld rows pass; atomics %.3f ms vs partitioned %.3f ms\n",
+                           passing, (long long)rows, direct * 1e3, parted * 1e3);
+        if (direct <= parted) { launchPipeline(q, p, -1); return; }
+    }
+    const uint64_t total = countPass(1);
+    if (total >= 0xffffffffull) { launchPipeline(q, p, -1); return; }          // record positions are 32-bit
+    if (q.partRecordCapacity < total || q.dPartRecords.empty()) {
+        // the record buffer comes from the context's scratch cache: a 15 GB hipMalloc per query costs more than the passes
+        for (void* r : q.dPartRecords) ctx.scratchFree(r);
+        q.dPartRecords.clear();
+        q.partRecordCapacity = std::max<uint64_t>(total, 1);
+        q.dPartRecords.push_back(ctx.scratchAlloc((size_t)q.partRecordCapacity * (size_t)recBytes));
+    }
+    launchPipelineKernel(q, p, *p.kernelPartScatter, -1, grid, block);
+    std::vector<uint64_t> args;
+    for (auto& a : p.argsPartAgg) args.push_back(argValue(q, p, a, -1));
+    launch(ctx, *p.kernelPartAgg, (unsigned)P, 1024u, args);
     q.report.num_kernels++;
 }
 
@@ -384,7 +469,8 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
             continue;
         }
-        launchPipeline(q, p, -1);
+        if (p.partitioned) runLargeDenseAggregation(q, p);
+        else launchPipeline(q, p, -1);
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
         tracePoint(p);
     }

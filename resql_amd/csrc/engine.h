@@ -80,6 +80,11 @@ struct Context {
     void* alloc(size_t bytes);
     void free(void* p);
     void setStream(hipStream_t s, bool callers);   // callers == false: back to the context's own stream
+    // large transient device buffers (partition records): freed buffers are kept and handed out again, because
+    // hipMalloc / hipFree of multi-GB buffers costs tens to hundreds of ms
+    void* scratchAlloc(size_t bytes);
+    void scratchFree(void* p);
+    std::vector<std::pair<void*, size_t>> scratchFreeList, scratchLive;
 };
 
 // launch helper: kernel takes one struct of 8-byte slots by value
@@ -92,6 +97,9 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
 size_t scanTempBytes(int64_t n);
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
+// partitioned aggregation: counts[workgroup][partition] -> exclusive prefix inside each partition (in place), partition
+// bounds partStart[0..P] and the record total
+void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPartitions, uint64_t* totals, uint32_t* partStart, uint64_t* total);
 // gather the occupied entries (first-row word != INT64_MAX) of a hash table that carries aggregates into
 // packed rows [first row | table words | accumulator blocks]; *count receives the number of rows
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,

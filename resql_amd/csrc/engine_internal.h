@@ -83,6 +83,16 @@ struct Pipeline {
     std::string source;              // generated HIP source
     std::string sourcePass1;         // SinkKind::MATERIALIZE: the counting pass of the same pipeline
     Kernel* kernelPass1 = nullptr;
+    // partitioned aggregation (large dense group domains, see emitDenseAggregation): the same pipeline compiled as a
+    // per-(workgroup, partition) counting pass and as a record scatter pass, plus the per-partition LDS aggregation
+    bool partitioned = false;
+    std::string sourcePartCount, sourcePartScatter, sourcePartAgg;
+    Kernel* kernelPartCount = nullptr; Kernel* kernelPartScatter = nullptr; Kernel* kernelPartAgg = nullptr;
+    std::vector<ArgSlot> argsPartAgg;
+    std::vector<int> partRecordInputs;   // accumulator indices whose input travels in the records (not row, not constant)
+    int partCount = 0;                   // P: number of partitions
+    int partGroups = 0;                  // groups per partition (power of two)
+    int partAtomicsPerRow = 0;           // HBM atomics the direct form issues per passing row (sum accumulators)
     std::string entry = "rsq_pipeline";
     std::vector<ArgSlot> args;
     Kernel* kernel = nullptr;
@@ -124,6 +134,15 @@ struct Query {
     uint64_t* hPinned = nullptr;           // pinned read-back: aggregate words + error word
     size_t pinnedWords = 0;
     std::vector<uint64_t> hAgg;
+
+    // partitioned aggregation buffers
+    uint32_t* dPartCounts = nullptr;       // [workgroups][P] counts, turned into offsets in place
+    size_t partCountsWords = 0;
+    uint32_t* dPartStart = nullptr;        // [P + 1]
+    uint64_t* dPartTotals = nullptr;       // [P] records per partition, [P] = grand total
+    std::vector<void*> dPartRecords;       // [0] keys (group-in-partition << 40 | row - row0), then one array per record input
+    uint64_t partRecordCapacity = 0;
+    int64_t partTileStep = 1;              // > 1: the counting pass samples every n-th tile (selectivity estimate)
 
     // device-side materialisation (plans without aggregation)
     OpNode* matOp = nullptr;

@@ -64,11 +64,40 @@ Context::~Context() {
     if (device >= 0) {
         (void)hipSetDevice(device);
         for (auto& kv : kernels) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
+        for (auto& e : scratchFreeList) (void)hipFree(e.first);
         if (dErr) (void)hipFree(dErr);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ownStream) (void)hipStreamDestroy(ownStream);
     }
+}
+
+void* Context::scratchAlloc(size_t bytes) {
+    size_t best = scratchFreeList.size();
+    for (size_t i = 0; i < scratchFreeList.size(); i++)
+        if (scratchFreeList[i].second >= bytes && (best == scratchFreeList.size() || scratchFreeList[i].second < scratchFreeList[best].second)) best = i;
+    if (best < scratchFreeList.size()) {
+        auto e = scratchFreeList[best];
+        scratchFreeList.erase(scratchFreeList.begin() + (long)best);
+        scratchLive.push_back(e);
+        return e.first;
+    }
+    // nothing cached is large enough: drop the cache first so that the new buffer finds room
+    for (auto& e : scratchFreeList) free(e.first);
+    scratchFreeList.clear();
+    void* p = alloc(bytes);
+    scratchLive.push_back({p, bytes});
+    return p;
+}
+void Context::scratchFree(void* p) {
+    for (size_t i = 0; i < scratchLive.size(); i++)
+        if (scratchLive[i].first == p) {
+            scratchFreeList.push_back(scratchLive[i]);
+            scratchLive.erase(scratchLive.begin() + (long)i);
+            if (scratchFreeList.size() > 2) { free(scratchFreeList.front().first); scratchFreeList.erase(scratchFreeList.begin()); }
+            return;
+        }
+    free(p);
 }
 
 void Context::setStream(hipStream_t s, bool callers) {

@@ -1,0 +1,79 @@
+"""Aggregation into a large dense group table (more cells than an LDS table holds): the engine either merges with HBM
+atomics or partitions the passing rows (count -> scatter records -> per-partition LDS aggregation), chosen per
+execution.  Both forms must give the oracle's bytes, including the emission order (first-row tracker)."""
+import numpy as np
+import pytest
+
+from resql_amd import plan as P, tpch
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+T = P.TypeInit
+
+
+def run_forced(gpu_ctx, monkeypatch, plan, mode):
+    monkeypatch.setenv("RSQ_PARTITION", str(mode))
+    tabs = [gpu_ctx.table(t) for t in plan.tables]
+    q = gpu_ctx.compile(plan, tabs)
+    try:
+        q.execute()
+        first = q.result().text
+        q.execute()                                   # buffers are reused by the second run
+        assert q.result().text == first
+        return first, q.explain
+    finally:
+        q.close()
+        for t in tabs:
+            t.close()
+
+
+@pytest.mark.parametrize("groups", [1 << 13, 1 << 16, 1 << 20])
+@pytest.mark.parametrize("selectivity", [0.0, 0.02, 0.5, 1.0])
+def test_partitioned_equals_atomics_equals_oracle(gpu_ctx, monkeypatch, groups, selectivity):
+    t = tpch.synthetic_table(300_001, groups)
+    plan = tpch.synthetic_plan(t, int(selectivity * (1 << 31)))
+    want = orc.execute(plan).text
+    got, explain = run_forced(gpu_ctx, monkeypatch, plan, 2)
+    assert "partitions" in explain
+    assert got == want
+    assert run_forced(gpu_ctx, monkeypatch, plan, 0)[0] == want
+
+
+def test_partitioned_with_min_max_avg_and_two_keys(gpu_ctx, monkeypatch):
+    rng = np.random.default_rng(5)
+    n = 200_000
+    t = P.Table("t", [P.Column("k1", T.BIGINT(), rng.integers(0, 300, n).astype(np.int64)),
+                      P.Column("k2", T.INT(), rng.integers(-20, 80, n).astype(np.int32)),
+                      P.Column("d", T.DATE(), (19920101 + rng.integers(0, 28, n)).astype(np.uint32)),
+                      P.Column("x", T.DECIMAL(12, 2), rng.integers(-5000, 100000, n).astype(np.int64)),
+                      P.Column("y", T.BIGINT(), rng.integers(0, 1000, n).astype(np.int64))], n)
+    p = P.Plan([t])
+    k1, k2 = p.attr("k1"), p.attr("k2")
+    aggs = [p.sum(p.attr("x")), p.min(p.attr("d")), p.max(p.attr("x")), p.avg(p.attr("x")), p.count(p.star()),
+            p.sum(p.mul(p.attr("x"), p.attr("y"))), p.min(p.attr("y"))]
+    node = p.selection(p.gt(p.attr("y"), p.constant("100", P.BIGINT)), p.scan("t"))
+    node = p.aggregation(aggs, [k1, k2], node)
+    node = p.projection([k1, k2] + [p.as_(f"a{i}", a) for i, a in enumerate(aggs)], node)
+    plan = p.set_root(p.materialize(node))
+    want = orc.execute(plan).text
+    got, explain = run_forced(gpu_ctx, monkeypatch, plan, 2)
+    assert "partitions" in explain and got == want
+
+
+def test_automatic_choice_on_a_larger_table(gpu_ctx, monkeypatch):
+    """above 4 M rows the engine samples the selectivity and decides; both outcomes must agree with the oracle"""
+    monkeypatch.delenv("RSQ_PARTITION", raising=False)
+    from resql_amd import engine
+    n, groups = 6_000_000, 1 << 18
+    host = tpch.synthetic_table(n, groups)
+    dev = gpu_ctx.generate(engine.GEN_SYNTHETIC, n, 1.0, param=groups)
+    for sel in (0.005, 0.6):
+        plan = tpch.synthetic_plan(host, int(sel * (1 << 31)))
+        q = gpu_ctx.compile(plan, [dev])
+        q.execute()
+        kernels = q.report().num_kernels
+        got = q.result().text
+        q.close()
+        assert got == orc.execute(plan).text
+        assert (kernels > 4) == (sel > 0.1)        # partitioned: sample + count (3 kernels each) + scatter + aggregate
+    dev.close()
