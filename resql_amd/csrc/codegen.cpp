@@ -196,11 +196,13 @@ std::string fromWord(const std::string& w, const Type& t) {
         case RSQ_INT: case RSQ_DATE: return "((i32)(" + w + "))";
         case RSQ_BOOL: return "((u8)(" + w + "))";
         case RSQ_CHAR: if (t.len == 1) return "((u8)(" + w + "))"; [[fallthrough]];
-        default: failUnsupported("string values cannot be carried through a join in this engine version");
+        case RSQ_VARCHAR: return "rsq::str_from_addr(" + w + ", " + std::to_string(t.len) + ")";     // payload strings travel by address
+        default: failUnsupported("value type cannot be carried in a hash table word");
     }
 }
 std::string toWord(const std::string& v, const Type& t) {
-    if (t.isString()) failUnsupported("string values cannot be carried through a join in this engine version");
+    // a string is carried as the device address of its bytes in the (immutable, device-resident) column it comes from
+    if (t.isString()) return "rsq::str_addr(" + v + ")";
     return "((i64)(" + v + "))";
 }
 
@@ -394,6 +396,28 @@ struct Walker {
         epilogue += "    { const u64 v = rsq::wave_sum((u64)st.n_" + T + "); if ((threadIdx.x & 63) == 0 && v) atomicAdd(a." + T + "_count, (u32)v); }\n";
     }
 
+    // Key value(s) of one expression as table words: one word for numbers, ceil(len / 8) words of bytes for strings
+    // (see rsq_device.h: str_word).  stripChar: CHAR(n) equality ignores trailing spaces (joins); group keys keep the
+    // exact bytes and the host merges space-equivalent groups, because the group shows the FIRST row's spelling.
+    std::vector<std::string> keyWords(Expr* e, const std::string& prefix, bool stripChar) {
+        std::vector<std::string> out;
+        const std::string v = eg.emit(e);
+        if (!e->type.isString()) {
+            line("const i64 " + prefix + " = " + toWord(v, e->type) + ";");
+            out.push_back(prefix);
+            return out;
+        }
+        if (e->tag == RSQ_E_CONSTANT) failUnsupported("a string constant as a join or group key");
+        const bool strip = stripChar && e->type.tag == RSQ_CHAR;
+        line("const int " + prefix + "_n = " + (strip ? "rsq::str_len_char(" : "rsq::str_len_exact(") + v + ");");
+        for (int w = 0; w < (e->type.len + 7) / 8; w++) {
+            std::string kv = prefix + "_" + std::to_string(w);
+            line("const i64 " + kv + " = rsq::str_word(" + v + ", " + prefix + "_n, " + std::to_string(w) + ");");
+            out.push_back(kv);
+        }
+        return out;
+    }
+
     // ---- hash join build (hashjoin.h:226-256) ---------------------------------------------------
     std::string hashOf(const std::vector<std::string>& keyVars) {
         std::string h = "rsq::hash64((u64)" + keyVars[0] + ")";
@@ -414,10 +438,10 @@ struct Walker {
             if (eq->tag != RSQ_E_EQ) failType("The elements of the expression list passed to equalitiesLeftSide(..) need the tag Expr::EQ");
             Expr* l = eq->child;
             q.pool.addId(l);
-            std::string kv = T + "_k" + std::to_string(k++);
-            line("const i64 " + kv + " = " + toWord(eg.emit(l), l->type) + ";");
-            keyVars.push_back(kv);
-            ht->keys.push_back({expressionName(l), l->type});
+            size_t w0 = keyVars.size();
+            for (auto& kv : keyWords(l, T + "_k" + std::to_string(k++), true)) keyVars.push_back(kv);
+            for (size_t w = w0; w < keyVars.size(); w++)
+                ht->keys.push_back({w == w0 ? expressionName(l) : expressionName(l) + "#" + std::to_string(w - w0), w == w0 && !l->type.isString() ? l->type : Type(RSQ_BIGINT)});
         }
         // build payload = the attributes of the left child's schema (Values::get(_lChild->_schema))
         for (auto& a : from->schema) {
@@ -474,11 +498,13 @@ struct Walker {
         for (Expr* eq : o->exprs) {
             Expr* r = eq->child->next;
             q.pool.addId(r);
-            std::string kv = T + "_p" + std::to_string(k++);
-            line("const i64 " + kv + " = " + toWord(eg.emit(r), r->type) + ";");
-            keyVars.push_back(kv);
-            probeKeyNames.push_back(expressionName(r));
+            const size_t w0 = keyVars.size();
+            for (auto& kv : keyWords(r, T + "_p" + std::to_string(k++), true)) keyVars.push_back(kv);
+            // (only a one-word key can stand in for the build key of the matched entry, see tryJoinEntry)
+            probeKeyNames.push_back(keyVars.size() - w0 == 1 ? expressionName(r) : std::string());
+            for (size_t w = w0 + 1; w < keyVars.size(); w++) probeKeyNames.push_back(std::string());
         }
+        if (keyVars.size() != ht.keys.size()) failUnsupported("string join keys of different declared lengths");
         addArg(T + "_state", "const u32*", 0); addArg(T + "_words", "const i64*", 0); addArg(T + "_cap", "u64", 0);
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
         line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
@@ -499,7 +525,7 @@ struct Walker {
         }
         // probe-side key attributes are equal to the build keys of the matched entry
         for (size_t i = 0; i < probeKeyNames.size(); i++)
-            if (symbolOrigin.count(probeKeyNames[i]) && symbolOrigin[probeKeyNames[i]] == -1) probeKeyOf[probeKeyNames[i]] = {ht.id, (int)i};
+            if (!probeKeyNames[i].empty() && symbolOrigin.count(probeKeyNames[i]) && symbolOrigin[probeKeyNames[i]] == -1) probeKeyOf[probeKeyNames[i]] = {ht.id, (int)i};
         int prevMatch = matchSlotTable; bool prevMulti = multiMatchAbove;
         slotVar[ht.id] = T + "_s";
         if (o->singleMatch) matchSlotTable = ht.id; else { multiMatchAbove = true; }
@@ -561,6 +587,7 @@ struct Walker {
             int ci = t->findCol(g->symbol);
             if (ci < 0 || !t->cols[(size_t)ci].dptr) return false;
             const TableColumn& c = t->cols[(size_t)ci];
+            if (c.type.isString()) return false;               // string keys: generic hash aggregation (bytes as key words)
             DenseKey k; k.expr = g; k.type = c.type;
             if (t->nRows == 0) { k.card = 1; k.min = 0; }      // empty input: no row reaches the aggregation
             else if (!c.stats.valid) return false;
@@ -591,6 +618,7 @@ struct Walker {
         q.groupSource.clear();
         for (Expr* g : o->exprs2) {
             if (g->tag != RSQ_E_ATTRIBUTE) return false;
+            if (g->type.isString()) return false;      // string keys go through the generic table (bytes as key words)
             auto org = symbolOrigin.find(g->symbol);
             if (org != symbolOrigin.end() && org->second == matchSlotTable) { q.groupSource.push_back(symbolWord[g->symbol]); continue; }
             auto pk = probeKeyOf.find(g->symbol);
@@ -645,11 +673,11 @@ struct Walker {
         int k = 0;
         q.groupSource.clear();
         for (Expr* g : o->exprs2) {
-            std::string kv = T + "_g" + std::to_string(k);
-            line("const i64 " + kv + " = " + toWord(eg.emit(g), g->type) + ";");
-            keyVars.push_back(kv);
-            ht->keys.push_back({expressionName(g), g->type});
-            q.groupSource.push_back(k++);
+            const size_t w0 = keyVars.size();
+            q.groupSource.push_back((int)w0);           // first table word of this group value
+            for (auto& kv : keyWords(g, T + "_g" + std::to_string(k++), false)) keyVars.push_back(kv);
+            for (size_t w = w0; w < keyVars.size(); w++)
+                ht->keys.push_back({w == w0 ? expressionName(g) : expressionName(g) + "#" + std::to_string(w - w0), w == w0 && !g->type.isString() ? g->type : Type(RSQ_BIGINT)});
         }
         if (keyVars.empty()) failUnsupported("hash aggregation without group keys");
         for (int w = 1; w < W; w++) line("const i64 in" + std::to_string(w) + " = " + q.accums[(size_t)w].input + ";");

@@ -157,6 +157,21 @@ RSQ_DEV u8 compare_varchar(const Str& a, const Str& b) {
     return str_at(a, i) == str_at(b, i);
 }
 
+// Strings as hash-table KEY words: bytes [8w, 8w+8) of the string, little-endian, NUL padded, so that word-wise
+// equality is compareVarchar (exact) — or compareChar when the effective length excludes trailing spaces
+// (str_len_char): the reference's CHAR(n) equality ignores them (qlib/scalar.h:27-46).
+// Strings as hash-table PAYLOAD are not copied at all: the word is the device address of the column bytes.
+RSQ_DEV int str_len_exact(const Str& s) { int n = 0; while (n < s.cap && s.p[n] != '\0') n++; return n; }
+RSQ_DEV int str_len_char(const Str& s) { int n = str_len_exact(s); while (n > 0 && s.p[n - 1] == ' ') n--; return n; }
+RSQ_DEV i64 str_word(const Str& s, int n, int w) {
+    u64 v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const int k = w * 8 + i; v |= (u64)(k < n ? (u8)s.p[k] : (u8)0) << (8 * i); }
+    return (i64)v;
+}
+RSQ_DEV i64 str_addr(const Str& s) { return (i64)(u64)reinterpret_cast<unsigned long long>(s.p); }
+RSQ_DEV Str str_from_addr(i64 w, int cap) { return str(reinterpret_cast<const char*>((unsigned long long)(u64)w), cap); }
+
 // stringLikeCheck (reference src/qlib/scalar.h:49-118): '%' any run, '_' any one character.  Restated with indices;
 // the reference's behaviour is kept where it is peculiar (prefix and suffix of the pattern are matched independently
 // and may overlap in the string; infixes are searched greedily left to right).  str_at() yields the NUL the reference

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <thread>
 
 #include "engine_internal.h"
@@ -201,6 +202,7 @@ struct Groups {
     std::vector<int64_t> firstRow;                 // [n]
     std::vector<Val> keyData;                      // [n][nKeys], flat
     std::vector<int64_t> accData;                  // [n][nAcc], flat (index = accums index)
+    std::vector<char> strings;                     // NUL-terminated bytes of string key values (Val::s points in here)
     const Val* keys(size_t i) const { return keyData.data() + i * nKeys; }
     const int64_t* acc(size_t i) const { return accData.data() + i * nAcc; }
 };
@@ -252,14 +254,87 @@ Groups groupsFromJoinEntries(Query& q) {
     Groups G;
     G.n = (size_t)q.nGroupRows; G.nKeys = q.groupSource.size(); G.nAcc = W;
     G.firstRow.resize(G.n); G.keyData.resize(G.n * G.nKeys); G.accData.resize(G.n * W);
+    // string group values arrive as their bytes in consecutive key words (rsq_device.h: str_word)
+    size_t strBytes = 0;
+    for (Expr* g : q.agg->exprs2) if (g->type.isString()) strBytes += (size_t)g->type.len + 1;
+    G.strings.assign(G.n * strBytes, 0);
+    size_t sp = 0;
     for (size_t i = 0; i < G.n; i++) {
         const int64_t* r = &q.hGroupRows[i * stride];
         G.firstRow[i] = r[0];
-        for (size_t k = 0; k < G.nKeys; k++) G.keyData[i * G.nKeys + k].i = r[1 + (size_t)q.groupSource[k]];
+        for (size_t k = 0; k < G.nKeys; k++) {
+            const Type& t = q.agg->exprs2[k]->type;
+            if (t.isString()) {
+                memcpy(&G.strings[sp], &r[1 + (size_t)q.groupSource[k]], (size_t)t.len);      // little-endian words = the bytes in order
+                G.keyData[i * G.nKeys + k].s = &G.strings[sp];
+                sp += (size_t)t.len + 1;
+            } else G.keyData[i * G.nKeys + k].i = r[1 + (size_t)q.groupSource[k]];
+        }
         for (size_t w = 0; w < W; w++) G.accData[i * W + w] = r[1 + nTabWords + (size_t)q.accumSlot[w]];
         G.accData[i * W] = r[0];
     }
     return G;
+}
+
+// The device groups CHAR(n) keys by their exact bytes; the reference's group equality for CHAR ignores trailing spaces
+// (Values::checkEqualityBool -> compareChar, qlib/scalar.h:27-46) and shows the spelling of the group's FIRST row.
+// Merge the device groups that are equal in that sense: accumulators by their merge kind, keys from the member with the
+// smallest first row.
+void mergeSpaceEquivalentGroups(Query& q, Groups& G) {
+    bool any = false;
+    for (Expr* g : q.agg->exprs2) if (g->type.tag == RSQ_CHAR && g->type.len > 1) any = true;
+    if (!any || G.n < 2) return;
+    auto normalised = [&](size_t i) {
+        std::string key;
+        for (size_t k = 0; k < G.nKeys; k++) {
+            const Type& t = q.agg->exprs2[k]->type;
+            const Val& v = G.keys(i)[k];
+            if (t.isString()) {
+                std::string sv(v.s);
+                if (t.tag == RSQ_CHAR) while (!sv.empty() && sv.back() == ' ') sv.pop_back();
+                key += sv; key.push_back('\0');
+            } else key.append((const char*)&v.i, 8);
+        }
+        return key;
+    };
+    std::map<std::string, size_t> rep;
+    std::vector<size_t> target(G.n);
+    bool merged = false;
+    for (size_t i = 0; i < G.n; i++) {
+        auto it = rep.emplace(normalised(i), i);
+        target[i] = it.first->second;
+        if (!it.second) merged = true;
+    }
+    if (!merged) return;
+    const size_t W = G.nAcc;
+    std::vector<size_t> bestMember(G.n);
+    for (size_t i = 0; i < G.n; i++) bestMember[i] = i;
+    for (size_t i = 0; i < G.n; i++) {
+        const size_t t = target[i];
+        if (t == i) continue;
+        int64_t* dst = &G.accData[t * W];
+        const int64_t* src = &G.accData[i * W];
+        for (size_t w = 0; w < W; w++) {
+            const int m = q.accums[w].merge;
+            if (m == 0) dst[w] = (int64_t)((uint64_t)dst[w] + (uint64_t)src[w]);
+            else if (m == 2) dst[w] = std::min(dst[w], src[w]);
+            else dst[w] = std::max(dst[w], src[w]);
+        }
+        if (G.firstRow[i] < G.firstRow[bestMember[t]]) bestMember[t] = i;
+    }
+    Groups R;
+    R.nKeys = G.nKeys; R.nAcc = W;
+    R.strings.swap(G.strings);                     // Val::s pointers stay valid
+    for (size_t i = 0; i < G.n; i++) {
+        if (target[i] != i) continue;
+        const size_t b = bestMember[i];
+        R.firstRow.push_back(G.firstRow[b]);
+        for (size_t k = 0; k < G.nKeys; k++) R.keyData.push_back(G.keys(b)[k]);
+        for (size_t w = 0; w < W; w++) R.accData.push_back(G.accData[i * W + w]);
+        R.accData[R.firstRow.size() * W - W] = G.firstRow[b];
+    }
+    R.n = R.firstRow.size();
+    G = std::move(R);
 }
 
 }  // namespace
@@ -323,6 +398,7 @@ void runTail(Query& q) {
         tPhase = t;
     };
     Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) ? groupsFromJoinEntries(q) : groupsFromDense(q);
+    if (q.aggMode == AggMode::HASH) mergeSpaceEquivalentGroups(q, G);
     phase("groups from the device tables");
 
     // ---- operators above the aggregation (bottom-up) and their schemas ----

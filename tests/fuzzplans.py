@@ -2,7 +2,8 @@
 
 Every seed gives one (tables, plan) pair built with the same ExprGen / operator constructors the reference's
 tests use (test/test_operators.h), restricted to the operators of the hot path: scan, selection,
-hash join (single and multi match), aggregation (0..3 group keys; sum/count/avg/min/max; CASE inside), projection,
+hash join (single and multi match, strings carried across), aggregation (0..3 group keys incl. CHAR(n) / VARCHAR(n)
+keys with trailing-space variants; sum/count/avg/min/max; CASE inside), projection,
 materialize, order by, limit.  The same pair is fed to
   * the unmodified reference  vs  the oracle   (CPU suite, tests/test_oracle.py, when /root/reference is here)
   * the HIP engine            vs  the oracle   (GPU suite, tests/test_gpu_fuzz.py)
@@ -60,6 +61,8 @@ def dim_table(rng, m, key_domain, unique):
         P.Column("dx", T.DECIMAL(10, 2), rng.integers(0, 5000, m).astype(np.int64)),
         P.Column("dd", T.DATE(), _dates(rng, m)),
         P.Column("dc", T.CHAR(1), rng.choice(np.frombuffer(b"XYZ", dtype=np.uint8), m)),
+        P.Column("ds", T.CHAR(6), _strings(rng, m, 6, True)),
+        P.Column("dv", T.VARCHAR(9), _strings(rng, m, 9, False)),
     ]
     return P.Table("d", cols, m)
 
@@ -181,9 +184,9 @@ class Gen:
             single = unique and r.random() < 0.7
             node = p.hashjoin([p.eq(p.attr("dk"), p.attr("fk"))], left, right, single_match=single)
             num_cols = ["fx", "fy", "fz", "fi", "dx", "di"]
-            group_pool = ["fk", "fi", "fc", "di", "dc", "dd", "dk"]
+            group_pool = ["fk", "fi", "fc", "di", "dc", "dd", "dk", "ds", "dv", "fs", "fv"]
             if shape == "joinmat":
-                outs = [p.attr(c) for c in r.sample(["fk", "fx", "fd", "dx", "dd", "di", "dc", "fz"], r.randint(1, 5))]
+                outs = [p.attr(c) for c in r.sample(["fk", "fx", "fd", "dx", "dd", "di", "dc", "fz", "ds", "dv", "fs"], r.randint(1, 5))]
                 node = p.materialize(p.projection(outs, node))
                 # matches of one probe row come out in hash-table order (the engine's table is not the reference's)
                 limit = r.choice([None, None, 0, 5])
@@ -195,7 +198,7 @@ class Gen:
             if r.random() < 0.75:
                 node = p.selection(self.predicate(p, "f"), node)
             num_cols = ["fx", "fy", "fz", "fi", "fk"]
-            group_pool = ["fk", "fi", "fc", "fd", "fb"]
+            group_pool = ["fk", "fi", "fc", "fd", "fb", "fs", "fv"]
             if shape == "select":
                 if r.random() < 0.5:
                     outs = [p.attr(c) for c in r.sample(["fk", "fx", "fd", "fs", "fv", "fc", "fb", "fi"], r.randint(1, 5))]
