@@ -70,3 +70,67 @@ class PartialMerger:
             torch.amax(self.all[:, a:b], dim=0, out=self.partial[a:b])
         if self.n_sum:
             torch.sum(self.all[:, b:], dim=0, out=self.partial[b:])
+
+
+# ------------------------------------------------------------------------------------------------
+# Joins + high-cardinality groups across GPUs (TPC-H Q3): the small build sides are replicated (every
+# rank builds its own hash tables from the full customer / orders tables), the big probe-side scan is sharded by row
+# range with the boundaries moved to a change of the clustering key (lineitem is clustered by l_orderkey and the groups
+# are keyed by it), so every group lives on exactly one rank.  Each rank then runs the WHOLE plan on its shard — same
+# kernels, same host tail, ORDER BY ... LIMIT k included — and the only exchange is an all-gather of k result rows per
+# rank, merged by the sort keys.  No partial-aggregate exchange at all.
+# ------------------------------------------------------------------------------------------------
+def shard_rows_on_key(n_total: int, world: int, rank: int, key_at, tile: int = 128) -> Tuple[int, int]:
+    """like shard_rows, but every boundary is moved forward to the first row whose clustering key differs from the row
+    before it (key_at(i) -> key of row i), so that no key value spans two shards.  Boundaries no longer fall on tile
+    multiples; the engine's scan handles any row0 (rows are addressed relative to the shard's own columns)."""
+    def snap(b: int) -> int:
+        if b <= 0 or b >= n_total:
+            return max(0, min(b, n_total))
+        while b < n_total and key_at(b) == key_at(b - 1):
+            b += 1
+        return b
+    per = (n_total // (tile * world)) * tile
+    lo = snap(rank * per)
+    hi = n_total if rank == world - 1 else snap((rank + 1) * per)
+    return lo, max(0, hi - lo)
+
+
+def merge_ordered_results(dist, result, order, limit, world: int, device=None):
+    """All-gather the (at most `limit`) ordered result rows of every rank and merge them by `order`
+    = [(column name, ascending)], keeping `limit` rows.  Returns a plan.Result on every rank.  Rows are ReSQL packed
+    tuples (identical schema on all ranks); ties across ranks come out in rank order."""
+    import functools
+    import torch
+    from . import plan as P
+    ts = result.tuple_size
+    rows = min(result.n_rows, limit)
+    buf = torch.zeros(limit * ts + 8, dtype=torch.uint8, device=device)
+    if rows:
+        buf[:rows * ts] = torch.frombuffer(bytearray(result.tuples[:rows * ts]), dtype=torch.uint8).to(buf.device)
+    buf[limit * ts:] = torch.frombuffer(bytearray(int(rows).to_bytes(8, "little")), dtype=torch.uint8).to(buf.device)
+    if world > 1:
+        every = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
+        dist.all_gather_into_tensor(every, buf)
+    else:
+        every = buf
+    every = every.cpu().numpy().tobytes()
+    tuples = b""
+    for r in range(world):
+        chunk = every[r * (limit * ts + 8):(r + 1) * (limit * ts + 8)]
+        n = int.from_bytes(chunk[limit * ts:], "little")
+        tuples += chunk[:n * ts]
+    merged = P.Result(result.names, result.types, result.offsets, ts, len(tuples) // ts, tuples)
+    cols = [(merged.names.index(name), asc) for name, asc in order]
+
+    def cmp(a, b):
+        for c, asc in cols:
+            va, vb = merged.value(a, c), merged.value(b, c)
+            if va != vb:
+                return (-1 if va < vb else 1) * (1 if asc else -1)
+        return 0
+    idx = sorted(range(merged.n_rows), key=functools.cmp_to_key(cmp))[:limit]
+    out = b"".join(tuples[i * ts:(i + 1) * ts] for i in idx)
+    res = P.Result(result.names, result.types, result.offsets, ts, len(idx), out)
+    res.text = res.serialize()
+    return res

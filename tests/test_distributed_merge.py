@@ -87,3 +87,60 @@ def test_two_rank_merge_equals_single_run(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     li = tpch.lineitem_table(0.01, tpch.Q1_COLUMNS, n_rows=N_ROWS)
     assert open(out).read() == orc.execute(tpch.q1_plan(li)).text
+
+
+# ---- joins + high-cardinality groups (TPC-H Q3) across ranks: key-aligned shards, all-gather of the top-k rows ----------
+def _q3_shard_tables(sf, world, rank):
+    from resql_amd import datagen, tpch, plan as P
+    from resql_amd.dist import shard_rows_on_key
+    n = datagen.n_lineitem(sf)
+    keys = datagen.lineitem_columns(0, n, sf, columns={"l_orderkey"})["l_orderkey"]
+    row0, cnt = shard_rows_on_key(n, world, rank, lambda i: int(keys[i]))
+    cols = datagen.lineitem_columns(row0, cnt, sf, columns=set(tpch.Q3_LINEITEM_COLUMNS))
+    li = tpch.make_table("lineitem", tpch.LINEITEM_SCHEMA, cols, cnt)
+    return tpch.customer_table(sf), tpch.orders_table(sf), li, (row0, cnt)
+
+
+def _q3_worker(rank: int, world: int, port: int, out_path: str):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from resql_amd import tpch
+        from resql_amd.dist import merge_ordered_results
+        from oracle import orc
+        cu, od, li, _ = _q3_shard_tables(0.05, world, rank)
+        local = orc.execute(tpch.q3_plan(cu, od, li))          # stands in for the engine: same plan on this rank's shard
+        merged = merge_ordered_results(dist, local, [("revenue", False), ("o_orderdate", True)], 10, world)
+        if rank == 0:
+            with open(out_path, "w") as f:
+                f.write(merged.text)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_key_aligned_shards_never_split_a_key():
+    from resql_amd import datagen
+    from resql_amd.dist import shard_rows_on_key
+    sf = 0.02
+    n = datagen.n_lineitem(sf)
+    keys = datagen.lineitem_columns(0, n, sf, columns={"l_orderkey"})["l_orderkey"]
+    for world in (1, 2, 3, 8):
+        ranges = [shard_rows_on_key(n, world, r, lambda i: int(keys[i])) for r in range(world)]
+        assert ranges[0][0] == 0 and sum(c for _, c in ranges) == n
+        for (a0, an), (b0, _) in zip(ranges, ranges[1:]):
+            assert a0 + an == b0
+            if 0 < b0 < n:
+                assert keys[b0] != keys[b0 - 1]
+
+
+def test_two_rank_q3_equals_single_run(tmp_path):
+    from resql_amd import tpch
+    from oracle import orc
+    out = str(tmp_path / "q3.txt")
+    mp.spawn(_q3_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    sf = 0.05
+    li = tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+    want = orc.execute(tpch.q3_plan(tpch.customer_table(sf), tpch.orders_table(sf), li)).text
+    assert open(out).read() == want
