@@ -393,7 +393,11 @@ struct Walker {
     // ballot folds them, the matching lanes arrive one at a time.)
     void countPerThread(const std::string& T) {
         stateDecl += "    u32 n_" + T + " = 0;\n";
-        epilogue += "    { const u64 v = rsq::wave_sum((u64)st.n_" + T + "); if ((threadIdx.x & 63) == 0 && v) atomicAdd(a." + T + "_count, (u32)v); }\n";
+        // wave sum -> LDS -> ONE global atomic per workgroup: atomics on a single word serialise (~11 ns each), and a
+        // random-access pipeline launches 8 workgroups per CU
+        epilogue += "    {\n        __shared__ u32 s_n_" + T + ";\n        if (threadIdx.x == 0) s_n_" + T + " = 0;\n        __syncthreads();\n";
+        epilogue += "        const u64 v = rsq::wave_sum((u64)st.n_" + T + ");\n        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_n_" + T + ", (u32)v);\n";
+        epilogue += "        __syncthreads();\n        if (threadIdx.x == 0 && s_n_" + T + ") atomicAdd(a." + T + "_count, s_n_" + T + ");\n    }\n";
     }
 
     // Key value(s) of one expression as table words: one word for numbers, ceil(len / 8) words of bytes for strings
@@ -449,6 +453,19 @@ struct Walker {
             if (it == eg.symbols.end()) failType("hash join build value " + a.name + " has no symbol");
             ht->payload.push_back({a.name, it->second.type});
         }
+        // key-domain bitmap (see HashTable): one integer key that is a column of this pipeline's scan with usable statistics
+        if (o->exprs.size() == 1 && keyVars.size() == 1 && envInt("RSQ_JOIN_BITMAP", 1, 0, 1)) {
+            Expr* l = o->exprs[0]->child;
+            auto org = symbolOrigin.find(l->symbol);
+            if (l->tag == RSQ_E_ATTRIBUTE && !l->type.isString() && org != symbolOrigin.end() && org->second == -1) {
+                int ci = pipe.src->findCol(l->symbol);
+                if (ci >= 0 && pipe.src->cols[(size_t)ci].stats.valid && pipe.src->nRows > 0) {
+                    const ColumnStats& st = pipe.src->cols[(size_t)ci].stats;
+                    unsigned __int128 range = (unsigned __int128)((__int128)st.max - (__int128)st.min) + 1;
+                    if (range <= ((unsigned __int128)1 << 28)) { ht->hasBitmap = true; ht->bmMin = st.min; ht->bmBits = (int64_t)range; }
+                }
+            }
+        }
         // capacity: the reference sizes its table lChild.getSize() * 5 / 3 and grows it; ours cannot grow
         // inside a kernel, so it is sized for twice the rows the build pipeline can deliver and re-run
         // at double size if it still overflows (engine.cpp).
@@ -472,6 +489,10 @@ struct Walker {
         for (auto& p : ht->payload)
             line("a." + T + "_words[" + std::to_string(w++) + " * a." + T + "_cap + " + T + "_s] = " + toWord(eg.symbols[p.name].var, p.type) + ";");
         line("st.n_" + T + "++;");
+        if (ht->hasBitmap) {
+            addArg(T + "_bm", "u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht->bmMin);
+            line("{ const u64 d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin); atomicOr(&a." + T + "_bm[d >> 5], 1u << (d & 31)); }");
+        }
         closeScope();
         closeScope();
         closeScope();
@@ -479,7 +500,8 @@ struct Walker {
         pipe.buildTable = ht->id;
         o->hashTable = ht->id;
         explainSteps.push_back("build hash table " + T + " (" + std::to_string(ht->keys.size()) + " key(s), " +
-                               std::to_string(ht->payload.size()) + " payload word(s), sized by a counting pass)");
+                               std::to_string(ht->payload.size()) + " payload word(s), sized by a counting pass" +
+                               (ht->hasBitmap ? ", key bitmap of " + std::to_string((long long)ht->bmBits) + " bits" : "") + ")");
         q.hashTables.push_back(std::move(ht));
     }
 
@@ -506,6 +528,12 @@ struct Walker {
         }
         if (keyVars.size() != ht.keys.size()) failUnsupported("string join keys of different declared lengths");
         addArg(T + "_state", "const u32*", 0); addArg(T + "_words", "const i64*", 0); addArg(T + "_cap", "u64", 0);
+        if (ht.hasBitmap) {
+            // keys outside the build side's [min, max] or with a clear bit cannot match: skip the table altogether
+            addArg(T + "_bm", "const u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht.bmMin); addArg(T + "_bmbits", "u64", (uint64_t)ht.bmBits);
+            line("const u64 " + T + "_d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin);");
+            openScope("if (" + T + "_d < a." + T + "_bmbits && ((a." + T + "_bm[" + T + "_d >> 5] >> (" + T + "_d & 31)) & 1u)) {");
+        }
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
         line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
         openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
@@ -535,6 +563,7 @@ struct Walker {
         if (o->singleMatch) line("break;");
         closeScope();
         closeScope();
+        if (ht.hasBitmap) closeScope();
         closeScope();
     }
     std::map<std::string, std::pair<int, int>> probeKeyOf;   // probe-side key symbol -> (table, key word)

@@ -111,6 +111,7 @@ Query::~Query() {
     if (dAgg && dAggOwned) ctx.free(dAgg);
     if (dAggInit) ctx.free(dAggInit);
     if (hPinned) (void)hipHostFree(hPinned);
+    if (hGroupRows) (void)hipHostFree(hGroupRows);
     if (dMatCnt) ctx.free(dMatCnt);
     if (dMatOffs) ctx.free(dMatOffs);
     if (dScanTemp) ctx.free(dScanTemp);
@@ -126,6 +127,7 @@ Query::~Query() {
         if (h->dWords) ctx.free(h->dWords);
         if (h->dAcc) ctx.free(h->dAcc);
         if (h->dCount) ctx.free(h->dCount);
+        if (h->dBitmap) ctx.free(h->dBitmap);
     }
 }
 
@@ -244,6 +246,7 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
         if (f == "count") return (uint64_t)(uintptr_t)h.dCount;
         if (f == "acc") return (uint64_t)(uintptr_t)h.dAcc;
         if (f == "countonly") return id == countOnlyTable ? 1ull : 0ull;
+        if (f == "bm") return (uint64_t)(uintptr_t)h.dBitmap;
     }
     return a.value;
 }
@@ -388,6 +391,11 @@ static void buildHashTable(Query& q, Pipeline& p) {
         RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
     }
     RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
+    if (h.hasBitmap) {
+        const size_t bmBytes = ((size_t)h.bmBits + 31) / 32 * 4;
+        if (!h.dBitmap) h.dBitmap = (uint32_t*)ctx.alloc(bmBytes);
+        RSQ_HIP(hipMemsetAsync(h.dBitmap, 0, bmBytes, ctx.stream));
+    }
     launchPipeline(q, p, -1);
     q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
 }
@@ -482,10 +490,13 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         RSQ_HIP(hipMemcpyAsync(&nEntries, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         RSQ_HIP(hipStreamSynchronize(ctx.stream));
         size_t need = (size_t)std::max<uint32_t>(1, nEntries) * (size_t)q.groupRowWords;
-        if (q.hGroupRows.size() < need) {
+        if (q.hGroupRowsWords < need) {
             if (q.dGroupRows) ctx.free(q.dGroupRows);
             q.dGroupRows = (int64_t*)ctx.alloc(need * 8);
-            q.hGroupRows.resize(need);
+            if (q.hGroupRows) (void)hipHostFree(q.hGroupRows);
+            q.hGroupRows = nullptr;
+            RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocDefault));
+            q.hGroupRowsWords = need;
         }
         RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.dAcc, h.nAccBlocks,
@@ -521,7 +532,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             }
         } else {
             q.nGroupRows = (int64_t)(uint32_t)q.hPinned[words + 1];
-            if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows.data(), q.dGroupRows, (size_t)q.nGroupRows * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost));
+            if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost));
         }
         runTail(q);
         q.report.finalize_time_ms = nowMs() - t1;

@@ -17,9 +17,10 @@ namespace rsq {
 // Run fn(begin, end, part) over [0, n) on up to 16 host threads; small ranges stay on the calling thread.
 // An exception in any part (e.g. a division by zero in a projection) is re-thrown on the calling thread.
 static int tailThreads(size_t n) {
-    if (n < 65536) return 1;
+    if (n < 32768) return 1;
     unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(16u, hw ? hw : 1u));
+    unsigned want = (unsigned)std::min<size_t>(16, n / 16384);      // starting a thread costs about as much as 16 K rows
+    return (int)std::max(1u, std::min(want, hw ? hw : 1u));
 }
 static void parallelFor(size_t n, int parts, const std::function<void(size_t, size_t, int)>& fn) {
     if (parts <= 1) { fn(0, n, 0); return; }
@@ -258,21 +259,23 @@ Groups groupsFromJoinEntries(Query& q) {
     size_t strBytes = 0;
     for (Expr* g : q.agg->exprs2) if (g->type.isString()) strBytes += (size_t)g->type.len + 1;
     G.strings.assign(G.n * strBytes, 0);
-    size_t sp = 0;
-    for (size_t i = 0; i < G.n; i++) {
-        const int64_t* r = &q.hGroupRows[i * stride];
-        G.firstRow[i] = r[0];
-        for (size_t k = 0; k < G.nKeys; k++) {
-            const Type& t = q.agg->exprs2[k]->type;
-            if (t.isString()) {
-                memcpy(&G.strings[sp], &r[1 + (size_t)q.groupSource[k]], (size_t)t.len);      // little-endian words = the bytes in order
-                G.keyData[i * G.nKeys + k].s = &G.strings[sp];
-                sp += (size_t)t.len + 1;
-            } else G.keyData[i * G.nKeys + k].i = r[1 + (size_t)q.groupSource[k]];
+    parallelFor(G.n, tailThreads(G.n), [&](size_t lo, size_t hi, int) {
+        for (size_t i = lo; i < hi; i++) {
+            const int64_t* r = &q.hGroupRows[i * stride];
+            size_t sp = i * strBytes;
+            G.firstRow[i] = r[0];
+            for (size_t k = 0; k < G.nKeys; k++) {
+                const Type& t = q.agg->exprs2[k]->type;
+                if (t.isString()) {
+                    memcpy(&G.strings[sp], &r[1 + (size_t)q.groupSource[k]], (size_t)t.len);      // little-endian words = the bytes in order
+                    G.keyData[i * G.nKeys + k].s = &G.strings[sp];
+                    sp += (size_t)t.len + 1;
+                } else G.keyData[i * G.nKeys + k].i = r[1 + (size_t)q.groupSource[k]];
+            }
+            for (size_t w = 0; w < W; w++) G.accData[i * W + w] = r[1 + nTabWords + (size_t)q.accumSlot[w]];
+            G.accData[i * W] = r[0];
         }
-        for (size_t w = 0; w < W; w++) G.accData[i * W + w] = r[1 + nTabWords + (size_t)q.accumSlot[w]];
-        G.accData[i * W] = r[0];
-    }
+    });
     return G;
 }
 
