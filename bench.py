@@ -159,6 +159,12 @@ def main():
             traffic = None
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = tpch.Q1_BYTES_PER_ROW * n_rows / (avg_kernel_ms * 1e-3) / 1e9
+        # the read-only streaming roofline of THIS box, measured after the timed region with the access form the scan
+        # uses (16 B per lane, non-temporal, 2 workgroups per CU): SURVEY.md §8d asks for the fraction against it too
+        try:
+            measured = ctx.read_bandwidth(4 << 30, 5)
+        except Exception:
+            measured = None
         out = {
             "metric": "TPC-H Q1 rows/s at SF10",
             "value": n_total * args.steps / elapsed,
@@ -180,7 +186,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "rsq_pipeline (scan+filter+dense aggregation)", "kernel_ms": avg_kernel_ms,
-                         "bytes_per_launch": tpch.Q1_BYTES_PER_ROW * n_rows},
+                         "bytes_per_launch": tpch.Q1_BYTES_PER_ROW * n_rows,
+                         "measured_read_roofline": measured,
+                         "frac_of_measured_read_roofline": (achieved / measured) if measured else None},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
