@@ -112,6 +112,7 @@ Query::~Query() {
     if (dAggInit) ctx.free(dAggInit);
     if (hPinned) (void)hipHostFree(hPinned);
     if (hGroupRows) (void)hipHostFree(hGroupRows);
+    if (graphExec) (void)hipGraphExecDestroy(graphExec);
     if (dMatCnt) ctx.free(dMatCnt);
     if (dMatOffs) ctx.free(dMatOffs);
     if (dScanTemp) ctx.free(dScanTemp);
@@ -419,6 +420,55 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     double t0 = nowMs();
     const size_t words = q.pinnedWords;
     q.report.num_kernels = 0; q.report.bytes_read = 0;
+    const bool trace0 = getenv("RSQ_TRACE") != nullptr;
+    const char* genv = getenv("RSQ_GRAPH");
+    // ---- graph path: one plain pipeline into a dense table, on the context's own stream ----
+    if (denseMode(q) && q.pipelines.size() == 1 && q.pipelines[0].sink == SinkKind::AGGREGATE && !q.pipelines[0].partitioned &&
+        !trace0 && !q.graphFailed && ctx.stream == ctx.ownStream && !(genv && atoi(genv) == 0)) {
+        Pipeline& p = q.pipelines[0];
+        if (!q.graphExec || q.graphAggPtr != (void*)q.dAgg || q.graphPartial != partialOnly) {
+            if (q.graphExec) { (void)hipGraphExecDestroy(q.graphExec); q.graphExec = nullptr; }
+            hipGraph_t g = nullptr;
+            bool ok = hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                try {
+                    RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, words * 8, hipMemcpyDeviceToDevice, ctx.stream));
+                    RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+                    RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+                    launchPipeline(q, p, -1);
+                    RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+                    RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+                    if (!partialOnly) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, words * 8, hipMemcpyDeviceToHost, ctx.stream));
+                } catch (...) { ok = false; }
+                if (hipStreamEndCapture(ctx.stream, &g) != hipSuccess) ok = false;
+            }
+            if (ok && hipGraphInstantiate(&q.graphExec, g, nullptr, nullptr, 0) != hipSuccess) { ok = false; q.graphExec = nullptr; }
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            if (!ok) q.graphFailed = true;
+            else { q.graphAggPtr = (void*)q.dAgg; q.graphPartial = partialOnly; }
+        }
+        if (q.graphExec) {
+            RSQ_HIP(hipGraphLaunch(q.graphExec, ctx.stream));
+            q.report.num_kernels = 1;
+            q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
+            if (async && partialOnly) { q.pendingAsync = true; q.report.execution_time_ms = nowMs() - t0; return; }
+            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            float gms = 0;
+            if (hipEventElapsedTime(&gms, ctx.ev0, ctx.ev1) != hipSuccess) { (void)hipGetLastError(); q.graphFailed = true; gms = 0; }
+            q.report.kernel_time_ms = gms;
+            q.report.hbm_gbps = gms > 0 ? (double)q.report.bytes_read / (gms * 1e-3) / 1e9 : 0;
+            checkDeviceError((uint32_t)q.hPinned[words]);
+            if (!partialOnly) {
+                double t1 = nowMs();
+                memcpy(q.hAgg.data(), q.hPinned, words * 8);
+                runTail(q);
+                q.report.finalize_time_ms = nowMs() - t1;
+            }
+            q.report.execution_time_ms = nowMs() - t0;
+            return;
+        }
+    }
     if (denseMode(q)) RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, words * 8, hipMemcpyDeviceToDevice, ctx.stream));
     RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));

@@ -180,6 +180,11 @@ struct Query {
     std::vector<int32_t> rvOffsets;
 
     rsq_report report{};
+    // single-pipeline dense aggregations replay one captured HIP graph per execution (init copy, error word reset,
+    // kernel between two event records, read-back): one submission instead of six
+    hipGraphExec_t graphExec = nullptr;
+    void* graphAggPtr = nullptr;
+    bool graphPartial = false, graphFailed = false;
     bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
     std::string allSource, explainText;
 

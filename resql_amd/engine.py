@@ -51,6 +51,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C resql_amd/csrc` "
                               f"(or __graft_entry__.build()); the engine has no Python/CPU fallback")
+        # PyTorch-ROCm wheels bundle their own HIP runtime.  If this library brings the system runtime up first and
+        # torch is imported later in the same process (multi-GPU merge, torch.distributed), torch's copy reports
+        # "No HIP GPUs are available".  Loading torch's runtime first makes both share it.  Skipped when torch is not
+        # installed or RSQ_NO_TORCH_PRELOAD is set (pure C/C++ hosts never see this).
+        if "torch" not in __import__("sys").modules and not os.environ.get("RSQ_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
         L.rsq_ctx_create.argtypes = [C.POINTER(rsq_config), C.POINTER(vp)]
