@@ -303,6 +303,7 @@ struct Walker {
         // tuned on MI355X with TPC-H Q1 SF10 (profiles/): 1 tile in flight per wave + non-temporal loads
         // 0.395 ms; 2 tiles 0.42 ms; 4 tiles 0.47 ms (fewer resident waves); without nt loads 0.45-0.47 ms
         pipe.unroll = envInt("RSQ_UNROLL", 1, 1, 8);
+        pipe.blockThreads = envInt("RSQ_BLOCK", 256, 64, 1024);
         // workgroups (of 256 threads) per launch; 0 = 2 per CU.  Measured on MI355X (Q1 SF10): 512 workgroups 0.348 ms,
         // 768: 0.367, 1024: 0.374, 2048: 0.395, 4096: 0.448 - a streaming kernel wants exactly 2 resident workgroups per CU
         pipe.maxGrid = (unsigned)envInt("RSQ_MAXGRID", 0, 0, 1 << 20);
@@ -786,12 +787,14 @@ struct Walker {
                std::to_string((long long)(q.nMinBlocks + q.nMaxBlocks)) + " ? 0x8000000000000000ull : 0ull";
     }
 
-    void emitGlobalFlush(std::ostringstream& s, const std::string& count, const std::string& srcExpr, int64_t D) {
+    // `stride` words between the cells of the table the kernel flushes into (1: the [block][group] table itself)
+    void emitGlobalFlush(std::ostringstream& s, const std::string& count, const std::string& srcExpr, int64_t D, int stride = 1) {
+        const std::string at = stride == 1 ? "a.out + i" : "a.out + i * " + std::to_string(stride);
         s << "    for (int i = threadIdx.x; i < " << count << "; i += blockDim.x) {\n";
         s << "        const int blk = i / " << D << ";\n        const u64 v = " << srcExpr << ";\n";
-        s << "        if (blk < " << q.nMinBlocks << ") rsq::global_merge<2>(a.out + i, v);\n";
-        s << "        else if (blk < " << (q.nMinBlocks + q.nMaxBlocks) << ") rsq::global_merge<3>(a.out + i, v);\n";
-        s << "        else rsq::global_merge<0>(a.out + i, v);\n    }\n";
+        s << "        if (blk < " << q.nMinBlocks << ") rsq::global_merge<2>(" << at << ", v);\n";
+        s << "        else if (blk < " << (q.nMinBlocks + q.nMaxBlocks) << ") rsq::global_merge<3>(" << at << ", v);\n";
+        s << "        else rsq::global_merge<0>(" << at << ", v);\n    }\n";
     }
 
     void emitDenseAggregation(OpNode* o) {
@@ -846,7 +849,16 @@ struct Walker {
                 for (int64_t g = 0; g < D; g++)
                     ep << "    rsq::wave_to_lds<" << q.accums[(size_t)w].merge << ">(&s_acc[" << (q.accumSlot[(size_t)w] * D + g) << "], (u64)st.acc_" << w << "_" << g << ");\n";
             ep << "    __syncthreads();\n";
-            emitGlobalFlush(ep, std::to_string((long long)(W * D)), "s_acc[i]", D);
+            // The workgroups flush into a PADDED copy of the table, one cell per 64-byte line (engine.cpp unpads it):
+            // memory-side atomics serialise per line, and the 42 cells of TPC-H Q1 otherwise share six lines.
+            q.aggPad = envInt("RSQ_AGG_PAD", 8, 1, 16);
+            emitGlobalFlush(ep, std::to_string((long long)(W * D)), "s_acc[i]", D, q.aggPad);
+            // One 512-thread workgroup per CU: the same 8 waves per CU as 2 x 256, but half as many workgroups flush.
+            // The flush is 42 atomics per workgroup (TPC-H Q1) onto six 64-byte lines, where they serialise: going from
+            // 512 to 256 workgroups took 8 us off the 352 us SF10 kernel and 9 off the 67 us SF1 kernel (1024 and 2048
+            // workgroups: +25 / +75 us).  A slab-per-workgroup + ticket + last-workgroup reduction was tried instead of
+            // the atomics and measured 28 us SLOWER (write-through slab stores, a serial reducer), so it is not here.
+            if (!getenv("RSQ_BLOCK")) pipe.blockThreads = 512;
         } else if (q.aggMode == AggMode::DENSE_LDS_PRIVATE) {
             // one private copy of the [block][group] table per LANE in LDS, laid out [cell][thread] so that a
             // wave's 64 accesses to one cell are 64 consecutive 8-byte words: conflict-free, no contention,

@@ -110,6 +110,8 @@ uint64_t opSize(OpNode* o) {   // getSize() estimates (reference src/operators/*
 Query::~Query() {
     if (dAgg && dAggOwned) ctx.free(dAgg);
     if (dAggInit) ctx.free(dAggInit);
+    if (dAggWork) ctx.free(dAggWork);
+    if (dAggWorkInit) ctx.free(dAggWorkInit);
     if (hPinned) (void)hipHostFree(hPinned);
     if (hGroupRows) (void)hipHostFree(hGroupRows);
     if (graphExec) (void)hipGraphExecDestroy(graphExec);
@@ -156,6 +158,17 @@ static void prepareDenseBuffers(Query& q) {
     RSQ_HIP(hipMemcpy(q.dAggInit, init.data(), words * 8, hipMemcpyHostToDevice));
     q.hAgg.assign(words, 0);
     q.pinnedWords = words;
+    q.tableWords = words;
+    if (q.aggPad > 1) {
+        // padded working table (one cell per 64-byte line) the register-mode kernels flush into
+        q.padWords = words * (size_t)q.aggPad;
+        std::vector<uint64_t> pinit(q.padWords, 0);
+        for (size_t i = 0; i < words; i++) pinit[i * (size_t)q.aggPad] = init[i];
+        q.dAggWork = (uint64_t*)q.ctx.alloc(q.padWords * 8);
+        q.dAggWorkInit = (uint64_t*)q.ctx.alloc(q.padWords * 8);
+        RSQ_HIP(hipMemcpy(q.dAggWorkInit, pinit.data(), q.padWords * 8, hipMemcpyHostToDevice));
+        q.pinnedWords = q.padWords;          // the read-back of a full execution takes the padded table
+    }
 }
 
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables) {
@@ -223,7 +236,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
 // execute
 // ================================================================================================
 static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTable) {
-    if (a.name == "out") return (uint64_t)(uintptr_t)q.dAgg;
+    if (a.name == "out") return (uint64_t)(uintptr_t)(q.aggPad > 1 ? q.dAggWork : q.dAgg);
     if (a.name == "part_counts") return (uint64_t)(uintptr_t)q.dPartCounts;
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
@@ -408,6 +421,20 @@ static void checkDeviceError(uint32_t err) {
     if (err) failRuntime("device error word " + std::to_string(err));
 }
 
+// the dense aggregate table at the start / end of an execution: register-mode kernels work on the padded copy
+static void enqueueTableInit(Query& q) {
+    if (q.aggPad > 1) RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
+    else RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, q.tableWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
+}
+static void enqueueTableReadback(Query& q) {
+    if (q.aggPad > 1) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAggWork, q.padWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
+    else RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
+}
+static void tableFromPinned(Query& q) {
+    if (q.aggPad > 1) for (size_t i = 0; i < q.tableWords; i++) q.hAgg[i] = q.hPinned[i * (size_t)q.aggPad];
+    else memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
+}
+
 void executeQuery(Query& q, bool partialOnly, bool async) {
     Context& ctx = q.ctx;
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
@@ -432,13 +459,14 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             bool ok = hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 try {
-                    RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, words * 8, hipMemcpyDeviceToDevice, ctx.stream));
+                    enqueueTableInit(q);
                     RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
                     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
                     launchPipeline(q, p, -1);
                     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+                    if (partialOnly && q.aggPad > 1) unpadAsync(ctx, q.dAggWork, q.dAgg, q.tableWords, q.aggPad);
                     RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
-                    if (!partialOnly) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, words * 8, hipMemcpyDeviceToHost, ctx.stream));
+                    if (!partialOnly) enqueueTableReadback(q);
                 } catch (...) { ok = false; }
                 if (hipStreamEndCapture(ctx.stream, &g) != hipSuccess) ok = false;
             }
@@ -461,7 +489,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             checkDeviceError((uint32_t)q.hPinned[words]);
             if (!partialOnly) {
                 double t1 = nowMs();
-                memcpy(q.hAgg.data(), q.hPinned, words * 8);
+                tableFromPinned(q);
                 runTail(q);
                 q.report.finalize_time_ms = nowMs() - t1;
             }
@@ -469,7 +497,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             return;
         }
     }
-    if (denseMode(q)) RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, words * 8, hipMemcpyDeviceToDevice, ctx.stream));
+    if (denseMode(q)) enqueueTableInit(q);
     RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     const bool trace = getenv("RSQ_TRACE") != nullptr;      // per-pipeline wall time (synchronises after each one)
@@ -554,8 +582,9 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         q.report.num_kernels++;
     }
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+    if (partialOnly && denseMode(q) && q.aggPad > 1) unpadAsync(ctx, q.dAggWork, q.dAgg, q.tableWords, q.aggPad);
     RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
-    if (!partialOnly && denseMode(q)) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, words * 8, hipMemcpyDeviceToHost, ctx.stream));
+    if (!partialOnly && denseMode(q)) enqueueTableReadback(q);
     if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH))
         RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
     if (async && partialOnly) {
@@ -572,7 +601,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     checkDeviceError((uint32_t)q.hPinned[words]);
     if (!partialOnly) {
         double t1 = nowMs();
-        if (denseMode(q)) memcpy(q.hAgg.data(), q.hPinned, words * 8);
+        if (denseMode(q)) tableFromPinned(q);
         else if (q.matOp && !q.agg) {
             q.hMatCols.resize(q.matSchema.size());
             for (size_t c = 0; c < q.matSchema.size(); c++) {
@@ -595,7 +624,7 @@ void finalizeQuery(Query& q) {
     if (!denseMode(q)) failUnsupported("partial execution / finalize is available for dense aggregations only");
     RSQ_HIP(hipSetDevice(ctx.device));
     double t1 = nowMs();
-    RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.pinnedWords * 8, hipMemcpyDeviceToHost, ctx.stream));
+    RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, ctx.stream));
     RSQ_HIP(hipStreamSynchronize(ctx.stream));
     if (q.pendingAsync) {         // the step was enqueued by rsq_query_execute_partial_async: account for it now
         q.pendingAsync = false;
@@ -604,7 +633,7 @@ void finalizeQuery(Query& q) {
         q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
         checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
     }
-    memcpy(q.hAgg.data(), q.hPinned, q.pinnedWords * 8);
+    memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
     runTail(q);
     q.report.finalize_time_ms = nowMs() - t1;
 }

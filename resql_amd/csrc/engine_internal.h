@@ -134,6 +134,11 @@ struct Query {
     int aggTable = -1;                     // AT_JOIN_ENTRY: hash table whose entries carry the aggregates
     std::vector<int> groupSource;          // AT_JOIN_ENTRY: per group expr, word index in the table (keys then payload)
 
+    int aggPad = 1;                        // > 1 (register mode): kernels flush into dAggWork, cells `aggPad` words apart
+    uint64_t* dAggWork = nullptr;          // padded working table and its identity image
+    uint64_t* dAggWorkInit = nullptr;
+    size_t padWords = 0;                   // cells * aggPad
+    size_t tableWords = 0;                 // accumulators * dense groups (the [block][group] table)
     bool dAggOwned = true;
     uint64_t* dAgg = nullptr;              // dense modes: [blocks][denseGroups]
     uint64_t* dAggInit = nullptr;          // identity image copied over dAgg at the start of every execute
