@@ -1062,6 +1062,11 @@ struct Walker {
         addArg("n_rows", "i64", (uint64_t)pipe.src->nRows);
         addArg("row0", "i64", (uint64_t)pipe.src->row0);
         addArg("err", "u32*", (uint64_t)(uintptr_t)q.ctx.dErr);
+        // Bytes in flight: a CU streams fastest with ~40 KB of loads outstanding (8 waves x one 128-row tile of TPC-H Q1's
+        // 38 B rows).  Narrower rows keep the same amount in flight with more tiles per wave: Q6 (28 B/row) went
+        // 0.293 -> 0.254 ms with two tiles, the 32 B synthetic rows gained ~1.5 %; Q1 itself is slower with two (0.363 vs 0.348).
+        if (!getenv("RSQ_UNROLL") && pipe.gridPerCU == 2 && pipe.bytesPerRow > 0)
+            pipe.unroll = (int)std::max<int64_t>(1, std::min<int64_t>(4, (4608 + pipe.bytesPerRow * 128 - 1) / (pipe.bytesPerRow * 128)));
         const int U = pipe.unroll;
         const bool mat = pipe.sink == SinkKind::MATERIALIZE;
         std::ostringstream s;
