@@ -573,7 +573,8 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             q.dGroupRows = (int64_t*)ctx.alloc(need * 8);
             if (q.hGroupRows) (void)hipHostFree(q.hGroupRows);
             q.hGroupRows = nullptr;
-            RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocDefault));
+            // non-coherent pinned memory: cached on the host (the tail reads every word), valid after the copy's sync
+            RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
             q.hGroupRowsWords = need;
         }
         RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
