@@ -113,6 +113,14 @@ def main():
 
     multi = dist is not None
     merger = None
+    if multi and world > 1:
+        # the partial tables are only mergeable if every rank derived the same dense group layout from its shard's
+        # column statistics (same byte-value sets / ranges): compare the layout line of `explain` across the ranks
+        layout = [l for l in q.explain.splitlines() if l.startswith("partial table:")]
+        every = [None] * world
+        dist.all_gather_object(every, layout)
+        if any(e != every[0] for e in every):
+            raise SystemExit(f"rank {rank}: shards disagree on the partial aggregate table layout: {every}")
     if multi:
         # one stream for the whole step: scan+aggregate kernel -> merge collective (RCCL over xGMI) -> read-back, with a
         # single host synchronisation (inside finalize) per step on rank 0 and none on the other ranks

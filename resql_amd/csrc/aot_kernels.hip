@@ -296,14 +296,6 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value) {
     RSQ_HIP(hipGetLastError());
 }
 
-__global__ void __launch_bounds__(256) k_unpad(const u64* __restrict__ src, u64* __restrict__ dst, i64 n, int stride) {
-    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) dst[i] = src[i * stride];
-}
-void unpadAsync(Context& ctx, const uint64_t* src, uint64_t* dst, size_t n, int stride) {
-    hipLaunchKernelGGL(k_unpad, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(256, (n + 255) / 256))), dim3(256), 0, ctx.stream, (const u64*)src, (u64*)dst, (i64)n, stride);
-    RSQ_HIP(hipGetLastError());
-}
-
 __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__ first, i64 cap, const i64* __restrict__ words, int nWords,
                                                          const i64* __restrict__ acc, int nAcc, i64* __restrict__ out, unsigned* count) {
     const int stride = 1 + nWords + nAcc;

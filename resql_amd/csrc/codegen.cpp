@@ -789,7 +789,8 @@ struct Walker {
 
     // `stride` words between the cells of the table the kernel flushes into (1: the [block][group] table itself)
     void emitGlobalFlush(std::ostringstream& s, const std::string& count, const std::string& srcExpr, int64_t D, int stride = 1) {
-        const std::string at = stride == 1 ? "a.out + i" : "a.out + i * " + std::to_string(stride);
+        // padded flush: the stride is a macro, so that the same source also gives the unpadded kernel partial executions use
+        const std::string at = stride == 1 ? "a.out + i" : "a.out + i * RSQ_OUT_STRIDE";
         s << "    for (int i = threadIdx.x; i < " << count << "; i += blockDim.x) {\n";
         s << "        const int blk = i / " << D << ";\n        const u64 v = " << srcExpr << ";\n";
         s << "        if (blk < " << q.nMinBlocks << ") rsq::global_merge<2>(" << at << ", v);\n";
@@ -1122,6 +1123,12 @@ struct Walker {
         if (mat) {   // two code objects from one source
             pipe.sourcePass1 = "#define RSQ_PASS 1\n" + pipe.source;
             pipe.source = "#define RSQ_PASS 2\n" + pipe.source;
+        }
+        if (q.aggPad > 1 && pipe.sink == SinkKind::AGGREGATE && !pipe.partitioned) {
+            // padded flush for full executions, flat flush (straight into the [block][group] table that is merged
+            // across GPUs) for partial ones
+            pipe.sourceFlat = "#define RSQ_OUT_STRIDE 1\n" + pipe.source;
+            pipe.source = "#define RSQ_OUT_STRIDE " + std::to_string(q.aggPad) + "\n" + pipe.source;
         }
         if (pipe.partitioned) {   // three code objects from one source (see emitDenseAggregation)
             // count and scatter run as ONE 1024-thread workgroup per CU (see the note at the record stores)

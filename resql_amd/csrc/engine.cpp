@@ -188,6 +188,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     buildPipelines(*q);
     for (auto& p : q->pipelines) {
         if (!p.sourcePass1.empty()) p.kernelPass1 = &ctx.getKernel(p.sourcePass1, p.entry);
+        if (!p.sourceFlat.empty()) p.kernelFlat = &ctx.getKernel(p.sourceFlat, p.entry);
         if (p.partitioned) {
             p.kernelPartCount = &ctx.getKernel(p.sourcePartCount, p.entry);
             p.kernelPartScatter = &ctx.getKernel(p.sourcePartScatter, p.entry);
@@ -236,7 +237,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
 // execute
 // ================================================================================================
 static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTable) {
-    if (a.name == "out") return (uint64_t)(uintptr_t)(q.aggPad > 1 ? q.dAggWork : q.dAgg);
+    if (a.name == "out") return (uint64_t)(uintptr_t)(q.aggPad > 1 && !q.flatRun ? q.dAggWork : q.dAgg);
     if (a.name == "part_counts") return (uint64_t)(uintptr_t)q.dPartCounts;
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
@@ -281,7 +282,8 @@ static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnly
 }
 
 static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
-    launchPipelineKernel(q, p, pass1 ? *p.kernelPass1 : *p.kernel, countOnlyTable);
+    Kernel& k = pass1 ? *p.kernelPass1 : (q.flatRun && p.kernelFlat ? *p.kernelFlat : *p.kernel);
+    launchPipelineKernel(q, p, k, countOnlyTable);
 }
 
 // Aggregation into a large dense table (see emitDenseAggregation, DENSE_GLOBAL): pick, per execution, between HBM
@@ -423,7 +425,7 @@ static void checkDeviceError(uint32_t err) {
 
 // the dense aggregate table at the start / end of an execution: register-mode kernels work on the padded copy
 static void enqueueTableInit(Query& q) {
-    if (q.aggPad > 1) RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
+    if (q.aggPad > 1 && !q.flatRun) RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
     else RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, q.tableWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
 }
 static void enqueueTableReadback(Query& q) {
@@ -447,6 +449,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     double t0 = nowMs();
     const size_t words = q.pinnedWords;
     q.report.num_kernels = 0; q.report.bytes_read = 0;
+    q.flatRun = partialOnly && q.aggPad > 1;
     const bool trace0 = getenv("RSQ_TRACE") != nullptr;
     const char* genv = getenv("RSQ_GRAPH");
     // ---- graph path: one plain pipeline into a dense table, on the context's own stream ----
@@ -464,7 +467,6 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
                     launchPipeline(q, p, -1);
                     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
-                    if (partialOnly && q.aggPad > 1) unpadAsync(ctx, q.dAggWork, q.dAgg, q.tableWords, q.aggPad);
                     RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
                     if (!partialOnly) enqueueTableReadback(q);
                 } catch (...) { ok = false; }
@@ -583,7 +585,6 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         q.report.num_kernels++;
     }
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
-    if (partialOnly && denseMode(q) && q.aggPad > 1) unpadAsync(ctx, q.dAggWork, q.dAgg, q.tableWords, q.aggPad);
     RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
     if (!partialOnly && denseMode(q)) enqueueTableReadback(q);
     if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH))

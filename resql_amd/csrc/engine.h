@@ -97,8 +97,6 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
 size_t scanTempBytes(int64_t n);
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
-// dst[i] = src[i * stride] for i < n (padded working table -> the contiguous aggregate table)
-void unpadAsync(Context& ctx, const uint64_t* src, uint64_t* dst, size_t n, int stride);
 // partitioned aggregation: counts[workgroup][partition] -> exclusive prefix inside each partition (in place), partition
 // bounds partStart[0..P] and the record total
 void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPartitions, uint64_t* totals, uint32_t* partStart, uint64_t* total);

@@ -87,6 +87,8 @@ struct Pipeline {
     SinkKind sink = SinkKind::AGGREGATE;
     int buildTable = -1;             // SinkKind::BUILD
     std::string source;              // generated HIP source
+    std::string sourceFlat;          // register-mode aggregation: the variant that flushes into the unpadded table
+    Kernel* kernelFlat = nullptr;
     std::string sourcePass1;         // SinkKind::MATERIALIZE: the counting pass of the same pipeline
     Kernel* kernelPass1 = nullptr;
     // partitioned aggregation (large dense group domains, see emitDenseAggregation): the same pipeline compiled as a
@@ -138,6 +140,7 @@ struct Query {
     uint64_t* dAggWork = nullptr;          // padded working table and its identity image
     uint64_t* dAggWorkInit = nullptr;
     size_t padWords = 0;                   // cells * aggPad
+    bool flatRun = false;                  // this execution is partial: kernels flush straight into dAgg
     size_t tableWords = 0;                 // accumulators * dense groups (the [block][group] table)
     bool dAggOwned = true;
     uint64_t* dAgg = nullptr;              // dense modes: [blocks][denseGroups]
