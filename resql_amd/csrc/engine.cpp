@@ -534,6 +534,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             // the kernel reports a full table.
             HashTable& h = *q.hashTables[(size_t)q.aggTable];
             if (h.capacity == 0) h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)opSize(q.agg)));
+            if ((int64_t)h.lastCount * 2 > h.capacity) {        // the previous execution filled more than half of the table
+                if (h.dState) { ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc); }
+                h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
+                while ((int64_t)h.lastCount * 2 > h.capacity) h.capacity *= 2;
+            }
             for (;;) {
                 if (!h.dState) {
                     h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
@@ -569,6 +574,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         uint32_t nEntries = 0;
         RSQ_HIP(hipMemcpyAsync(&nEntries, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        h.lastCount = nEntries;
         size_t need = (size_t)std::max<uint32_t>(1, nEntries) * (size_t)q.groupRowWords;
         if (q.hGroupRowsWords < need) {
             if (q.dGroupRows) ctx.free(q.dGroupRows);

@@ -49,6 +49,7 @@ struct HashTable {
     int64_t* dAcc = nullptr;         // [nAccBlocks][capacity] when aggregated at the entry
     int nAccBlocks = 0;
     uint32_t* dCount = nullptr;      // number of occupied slots (set by the build kernel)
+    uint32_t lastCount = 0;          // generic aggregation: groups found by the previous execution (keeps the load below 1/2)
     // key-domain bitmap (single integer key whose column statistics give a modest range): one bit per possible key
     // value, set by the build, tested by the probe BEFORE it touches the table.  A probe that cannot match costs one
     // cached 4-byte load instead of two random line fetches from a table many times larger.

@@ -77,3 +77,27 @@ def test_automatic_choice_on_a_larger_table(gpu_ctx, monkeypatch):
         assert got == orc.execute(plan).text
         assert (kernels > 4) == (sel > 0.1)        # partitioned: sample + count (3 kernels each) + scatter + aggregate
     dev.close()
+
+
+def test_generic_hash_aggregation_with_many_groups(gpu_ctx):
+    """a computed group key (no dense id) with about as many groups as the first table has slots: the table must grow
+    before linear probing degenerates (this shape took 90 ns per row — seconds — until the probe length was bounded)"""
+    n, groups = 2_000_000, 1 << 19
+    t = tpch.synthetic_table(n, groups)
+    p = P.Plan([t])
+    key = p.add(p.mul(p.attr("b"), p.constant("2", P.BIGINT)), p.constant("1", P.BIGINT))
+    sc, cnt, lo = p.sum(p.attr("c")), p.count(p.star()), p.min(p.attr("d"))
+    node = p.aggregation([sc, cnt, lo], [key], p.scan("t"))
+    node = p.projection([p.as_("k", key), p.as_("s", sc), p.as_("n", cnt), p.as_("lo", lo)], node)
+    plan = p.set_root(p.materialize(node))
+    tabs = [gpu_ctx.table(t)]
+    q = gpu_ctx.compile(plan, tabs)
+    assert "hash aggregation" in q.explain
+    q.execute()                       # finds the table too small, grows it
+    q.execute()                       # steady state
+    assert q.report().kernel_time_ms < 100
+    got = q.result()
+    q.close(); tabs[0].close()
+    want = orc.execute(plan)
+    assert got.n_rows == want.n_rows > 400_000
+    assert got.text == want.text
