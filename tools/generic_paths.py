@@ -20,7 +20,7 @@ def run(label, plan, tables, reps=3):
     q.close()
 
 
-for groups in (1024, 1 << 20):
+for groups in tuple(int(g) for g in os.environ.get('RSQ_TEST_GROUPS', '1024,1048576').split(',')):
     t = ctx.generate(engine.GEN_SYNTHETIC, n, 1.0, param=groups)
     for sel in (0.01, 0.1):
         thr = str(int(sel * (1 << 31)))
