@@ -8,6 +8,7 @@
 // reductions, hash-table access) comes from kernels/rsq_device.h.
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <sstream>
 
 #include "engine_internal.h"
@@ -217,7 +218,7 @@ struct Walker {
     Pipeline pipe;
     std::vector<std::string> colTypes;        // device type per scanned (vector-loadable) column
     std::vector<int> colIsString;
-    std::string rowParams, rowArgsTail;
+    std::string rowParams, rowArgsTail, rowArgsTailGuarded;
     std::string body;                          // row function body
     std::string closers;                       // closing braces of the open scopes
     std::string stateDecl, stateInit, prologue, epilogue, fileScope;
@@ -228,6 +229,10 @@ struct Walker {
     std::map<std::string, int> symbolOrigin;   // symbol -> hash table id it was read from (or -1: scan column)
     std::map<std::string, int> symbolWord;     // symbol -> word index in that table
     bool multiMatchAbove = false;
+    // wave-level compaction (see compactThen)
+    bool selective = false, compacted = false;
+    std::string stage2Body;
+    std::vector<std::pair<std::string, Sym>> cqLive;     // carried symbols: name -> stage-1 variable and type
 
     explicit Walker(Query& q_) : q(q_) {}
 
@@ -307,10 +312,11 @@ struct Walker {
         // workgroups (of 256 threads) per launch; 0 = 2 per CU.  Measured on MI355X (Q1 SF10): 512 workgroups 0.348 ms,
         // 768: 0.367, 1024: 0.374, 2048: 0.395, 4096: 0.448 - a streaming kernel wants exactly 2 resident workgroups per CU
         pipe.maxGrid = (unsigned)envInt("RSQ_MAXGRID", 0, 0, 1 << 20);
-        colTypes.clear(); colIsString.clear(); rowParams.clear(); rowArgsTail.clear();
+        colTypes.clear(); colIsString.clear(); rowParams.clear(); rowArgsTail.clear(); rowArgsTailGuarded.clear();
         body.clear(); stateDecl.clear(); stateInit.clear(); prologue.clear(); epilogue.clear(); fileScope.clear();
         explainSteps.clear(); indent = 1; matchSlotTable = -1; slotVar.clear(); symbolOrigin.clear(); symbolWord.clear();
         multiMatchAbove = false;
+        selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
         eg.symbols.clear();
         o->schema.clear();
         for (size_t ci = 0; ci < t->cols.size(); ci++) {
@@ -339,6 +345,7 @@ struct Walker {
                 colIsString.push_back(0); colTypes.push_back(ct);
                 rowParams += ", " + ct + " " + var;
                 rowArgsTail += ", a.c" + std::to_string(k) + "[r]";
+                rowArgsTailGuarded += ", (valid ? a.c" + std::to_string(k) + "[r] : (" + ct + ")0)";
             }
         }
         explainSteps.push_back("scan " + t->name + " [" + std::to_string((long long)t->nRows) + " rows, " +
@@ -355,6 +362,7 @@ struct Walker {
                 o->schema = from->schema;
                 if (!q.requestAll) o->schema = prune(o->schema, requestOf[o]);
                 q.pool.addId(o->exprs[0]);
+                selective = true;
                 openScope("if (" + eg.emit(o->exprs[0]) + ") {");
                 explainSteps.push_back("selection " + serializeExpr(o->exprs[0]));
                 consume(o->parent, o);
@@ -386,6 +394,47 @@ struct Walker {
             case RSQ_OP_MATERIALIZE: consumeMaterialize(o, from); break;
             default: failUnsupported("operator not supported by the GPU engine");
         }
+    }
+
+    // ---- wave-level selection compaction ---------------------------------------------------------
+    // A selective predicate (or a join's key bitmap) leaves few lanes of a wave alive, and everything after it — hash
+    // probes, inserts, HBM atomics — is a chain of dependent random accesses whose latency the wave pays for no matter
+    // how few lanes take part.  So the row function is cut at that point: stage 1 (scan, predicates, bitmap test) pushes
+    // the values the rest needs into a per-wave LDS queue (ballot + prefix popcount, no atomics), and stage 2 runs only
+    // when 64 rows are queued, with every lane busy.  TPC-H Q3's orders pipeline (9.7 % of the rows reach the probe) then
+    // pays for one probe / insert pass per ~5 tiles instead of two per tile.
+    // Not for pipelines that materialise (output positions depend on the scan order of each lane).
+    bool downstreamMaterializes(OpNode* o) {
+        for (OpNode* p = o; p; p = p->parent) {
+            if (p->tag == RSQ_OP_AGGREGATION) return false;
+            if (p->tag == RSQ_OP_HASHJOIN && joinPhase[p] == 1) return false;
+            if (p->tag == RSQ_OP_MATERIALIZE) return true;
+        }
+        return true;
+    }
+    bool compactThen(OpNode* o, const std::function<void()>& downstream) {
+        if (compacted || !selective || !envInt("RSQ_COMPACT", 1, 0, 1) || downstreamMaterializes(o)) return false;
+        compacted = true;
+        pipe.compact = true;
+        cqLive.assign(eg.symbols.begin(), eg.symbols.end());
+        line("cq_pass = true;");
+        for (size_t k = 0; k < cqLive.size(); k++) line("cq_" + std::to_string(k) + " = " + toWord(cqLive[k].second.var, cqLive[k].second.type) + ";");
+        // ---- everything downstream goes into stage 2, which sees the carried values as its parameters ----
+        std::string savedBody = body; int savedIndent = indent;
+        body.clear(); indent = 1;
+        for (size_t k = 0; k < cqLive.size(); k++) {
+            const Type& t = cqLive[k].second.type;
+            const std::string v = "q_" + std::to_string(k);
+            line("const " + ExprGen::ctype(t) + " " + v + " = " + fromWord("qw_" + std::to_string(k), t) + ";");
+            eg.symbols[cqLive[k].first] = Sym{v, t};
+        }
+        explainSteps.push_back("wave compaction");
+        downstream();
+        while (indent > 1) closeScope();
+        stage2Body = body;
+        body = savedBody; indent = savedIndent;
+        pipe.compactWords = (int)cqLive.size();
+        return true;
     }
 
     // Entries are counted per thread in a register and added to the table's counter once per wave at the end of
@@ -431,6 +480,10 @@ struct Walker {
     }
 
     void consumeBuild(OpNode* o, OpNode* from) {
+        if (compactThen(o, [&] { consumeBuildBody(o, from); })) return;
+        consumeBuildBody(o, from);
+    }
+    void consumeBuildBody(OpNode* o, OpNode* from) {
         pipe.gridPerCU = 8;
         std::unique_ptr<HashTable> ht(new HashTable());
         ht->id = (int)q.hashTables.size();
@@ -507,17 +560,9 @@ struct Walker {
     }
 
     // ---- hash join probe (hashjoin.h:118-214) ---------------------------------------------------
-    void consumeProbe(OpNode* o, OpNode* from) {
-        pipe.gridPerCU = 8;
-        HashTable& ht = *q.hashTables[(size_t)o->hashTable];
-        const std::string T = "ht" + std::to_string(ht.id);
-        o->schema = o->child[0]->schema;
-        for (auto& a : from->schema) o->schema.push_back(a);
-        if (!q.requestAll) o->schema = prune(o->schema, requestOf[o]);
-        std::vector<std::string> keyVars;
-        openScope("{");
+    // key words of the probe side of join `o` (emits their computation at the current position)
+    void probeKeys(OpNode* o, const std::string& T, std::vector<std::string>& keyVars, std::vector<std::string>& probeKeyNames) {
         int k = 0;
-        std::vector<std::string> probeKeyNames;
         for (Expr* eq : o->exprs) {
             Expr* r = eq->child->next;
             q.pool.addId(r);
@@ -527,6 +572,18 @@ struct Walker {
             probeKeyNames.push_back(keyVars.size() - w0 == 1 ? expressionName(r) : std::string());
             for (size_t w = w0 + 1; w < keyVars.size(); w++) probeKeyNames.push_back(std::string());
         }
+    }
+
+    void consumeProbe(OpNode* o, OpNode* from) {
+        pipe.gridPerCU = 8;
+        HashTable& ht = *q.hashTables[(size_t)o->hashTable];
+        const std::string T = "ht" + std::to_string(ht.id);
+        o->schema = o->child[0]->schema;
+        for (auto& a : from->schema) o->schema.push_back(a);
+        if (!q.requestAll) o->schema = prune(o->schema, requestOf[o]);
+        std::vector<std::string> keyVars, probeKeyNames;
+        openScope("{");
+        probeKeys(o, T, keyVars, probeKeyNames);
         if (keyVars.size() != ht.keys.size()) failUnsupported("string join keys of different declared lengths");
         addArg(T + "_state", "const u32*", 0); addArg(T + "_words", "const i64*", 0); addArg(T + "_cap", "u64", 0);
         if (ht.hasBitmap) {
@@ -534,7 +591,23 @@ struct Walker {
             addArg(T + "_bm", "const u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht.bmMin); addArg(T + "_bmbits", "u64", (uint64_t)ht.bmBits);
             line("const u64 " + T + "_d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin);");
             openScope("if (" + T + "_d < a." + T + "_bmbits && ((a." + T + "_bm[" + T + "_d >> 5] >> (" + T + "_d & 31)) & 1u)) {");
+            selective = true;
         }
+        // the table walk (dependent random accesses) runs behind the wave compaction when the pipeline is selective
+        const bool cut = compactThen(o, [&] {
+            std::vector<std::string> kv2, names2;
+            openScope("{");
+            probeKeys(o, T, kv2, names2);
+            probeTable(o, ht, T, kv2, names2);
+            closeScope();
+        });
+        if (!cut) probeTable(o, ht, T, keyVars, probeKeyNames);
+        if (ht.hasBitmap) closeScope();
+        closeScope();
+    }
+
+    void probeTable(OpNode* o, HashTable& ht, const std::string& T, const std::vector<std::string>& keyVars,
+                    const std::vector<std::string>& probeKeyNames) {
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
         line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
         openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
@@ -559,12 +632,11 @@ struct Walker {
         slotVar[ht.id] = T + "_s";
         if (o->singleMatch) matchSlotTable = ht.id; else { multiMatchAbove = true; }
         explainSteps.push_back(std::string("probe ") + T + (o->singleMatch ? " (single match)" : " (all matches)"));
+        selective = true;                       // whatever follows a join probe sees only the matching rows
         consume(o->parent, o);
         matchSlotTable = prevMatch; multiMatchAbove = prevMulti;
         if (o->singleMatch) line("break;");
         closeScope();
-        closeScope();
-        if (ht.hasBitmap) closeScope();
         closeScope();
     }
     std::map<std::string, std::pair<int, int>> probeKeyOf;   // probe-side key symbol -> (table, key word)
@@ -682,7 +754,8 @@ struct Walker {
             emitJoinEntryAggregation(o);
         } else {
             q.aggMode = AggMode::HASH;
-            emitHashAggregation(o);
+            // (behind the compaction the accumulator inputs must be emitted again: they name stage-2 values now)
+            if (!compactThen(o, [&] { collectAccumulators(o); emitHashAggregation(o); })) emitHashAggregation(o);
         }
         pipe.sink = SinkKind::AGGREGATE;
     }
@@ -1081,12 +1154,44 @@ struct Walker {
         if (envInt("RSQ_NT", 1, 0, 1)) s << "#define RSQ_NT_LOADS 1\n";
         s << "#include \"rsq_device.h\"\n";
         s << fileScope;
+        const bool cq = pipe.compact;
+        const int QCAP = 192;                       // 63 left over + 128 pushed by one tile, rounded up
+        const int NV = 1 + pipe.compactWords;       // the row index + the carried values
+        if (cq) {
+            // the queues take LDS: as many workgroups per CU as fit next to each other, at most the 8 of a random-access pipeline
+            const int ldsPerWG = (pipe.blockThreads / 64) * NV * QCAP * 8;
+            pipe.gridPerCU = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(8, (144 * 1024) / std::max(1, ldsPerWG))), 1, 16);
+            stateDecl += "    int cq_n = 0;\n    i64* cq;\n";
+            prologue += "    __shared__ i64 s_cq[(RSQ_BLOCK_THREADS / 64) * " + std::to_string(NV * QCAP) + "];\n";
+            prologue += "    st.cq = s_cq + (threadIdx.x >> 6) * " + std::to_string(NV * QCAP) + ";\n";
+        }
+        s << "#ifndef RSQ_BLOCK_THREADS\n#define RSQ_BLOCK_THREADS " << pipe.blockThreads << "\n#endif\n";
         s << "struct Args {\n";
         for (auto& a : pipe.args) s << "    " << a.ctype << " " << a.name << ";\n";
         s << "};\nstruct State {\n" << stateDecl << "};\n";
-        s << "static RSQ_DEV void row_fn(const Args& a, State& st, const i64 lr" << rowParams << ") {\n";
-        s << "    const i64 row = a.row0 + lr;\n" << body << "}\n";
-        s << "#ifndef RSQ_BLOCK_THREADS\n#define RSQ_BLOCK_THREADS " << pipe.blockThreads << "\n#endif\n";
+        if (cq) {
+            // stage 2: everything behind the compaction point, called with dense lanes
+            s << "static RSQ_DEV void stage2(const Args& a, State& st, const i64 row";
+            for (int k = 0; k < pipe.compactWords; k++) s << ", const i64 qw_" << k;
+            s << ") {\n" << stage2Body << "}\n";
+            s << "static RSQ_DEV void cq_drain(const Args& a, State& st, const int count) {\n";
+            s << "    const int lane = threadIdx.x & 63;\n    const int i = st.cq_n - count + lane;\n";
+            s << "    if (lane < count) {\n        stage2(a, st, st.cq[i]";
+            for (int k = 0; k < pipe.compactWords; k++) s << ", st.cq[" << (k + 1) * QCAP << " + i]";
+            s << ");\n    }\n    st.cq_n -= count;\n}\n";
+        }
+        s << "static RSQ_DEV void row_fn(const Args& a, State& st, const i64 lr" << (cq ? ", const bool valid" : "") << rowParams << ") {\n";
+        s << "    const i64 row = a.row0 + lr;\n";
+        if (cq) {
+            s << "    bool cq_pass = false;\n";
+            for (int k = 0; k < pipe.compactWords; k++) s << "    i64 cq_" << k << " = 0;\n";
+            s << "    if (valid) {\n" << body << "    }\n";
+            // push: every lane of the wave is here (the callers keep the control flow wave-uniform)
+            s << "    {\n        const int lane = threadIdx.x & 63;\n        const u64 m = __ballot(cq_pass);\n";
+            s << "        if (cq_pass) {\n            const int s = st.cq_n + (int)__popcll(m & ((1ull << lane) - 1ull));\n            st.cq[s] = row;\n";
+            for (int k = 0; k < pipe.compactWords; k++) s << "            st.cq[" << (k + 1) * QCAP << " + s] = cq_" << k << ";\n";
+            s << "        }\n        st.cq_n += (int)__popcll(m);\n    }\n}\n";
+        } else s << body << "}\n";
         s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) rsq_pipeline(Args a) {\n";
         s << "    State st;\n" << prologue;
         s << "    const int lane = threadIdx.x & 63;\n";
@@ -1109,19 +1214,29 @@ struct Walker {
             s << "        if (tt" << u << " < ntiles) {\n";
             if (mat) s << "            const i64 slot = tt" << u << " * 64 + lane;\n#if RSQ_PASS == 2\n            st.pos = a.offs[slot];\n#endif\n";
             for (int j = 0; j < 2; j++) {
-                s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j;
+                s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");
                 for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
                 s << ");\n";
             }
+            if (cq) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";
             if (mat) s << "#if RSQ_PASS == 1\n            a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
             s << "        }\n";
         }
         s << "    }\n";
-        s << "    for (i64 r = (ntiles << 7) + (i64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (i64)gridDim.x * blockDim.x) {\n";
-        if (mat) s << "        const i64 slot = ntiles * 64 + (r - (ntiles << 7));\n#if RSQ_PASS == 2\n        st.pos = a.offs[slot];\n#endif\n";
-        s << "        row_fn(a, st, r" << rowArgsTail << ");\n";
-        if (mat) s << "#if RSQ_PASS == 1\n        a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
-        s << "    }\n";
+        if (cq) {
+            // tail rows with a wave-uniform trip count (the push votes across the wave)
+            s << "    for (i64 rb = (ntiles << 7) + (i64)blockIdx.x * blockDim.x; rb < a.n_rows; rb += (i64)gridDim.x * blockDim.x) {\n";
+            s << "        const i64 r = rb + threadIdx.x;\n        const bool valid = r < a.n_rows;\n";
+            s << "        row_fn(a, st, r, valid" << rowArgsTailGuarded << ");\n";
+            s << "        while (st.cq_n >= 64) cq_drain(a, st, 64);\n    }\n";
+            s << "    while (st.cq_n > 0) cq_drain(a, st, st.cq_n < 64 ? st.cq_n : 64);\n";
+        } else {
+            s << "    for (i64 r = (ntiles << 7) + (i64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (i64)gridDim.x * blockDim.x) {\n";
+            if (mat) s << "        const i64 slot = ntiles * 64 + (r - (ntiles << 7));\n#if RSQ_PASS == 2\n        st.pos = a.offs[slot];\n#endif\n";
+            s << "        row_fn(a, st, r" << rowArgsTail << ");\n";
+            if (mat) s << "#if RSQ_PASS == 1\n        a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
+            s << "    }\n";
+        }
         s << epilogue << "}\n";
         pipe.source = s.str();
         if (mat) {   // two code objects from one source

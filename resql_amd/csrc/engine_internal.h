@@ -106,6 +106,8 @@ struct Pipeline {
     std::vector<ArgSlot> args;
     Kernel* kernel = nullptr;
     int64_t bytesPerRow = 0;
+    bool compact = false;            // wave-level selection compaction (codegen.cpp compactThen): carried 8-byte values
+    int compactWords = 0;
     int blockThreads = 256;
     int unroll = 2;
     unsigned maxGrid = 0;            // 256-thread workgroups per launch; 0 = gridPerCU per CU
