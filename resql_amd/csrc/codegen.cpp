@@ -490,6 +490,7 @@ struct Walker {
         ht->unique = o->singleMatch;
         const std::string T = "ht" + std::to_string(ht->id);
         std::vector<std::string> keyVars;
+        std::vector<int> keyFirstWord;           // per key expression: its table word (-1 for multi-word string keys)
         openScope("{");
         int k = 0;
         for (Expr* eq : o->exprs) {
@@ -497,15 +498,23 @@ struct Walker {
             Expr* l = eq->child;
             q.pool.addId(l);
             size_t w0 = keyVars.size();
+            keyFirstWord.push_back(l->type.isString() ? -1 : (int)w0);
             for (auto& kv : keyWords(l, T + "_k" + std::to_string(k++), true)) keyVars.push_back(kv);
             for (size_t w = w0; w < keyVars.size(); w++)
                 ht->keys.push_back({w == w0 ? expressionName(l) : expressionName(l) + "#" + std::to_string(w - w0), w == w0 && !l->type.isString() ? l->type : Type(RSQ_BIGINT)});
         }
-        // build payload = the attributes of the left child's schema (Values::get(_lChild->_schema))
+        // build payload = the attributes of the left child's schema (Values::get(_lChild->_schema)); an attribute that is
+        // itself a (one-word) join key is not stored again: a matching probe already holds its value
         for (auto& a : from->schema) {
             auto it = eg.symbols.find(a.name);
             if (it == eg.symbols.end()) failType("hash join build value " + a.name + " has no symbol");
-            ht->payload.push_back({a.name, it->second.type});
+            int alias = -1;
+            for (size_t ki = 0; ki < o->exprs.size(); ki++) {
+                Expr* l = o->exprs[ki]->child;
+                if (l->tag == RSQ_E_ATTRIBUTE && l->symbol == a.name && !l->type.isString() && keyFirstWord[ki] >= 0) alias = keyFirstWord[ki];
+            }
+            if (alias >= 0) ht->keyAlias.push_back({{a.name, it->second.type}, alias});
+            else ht->payload.push_back({a.name, it->second.type});
         }
         // key-domain bitmap (see HashTable): one integer key that is a column of this pipeline's scan with usable statistics
         if (o->exprs.size() == 1 && keyVars.size() == 1 && envInt("RSQ_JOIN_BITMAP", 1, 0, 1)) {
@@ -623,6 +632,14 @@ struct Walker {
             line("const " + ExprGen::ctype(p.type) + " " + var + " = " + fromWord("a." + T + "_words[" + std::to_string(w) + " * a." + T + "_cap + " + T + "_s]", p.type) + ";");
             eg.symbols[p.name] = Sym{var, p.type};
             symbolOrigin[p.name] = ht.id; symbolWord[p.name] = w;
+            w++;
+        }
+        // build-side attributes that are key values: equal to this row's probe key, nothing to load
+        for (auto& al : ht.keyAlias) {
+            std::string var = T + "_a" + std::to_string(al.second) + "_" + std::to_string(w);
+            line("const " + ExprGen::ctype(al.first.type) + " " + var + " = " + fromWord(keyVars[(size_t)al.second], al.first.type) + ";");
+            eg.symbols[al.first.name] = Sym{var, al.first.type};
+            symbolOrigin[al.first.name] = ht.id; symbolWord[al.first.name] = al.second;
             w++;
         }
         // probe-side key attributes are equal to the build keys of the matched entry

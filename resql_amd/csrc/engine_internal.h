@@ -42,6 +42,7 @@ struct HashTable {
     int id = 0;
     std::vector<Attr> keys;          // build-side key values (names of the build key expressions)
     std::vector<Attr> payload;       // build-side attributes carried to the probe side
+    std::vector<std::pair<Attr, int>> keyAlias;   // build-side attributes that ARE a key value: (attribute, key word) — not stored twice
     int64_t capacity = 0;
     bool unique = false;             // probed single-match
     uint32_t* dState = nullptr;
