@@ -162,11 +162,11 @@ static void prepareDenseBuffers(Query& q) {
     if (q.aggPad > 1) {
         // padded working table (one cell per 64-byte line) the register-mode kernels flush into
         q.padWords = words * (size_t)q.aggPad;
-        std::vector<uint64_t> pinit(q.padWords, 0);
+        std::vector<uint64_t> pinit(q.padWords + 1, 0);        // + one word: the device error word of graph replays
         for (size_t i = 0; i < words; i++) pinit[i * (size_t)q.aggPad] = init[i];
-        q.dAggWork = (uint64_t*)q.ctx.alloc(q.padWords * 8);
-        q.dAggWorkInit = (uint64_t*)q.ctx.alloc(q.padWords * 8);
-        RSQ_HIP(hipMemcpy(q.dAggWorkInit, pinit.data(), q.padWords * 8, hipMemcpyHostToDevice));
+        q.dAggWork = (uint64_t*)q.ctx.alloc((q.padWords + 1) * 8);
+        q.dAggWorkInit = (uint64_t*)q.ctx.alloc((q.padWords + 1) * 8);
+        RSQ_HIP(hipMemcpy(q.dAggWorkInit, pinit.data(), (q.padWords + 1) * 8, hipMemcpyHostToDevice));
         q.pinnedWords = q.padWords;          // the read-back of a full execution takes the padded table
     }
 }
@@ -237,6 +237,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
 // execute
 // ================================================================================================
 static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTable) {
+    if (a.name == "err" && q.errInTable) return (uint64_t)(uintptr_t)(q.dAggWork + q.padWords);
     if (a.name == "out") return (uint64_t)(uintptr_t)(q.aggPad > 1 && !q.flatRun ? q.dAggWork : q.dAgg);
     if (a.name == "part_counts") return (uint64_t)(uintptr_t)q.dPartCounts;
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
@@ -425,11 +426,11 @@ static void checkDeviceError(uint32_t err) {
 
 // the dense aggregate table at the start / end of an execution: register-mode kernels work on the padded copy
 static void enqueueTableInit(Query& q) {
-    if (q.aggPad > 1 && !q.flatRun) RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
+    if (q.aggPad > 1 && !q.flatRun) RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, (q.padWords + (q.errInTable ? 1 : 0)) * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
     else RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, q.tableWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
 }
 static void enqueueTableReadback(Query& q) {
-    if (q.aggPad > 1) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAggWork, q.padWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
+    if (q.aggPad > 1) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAggWork, (q.padWords + (q.errInTable ? 1 : 0)) * 8, hipMemcpyDeviceToHost, q.ctx.stream));
     else RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
 }
 static void tableFromPinned(Query& q) {
@@ -450,12 +451,16 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     const size_t words = q.pinnedWords;
     q.report.num_kernels = 0; q.report.bytes_read = 0;
     q.flatRun = partialOnly && q.aggPad > 1;
+    q.errInTable = false;
     const bool trace0 = getenv("RSQ_TRACE") != nullptr;
     const char* genv = getenv("RSQ_GRAPH");
     // ---- graph path: one plain pipeline into a dense table, on the context's own stream ----
     if (denseMode(q) && q.pipelines.size() == 1 && q.pipelines[0].sink == SinkKind::AGGREGATE && !q.pipelines[0].partitioned &&
         !trace0 && !q.graphFailed && ctx.stream == ctx.ownStream && !(genv && atoi(genv) == 0)) {
         Pipeline& p = q.pipelines[0];
+        // full executions of register-mode queries keep the error word behind the padded table: the init copy clears it
+        // and the read-back fetches it, so a replay is {copy, kernel, copy}
+        q.errInTable = q.aggPad > 1 && !partialOnly;
         if (!q.graphExec || q.graphAggPtr != (void*)q.dAgg || q.graphPartial != partialOnly) {
             if (q.graphExec) { (void)hipGraphExecDestroy(q.graphExec); q.graphExec = nullptr; }
             hipGraph_t g = nullptr;
@@ -463,11 +468,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (ok) {
                 try {
                     enqueueTableInit(q);
-                    RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+                    if (!q.errInTable) RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
                     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
                     launchPipeline(q, p, -1);
                     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
-                    RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+                    if (!q.errInTable) RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
                     if (!partialOnly) enqueueTableReadback(q);
                 } catch (...) { ok = false; }
                 if (hipStreamEndCapture(ctx.stream, &g) != hipSuccess) ok = false;
@@ -475,7 +480,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (ok && hipGraphInstantiate(&q.graphExec, g, nullptr, nullptr, 0) != hipSuccess) { ok = false; q.graphExec = nullptr; }
             if (g) (void)hipGraphDestroy(g);
             (void)hipGetLastError();
-            if (!ok) q.graphFailed = true;
+            if (!ok) { q.graphFailed = true; q.errInTable = false; }
             else { q.graphAggPtr = (void*)q.dAgg; q.graphPartial = partialOnly; }
         }
         if (q.graphExec) {

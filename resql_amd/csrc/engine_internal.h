@@ -145,6 +145,7 @@ struct Query {
     uint64_t* dAggWorkInit = nullptr;
     size_t padWords = 0;                   // cells * aggPad
     bool flatRun = false;                  // this execution is partial: kernels flush straight into dAgg
+    bool errInTable = false;               // graph path: the error word is the word behind the padded table (one init copy, one read-back)
     size_t tableWords = 0;                 // accumulators * dense groups (the [block][group] table)
     bool dAggOwned = true;
     uint64_t* dAgg = nullptr;              // dense modes: [blocks][denseGroups]
