@@ -350,6 +350,133 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// ORDER BY ... LIMIT k over many groups: pre-selection of the candidate rows on the device.
+// The first sort key of every group row is mapped to an unsigned image in which "earlier in the requested order" is
+// "larger"; an MSB-first radix select (11-bit digits, one histogram launch per digit, no host round trip: every
+// workgroup re-derives the prefix chosen so far from the previous histograms, 2048 bins each) finds T, the `want`-th
+// largest image; the gather writes the rows with image >= T.  The rows that lead the full lexicographic order are among
+// them, so the host tail sorts a few dozen rows instead of every group.
+// ------------------------------------------------------------------------------------------------
+enum { TOPK_PASSES = 6, TOPK_BINS = 2048 };
+__device__ __forceinline__ int topk_shift(int p) { return p < 5 ? 53 - 11 * p : 0; }
+__device__ __forceinline__ int topk_bits(int p) { return p < 5 ? 11 : 9; }
+
+__device__ __forceinline__ u64 topk_image(i64 w, int is32, int desc) {
+    const i64 v = is32 ? (i64)(int)(unsigned)w : w;
+    const u64 u = (u64)v ^ 0x8000000000000000ull;
+    return desc ? u : ~u;
+}
+
+// Replays the digit choices of passes [0, upto): returns the chosen prefix (the top bits of T, right-aligned) and, in
+// *remOut, how many rows with exactly that prefix are still wanted.  *allOut is set when fewer than `want` rows exist
+// (then every row qualifies).  Called by all 256 threads of a workgroup.
+__device__ u64 topk_prefix(const unsigned* __restrict__ hists, int upto, unsigned want, unsigned* remOut, int* allOut) {
+    __shared__ unsigned s_above[256];
+    __shared__ unsigned s_digit, s_rem;
+    __shared__ int s_found;
+    const int t = threadIdx.x;
+    u64 prefix = 0;
+    unsigned rem = want;
+    int all = 0;
+    for (int p = 0; p < upto && !all; p++) {
+        const unsigned* h = hists + (size_t)p * TOPK_BINS;
+        unsigned c[8], local = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) { c[b] = h[t * 8 + b]; local += c[b]; }
+        if (t == 0) s_found = 0;
+        s_above[t] = local;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {                  // inclusive suffix sums over the threads
+            const unsigned v = t + d < 256 ? s_above[t + d] : 0u;
+            __syncthreads();
+            s_above[t] += v;
+            __syncthreads();
+        }
+        unsigned running = s_above[t] - local;               // rows in bins above this thread's eight
+#pragma unroll
+        for (int b = 7; b >= 0; b--) {
+            if (running < rem && rem <= running + c[b]) { s_digit = (unsigned)(t * 8 + b); s_rem = rem - running; s_found = 1; }
+            running += c[b];
+        }
+        __syncthreads();
+        if (!s_found) all = 1;
+        else { prefix = (prefix << topk_bits(p)) | (u64)s_digit; rem = s_rem; }
+        __syncthreads();
+    }
+    *remOut = rem; *allOut = all;
+    return prefix;
+}
+
+// pass p: histogram of digit p over the rows whose higher digits equal the prefix chosen so far.  Pass 0 also
+// extracts the key images from the group rows.
+__global__ void __launch_bounds__(256) k_topk_hist(const i64* __restrict__ rows, int stride, int keyWord, int is32, int desc,
+                                                   const unsigned* __restrict__ nRows, u64* __restrict__ images,
+                                                   unsigned* __restrict__ hists, int pass, unsigned want) {
+    __shared__ unsigned s_hist[TOPK_BINS];
+    for (int b = threadIdx.x; b < TOPK_BINS; b += 256) s_hist[b] = 0;
+    unsigned rem; int all;
+    const u64 prefix = topk_prefix(hists, pass, want, &rem, &all);      // contains the barriers that publish s_hist = 0
+    if (all) return;
+    const unsigned n = *nRows;
+    const int shift = topk_shift(pass);
+    const unsigned mask = (1u << topk_bits(pass)) - 1u;
+    const int above = shift + topk_bits(pass);                          // bits above this digit
+    __syncthreads();
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        u64 u;
+        if (pass == 0) { u = topk_image(rows[(size_t)i * stride + keyWord], is32, desc); images[i] = u; }
+        else u = images[i];
+        if (pass == 0 || (u >> above) == prefix) atomicAdd(&s_hist[(unsigned)(u >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    unsigned* h = hists + (size_t)pass * TOPK_BINS;
+    for (int b = threadIdx.x; b < TOPK_BINS; b += 256) { const unsigned c = s_hist[b]; if (c) atomicAdd(&h[b], c); }
+}
+
+// rows whose image is >= T, in no particular order; *candCount counts all of them, rows beyond `capacity` are dropped
+// (the host then falls back to reading every group)
+__global__ void __launch_bounds__(256) k_topk_gather(const i64* __restrict__ rows, int stride, const unsigned* __restrict__ nRows,
+                                                     const u64* __restrict__ images, const unsigned* __restrict__ hists, unsigned want,
+                                                     i64* __restrict__ cand, unsigned capacity, unsigned* candCount) {
+    unsigned rem; int all;
+    const u64 T = topk_prefix(hists, TOPK_PASSES, want, &rem, &all);
+    const unsigned n = *nRows;
+    const int lane = threadIdx.x & 63;
+    const unsigned rounds = (n + gridDim.x * 256u - 1) / (gridDim.x * 256u);
+    for (unsigned r = 0; r < rounds; r++) {
+        const unsigned i = (r * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+        const bool take = i < n && (all || images[i] >= T);
+        const unsigned long long vote = __ballot(take);
+        if (vote == 0) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(candCount, (unsigned)__popcll(vote));
+        base = (unsigned)__shfl((int)base, 0, 64);
+        if (!take) continue;
+        const unsigned pos = base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull));
+        if (pos >= capacity) continue;
+        const i64* src = rows + (size_t)i * stride;
+        i64* dst = cand + (size_t)pos * stride;
+        for (int w = 0; w < stride; w++) dst[w] = src[w];
+    }
+}
+
+size_t topkHistBytes() { return (size_t)TOPK_PASSES * TOPK_BINS * sizeof(unsigned); }
+
+void selectTopCandidates(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
+                         uint32_t rowsUpperBound, uint32_t want, uint64_t* images, uint32_t* hists, int64_t* cand, uint32_t capacity,
+                         uint32_t* candCount) {
+    const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx.numCUs, (rowsUpperBound + 2047) / 2048));
+    RSQ_HIP(hipMemsetAsync(hists, 0, topkHistBytes(), ctx.stream));
+    RSQ_HIP(hipMemsetAsync(candCount, 0, 4, ctx.stream));
+    for (int p = 0; p < TOPK_PASSES; p++)
+        hipLaunchKernelGGL(k_topk_hist, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
+                           (const unsigned*)nRows, (u64*)images, (unsigned*)hists, p, (unsigned)want);
+    hipLaunchKernelGGL(k_topk_gather, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, (const unsigned*)nRows, (const u64*)images,
+                       (const unsigned*)hists, (unsigned)want, (i64*)cand, (unsigned)capacity, (unsigned*)candCount);
+    RSQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // partitioned aggregation: per-(workgroup, partition) record counts -> record positions.
 // m[wg][p] becomes the position of workgroup wg's first record of partition p when partitions are laid out one after
 // the other and, inside a partition, workgroups in order; partStart[p] / partStart[P] are the partition bounds.

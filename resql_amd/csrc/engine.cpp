@@ -121,6 +121,10 @@ Query::~Query() {
     for (void* p : dMatCols) if (p) ctx.free(p);
     if (dGroupRows) ctx.free(dGroupRows);
     if (dGroupCount) ctx.free(dGroupCount);
+    if (dTopkImages) ctx.free(dTopkImages);
+    if (dTopkHists) ctx.free(dTopkHists);
+    if (dCandRows) ctx.free(dCandRows);
+    if (dCandCount) ctx.free(dCandCount);
     if (dPartCounts) ctx.free(dPartCounts);
     if (dPartStart) ctx.free(dPartStart);
     if (dPartTotals) ctx.free(dPartTotals);
@@ -454,6 +458,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     q.errInTable = false;
     const bool trace0 = getenv("RSQ_TRACE") != nullptr;
     const char* genv = getenv("RSQ_GRAPH");
+    uint32_t topkCapacity = 0, topkSpec = 0;      // > 0: this execution pre-selects ORDER BY ... LIMIT candidates on the device
     // ---- graph path: one plain pipeline into a dense table, on the context's own stream ----
     if (denseMode(q) && q.pipelines.size() == 1 && q.pipelines[0].sink == SinkKind::AGGREGATE && !q.pipelines[0].partitioned &&
         !trace0 && !q.graphFailed && ctx.stream == ctx.ownStream && !(genv && atoi(genv) == 0)) {
@@ -594,12 +599,37 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.dAcc, h.nAccBlocks,
                        q.dGroupRows, q.dGroupCount);
         q.report.num_kernels++;
+        // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
+        if (q.topkWord == -2) planDeviceTopK(q);
+        if (q.topkWord >= 0 && nEntries >= 2048 && (uint64_t)nEntries > 4ull * q.topkWant) {
+            topkCapacity = std::min<uint32_t>(nEntries, std::max<uint32_t>(256, 4 * q.topkWant));
+            if (q.topkImageRows < nEntries) {
+                if (q.dTopkImages) ctx.free(q.dTopkImages);
+                q.dTopkImages = (uint64_t*)ctx.alloc((size_t)nEntries * 8);
+                q.topkImageRows = nEntries;
+            }
+            if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = (uint32_t*)ctx.alloc(4); }
+            if (q.candCapacity < topkCapacity || q.candRowWords != q.groupRowWords) {
+                if (q.dCandRows) ctx.free(q.dCandRows);
+                q.dCandRows = (int64_t*)ctx.alloc((size_t)topkCapacity * (size_t)q.groupRowWords * 8);
+                q.candCapacity = topkCapacity; q.candRowWords = q.groupRowWords;
+            }
+            selectTopCandidates(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, nEntries, q.topkWant,
+                                q.dTopkImages, q.dTopkHists, q.dCandRows, topkCapacity, q.dCandCount);
+            q.report.num_kernels += 7;
+            // the leading candidates travel with the same synchronisation as the counts (usually that is all of them)
+            topkSpec = std::min<uint32_t>(topkCapacity, std::max<uint32_t>(q.topkWant + 64, 65536u / (uint32_t)(q.groupRowWords * 8)));
+        }
     }
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
     if (!partialOnly && denseMode(q)) enqueueTableReadback(q);
     if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH))
         RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+    if (topkCapacity) {
+        RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 2, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+        RSQ_HIP(hipMemcpyAsync(q.hGroupRows, q.dCandRows, (size_t)topkSpec * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost, ctx.stream));
+    }
     if (async && partialOnly) {
         // everything is enqueued; the caller orders its own work (the group-by merge collective) behind it on the same
         // stream and finalizeQuery() does the one host synchronisation of the step
@@ -623,8 +653,27 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 if (bytes) RSQ_HIP(hipMemcpy(q.hMatCols[c].data(), q.dMatCols[c], bytes, hipMemcpyDeviceToHost));
             }
         } else {
-            q.nGroupRows = (int64_t)(uint32_t)q.hPinned[words + 1];
-            if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost));
+            const int64_t nGroups = (int64_t)(uint32_t)q.hPinned[words + 1];
+            const int64_t nCand = topkCapacity ? (int64_t)(uint32_t)q.hPinned[words + 2] : 0;
+            const size_t rowBytes = (size_t)q.groupRowWords * 8;
+            q.candidateRun = false;
+            if (topkCapacity && nCand <= (int64_t)topkCapacity && nCand < nGroups) {
+                if (nCand > (int64_t)topkSpec)
+                    RSQ_HIP(hipMemcpy((char*)q.hGroupRows + (size_t)topkSpec * rowBytes, (char*)q.dCandRows + (size_t)topkSpec * rowBytes,
+                                      (size_t)(nCand - topkSpec) * rowBytes, hipMemcpyDeviceToHost));
+                q.candidateRun = true;
+                q.nGroupRows = nCand; q.totalGroups = nGroups;
+                runTail(q);
+                q.candidateRun = false;
+            }
+            if (!topkCapacity || q.tailNeedsAllGroups || !(nCand <= (int64_t)topkCapacity && nCand < nGroups)) {
+                q.nGroupRows = nGroups;
+                if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * rowBytes, hipMemcpyDeviceToHost));
+                runTail(q);
+            }
+            q.report.finalize_time_ms = nowMs() - t1;
+            q.report.execution_time_ms = nowMs() - t0;
+            return;
         }
         runTail(q);
         q.report.finalize_time_ms = nowMs() - t1;

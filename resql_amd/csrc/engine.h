@@ -104,6 +104,12 @@ void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPart
 // packed rows [first row | table words | accumulator blocks]; *count receives the number of rows
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t* count);
+// ORDER BY ... LIMIT pre-selection: the rows of `rows` ([*nRows][stride] words) whose word `keyWord` is among the `want`
+// leading values of the requested order (ties of the last one included) are copied to `cand`; *candCount counts them
+size_t topkHistBytes();
+void selectTopCandidates(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
+                         uint32_t rowsUpperBound, uint32_t want, uint64_t* images, uint32_t* hists, int64_t* cand, uint32_t capacity,
+                         uint32_t* candCount);
 
 // tbl.cpp: '.tbl' text -> columns with the reference's BULK INSERT semantics (execute.h:332-388)
 void parseTblFile(const std::string& path, const std::vector<Type>& types, char terminator, int nThreads,

@@ -184,6 +184,21 @@ struct Query {
     int64_t nGroupRows = 0;
     int groupRowWords = 0;
 
+    // ORDER BY ... LIMIT k above a join-entry / hash aggregation: candidate rows pre-selected on the device
+    // (aot_kernels.hip selectTopCandidates; planDeviceTopK in tail.cpp decides whether the first sort key is a word of
+    // the group row).  A candidate run hands the tail `nGroupRows` candidates of `totalGroups` groups; the tail sets
+    // tailNeedsAllGroups when the candidates do not determine the answer (ties on all keys among the leading rows).
+    int topkWord = -2;                     // -2 not analysed yet, -1 not applicable, else word index in the group row
+    bool topkIs32 = false, topkDesc = false;
+    uint32_t topkWant = 0;                 // k + 1
+    uint64_t* dTopkImages = nullptr; size_t topkImageRows = 0;
+    uint32_t* dTopkHists = nullptr;
+    int64_t* dCandRows = nullptr; uint32_t candCapacity = 0; int candRowWords = 0;
+    uint32_t* dCandCount = nullptr;
+    bool candidateRun = false;
+    int64_t totalGroups = 0;
+    bool tailNeedsAllGroups = false;
+
     // result
     Schema resultSchema;
     std::vector<uint8_t> resultTuples;
@@ -217,5 +232,7 @@ void buildPipelines(Query& q);
 
 // tail.cpp: aggregate table / group rows -> result relation (AVG, projection, materialize, order by, limit)
 void runTail(Query& q);
+// tail.cpp: is the first ORDER BY key of an `ORDER BY ... LIMIT k` above the aggregation one word of the group rows?
+void planDeviceTopK(Query& q);
 
 }  // namespace rsq

@@ -392,7 +392,74 @@ static void runMaterializeTail(Query& q) {
     }
 }
 
+// Device-side pre-selection for `ORDER BY ... LIMIT k` (orderby.h:87-93 sorts everything, then applyLimit): possible when
+// the first sort key is, through AS / pass-through projections only, a non-string group value or a non-AVG aggregate,
+// i.e. one word of the group rows the device compacts.  Symbols are resolved the way the tail's HostCompiler does.
+void planDeviceTopK(Query& q) {
+    q.topkWord = -1;
+    const char* env = getenv("RSQ_DEVICE_TOPK");
+    if (env && atoi(env) == 0) return;
+    OpNode* agg = q.agg;
+    if (!agg || (q.aggMode != AggMode::AT_JOIN_ENTRY && q.aggMode != AggMode::HASH)) return;
+    OpNode* mat = nullptr; OpNode* orderBy = nullptr;
+    std::vector<OpNode*> projections;
+    for (OpNode* o = agg->parent; o; o = o->parent) {
+        if (o->tag == RSQ_OP_PROJECTION) { if (mat) return; projections.push_back(o); }
+        else if (o->tag == RSQ_OP_MATERIALIZE) { if (mat) return; mat = o; }
+        else if (o->tag == RSQ_OP_ORDERBY) orderBy = o;
+        else return;
+    }
+    if (!mat || mat->hasLimit || !orderBy || !orderBy->hasLimit || orderBy->exprs.empty()) return;
+    if (orderBy->limit < 0 || orderBy->limit > (1 << 20)) return;
+    for (Expr* g : agg->exprs2) if (g->type.isString()) return;      // CHAR groups are merged on the host (trailing spaces)
+    const HashTable& ht = *q.hashTables[(size_t)q.aggTable];
+    const int nTab = (int)(ht.keys.size() + ht.payload.size());
+    typedef std::pair<int, Type> Src;
+    std::map<std::string, Src> src;
+    for (size_t k = 0; k < agg->exprs2.size(); k++) src[expressionName(agg->exprs2[k])] = Src(1 + q.groupSource[k], agg->exprs2[k]->type);
+    {
+        size_t si = 0;
+        for (Expr* a : agg->exprs) {
+            if (a->tag == RSQ_E_AVG) { q.pool.addId(a); src.erase(expressionName(a)); si += 2; }
+            else {
+                Expr* s = agg->splitAgg[si];
+                src[expressionName(s)] = Src(1 + nTab + q.accumSlot[(size_t)q.splitToAccum[si]], s->type);
+                si += 1;
+            }
+        }
+    }
+    std::function<const Src*(Expr*)> resolve = [&](Expr* e) -> const Src* {
+        auto it = src.find(expressionName(e));
+        if (it != src.end()) return &it->second;
+        if (e->structure == UNARY && e->tag == RSQ_E_AS) return resolve(e->child);
+        return nullptr;
+    };
+    for (OpNode* p : projections) {
+        for (Expr* e : p->exprs) q.pool.addId(e);
+        std::vector<std::pair<std::string, const Src*>> defs;
+        std::vector<Src> keep;
+        keep.reserve(p->exprs.size());
+        for (Expr* e : p->exprs) {
+            const Src* r = resolve(e);
+            if (r) { keep.push_back(*r); defs.emplace_back(expressionName(e), &keep.back()); }
+            else defs.emplace_back(expressionName(e), nullptr);
+        }
+        for (auto& d : defs) { if (d.second) src[d.first] = *d.second; else src.erase(d.first); }
+    }
+    Expr* first = orderBy->exprs[0];
+    auto it = src.find(first->child->symbol);
+    if (it == src.end()) return;
+    const Type& t = it->second.second;
+    if (t.tag == RSQ_BIGINT || t.tag == RSQ_DECIMAL) q.topkIs32 = false;
+    else if (t.tag == RSQ_INT || t.tag == RSQ_DATE) q.topkIs32 = true;
+    else return;
+    q.topkDesc = first->tag == RSQ_E_DESC;
+    q.topkWant = (uint32_t)orderBy->limit + 1;
+    q.topkWord = it->second.first;
+}
+
 void runTail(Query& q) {
+    q.tailNeedsAllGroups = false;
     if (!q.agg) { runMaterializeTail(q); return; }
     OpNode* agg = q.agg;
     const bool trace = getenv("RSQ_TRACE") != nullptr;
@@ -544,7 +611,12 @@ void runTail(Query& q) {
 
     // ---- ORDER BY ... LIMIT k over many groups: the k first rows of the sorted order are determined by the
     // sort keys alone unless rows tie on ALL of them; select them without sorting (or replaying) everything ----
-    if (orderBy && orderBy->hasLimit && !mat->hasLimit && orderBy->limit >= 0 && (size_t)orderBy->limit * 4 < G.n) {
+    const size_t allGroups = q.candidateRun ? (size_t)q.totalGroups : G.n;
+    if (q.candidateRun && !(orderBy && orderBy->hasLimit && !mat->hasLimit && orderBy->limit >= 0 && (size_t)orderBy->limit * 4 < allGroups)) {
+        q.tailNeedsAllGroups = true;
+        return;
+    }
+    if (orderBy && orderBy->hasLimit && !mat->hasLimit && orderBy->limit >= 0 && (size_t)orderBy->limit * 4 < allGroups) {
         const size_t k = (size_t)orderBy->limit;
         std::vector<uint8_t> all(G.n * ts);
         materializeMany(G.n, [](size_t i) { return i; }, all.data());
@@ -570,7 +642,8 @@ void runTail(Query& q) {
             q.resultRows = (int64_t)std::min(k, G.n);
             return;
         }
-        // ties among the leading rows: fall through to the faithful path
+        // ties among the leading rows: fall through to the faithful path, which needs every group
+        if (q.candidateRun) { q.tailNeedsAllGroups = true; return; }
     }
 
     std::vector<size_t> order = emissionOrder();

@@ -117,7 +117,7 @@ def q6_plan(lineitem: P.Table, date_lo: str = "1994-01-01", date_hi: str = "1995
 
 
 def q3_plan(customer: P.Table, orders: P.Table, lineitem: P.Table, segment: str = "BUILDING",
-            date: str = "1995-03-15", limit: int = 10) -> P.Plan:
+            date: str = "1995-03-15", limit: int = 10, order_by=None) -> P.Plan:
     """tpch/queries/q3.sql; plan:
     OrderBy <- Materialize <- Projection <- Aggregation <-
         HashJoin[ build = HashJoin[ build = sel(customer), probe = sel(orders) ] (multi-match),
@@ -132,7 +132,7 @@ def q3_plan(customer: P.Table, orders: P.Table, lineitem: P.Table, segment: str 
     rev = p.sum(p.mul(p.attr("l_extendedprice"), p.sub(p.constant("1", P.BIGINT), p.attr("l_discount"))))
     plan = p.aggregation([rev], [g_ok, g_od, g_sp], hj2)
     plan = p.projection([g_ok, p.as_("revenue", rev), g_od, g_sp], plan)
-    plan = p.orderby([p.desc(p.attr("revenue")), p.attr("o_orderdate")], plan)
+    plan = p.orderby(order_by(p) if order_by else [p.desc(p.attr("revenue")), p.attr("o_orderdate")], plan)
     return p.set_root(plan, limit=limit)
 
 
