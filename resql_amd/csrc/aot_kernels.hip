@@ -296,56 +296,67 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value) {
     RSQ_HIP(hipGetLastError());
 }
 
+// Each workgroup owns chunks of 256 x 16 consecutive slots.  All 16 first-row words of a thread are loaded up front
+// (independent, coalesced across the workgroup), the occupied ones are counted, an LDS scan gives every thread its
+// offset and ONE global atomic per workgroup and chunk reserves the output rows: returning atomics on a single word
+// serialise at ~11 ns each on MI355X (MI355X_MICROARCH.md, "fanin"), so one per occupied slot — or one per wave and
+// round, 54 K of them for TPC-H Q3 at SF10 — cost 620 us.  The table's first-row block is read once (the earlier
+// count-then-write form read it twice with 32 dependent rounds per thread: 73 us for 4 M slots; this form: see DESIGN).
+// Rows beyond `maxRows` are counted but not written (the host re-runs with a larger buffer).
+enum { COMPACT_PER_THREAD = 16 };
 __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__ first, i64 cap, const i64* __restrict__ words, int nWords,
-                                                         const i64* __restrict__ acc, int nAcc, i64* __restrict__ out, unsigned* count) {
+                                                         const i64* __restrict__ acc, int nAcc, i64* __restrict__ out, unsigned maxRows,
+                                                         unsigned* count) {
     const int stride = 1 + nWords + nAcc;
-    const int lane = threadIdx.x & 63;
-    // Output rows are reserved with ONE global atomic per workgroup: returning atomics on a single word serialise at
-    // ~11 ns each on MI355X (MI355X_MICROARCH.md, "fanin"), so one per occupied slot — or even one per wave and
-    // iteration, 54 K of them for TPC-H Q3 at SF10 — cost 620 us, a third of the query's device time.
-    // Each workgroup owns a contiguous chunk of slots: pass A counts its occupied slots, one atomic reserves the rows,
-    // pass B writes them at positions handed out by an LDS cursor.
-    __shared__ unsigned s_total, s_base, s_cursor;
-    if (threadIdx.x == 0) { s_total = 0; s_cursor = 0; }
-    __syncthreads();
-    const i64 chunk = (cap + gridDim.x - 1) / gridDim.x;
-    const i64 lo = (i64)blockIdx.x * chunk, hi = lo + chunk < cap ? lo + chunk : cap;
-    const i64 rounds = (chunk + blockDim.x - 1) / blockDim.x;
-    unsigned mine = 0;
-    for (i64 r = 0; r < rounds; r++) {
-        const i64 s = lo + r * blockDim.x + threadIdx.x;
-        if (s < hi && first[s] != 0x7fffffffffffffffll) mine++;
-    }
-    for (int m = 32; m >= 1; m >>= 1) mine += (unsigned)__shfl_xor((int)mine, m, 64);
-    if (lane == 0 && mine) atomicAdd(&s_total, mine);
-    __syncthreads();
-    if (threadIdx.x == 0) s_base = s_total ? atomicAdd(count, s_total) : 0u;
-    __syncthreads();
-    if (s_total == 0) return;
-    const unsigned base = s_base;
-    for (i64 r = 0; r < rounds; r++) {
-        const i64 s = lo + r * blockDim.x + threadIdx.x;
-        const i64 f = s < hi ? first[s] : 0x7fffffffffffffffll;
-        const bool has = f != 0x7fffffffffffffffll;
-        const unsigned long long vote = __ballot(has);
-        if (vote == 0) continue;
-        unsigned wbase = 0;
-        if (lane == 0) wbase = atomicAdd(&s_cursor, (unsigned)__popcll(vote));
-        wbase = (unsigned)__shfl((int)wbase, 0, 64);
-        if (!has) continue;
-        const unsigned pos = base + wbase + (unsigned)__popcll(vote & ((1ull << lane) - 1ull));
-        i64* o = out + (size_t)pos * stride;
-        o[0] = f;
-        for (int w = 0; w < nWords; w++) o[1 + w] = words[(size_t)w * cap + s];
-        for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned s_base;
+    const i64 chunkSlots = 256 * COMPACT_PER_THREAD;
+    for (i64 lo = (i64)blockIdx.x * chunkSlots; lo < cap; lo += (i64)gridDim.x * chunkSlots) {
+        i64 f[COMPACT_PER_THREAD];
+        unsigned mine = 0;
+#pragma unroll
+        for (int r = 0; r < COMPACT_PER_THREAD; r++) {
+            const i64 s = lo + r * 256 + t;
+            f[r] = s < cap ? first[s] : 0x7fffffffffffffffll;
+            mine += f[r] != 0x7fffffffffffffffll ? 1u : 0u;
+        }
+        // exclusive prefix of `mine` over the workgroup: wave scan (shuffles), then the four wave totals
+        unsigned incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned v = (unsigned)__shfl_up((int)incl, d, 64); if (lane >= d) incl += v; }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const unsigned c = s_wave[w]; if (w < wave) before += c; total += c; }
+        if (t == 0) s_base = total ? atomicAdd(count, total) : 0u;
+        __syncthreads();
+        if (total) {
+            unsigned pos = s_base + before + incl - mine;
+#pragma unroll
+            for (int r = 0; r < COMPACT_PER_THREAD; r++) {
+                if (f[r] == 0x7fffffffffffffffll) continue;
+                if (pos < maxRows) {
+                    const i64 s = lo + r * 256 + t;
+                    i64* o = out + (size_t)pos * stride;
+                    o[0] = f[r];
+                    for (int w = 0; w < nWords; w++) o[1 + w] = words[(size_t)w * cap + s];
+                    for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
+                }
+                pos++;
+            }
+        }
+        __syncthreads();          // s_wave / s_base are rewritten by the next chunk
     }
 }
 
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,
-                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t* count) {
-    unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512, (capacity + 2047) / 2048));
+                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count) {
+    const int64_t chunkSlots = 256 * COMPACT_PER_THREAD;
+    unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8 * (int64_t)ctx.numCUs, (capacity + chunkSlots - 1) / chunkSlots));
     hipLaunchKernelGGL(k_compact_entries, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, (const i64*)words, nWords,
-                       (const i64*)acc, nAcc, (i64*)outRows, count);
+                       (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count);
     RSQ_HIP(hipGetLastError());
 }
 
@@ -410,14 +421,14 @@ __device__ u64 topk_prefix(const unsigned* __restrict__ hists, int upto, unsigne
 // pass p: histogram of digit p over the rows whose higher digits equal the prefix chosen so far.  Pass 0 also
 // extracts the key images from the group rows.
 __global__ void __launch_bounds__(256) k_topk_hist(const i64* __restrict__ rows, int stride, int keyWord, int is32, int desc,
-                                                   const unsigned* __restrict__ nRows, u64* __restrict__ images,
+                                                   const unsigned* __restrict__ nRows, unsigned maxRows, u64* __restrict__ images,
                                                    unsigned* __restrict__ hists, int pass, unsigned want) {
     __shared__ unsigned s_hist[TOPK_BINS];
     for (int b = threadIdx.x; b < TOPK_BINS; b += 256) s_hist[b] = 0;
     unsigned rem; int all;
     const u64 prefix = topk_prefix(hists, pass, want, &rem, &all);      // contains the barriers that publish s_hist = 0
     if (all) return;
-    const unsigned n = *nRows;
+    const unsigned n = *nRows < maxRows ? *nRows : maxRows;
     const int shift = topk_shift(pass);
     const unsigned mask = (1u << topk_bits(pass)) - 1u;
     const int above = shift + topk_bits(pass);                          // bits above this digit
@@ -435,12 +446,12 @@ __global__ void __launch_bounds__(256) k_topk_hist(const i64* __restrict__ rows,
 
 // rows whose image is >= T, in no particular order; *candCount counts all of them, rows beyond `capacity` are dropped
 // (the host then falls back to reading every group)
-__global__ void __launch_bounds__(256) k_topk_gather(const i64* __restrict__ rows, int stride, const unsigned* __restrict__ nRows,
+__global__ void __launch_bounds__(256) k_topk_gather(const i64* __restrict__ rows, int stride, const unsigned* __restrict__ nRows, unsigned maxRows,
                                                      const u64* __restrict__ images, const unsigned* __restrict__ hists, unsigned want,
                                                      i64* __restrict__ cand, unsigned capacity, unsigned* candCount) {
     unsigned rem; int all;
     const u64 T = topk_prefix(hists, TOPK_PASSES, want, &rem, &all);
-    const unsigned n = *nRows;
+    const unsigned n = *nRows < maxRows ? *nRows : maxRows;
     const int lane = threadIdx.x & 63;
     const unsigned rounds = (n + gridDim.x * 256u - 1) / (gridDim.x * 256u);
     for (unsigned r = 0; r < rounds; r++) {
@@ -470,9 +481,9 @@ void selectTopCandidates(Context& ctx, const int64_t* rows, int stride, int keyW
     RSQ_HIP(hipMemsetAsync(candCount, 0, 4, ctx.stream));
     for (int p = 0; p < TOPK_PASSES; p++)
         hipLaunchKernelGGL(k_topk_hist, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
-                           (const unsigned*)nRows, (u64*)images, (unsigned*)hists, p, (unsigned)want);
-    hipLaunchKernelGGL(k_topk_gather, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, (const unsigned*)nRows, (const u64*)images,
-                       (const unsigned*)hists, (unsigned)want, (i64*)cand, (unsigned)capacity, (unsigned*)candCount);
+                           (const unsigned*)nRows, (unsigned)rowsUpperBound, (u64*)images, (unsigned*)hists, p, (unsigned)want);
+    hipLaunchKernelGGL(k_topk_gather, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, (const unsigned*)nRows, (unsigned)rowsUpperBound,
+                       (const u64*)images, (const unsigned*)hists, (unsigned)want, (i64*)cand, (unsigned)capacity, (unsigned*)candCount);
     RSQ_HIP(hipGetLastError());
 }
 

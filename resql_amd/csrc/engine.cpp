@@ -459,6 +459,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     const bool trace0 = getenv("RSQ_TRACE") != nullptr;
     const char* genv = getenv("RSQ_GRAPH");
     uint32_t topkCapacity = 0, topkSpec = 0;      // > 0: this execution pre-selects ORDER BY ... LIMIT candidates on the device
+    uint32_t groupRowsAllocated = 0;              // rows the group-row buffers of this execution can take
     // ---- graph path: one plain pipeline into a dense table, on the context's own stream ----
     if (denseMode(q) && q.pipelines.size() == 1 && q.pipelines[0].sink == SinkKind::AGGREGATE && !q.pipelines[0].partitioned &&
         !trace0 && !q.graphFailed && ctx.stream == ctx.ownStream && !(genv && atoi(genv) == 0)) {
@@ -581,11 +582,18 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         HashTable& h = *q.hashTables[(size_t)q.aggTable];
         const int nTab = (int)(h.keys.size() + h.payload.size());
         q.groupRowWords = 1 + nTab + h.nAccBlocks;
-        uint32_t nEntries = 0;
-        RSQ_HIP(hipMemcpyAsync(&nEntries, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
-        RSQ_HIP(hipStreamSynchronize(ctx.stream));
-        h.lastCount = nEntries;
-        size_t need = (size_t)std::max<uint32_t>(1, nEntries) * (size_t)q.groupRowWords;
+        // Rows to provide for: the number of occupied entries.  It is read back (one synchronisation) on the first
+        // execution; later executions of a join-entry aggregation reuse it — the build reads the same table — and the
+        // compaction never writes beyond the buffer: a larger count is noticed after the final synchronisation and
+        // the execution is repeated with a fresh count.
+        uint32_t nEntries = h.lastCount;
+        if (q.aggMode != AggMode::AT_JOIN_ENTRY || nEntries == 0 || getenv("RSQ_TRACE")) {
+            RSQ_HIP(hipMemcpyAsync(&nEntries, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            h.lastCount = nEntries;
+        }
+        groupRowsAllocated = std::max<uint32_t>(1, nEntries);
+        size_t need = (size_t)groupRowsAllocated * (size_t)q.groupRowWords;
         if (q.hGroupRowsWords < need) {
             if (q.dGroupRows) ctx.free(q.dGroupRows);
             q.dGroupRows = (int64_t*)ctx.alloc(need * 8);
@@ -597,7 +605,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
         RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.dAcc, h.nAccBlocks,
-                       q.dGroupRows, q.dGroupCount);
+                       q.dGroupRows, groupRowsAllocated, q.dGroupCount);
         q.report.num_kernels++;
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
         if (q.topkWord == -2) planDeviceTopK(q);
@@ -614,7 +622,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 q.dCandRows = (int64_t*)ctx.alloc((size_t)topkCapacity * (size_t)q.groupRowWords * 8);
                 q.candCapacity = topkCapacity; q.candRowWords = q.groupRowWords;
             }
-            selectTopCandidates(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, nEntries, q.topkWant,
+            selectTopCandidates(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated, q.topkWant,
                                 q.dTopkImages, q.dTopkHists, q.dCandRows, topkCapacity, q.dCandCount);
             q.report.num_kernels += 7;
             // the leading candidates travel with the same synchronisation as the counts (usually that is all of them)
@@ -654,6 +662,13 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             }
         } else {
             const int64_t nGroups = (int64_t)(uint32_t)q.hPinned[words + 1];
+            if (nGroups > (int64_t)groupRowsAllocated) {
+                // more groups than the remembered entry count provided for (the build side changed under us): start over
+                q.hashTables[(size_t)q.aggTable]->lastCount = 0;
+                if (q.aggMode != AggMode::AT_JOIN_ENTRY) failRuntime("internal error: more groups than hash-table entries");
+                executeQuery(q, partialOnly, async);
+                return;
+            }
             const int64_t nCand = topkCapacity ? (int64_t)(uint32_t)q.hPinned[words + 2] : 0;
             const size_t rowBytes = (size_t)q.groupRowWords * 8;
             q.candidateRun = false;
