@@ -162,6 +162,32 @@ char* rsq_serialize_expr(rsq_ctx* ctx, const rsq_plan_desc* plan, int32_t expr, 
 char* rsq_result_serialize(const rsq_result_view* view);
 void  rsq_free(void* p);
 
+/* ---- SQL text in front of the path --------------------------------------
+ * The reference turns SQL text into an operator tree with parseSql (src/parser/parseSql.h:130-166:
+ * tokens of src/parser/lexer.y, grammar of src/parser/parser.y) and buildQuery (src/planner.h:409-497),
+ * then calls executeSelectPlan (src/execute.h:213-247) — the boundary above.  These entry points are
+ * that front end for a host that has no ReSQL planner of its own: the same tokens, grammar, desugaring
+ * (BETWEEN, IN, CASE) and planning rules, producing the plan description of resql_plan.h.
+ *
+ * `tables` is the database: every table a FROM clause may name (rsq_table carries name, schema and
+ * row count — what Database::relations holds, src/dbdata.h).  Scan operators of the plan index into it,
+ * so the same array goes to rsq_query_compile.  Errors: RSQ_ERR_INVALID "Syntax error." (execute.h:520-523),
+ * "Table x does not exist." (planner.h:437-439); RSQ_ERR_UNSUPPORTED for plans that need a nested-loops join. */
+typedef struct rsq_sql_plan rsq_sql_plan;
+int  rsq_sql_plan_select(rsq_ctx* ctx, const char* sql, rsq_table* const* tables, int32_t n_tables, rsq_sql_plan** out);
+const rsq_plan_desc* rsq_sql_plan_desc(const rsq_sql_plan* plan);
+void rsq_sql_plan_destroy(rsq_sql_plan* plan);
+/* the operator tree as text (what `showplan` prints in spirit; tests compare it with the reference's planner);
+ * malloc'ed, rsq_free.  The tables passed to rsq_sql_plan_select must still be alive. */
+char* rsq_sql_plan_text(const rsq_sql_plan* plan);
+/* parse + plan + rsq_query_compile in one call (executeSelect, src/execute.h:250-260, up to ctx.compile()) */
+int  rsq_sql_compile(rsq_ctx* ctx, const char* sql, rsq_table* const* tables, int32_t n_tables, rsq_query** out);
+/* The statement as text, for hosts that dispatch on its kind (executeStatement, src/execute.h:508-545) and for
+ * tests: what = 0 the token names one per line ("NAME text"), what = 1 the parsed statement ("SELECT" with its
+ * clause expressions, "CREATE_TABLE name" + "column name TYPE" lines, "BULK_INSERT name" + file / fieldterminator /
+ * firstrow lines).  Returns a malloc'ed string (rsq_free) or NULL with rsq_last_error set. */
+char* rsq_sql_describe(rsq_ctx* ctx, const char* sql, int32_t what);
+
 /* Sustained read-only streaming bandwidth of this GPU (grid-stride int64 sum over `bytes` of
  * resident memory): the measured roofline SURVEY.md §8(d) quotes fractions against. */
 int  rsq_measure_read_bandwidth(rsq_ctx* ctx, size_t bytes, int32_t iters, double* gb_per_s);

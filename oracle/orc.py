@@ -181,3 +181,47 @@ def run_reference(plan: P.Plan, threads: int = 1, repeat: int = 1, blocksize: Op
         if own:
             import shutil
             shutil.rmtree(tmp, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# the compiled reference's SQL front end: its Lemon grammar and its planner, driven by token streams
+# (no flex in the image: the tokenizer is the one piece of the front end the reference cannot provide here)
+# ------------------------------------------------------------------------------------------------
+def reference_parse(tokens_text: str) -> str:
+    """tokens ("NAME text" per line) -> the reference's Parse() -> canonical dump of its Query"""
+    if not have_reference():
+        raise OracleError("oracle/_ref/ref_harness is not built")
+    with tempfile.TemporaryDirectory(prefix="resql_sql_") as tmp:
+        tp = os.path.join(tmp, "tokens.txt")
+        with open(tp, "w", encoding="latin1") as f:
+            f.write(tokens_text)
+        pr = subprocess.run([REF_HARNESS, "-", "--sql-tokens", tp, "--dump-parse"], capture_output=True, text=True, errors="replace")
+        if pr.returncode != 0:
+            raise OracleError(f"ref_harness failed ({pr.returncode}): {pr.stderr[-2000:]}")
+        return pr.stdout
+
+
+def run_reference_sql(tables: Sequence[P.Table], tokens_text: str, dump_plan: bool = False, threads: int = 1) -> str:
+    """tokens -> the reference's parser -> the reference's planner (buildQuery over `tables`) -> either the plan dump or
+    the result of the reference's own execution"""
+    if not have_reference():
+        raise OracleError("oracle/_ref/ref_harness is not built")
+    with tempfile.TemporaryDirectory(prefix="resql_sql_") as tmp:
+        shell = P.Plan(tables)
+        shell.root = 0
+        case = write_case(shell, tmp)
+        tp = os.path.join(tmp, "tokens.txt")
+        with open(tp, "w", encoding="latin1") as f:
+            f.write(tokens_text)
+        cmd = [REF_HARNESS, case, "--sql-tokens", tp, "--threads", str(threads)]
+        if dump_plan:
+            cmd.append("--dump-plan")
+        pr = subprocess.run(cmd, capture_output=True, text=True, errors="replace")
+        if pr.returncode == 3:
+            raise OracleError("reference refused the statement: " + pr.stderr[-500:])
+        if pr.returncode != 0:
+            raise OracleError(f"ref_harness failed ({pr.returncode}): {pr.stderr[-2000:]}")
+        if not dump_plan and "#timing" not in pr.stderr:
+            msg = [l for l in pr.stderr.splitlines() if l.startswith("Error: ")]
+            raise OracleError("reference refused the plan: " + (msg[0][7:] if msg else pr.stderr[-500:]))
+        return pr.stdout

@@ -20,6 +20,16 @@
 #include "dbdata.h"
 #include "schema.h"
 #include "JitContextFlounder.h"
+// The reference's SQL front end: its Lemon grammar (parser.h / parser.c are generated into oracle/_ref/ by the
+// reference's own vendored lemon.c from src/parser/parser.y — see oracle/Makefile) and its planner.  The flex
+// tokenizer (src/parser/lexer.y) cannot be generated here (no flex in the image), so `--sql-tokens FILE` feeds the
+// reference's Parse() a token stream instead of calling yylex().  parseSql() — the only user of the flex symbols — is
+// given internal linkage for this translation unit (`Query static parseSql_unused(...)`): it is never called, so it is
+// not emitted and the binary links without any stand-in for the tokenizer.
+#define parseSql static parseSql_unused
+#include "parser/parseSql.h"
+#undef parseSql
+#include "planner.h"
 
 #ifdef RSQ_WITH_HIP_BINDING
 #include "resql_hip_binding.h"     // integration/: ReSQL operator tree -> include/resql_hip.h
@@ -253,7 +263,15 @@ struct PlanBuilder {
         Expr* e = nullptr;
         const std::string& t = s.tag;
         if (t == "ATTRIBUTE") e = ExprGen::attr(s.args.at(0));
-        else if (t == "CONSTANT") e = ExprGen::constant(s.rest, parseCategory(s.args.at(0)));
+        else if (t == "CONSTANT") {
+            if (s.rest.compare(0, 4, "neg ") == 0) {
+                // a negated literal of the SQL grammar (parser.y:149-151): parsed from the unsigned text, then the value is negated
+                e = ExprGen::constant(s.rest.substr(4), parseCategory(s.args.at(0)));
+                if (e->type.tag == SqlType::BIGINT) e->value.bigintData *= -1;
+                else if (e->type.tag == SqlType::DECIMAL) e->value.decimalData *= -1;
+                else die("neg constant of unsupported category");
+            } else e = ExprGen::constant(s.rest, parseCategory(s.args.at(0)));
+        }
         else if (t == "STAR") e = ExprGen::star();
         else if (t == "AS") e = ExprGen::as(s.args.at(0), expr(std::stoi(s.args.at(1))));
         else if (t == "SUM") e = ExprGen::sum(A(0));
@@ -341,6 +359,98 @@ struct PlanBuilder {
     }
 };
 
+// ---- SQL front end: tokens -> the reference's Lemon parser -> the reference's planner --------------------------
+struct TokenName { const char* name; int code; };
+#define TKN(x) {#x, x}
+const TokenName kTokenNames[] = {
+    TKN(OR_TK), TKN(AND_TK), TKN(LT_TK), TKN(GT_TK), TKN(LE_TK), TKN(GE_TK), TKN(EQ_TK), TKN(NEQ_TK), TKN(BETWEEN_TK), TKN(IN_TK),
+    TKN(PLUS_TK), TKN(MINUS_TK), TKN(MUL_TK), TKN(DIV_TK), TKN(LIKE_TK), TKN(TYPECAST_TK), TKN(SUM_TK), TKN(CREATE_TABLE_TK),
+    TKN(IDENTIFIER), TKN(LPAREN), TKN(RPAREN), TKN(BULK_INSERT_TK), TKN(FROM), TKN(STRING_CONSTANT), TKN(WITH_TK), TKN(COMMA),
+    TKN(FIRSTROW_TK), TKN(INTEGER_CONSTANT), TKN(FIELDTERMINATOR_TK), TKN(SELECT_TK), TKN(WHERE), TKN(GROUPBY), TKN(ORDERBY),
+    TKN(LIMIT_TK), TKN(AS_TK), TKN(AVG_TK), TKN(MIN_TK), TKN(MAX_TK), TKN(COUNT_TK), TKN(ASC_TK), TKN(DESC_TK), TKN(CASE_TK),
+    TKN(END_TK), TKN(ELSE_TK), TKN(WHEN_TK), TKN(THEN_TK), TKN(DECIMAL_CONSTANT), TKN(FLOAT_CONSTANT), TKN(DATE_TK), TKN(INT_TK),
+    TKN(BIGINT_TK), TKN(CHAR_TK), TKN(VARCHAR_TK), TKN(DECIMAL_TK),
+};
+#undef TKN
+
+// parseSql (parseSql.h:130-166) with the tokens read from a file ("NAME text" per line) instead of yylex()
+Query parseTokens(const std::string& path) {
+    Query query = {Query::UNKNOWN, nullptr, nullptr, nullptr, nullptr, nullptr, "", nullptr, "", ",", 0, false, false, nullptr, {}, {},
+                   false, false, 0};
+    std::ifstream f(path);
+    if (!f.is_open()) die("cannot open " + path);
+    void* parser = ParseAlloc(malloc);
+    std::string line;
+    while (std::getline(f, line)) {
+        if (line == "ERROR") { query.parseError = true; break; }        // the tokenizer met a character no rule matches
+        size_t sp = line.find(' ');
+        std::string name = line.substr(0, sp), text = sp == std::string::npos ? "" : line.substr(sp + 1);
+        int code = -1;
+        for (auto& t : kTokenNames) if (name == t.name) code = t.code;
+        if (code < 0) die("unknown token name " + name);
+        Expr* node = initializeIfConstant(code, text);
+        Parse(parser, code, node, &query);
+    }
+    Parse(parser, 0, 0, &query);
+    ParseFree(parser, free);
+    return query;
+}
+
+void dumpExpr(Expr* e, std::ostream& os) {
+    os << "(" << exprTagNames[e->tag];
+    if (e->tag == Expr::ATTRIBUTE || e->tag == Expr::AS || e->tag == Expr::TABLE) os << " " << e->symbol;
+    if (e->tag == Expr::CONSTANT) os << " " << serializeType(e->type) << " [" << serializeSqlValue(e->value, e->type) << "]";
+    if (e->tag == Expr::TYPECAST) os << " " << serializeType(e->type);
+    // operands as the reference's consumers see them (child, child->next for BINARY), not the whole sibling chain
+    const int limit = e->structureTag == Expr::UNARY ? 1 : e->structureTag == Expr::BINARY ? 2 : e->structureTag == Expr::LITERAL ? 0 : 1 << 30;
+    int n = 0;
+    for (Expr* c = e->child; c && n < limit; c = c->next, n++) { os << " "; dumpExpr(c, os); }
+    os << ")";
+}
+void dumpList(const char* label, Expr* e, std::ostream& os) {
+    os << label << ":";
+    for (; e; e = e->next) { os << " "; dumpExpr(e, os); }
+    os << "\n";
+}
+void dumpQuery(Query& q, std::ostream& os) {
+    if (q.parseError) { os << "SYNTAX ERROR\n"; return; }
+    if (q.tag == Query::SELECT) {
+        os << "SELECT\n";
+        dumpList("select", q.selectExpr, os); dumpList("from", q.fromExpr, os); dumpList("where", q.whereExpr, os);
+        dumpList("groupby", q.groupbyExpr, os); dumpList("orderby", q.orderbyExpr, os);
+        os << "limit: " << (q.useLimit ? std::to_string(q.limit) : std::string("none")) << "\n";
+    } else if (q.tag == Query::CREATE_TABLE) {
+        os << "CREATE_TABLE " << q.tableName << "\n";
+        for (Expr* e = q.schemaExpr; e; e = e->next) os << "column " << e->symbol << " " << serializeType(e->type) << "\n";
+    } else if (q.tag == Query::BULK_INSERT) {
+        os << "BULK_INSERT " << q.tableName << "\nfile " << q.fileName << "\nfieldterminator " << q.fieldTerminator << "\nfirstrow "
+           << q.firstRow << "\n";
+    } else os << "UNKNOWN\n";
+}
+void dumpVec(ExprVec& v, std::ostream& os) {
+    os << " [";
+    for (size_t i = 0; i < v.size(); i++) { if (i) os << " "; dumpExpr(v[i], os); }
+    os << "]";
+}
+void dumpOp(RelOperator* o, Database& db, std::ostream& os) {
+    // by dynamic type, not by RelOperator::tag: MaterializeOp constructs itself with the SELECTION tag (materialize.h:33)
+    if (dynamic_cast<MaterializeOp*>(o)) os << "MATERIALIZE";
+    else if (auto* sc = dynamic_cast<ScanOp*>(o)) {
+        os << "SCAN";
+        for (auto& r : db.relations) if (&r.second == sc->_rel) os << " " << r.first;
+    }
+    else if (auto* se = dynamic_cast<SelectionOp*>(o)) { os << "SELECTION ["; dumpExpr(se->_condition, os); os << "]"; }
+    else if (auto* pr = dynamic_cast<ProjectionOp*>(o)) { os << "PROJECTION"; dumpVec(pr->_expr, os); }
+    else if (auto* hj = dynamic_cast<HashJoinOp*>(o)) { os << "HASHJOIN single=" << (hj->_singleMatch ? 1 : 0); dumpVec(hj->_equalities, os); }
+    else if (auto* ag = dynamic_cast<AggregationOp*>(o)) { os << "AGGREGATION"; dumpVec(ag->_aggExpr, os); dumpVec(ag->_groupExpr, os); }
+    else if (auto* ob = dynamic_cast<OrderByOp*>(o)) { os << "ORDERBY"; dumpVec(ob->_orderExpressions, os); }
+    else if (dynamic_cast<NestedLoopsJoinOp*>(o)) os << "NESTEDLOOPSJOIN";
+    else os << "UNDEFINED";
+    os << " {";
+    for (size_t i = 0; i < o->children.size(); i++) { if (i) os << " "; dumpOp(o->children[i], db, os); }
+    os << "}";
+}
+
 std::map<std::string, SqlType> identTypes(Database& db) {
     std::map<std::string, SqlType> res;
     for (auto const& rel : db.relations)
@@ -355,6 +465,7 @@ int main(int argc, char** argv) {
     std::string casePath = argv[1];
     int threads = 1, repeat = 1; bool quiet = false; std::string outPath;
     std::string engine = "flounder"; int device = 0;
+    std::string sqlTokens; bool dumpParse = false, dumpPlan = false;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--threads") threads = atoi(argv[++i]);
@@ -364,9 +475,18 @@ int main(int argc, char** argv) {
         else if (a == "--quiet") quiet = true;
         else if (a == "--engine") engine = argv[++i];        // "flounder" (the reference's own JIT) | "hip"
         else if (a == "--device") device = atoi(argv[++i]);
+        else if (a == "--sql-tokens") sqlTokens = argv[++i];   // plan from the reference's parser + planner instead of the case's op lines
+        else if (a == "--dump-parse") dumpParse = true;
+        else if (a == "--dump-plan") dumpPlan = true;
         else die("unknown option " + a);
     }
 
+    if (dumpParse) {
+        if (sqlTokens.empty()) die("--dump-parse needs --sql-tokens");
+        Query q = parseTokens(sqlTokens);
+        dumpQuery(q, std::cout);
+        return 0;
+    }
     CaseSpec c = parseCase(casePath);
     Database db;
     Timer tLoad;
@@ -391,8 +511,28 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < repeat; rep++) {
         // plans are single use (operators own iterators / hash tables): rebuild per repetition
         PlanBuilder pb{c, db, {}, {}};
-        RelOperator* root = pb.op(c.root);
-        if (c.hasLimit) root->addLimit(c.limit);
+        RelOperator* root = nullptr;
+        if (!sqlTokens.empty()) {
+            // executeStatement / executeSelect (execute.h:508-545, 250-260) minus the tokenizer
+            Query query = parseTokens(sqlTokens);
+            if (query.parseError) { std::cerr << "ResqlError: Syntax error."; return 3; }
+            if (query.tag != Query::SELECT) die("--sql-tokens expects a select statement");
+            try { buildQuery(query, db); }
+            catch (ResqlError& err) { std::cerr << "ResqlError: " << err.message(); return 3; }
+            if (query.plan == nullptr) { std::cerr << "ResqlError: Could not generate query plan."; return 3; }
+            root = query.plan;
+            c.requestAll = query.requestAll;
+            if (dumpPlan) {
+                std::cout << "limit " << (query.useLimit ? std::to_string(query.limit) : std::string("none")) << " requestall "
+                          << (query.requestAll ? 1 : 0) << "\n";
+                dumpOp(root, db, std::cout);
+                std::cout << "\n";
+                return 0;
+            }
+        } else {
+            root = pb.op(c.root);
+            if (c.hasLimit) root->addLimit(c.limit);
+        }
 
 #ifdef RSQ_WITH_HIP_BINDING
         if (hip) {

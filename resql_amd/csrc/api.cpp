@@ -4,6 +4,7 @@
 #include <thread>
 
 #include "engine.h"
+#include "sqlfront.h"
 #include "hostref.h"
 
 using namespace rsq;
@@ -269,6 +270,63 @@ char* rsq_result_serialize(const rsq_result_view* view) {
 }
 
 void rsq_free(void* p) { free(p); }
+
+// ---- SQL front end (sqlfront.cpp) ----
+struct rsq_sql_plan { rsq::ExprPool pool; rsq::sql::Statement st; rsq::sql::PlanDesc plan; std::vector<Table*> db; };
+
+int rsq_sql_plan_select(rsq_ctx* ctx, const char* sqlText, rsq_table* const* tables, int32_t n_tables, rsq_sql_plan** out) {
+    if (!ctx || !sqlText || !out || n_tables < 0) return RSQ_ERR_INVALID;
+    *out = nullptr;
+    return guarded(C(ctx), [&] {
+        std::unique_ptr<rsq_sql_plan> p(new rsq_sql_plan());
+        std::vector<Table*> db;
+        for (int i = 0; i < n_tables; i++) { if (!tables[i]) failInvalid("null table"); db.push_back(T(tables[i])); }
+        rsq::sql::parse(sqlText, p->pool, p->st);
+        if (p->st.kind != rsq::sql::Statement::SELECT) failInvalid("not a select statement");
+        rsq::sql::planSelect(p->st, p->pool, db, p->plan);
+        p->db = db;
+        *out = p.release();
+    });
+}
+const rsq_plan_desc* rsq_sql_plan_desc(const rsq_sql_plan* plan) { return plan ? &plan->plan.desc : nullptr; }
+void rsq_sql_plan_destroy(rsq_sql_plan* plan) { delete plan; }
+char* rsq_sql_plan_text(const rsq_sql_plan* plan) {
+    if (!plan) return nullptr;
+    try { return strdup(rsq::sql::dumpPlan(plan->plan.desc, plan->db).c_str()); }
+    catch (const std::exception& e) { return strdup((std::string("error: ") + e.what()).c_str()); }
+    catch (...) { return nullptr; }
+}
+
+int rsq_sql_compile(rsq_ctx* ctx, const char* sqlText, rsq_table* const* tables, int32_t n_tables, rsq_query** out) {
+    if (!out) return RSQ_ERR_INVALID;
+    *out = nullptr;
+    rsq_sql_plan* p = nullptr;
+    int st = rsq_sql_plan_select(ctx, sqlText, tables, n_tables, &p);
+    if (st != RSQ_OK) return st;
+    st = rsq_query_compile(ctx, &p->plan.desc, tables, n_tables, out);
+    delete p;
+    return st;
+}
+
+char* rsq_sql_describe(rsq_ctx* ctx, const char* sqlText, int32_t what) {
+    if (!ctx || !sqlText) return nullptr;
+    char* res = nullptr;
+    guarded(C(ctx), [&] {
+        if (what == 0) {
+            bool err = false;
+            std::string out;
+            for (auto& t : rsq::sql::tokenize(sqlText, err)) { out += t.name; out += " "; out += t.text; out += "\n"; }
+            if (err) out += "ERROR\n";
+            res = strdup(out.c_str());
+        } else {
+            rsq::ExprPool pool;
+            rsq::sql::Statement stmt;
+            rsq::sql::parse(sqlText, pool, stmt);
+            res = strdup(rsq::sql::dumpStatement(stmt).c_str());
+        }
+    });
+    return res;
+}
 
 int rsq_measure_read_bandwidth(rsq_ctx* ctx, size_t bytes, int32_t iters, double* gb_per_s) {
     if (!ctx || !gb_per_s || iters <= 0) return RSQ_ERR_INVALID;

@@ -69,10 +69,18 @@ static int structureOf(int tag) {
     }
 }
 
+static void parseConstant(Expr* e, int category);
+
 Expr* ExprPool::make(int tag, int structure, const std::string& symbol) {
     nodes.emplace_back(new Expr());
     Expr* e = nodes.back().get();
     e->tag = tag; e->structure = structure; e->symbol = symbol;
+    return e;
+}
+
+Expr* ExprPool::constant(const std::string& symbol, int category) {
+    Expr* e = make(RSQ_E_CONSTANT, LITERAL, symbol);
+    parseConstant(e, category);
     return e;
 }
 
@@ -91,6 +99,15 @@ static long long stoll_strict(const std::string& s) {
 }
 
 static void parseConstant(Expr* e, int category) {
+    e->category = category;
+    if (e->symbol.compare(0, 4, "neg ") == 0 && (category == RSQ_DECIMAL || category == RSQ_BIGINT)) {
+        // a negated literal of the SQL grammar (value ::= MINUS_TK constant, parser.y:149-151): typed from the unsigned text
+        e->symbol = e->symbol.substr(4);
+        parseConstant(e, category);
+        e->ival = (int64_t)(0 - (uint64_t)e->ival);
+        e->negated = true;
+        return;
+    }
     const std::string& sym = e->symbol;
     switch (category) {
         case RSQ_DECIMAL: {

@@ -56,6 +56,10 @@ struct Expr {
     Type type;
     int64_t ival = 0;          // numeric / date / bool / char(1) constant value
     size_t id = 0;             // expression id, assigned when first evaluated (expressions.h:1354-1358)
+    int category = RSQ_NT;     // constants: the type category the literal was parsed as
+    bool negated = false;      // constants from SQL text: `- literal` negates the VALUE, the type still follows from the
+                               // unsigned text (parser.y:149-151); travels in the plan description as "neg <text>"
+    bool explicitCast = false; // TYPECAST written in the query (expr :: type)
     std::vector<Expr*> children() const { std::vector<Expr*> v; for (Expr* c = child; c; c = c->next) v.push_back(c); return v; }
 };
 
@@ -68,6 +72,7 @@ struct ExprPool {
     int exprIdGen = 1;                        // RelationalContext.h:16
     Expr* make(int tag, int structure, const std::string& symbol);
     Expr* unary(int tag, const std::string& symbol, Expr* child);
+    Expr* constant(const std::string& symbol, int category);      // ExprGen::constant (expressions.h:520-524)
     // build from the C description; returns node per index
     std::vector<Expr*> build(const rsq_plan_desc& plan);
     void derive(Expr* e);                     // deriveExpressionTypes, expressions.h:1367-1392

@@ -98,6 +98,15 @@ def lib():
         L.rsq_result_serialize.argtypes = [C.POINTER(P.rsq_result_view)]
         L.rsq_free.argtypes = [vp]
         L.rsq_measure_read_bandwidth.argtypes = [vp, C.c_size_t, i32, C.POINTER(C.c_double)]
+        L.rsq_sql_plan_select.argtypes = [vp, C.c_char_p, C.POINTER(vp), i32, C.POINTER(vp)]
+        L.rsq_sql_plan_desc.restype = C.POINTER(P.rsq_plan_desc)
+        L.rsq_sql_plan_desc.argtypes = [vp]
+        L.rsq_sql_plan_destroy.argtypes = [vp]
+        L.rsq_sql_plan_text.restype = vp
+        L.rsq_sql_plan_text.argtypes = [vp]
+        L.rsq_sql_compile.argtypes = [vp, C.c_char_p, C.POINTER(vp), i32, C.POINTER(vp)]
+        L.rsq_sql_describe.restype = vp
+        L.rsq_sql_describe.argtypes = [vp, C.c_char_p, i32]
         _lib = L
     return _lib
 
@@ -110,6 +119,7 @@ EXPORTED_SYMBOLS = [
     "rsq_query_finalize", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
     "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
     "rsq_measure_read_bandwidth",
+    "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
 ]
 
 GEN_LINEITEM, GEN_ORDERS, GEN_CUSTOMER, GEN_SYNTHETIC = 0, 1, 2, 3
@@ -218,6 +228,48 @@ class Context:
         self._L.rsq_free(p)
         return s
 
+    # ---- SQL text (the reference's parseSql + buildQuery in front of the path) ----
+    def sql_describe(self, sql: str, what: int = 1) -> str:
+        """what=0: token names, what=1: the parsed statement (see resql_hip.h rsq_sql_describe)"""
+        p = self._L.rsq_sql_describe(self.h, sql.encode("latin1"), what)
+        if not p:
+            raise EngineError(2, self._L.rsq_last_error(self.h).decode())
+        s = C.string_at(p).decode("latin1")
+        self._L.rsq_free(p)
+        return s
+
+    def sql_plan(self, sql: str, tables: Sequence["DeviceTable"], host_tables: Sequence[P.Table] = ()) -> P.Plan:
+        """plan of a select statement over the database `tables`, as a P.Plan (scan operators name their table;
+        `host_tables` — same order — become plan.tables so that the oracle / the reference harness can run it)"""
+        arr = (C.c_void_p * max(1, len(tables)))(*[t.h for t in tables])
+        h = C.c_void_p()
+        self._check(self._L.rsq_sql_plan_select(self.h, sql.encode("latin1"), arr, len(tables), C.byref(h)))
+        try:
+            d = self._L.rsq_sql_plan_desc(h).contents
+            return P.Plan.from_c(d, [t.name for t in tables], list(host_tables))
+        finally:
+            self._L.rsq_sql_plan_destroy(h)
+
+    def sql_plan_text(self, sql: str, tables: Sequence["DeviceTable"]) -> str:
+        arr = (C.c_void_p * max(1, len(tables)))(*[t.h for t in tables])
+        h = C.c_void_p()
+        self._check(self._L.rsq_sql_plan_select(self.h, sql.encode("latin1"), arr, len(tables), C.byref(h)))
+        try:
+            p = self._L.rsq_sql_plan_text(h)
+            if not p:
+                raise EngineError(2, "rsq_sql_plan_text failed")
+            s = C.string_at(p).decode("latin1")
+            self._L.rsq_free(p)
+            return s
+        finally:
+            self._L.rsq_sql_plan_destroy(h)
+
+    def sql_compile(self, sql: str, tables: Sequence["DeviceTable"]) -> "Query":
+        arr = (C.c_void_p * max(1, len(tables)))(*[t.h for t in tables])
+        h = C.c_void_p()
+        self._check(self._L.rsq_sql_compile(self.h, sql.encode("latin1"), arr, len(tables), C.byref(h)))
+        return Query(self, h)
+
     def read_bandwidth(self, nbytes: int = 8 << 30, iters: int = 5) -> float:
         v = C.c_double()
         self._check(self._L.rsq_measure_read_bandwidth(self.h, nbytes, iters, C.byref(v)))
@@ -302,3 +354,63 @@ class Query:
         if self.h:
             self.ctx._L.rsq_query_destroy(self.h)
             self.h = None
+
+
+class Database:
+    """The statement loop of the reference's executeStatement (execute.h:508-545) over the engine: CREATE TABLE records
+    a schema, BULK INSERT loads a '.tbl' file into device columns (rsq_table_load_tbl), SELECT is parsed, planned,
+    compiled and executed.  Statements of a script are split at ';' like expandExecStatements (execute.h:470-505)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.schemas: dict = {}      # name -> P.Table without data (CREATE TABLE)
+        self.tables: dict = {}       # name -> DeviceTable
+
+    def add_table(self, t: "DeviceTable"):
+        self.tables[t.name] = t
+
+    def _db(self):
+        return [self.tables[k] for k in sorted(self.tables)]
+
+    def execute(self, sql: str):
+        """returns a P.Result for a select, None otherwise"""
+        text = self.ctx.sql_describe(sql, 1)
+        lines = text.splitlines()
+        head = lines[0].split(" ")
+        if head[0] == "CREATE_TABLE":
+            name = head[1]
+            if name in self.schemas or name in self.tables:
+                raise EngineError(2, f"Table {name} already exists.")
+            cols = []
+            for l in lines[1:]:
+                _, cn, ty = l.split(" ", 2)
+                cols.append(P.Column(cn, P.parse_type(ty.replace("(", " ").replace(")", " ").replace(",", " ").split())))
+            self.schemas[name] = P.Table(name, cols, 0)
+            return None
+        if head[0] == "BULK_INSERT":
+            name = head[1]
+            if name not in self.schemas:
+                raise EngineError(2, f"Table {name} does not exist.")
+            fields = {l.split(" ", 1)[0]: l.split(" ", 1)[1] for l in lines[1:]}
+            if name in self.tables:
+                raise EngineError(3, "BULK INSERT into a table that already holds data")
+            self.tables[name] = self.ctx.load_tbl(self.schemas[name], fields["file"], fields["fieldterminator"])
+            return None
+        q = self.ctx.sql_compile(sql, self._db())
+        try:
+            q.execute()
+            return q.result()
+        finally:
+            q.close()
+
+    def execute_script(self, text: str):
+        res = None
+        for stmt in text.split(";"):
+            if stmt.strip():
+                res = self.execute(stmt.strip())
+        return res
+
+    def close(self):
+        for t in self.tables.values():
+            t.close()
+        self.tables.clear()

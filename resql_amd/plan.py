@@ -357,6 +357,26 @@ class Plan:
         d.limit = self.limit or 0
         return d
 
+    @staticmethod
+    def from_c(d: rsq_plan_desc, table_names: Sequence[str], tables: Sequence[Table] = ()) -> "Plan":
+        """the inverse of to_c: scan operators name their table through `table_names` (the array the description indexes)"""
+        p = Plan(tables)
+        for i in range(d.n_exprs):
+            e = d.exprs[i]
+            p.exprs.append(ExprNode(EXPR_TAGS[e.tag], [e.child[k] for k in range(e.n_children)], e.symbol.decode("latin1"),
+                                    e.const_category))
+        for i in range(d.n_ops):
+            o = d.ops[i]
+            tag = OP_TAGS[o.tag]
+            kids = [o.child[k] for k in range(2) if o.child[k] >= 0]
+            p.ops.append(OpNode(tag, kids, table_names[o.table] if tag == "SCAN" else "",
+                                [o.exprs[k] for k in range(o.n_exprs)], [o.exprs2[k] for k in range(o.n_exprs2)],
+                                bool(o.single_match)))
+        p.root = d.root
+        p.request_all = bool(d.request_all)
+        p.limit = d.limit if d.has_limit else None
+        return p
+
     # -- resqlplan text form --
     def to_text(self, table_sources: Optional[Dict[str, Dict[str, str]]] = None,
                 tbl_files: Optional[Dict[str, str]] = None) -> str:
