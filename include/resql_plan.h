@@ -71,6 +71,8 @@ enum rsq_expr_tag {
  *              type category the parser assigns (ExprGen::constant(symbol, category),
  *              expressions.h:520-524); value and exact type are derived from the text
  *              (parseConstant, expressions.h:369-515)
+ *              A literal the SQL grammar negates (`- 5`, `- 0.25`; parser.y:149-151) is typed from its unsigned
+ *              text and only its value is negated; it travels as symbol = "neg " + unsigned text.
  *  AS        : symbol = alias, child[0]
  *  unary / binary / CASE: child[0..n_children)
  */

@@ -62,14 +62,27 @@ public:
         if (it != exprIds_.end()) return it->second;           // shared Expr* => shared node (planner.h:90-99, :430)
         rsq_expr d{};
         d.tag = (int32_t)e->tag;                                 // Expr::Tag == rsq_expr_tag by construction
+        // operands as ReSQL's own code generation reads them: child for UNARY, child and child->next for BINARY — the
+        // sibling chain may be longer (planner.h rewrites leave stale ->next links, e.g. below a flattened BETWEEN)
+        const size_t limit = e->structureTag == Expr::UNARY ? 1 : e->structureTag == Expr::BINARY ? 2
+                           : e->structureTag == Expr::LITERAL ? 0 : (size_t)-1;
         std::vector<int> kids;
-        for (Expr* c = e->child; c != nullptr; c = c->next) kids.push_back(expr(c));
+        for (Expr* c = e->child; c != nullptr && kids.size() < limit; c = c->next) kids.push_back(expr(c));
         if (kids.size() > RSQ_MAX_CHILDREN) throw ResqlError("expression with too many children");
         d.n_children = (int32_t)kids.size();
         for (size_t i = 0; i < kids.size(); i++) d.child[i] = kids[i];
         d.const_category = (e->tag == Expr::CONSTANT) ? (int32_t)e->type.tag : RSQ_NT;
-        if (e->symbol.size() >= RSQ_SYMBOL_MAX) throw ResqlError("symbol too long: " + e->symbol);
-        std::strncpy(d.symbol, e->symbol.c_str(), RSQ_SYMBOL_MAX - 1);
+        std::string sym = e->symbol;
+        if (e->tag == Expr::CONSTANT && (e->type.tag == SqlType::BIGINT || e->type.tag == SqlType::DECIMAL)) {
+            // parser.y:149-151 negates the VALUE of `- literal` and leaves the text alone: tell the engine (resql_plan.h)
+            Expr* again = ExprGen::constant(e->symbol, e->type.tag);
+            const long long parsed = e->type.tag == SqlType::BIGINT ? (long long)again->value.bigintData : (long long)again->value.decimalData;
+            const long long held = e->type.tag == SqlType::BIGINT ? (long long)e->value.bigintData : (long long)e->value.decimalData;
+            freeExpr(again);
+            if (parsed != 0 && held == -parsed) sym = "neg " + sym;
+        }
+        if (sym.size() >= RSQ_SYMBOL_MAX) throw ResqlError("symbol too long: " + sym);
+        std::strncpy(d.symbol, sym.c_str(), RSQ_SYMBOL_MAX - 1);
         exprs.push_back(d);
         exprIds_[e] = (int)exprs.size() - 1;
         return (int)exprs.size() - 1;

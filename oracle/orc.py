@@ -201,7 +201,8 @@ def reference_parse(tokens_text: str) -> str:
         return pr.stdout
 
 
-def run_reference_sql(tables: Sequence[P.Table], tokens_text: str, dump_plan: bool = False, threads: int = 1) -> str:
+def run_reference_sql(tables: Sequence[P.Table], tokens_text: str, dump_plan: bool = False, threads: int = 1,
+                      engine: str = "flounder", device: int = 0) -> str:
     """tokens -> the reference's parser -> the reference's planner (buildQuery over `tables`) -> either the plan dump or
     the result of the reference's own execution"""
     if not have_reference():
@@ -214,6 +215,8 @@ def run_reference_sql(tables: Sequence[P.Table], tokens_text: str, dump_plan: bo
         with open(tp, "w", encoding="latin1") as f:
             f.write(tokens_text)
         cmd = [REF_HARNESS, case, "--sql-tokens", tp, "--threads", str(threads)]
+        if engine != "flounder":      # ReSQL's parser + planner, then integration/resql_hip_binding.h -> C ABI -> HIP engine
+            cmd += ["--engine", engine, "--device", str(device)]
         if dump_plan:
             cmd.append("--dump-plan")
         pr = subprocess.run(cmd, capture_output=True, text=True, errors="replace")

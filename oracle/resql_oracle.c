@@ -358,6 +358,14 @@ static long long parse_ll(const char* s) {
 
 static void parseConstant(Ctx* c, Expr* e, int category) {
     const char* sym = e->symbol;
+    if (strncmp(sym, "neg ", 4) == 0 && (category == RSQ_DECIMAL || category == RSQ_BIGINT)) {
+        /* a negated literal of the SQL grammar (parser.y:149-151 value ::= MINUS_TK constant): the constant is typed
+         * from the unsigned text, then its VALUE is negated (include/resql_plan.h, CONSTANT) */
+        memmove(e->symbol, e->symbol + 4, strlen(e->symbol + 4) + 1);
+        parseConstant(c, e, category);
+        e->value.i = (int64_t)(0 - (uint64_t)e->value.i);
+        return;
+    }
     switch (category) {
         case RSQ_DECIMAL: {   /* expressions.h:443-467 */
             char buf[RSQ_SYMBOL_MAX]; size_t n = 0; unsigned scale = 0;

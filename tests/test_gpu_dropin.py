@@ -50,3 +50,20 @@ def test_bulk_insert_through_the_binding(tmp_path, name):
         assert pr.returncode == 0 and b"#timing" in pr.stderr, pr.stderr[-600:]
         outs.append(pr.stdout)
     assert outs[0] == outs[1] and len(outs[0]) > 50
+
+
+@pytest.mark.parametrize("name", ["q1", "q3", "q5", "q6", "q10", "q12", "q14", "q19", "case6", "case13"])
+def test_sql_through_resql_parser_planner_and_the_binding(gpu_ctx, name):
+    """The whole drop-in as a ReSQL maintainer would wire it: ReSQL's OWN grammar (Lemon) and planner build the operator
+    tree from the statement, integration/resql_hip_binding.h hands it to the HIP engine — against ReSQL's JIT on the same
+    tree (the committed reference answers of tests/golden/sql_reference.json)."""
+    import json
+    import os
+    from resql_amd import tpch_full
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sql_reference.json")) as f:
+        gold = json.load(f)
+    db = tpch_full.database(gold["sf"])
+    host = [db[k] for k in gold["tables"]]
+    g = gold["results"][name]
+    hip = orc.run_reference_sql(host, gpu_ctx.sql_describe(g["sql"], 0), engine="hip")
+    assert hip == g["text"]
