@@ -73,6 +73,9 @@ enum rsq_expr_tag {
  *              (parseConstant, expressions.h:369-515)
  *              A literal the SQL grammar negates (`- 5`, `- 0.25`; parser.y:149-151) is typed from its unsigned
  *              text and only its value is negated; it travels as symbol = "neg " + unsigned text.
+ *  TYPECAST  : an explicit `expr :: type` of the query (ExprGen::typecast, expressions.h:656-660): child[0], symbol =
+ *              the target type in text form ("INT", "BIGINT", "DATE", "DECIMAL p s", "CHAR n", "VARCHAR n").  Casts
+ *              that type derivation inserts are never part of a description.
  *  AS        : symbol = alias, child[0]
  *  unary / binary / CASE: child[0..n_children)
  */

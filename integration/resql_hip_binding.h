@@ -56,8 +56,9 @@ public:
     std::vector<std::string> tableNames;
 
     int expr(Expr* e) {
-        // a TYPECAST that ReSQL's own type derivation already inserted is skipped: the engine derives types itself
-        if (e->tag == Expr::TYPECAST) return expr(e->child);
+        // The binding runs INSTEAD of ReSQL's deriveExpressionTypes (the engine derives types itself, with the same
+        // rules), so a TYPECAST met here was written in the query (expr :: type, parser.y:96): it travels with its
+        // target type as symbol (resql_plan.h).  Call run() on a plan whose types have not been derived.
         auto it = exprIds_.find(e);
         if (it != exprIds_.end()) return it->second;           // shared Expr* => shared node (planner.h:90-99, :430)
         rsq_expr d{};
@@ -73,6 +74,19 @@ public:
         for (size_t i = 0; i < kids.size(); i++) d.child[i] = kids[i];
         d.const_category = (e->tag == Expr::CONSTANT) ? (int32_t)e->type.tag : RSQ_NT;
         std::string sym = e->symbol;
+        if (e->tag == Expr::TYPECAST) {
+            SqlType t = e->type;
+            switch (t.tag) {
+                case SqlType::DECIMAL: sym = "DECIMAL " + std::to_string((int)t.decimalSpec().precision) + " " + std::to_string((int)t.decimalSpec().scale); break;
+                case SqlType::CHAR: sym = "CHAR " + std::to_string(t.charSpec().num); break;
+                case SqlType::VARCHAR: sym = "VARCHAR " + std::to_string(t.varcharSpec().num); break;
+                case SqlType::INT: sym = "INT"; break;
+                case SqlType::BIGINT: sym = "BIGINT"; break;
+                case SqlType::DATE: sym = "DATE"; break;
+                case SqlType::BOOL: sym = "BOOL"; break;
+                default: throw ResqlError("typecast to an unsupported type");
+            }
+        }
         if (e->tag == Expr::CONSTANT && (e->type.tag == SqlType::BIGINT || e->type.tag == SqlType::DECIMAL)) {
             // parser.y:149-151 negates the VALUE of `- literal` and leaves the text alone: tell the engine (resql_plan.h)
             Expr* again = ExprGen::constant(e->symbol, e->type.tag);

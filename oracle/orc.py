@@ -46,6 +46,8 @@ def lib():
         L.orc_result_agg_grows.argtypes = [C.c_void_p]
         L.orc_result_ref_oob_probes.restype = C.c_int64
         L.orc_result_ref_oob_probes.argtypes = [C.c_void_p]
+        L.orc_result_ref_narrow_casts.restype = C.c_int64
+        L.orc_result_ref_narrow_casts.argtypes = [C.c_void_p]
         L.orc_result_free.argtypes = [C.c_void_p]
         L.orc_free_string.argtypes = [C.c_void_p]
         L.orc_serialize_expr.restype = C.c_void_p
@@ -83,6 +85,7 @@ def execute(plan: P.Plan) -> P.Result:
         res.agg_slots = L.orc_result_agg_slots(out)
         res.agg_grows = L.orc_result_agg_grows(out)
         res.ref_oob_probes = L.orc_result_ref_oob_probes(out)
+        res.ref_narrow_casts = L.orc_result_ref_narrow_casts(out)
         res.text = _take_string(L.orc_result_serialize(out))
     finally:
         L.orc_result_free(out)

@@ -273,6 +273,12 @@ struct PlanBuilder {
             } else e = ExprGen::constant(s.rest, parseCategory(s.args.at(0)));
         }
         else if (t == "STAR") e = ExprGen::star();
+        else if (t == "TYPECAST") {                       // explicit `expr :: type`: "TYPECAST child TYPE..."
+            std::string ty;
+            for (size_t i = 1; i < s.args.size(); i++) ty += (i > 1 ? " " : "") + s.args[i];
+            std::istringstream tin(ty);
+            e = ExprGen::typecast(parseType(tin), A(0));
+        }
         else if (t == "AS") e = ExprGen::as(s.args.at(0), expr(std::stoi(s.args.at(1))));
         else if (t == "SUM") e = ExprGen::sum(A(0));
         else if (t == "COUNT") e = ExprGen::count(A(0));

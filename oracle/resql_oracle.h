@@ -46,6 +46,9 @@ int64_t orc_result_agg_grows(const orc_result* r);
 /* number of probes for which the reference itself reads one byte past its hash table (qlib/hash.h:441-451, a continued
  * probe after the last slot): when > 0 the reference's result for this input depends on heap contents */
 int64_t orc_result_ref_oob_probes(const orc_result* r);
+/* INT -> BIGINT casts of values outside the int16 range: the reference's asmjit back end sign-extends only the low 16
+ * bits there (see resql_oracle.c g_narrowCasts), so its own answer is not comparable when this is non-zero */
+int64_t orc_result_ref_narrow_casts(const orc_result* r);
 
 void orc_result_free(orc_result* r);
 void orc_free_string(char* s);

@@ -162,6 +162,23 @@ std::vector<Expr*> ExprPool::build(const rsq_plan_desc& p) {
         std::string sym(d.symbol, strnlen(d.symbol, RSQ_SYMBOL_MAX));
         v[i] = make(d.tag, structureOf(d.tag), sym);
         if (d.tag == RSQ_E_CONSTANT) parseConstant(v[i], d.const_category);
+        if (d.tag == RSQ_E_TYPECAST) {
+            // an explicit `expr :: type` of the query (ExprGen::typecast, expressions.h:656-660): the symbol is the target
+            // type in the plan text form ("BIGINT", "DECIMAL 12 2", "CHAR 3", ...); type derivation leaves it alone
+            char name[16] = {0}; int a = 0, b = 0;
+            const int n = sscanf(sym.c_str(), "%15s %d %d", name, &a, &b);
+            Type t;
+            const std::string nm = name;
+            if (nm == "INT" && n == 1) t = Type(RSQ_INT);
+            else if (nm == "BIGINT" && n == 1) t = Type(RSQ_BIGINT);
+            else if (nm == "DATE" && n == 1) t = Type(RSQ_DATE);
+            else if (nm == "BOOL" && n == 1) t = Type(RSQ_BOOL);
+            else if (nm == "DECIMAL" && n == 3) t = Type::decimal(a, b);
+            else if (nm == "CHAR" && n == 2) { t = Type(RSQ_CHAR); t.len = a; }
+            else if (nm == "VARCHAR" && n == 2) { t = Type(RSQ_VARCHAR); t.len = a; }
+            else failInvalid("TYPECAST needs its target type as symbol, got '" + sym + "'");
+            v[i]->type = t; v[i]->explicitCast = true; v[i]->symbol = "typecast";
+        }
     }
     for (int i = 0; i < p.n_exprs; i++) {
         const rsq_expr& d = p.exprs[i];

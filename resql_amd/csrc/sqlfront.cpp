@@ -663,7 +663,6 @@ struct PlanBuilder {
         const size_t limit = e->structure == UNARY ? 1 : e->structure == BINARY ? 2 : e->structure == LITERAL ? 0 : (size_t)-1;
         for (const Expr* c = e->child; c && kids.size() < limit; c = c->next) kids.push_back(addExpr(c));
         if (kids.size() > RSQ_MAX_CHILDREN) failUnsupported("expression with more than " + std::to_string(RSQ_MAX_CHILDREN) + " operands");
-        if (e->tag == RSQ_E_TYPECAST) failUnsupported("explicit typecast (expr :: type) is not carried by the plan description yet");
         rsq_expr d;
         memset(&d, 0, sizeof d);
         d.tag = e->tag;
@@ -672,6 +671,18 @@ struct PlanBuilder {
         d.const_category = e->tag == RSQ_E_CONSTANT ? e->category : RSQ_NT;
         std::string sym = e->symbol;
         if (e->tag == RSQ_E_CONSTANT && e->negated) sym = "neg " + sym;
+        if (e->tag == RSQ_E_TYPECAST) {          // the target type in the plan text form (include/resql_plan.h)
+            const Type& t = e->type;
+            switch (t.tag) {
+                case RSQ_DECIMAL: sym = "DECIMAL " + std::to_string(t.precision) + " " + std::to_string(t.scale); break;
+                case RSQ_CHAR: sym = "CHAR " + std::to_string(t.len); break;
+                case RSQ_VARCHAR: sym = "VARCHAR " + std::to_string(t.len); break;
+                case RSQ_INT: sym = "INT"; break;
+                case RSQ_BIGINT: sym = "BIGINT"; break;
+                case RSQ_DATE: sym = "DATE"; break;
+                default: failType("typecast to an unknown type");
+            }
+        }
         if (sym.size() >= RSQ_SYMBOL_MAX) failUnsupported("symbol or constant longer than " + std::to_string(RSQ_SYMBOL_MAX - 1) + " characters");
         memcpy(d.symbol, sym.c_str(), sym.size());
         exprs.push_back(d);

@@ -287,6 +287,7 @@ class Plan:
     def max(self, c): return self._e("MAX", [c])
     def asc(self, c): return self._e("ASC", [c])
     def desc(self, c): return self._e("DESC", [c])
+    def typecast(self, type_: "SqlType", c): return self._e("TYPECAST", [c], symbol=type_.text())
     def when_then(self, w, t): return self._e("WHENTHEN", [w, t])
     def case(self, *branches): return self._e("CASE", list(branches))
 
@@ -400,6 +401,8 @@ class Plan:
                 out.append(f"expr {i} AS {e.symbol} {e.children[0]}")
             elif e.tag == "STAR":
                 out.append(f"expr {i} STAR")
+            elif e.tag == "TYPECAST":       # an explicit `expr :: type`: the symbol is the target type in text form
+                out.append(f"expr {i} TYPECAST {e.children[0]} {e.symbol}")
             else:
                 out.append(f"expr {i} {e.tag} " + " ".join(str(c) for c in e.children))
         for i, o in enumerate(self.ops):
@@ -463,6 +466,8 @@ class Plan:
                     exprs[i] = ExprNode(tag, [int(tok[1])], tok[0])
                 elif tag == "STAR":
                     exprs[i] = ExprNode(tag, [], "*")
+                elif tag == "TYPECAST":
+                    exprs[i] = ExprNode(tag, [int(tok[0])], " ".join(tok[1:]))
                 else:
                     exprs[i] = ExprNode(tag, [int(x) for x in tok])
             elif kw == "op":

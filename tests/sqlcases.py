@@ -76,6 +76,11 @@ PLAN_CASES = [
     "select n_name from nation limit 0",
     "select p_brand, count(*) as n from part where p_size between 10 and 20 group by p_brand order by n desc, p_brand limit 5",
     "select o_orderpriority, count(*) from orders where o_orderdate >= date '1993-07-01' and o_orderdate < date '1993-10-01' group by o_orderpriority order by o_orderpriority",
+    "select c_name, c_acctbal from customer where c_acctbal < -900.00 order by c_acctbal limit 5",      # negated literal
+    "select l_quantity :: bigint, (l_extendedprice * 2) :: decimal(19,4) from lineitem where l_linenumber > 6",   # explicit casts
+    "select n_nationkey :: bigint + -3 from nation where n_nationkey :: bigint > 20",
+    "select l_orderkey from lineitem where l_orderkey < 3",              # INT -> BIGINT cast of keys beyond int16: see oracle g_narrowCasts
+    "select n_name :: int from nation",                                   # a cast the reference has no code for
     "select c_name from customer, nation",                                 # no equality: nested-loops join
     "select x from nosuchtable",
     "select nosuchcolumn from nation",

@@ -43,10 +43,8 @@ def test_sql_results_match_the_reference(gpu_ctx, small_db, name):
         got = q.result()
     finally:
         q.close()
-    if g.get("reference_undefined"):      # the reference's answer holds a group twice here (see test_sql_frontend.py)
-        want = orc.execute(gpu_ctx.sql_plan(g["sql"], tabs, host))
-        assert got.text == want.text
-        return
+    # "reference_undefined" cases (a group emitted twice after an out-of-bounds probe, 16-bit INT -> BIGINT casts of the
+    # asmjit back end; see test_sql_frontend.py) keep the oracle's answer in the golden
     assert got.text == g["text"]
 
 

@@ -135,7 +135,8 @@ def test_results_through_the_oracle_match_the_reference(compile_ctx, database, n
     res = orc.execute(compile_ctx.sql_plan(g["sql"], tabs, host))
     if g.get("reference_undefined"):
         # the reference read past its hash table here (qlib/hash.h:441-451) and emitted a group twice; the oracle counts it
-        assert res.ref_oob_probes > 0
+        assert res.ref_oob_probes > 0 or res.ref_narrow_casts > 0
+        assert res.text == g["text"]         # the golden keeps the oracle's (intended) answer for these
         return
     assert res.text == g["text"]
 
