@@ -453,7 +453,7 @@ struct Walker {
     // Key value(s) of one expression as table words: one word for numbers, ceil(len / 8) words of bytes for strings
     // (see rsq_device.h: str_word).  stripChar: CHAR(n) equality ignores trailing spaces (joins); group keys keep the
     // exact bytes and the host merges space-equivalent groups, because the group shows the FIRST row's spelling.
-    std::vector<std::string> keyWords(Expr* e, const std::string& prefix, bool stripChar) {
+    std::vector<std::string> keyWords(Expr* e, const std::string& prefix, bool stripChar, std::vector<std::string>* endsWithSpace = nullptr) {
         std::vector<std::string> out;
         const std::string v = eg.emit(e);
         if (!e->type.isString()) {
@@ -464,6 +464,8 @@ struct Walker {
         if (e->tag == RSQ_E_CONSTANT) failUnsupported("a string constant as a join or group key");
         const bool strip = stripChar && e->type.tag == RSQ_CHAR;
         line("const int " + prefix + "_n = " + (strip ? "rsq::str_len_char(" : "rsq::str_len_exact(") + v + ");");
+        if (endsWithSpace && e->type.tag == RSQ_CHAR && !strip)
+            endsWithSpace->push_back("(" + prefix + "_n > 0 && rsq::str_at(" + v + ", " + prefix + "_n - 1) == ' ')");
         for (int w = 0; w < (e->type.len + 7) / 8; w++) {
             std::string kv = prefix + "_" + std::to_string(w);
             line("const i64 " + kv + " = rsq::str_word(" + v + ", " + prefix + "_n, " + std::to_string(w) + ");");
@@ -794,13 +796,14 @@ struct Walker {
         const int W = (int)q.accums.size();
         ht->nAccBlocks = W;
         std::vector<std::string> keyVars;
+        std::vector<std::string> spaceSuffixed;       // per CHAR(n) group value: "its bytes end with a space"
         openScope("{");
         int k = 0;
         q.groupSource.clear();
         for (Expr* g : o->exprs2) {
             const size_t w0 = keyVars.size();
             q.groupSource.push_back((int)w0);           // first table word of this group value
-            for (auto& kv : keyWords(g, T + "_g" + std::to_string(k++), false)) keyVars.push_back(kv);
+            for (auto& kv : keyWords(g, T + "_g" + std::to_string(k++), false, &spaceSuffixed)) keyVars.push_back(kv);
             for (size_t w = w0; w < keyVars.size(); w++)
                 ht->keys.push_back({w == w0 ? expressionName(g) : expressionName(g) + "#" + std::to_string(w - w0), w == w0 && !g->type.isString() ? g->type : Type(RSQ_BIGINT)});
         }
@@ -827,6 +830,15 @@ struct Walker {
         line("__threadfence();");
         line("rsq::st_agent(&a." + T + "_state[" + T + "_s], 2u);");
         line("st.n_" + T + "++;");
+        if (!spaceSuffixed.empty()) {
+            // Groups are keyed by the exact bytes; the reference's CHAR equality ignores trailing spaces, so the host merges
+            // such groups — which is only ever needed when some group value ends with a space.  The lane that creates a
+            // group tells the host (once per group, nearly never): without the flag the host skips the merge and may take
+            // the candidate path of ORDER BY ... LIMIT.
+            std::string any;
+            for (size_t i = 0; i < spaceSuffixed.size(); i++) any += (i ? " || " : "") + spaceSuffixed[i];
+            line("if (" + any + ") atomicOr(a.err, (u32)rsq::NOTE_CHAR_GROUP_ENDS_WITH_SPACE);");
+        }
         closeScope();
         line("stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);      // our own publish, or whoever won the slot");
         closeScope();

@@ -115,6 +115,8 @@ Query::~Query() {
     if (hPinned) (void)hipHostFree(hPinned);
     if (hGroupRows) (void)hipHostFree(hGroupRows);
     if (graphExec) (void)hipGraphExecDestroy(graphExec);
+    if (gev0) (void)hipEventDestroy(gev0);
+    if (gev1) (void)hipEventDestroy(gev1);
     if (dMatCnt) ctx.free(dMatCnt);
     if (dMatOffs) ctx.free(dMatOffs);
     if (dScanTemp) ctx.free(dScanTemp);
@@ -422,6 +424,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
 }
 
 static void checkDeviceError(uint32_t err) {
+    err &= ~32u;          // NOTE_CHAR_GROUP_ENDS_WITH_SPACE is information for the host tail, not an error
     if (err & 1) failRuntime("Division by zero");
     if (err & 2) failRuntime("Hash table full");
     if (err & 16) failRuntime("internal error: a hash-table slot stayed in the 'being written' state");
@@ -475,9 +478,12 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 try {
                     enqueueTableInit(q);
                     if (!q.errInTable) RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
-                    RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+                    // the graph's own pair of events: an event that is also recorded outside a graph (the context's pair,
+                    // by multi-pipeline queries) keeps reporting that recording after a replay
+                    if (!q.gev0) { RSQ_HIP(hipEventCreate(&q.gev0)); RSQ_HIP(hipEventCreate(&q.gev1)); }
+                    RSQ_HIP(hipEventRecord(q.gev0, ctx.stream));
                     launchPipeline(q, p, -1);
-                    RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+                    RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
                     if (!q.errInTable) RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
                     if (!partialOnly) enqueueTableReadback(q);
                 } catch (...) { ok = false; }
@@ -493,10 +499,10 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             RSQ_HIP(hipGraphLaunch(q.graphExec, ctx.stream));
             q.report.num_kernels = 1;
             q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
-            if (async && partialOnly) { q.pendingAsync = true; q.report.execution_time_ms = nowMs() - t0; return; }
+            if (async && partialOnly) { q.pendingAsync = true; q.pendingGraph = true; q.report.execution_time_ms = nowMs() - t0; return; }
             RSQ_HIP(hipStreamSynchronize(ctx.stream));
             float gms = 0;
-            if (hipEventElapsedTime(&gms, ctx.ev0, ctx.ev1) != hipSuccess) { (void)hipGetLastError(); q.graphFailed = true; gms = 0; }
+            if (hipEventElapsedTime(&gms, q.gev0, q.gev1) != hipSuccess) { (void)hipGetLastError(); q.graphFailed = true; gms = 0; }
             q.report.kernel_time_ms = gms;
             q.report.hbm_gbps = gms > 0 ? (double)q.report.bytes_read / (gms * 1e-3) / 1e9 : 0;
             checkDeviceError((uint32_t)q.hPinned[words]);
@@ -563,6 +569,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 uint32_t err = 0;
                 RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
                 RSQ_HIP(hipStreamSynchronize(ctx.stream));
+                q.charGroupsNeedMerge = (err & 32u) != 0;
                 if (!(err & 2)) break;
                 if (h.capacity >= ((int64_t)1 << 31)) failRuntime("Hash table full");
                 ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc);
@@ -609,7 +616,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         q.report.num_kernels++;
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
         if (q.topkWord == -2) planDeviceTopK(q);
-        if (q.topkWord >= 0 && nEntries >= 2048 && (uint64_t)nEntries > 4ull * q.topkWant) {
+        if (q.topkWord >= 0 && nEntries >= 2048 && (uint64_t)nEntries > 4ull * q.topkWant && !(q.topkNeedsNoMerge && q.charGroupsNeedMerge)) {
             topkCapacity = std::min<uint32_t>(nEntries, std::max<uint32_t>(256, 4 * q.topkWant));
             if (q.topkImageRows < nEntries) {
                 if (q.dTopkImages) ctx.free(q.dTopkImages);
@@ -641,7 +648,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     if (async && partialOnly) {
         // everything is enqueued; the caller orders its own work (the group-by merge collective) behind it on the same
         // stream and finalizeQuery() does the one host synchronisation of the step
-        q.pendingAsync = true;
+        q.pendingAsync = true; q.pendingGraph = false;
         q.report.execution_time_ms = nowMs() - t0;
         return;
     }
@@ -705,7 +712,9 @@ void finalizeQuery(Query& q) {
     RSQ_HIP(hipStreamSynchronize(ctx.stream));
     if (q.pendingAsync) {         // the step was enqueued by rsq_query_execute_partial_async: account for it now
         q.pendingAsync = false;
-        float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+        float ms = 0;
+        if (q.pendingGraph) RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1));
+        else RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
         q.report.kernel_time_ms = ms;
         q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
         checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);

@@ -198,6 +198,10 @@ struct Query {
     bool candidateRun = false;
     int64_t totalGroups = 0;
     bool tailNeedsAllGroups = false;
+    // hash aggregation with CHAR(n) group values: set by the kernel when a group value ends with a space — only then can
+    // two device groups be one group of the reference (CHAR equality ignores trailing spaces) and the host has to merge
+    bool charGroupsNeedMerge = false;
+    bool topkNeedsNoMerge = false;         // the candidate pre-selection is valid only while no merge is needed
 
     // result
     Schema resultSchema;
@@ -211,8 +215,10 @@ struct Query {
     // single-pipeline dense aggregations replay one captured HIP graph per execution (init copy, error word reset,
     // kernel between two event records, read-back): one submission instead of six
     hipGraphExec_t graphExec = nullptr;
+    hipEvent_t gev0 = nullptr, gev1 = nullptr;   // recorded only inside the graph, around the kernel
     void* graphAggPtr = nullptr;
     bool graphPartial = false, graphFailed = false;
+    bool pendingGraph = false;             // ... and it was a graph replay (its kernel time is between gev0 and gev1)
     bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
     std::string allSource, explainText;
 

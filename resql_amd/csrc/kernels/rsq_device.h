@@ -32,7 +32,8 @@ typedef unsigned short u16;
 namespace rsq {
 
 // error word bits (set by kernels, read by the host after the final sync)
-enum { ERR_DIV_ZERO = 1, ERR_HT_FULL = 2, ERR_DUP_KEY = 4, ERR_GROUP_OVERFLOW = 8, ERR_STUCK = 16 };
+enum { ERR_DIV_ZERO = 1, ERR_HT_FULL = 2, ERR_DUP_KEY = 4, ERR_GROUP_OVERFLOW = 8, ERR_STUCK = 16,
+       NOTE_CHAR_GROUP_ENDS_WITH_SPACE = 32 /* not an error: a CHAR(n) group value ends with a space (host merges groups) */ };
 
 // ---- arithmetic: x86-64 add / sub / imul wrap, cqo+idiv truncates ---------------------------
 RSQ_DEV i64 add(i64 a, i64 b) { return (i64)((u64)a + (u64)b); }

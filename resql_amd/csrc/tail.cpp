@@ -286,7 +286,7 @@ Groups groupsFromJoinEntries(Query& q) {
 void mergeSpaceEquivalentGroups(Query& q, Groups& G) {
     bool any = false;
     for (Expr* g : q.agg->exprs2) if (g->type.tag == RSQ_CHAR && g->type.len > 1) any = true;
-    if (!any || G.n < 2) return;
+    if (!any || G.n < 2 || !q.charGroupsNeedMerge) return;
     auto normalised = [&](size_t i) {
         std::string key;
         for (size_t k = 0; k < G.nKeys; k++) {
@@ -411,7 +411,11 @@ void planDeviceTopK(Query& q) {
     }
     if (!mat || mat->hasLimit || !orderBy || !orderBy->hasLimit || orderBy->exprs.empty()) return;
     if (orderBy->limit < 0 || orderBy->limit > (1 << 20)) return;
-    for (Expr* g : agg->exprs2) if (g->type.isString()) return;      // CHAR groups are merged on the host (trailing spaces)
+    // CHAR(n) group values of a hash aggregation may need the host's merge of space-equivalent groups; the kernel
+    // reports whether any does (charGroupsNeedMerge), the candidate path is taken only when none does
+    q.topkNeedsNoMerge = false;
+    if (q.aggMode == AggMode::HASH)
+        for (Expr* g : agg->exprs2) if (g->type.tag == RSQ_CHAR && g->type.len > 1) q.topkNeedsNoMerge = true;
     const HashTable& ht = *q.hashTables[(size_t)q.aggTable];
     const int nTab = (int)(ht.keys.size() + ht.payload.size());
     typedef std::pair<int, Type> Src;

@@ -91,3 +91,37 @@ def test_q3_other_orders(gpu_ctx, order):
     li = tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
     plan = tpch.q3_plan(tpch.customer_table(sf), tpch.orders_table(sf), li, limit=20, order_by=orders[order])
     run_both_ways(gpu_ctx, plan)
+
+
+def test_string_group_keys_take_the_candidate_path(gpu_ctx):
+    """TPC-H Q10 (group by c_custkey, c_name, ..., five string values; ORDER BY revenue DESC LIMIT 20) at SF 0.2: ~7 K
+    groups keyed by 32 words.  No CHAR value ends with a space, the kernel reports that no host merge is needed and the
+    candidates are selected on the device; a second table whose CHAR values do end with spaces must take the full path."""
+    from resql_amd import tpch_full
+    db = tpch_full.database(0.2)
+    host = [db[k] for k in sorted(db)]
+    tabs = [gpu_ctx.table(t) for t in host]
+    try:
+        sql = tpch_full.QUERIES["q10"]
+        want = orc.execute(gpu_ctx.sql_plan(sql, tabs, host))
+        q = gpu_ctx.sql_compile(sql, tabs)
+        for _ in range(2):
+            q.execute()
+            assert q.result().text == want.text
+        q.close()
+        assert want.n_rows == 20
+    finally:
+        for t in tabs:
+            t.close()
+    # CHAR(6) group values that differ only in trailing spaces: one group in the reference, merged on the host
+    import numpy as np
+    n = 60_000
+    r = np.arange(n)
+    names = np.array([b"k%03d" % (i % 3000) + (b" " if (i // 3000) % 2 else b"") for i in range(n)], dtype="S6")
+    t = P.Table("t", [P.Column("name", P.TypeInit.CHAR(6), names), P.Column("v", P.TypeInit.BIGINT(), (r % 97).astype(np.int64))], n)
+    p = P.Plan([t])
+    s = p.sum(p.attr("v"))
+    node = p.aggregation([s], [p.attr("name")], p.scan("t"))
+    node = p.projection([p.attr("name"), p.as_("s", s)], node)
+    node = p.orderby([p.desc(p.attr("s")), p.attr("name")], node)
+    run_both_ways(gpu_ctx, p.set_root(node, limit=7))
