@@ -142,7 +142,39 @@ struct ExprGen {
             if (op.tag != RSQ_DECIMAL && op.tag != RSQ_DATE && op.tag != RSQ_BIGINT)
                 failType(std::string(exprTagNames[e->tag]) + " code generation not implemented for datatype");
         };
+        // string = constant: word-wise against the constant's bytes (rsq_device.h ld_bytes) instead of the byte loop
+        auto equalsConstant = [&](bool charSemantics) -> std::string {
+            Expr* lc = e->child; Expr* rc = e->child->next;
+            const bool lConst = lc->tag == RSQ_E_CONSTANT, rConst = rc->tag == RSQ_E_CONSTANT;
+            if (lConst == rConst || !lc->type.isString() || !rc->type.isString() || envInt("RSQ_STRING_WORDS", 1, 0, 1) == 0) return "";
+            const Expr* cst = lConst ? lc : rc;
+            const std::string& x = lConst ? r : l;
+            const int cap = (lConst ? rc : lc)->type.len;
+            std::string text = cst->symbol;
+            if (text.find('\0') != std::string::npos) return "";
+            if (charSemantics) while (!text.empty() && text.back() == ' ') text.pop_back();
+            if ((int)text.size() > cap) return "((u8)0)";            // longer than any value of the column
+            std::string cond;
+            for (int w = 0; w * 8 < cap; w++) {
+                const int rbytes = std::min(8, cap - w * 8);
+                uint64_t cw = 0, mask = 0;
+                for (int i = 0; i < rbytes; i++) {
+                    const size_t k = (size_t)(w * 8 + i);
+                    if (k < text.size()) { cw |= (uint64_t)(uint8_t)text[k] << (8 * i); mask |= 0xFFull << (8 * i); }
+                    else mask |= (charSemantics ? 0xDFull : 0xFFull) << (8 * i);
+                }
+                char buf[160];
+                snprintf(buf, sizeof buf, "((rsq::ld_bytes<%d>((%s).p + %d) ^ 0x%llxull) & 0x%llxull)", rbytes, x.c_str(), w * 8,
+                         (unsigned long long)cw, (unsigned long long)mask);
+                cond += (cond.empty() ? "" : " | ") + std::string(buf);
+            }
+            return "((u8)((" + cond + ") == 0ull))";
+        };
         auto equals = [&]() -> std::string {
+            if (op.tag == RSQ_VARCHAR || (op.tag == RSQ_CHAR && op.len > 1)) {
+                const std::string fast = equalsConstant(op.tag == RSQ_CHAR);
+                if (!fast.empty()) return fast;
+            }
             switch (op.tag) {
                 case RSQ_DECIMAL: case RSQ_INT: case RSQ_BIGINT: case RSQ_BOOL: case RSQ_DATE:
                     return "((u8)((" + l + ") == (" + r + ")))";

@@ -158,6 +158,24 @@ RSQ_DEV u8 compare_varchar(const Str& a, const Str& b) {
     return str_at(a, i) == str_at(b, i);
 }
 
+// Comparison with a string CONSTANT, word-wise: R (1..8) bytes at p as a little-endian word.  Column rows are not
+// 8-byte aligned (CHAR(10): stride 10); gfx950 global loads take any alignment and the compiler emits one
+// global_load_dwordx2 for the 8-byte form.  A byte-wise compare_char costs one dependent global_load_ubyte per character
+// (TPC-H Q3's customer filter ran at 0.44 TB/s, Q19's predicates at 0.5 TB/s); the generated form is
+//   ((word_k ^ CONST_k) & MASK_k) == 0 for every word,  MASK byte = 0xFF inside the constant, 0xDF behind it for CHAR
+// (a byte behind the constant may be NUL padding or a trailing space, which CHAR equality ignores), 0xFF for VARCHAR.
+// Relies on the column contract of resql_plan.h: values are NUL padded to their declared width.
+template <int R>
+RSQ_DEV u64 ld_bytes(const char* p) {
+    u64 v = 0;
+    if (R == 8) { __builtin_memcpy(&v, p, 8); return v; }
+    int o = 0;
+    if (R & 4) { u32 t; __builtin_memcpy(&t, p + o, 4); v |= (u64)t << (8 * o); o += 4; }
+    if (R & 2) { u16 t; __builtin_memcpy(&t, p + o, 2); v |= (u64)t << (8 * o); o += 2; }
+    if (R & 1) { v |= (u64)(u8)p[o] << (8 * o); }
+    return v;
+}
+
 // Strings as hash-table KEY words: bytes [8w, 8w+8) of the string, little-endian, NUL padded, so that word-wise
 // equality is compareVarchar (exact) — or compareChar when the effective length excludes trailing spaces
 // (str_len_char): the reference's CHAR(n) equality ignores them (qlib/scalar.h:27-46).
