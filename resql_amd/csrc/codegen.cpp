@@ -495,9 +495,19 @@ struct Walker {
         }
         if (e->tag == RSQ_E_CONSTANT) failUnsupported("a string constant as a join or group key");
         const bool strip = stripChar && e->type.tag == RSQ_CHAR;
-        line("const int " + prefix + "_n = " + (strip ? "rsq::str_len_char(" : "rsq::str_len_exact(") + v + ");");
-        if (endsWithSpace && e->type.tag == RSQ_CHAR && !strip)
-            endsWithSpace->push_back("(" + prefix + "_n > 0 && rsq::str_at(" + v + ", " + prefix + "_n - 1) == ' ')");
+        if (!strip) {
+            // exact bytes: the column is NUL padded to its width (resql_plan.h), so the key words ARE the stored bytes —
+            // one unaligned load per word instead of a byte loop per word (32 key words for TPC-H Q10's group-by)
+            if (endsWithSpace && e->type.tag == RSQ_CHAR) endsWithSpace->push_back("rsq::ends_with_space(" + v + ")");
+            for (int w = 0; w < (e->type.len + 7) / 8; w++) {
+                std::string kv = prefix + "_" + std::to_string(w);
+                const int rbytes = std::min(8, e->type.len - w * 8);
+                line("const i64 " + kv + " = (i64)rsq::ld_bytes<" + std::to_string(rbytes) + ">((" + v + ").p + " + std::to_string(w * 8) + ");");
+                out.push_back(kv);
+            }
+            return out;
+        }
+        line("const int " + prefix + "_n = rsq::str_len_char(" + v + ");");
         for (int w = 0; w < (e->type.len + 7) / 8; w++) {
             std::string kv = prefix + "_" + std::to_string(w);
             line("const i64 " + kv + " = rsq::str_word(" + v + ", " + prefix + "_n, " + std::to_string(w) + ");");
@@ -851,7 +861,7 @@ struct Walker {
         // stays inside the loop body.  (With `if (won) {publish; hit} if (!hit) continue; ...; break;` the compiler threads
         // the winner straight to the loop exit, the structurizer parks it there until the whole wave has left the loop,
         // and the losers of the same wave spin on a slot that is never published.)
-        line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0;");
+        line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0; bool " + T + "_found = false;");
         line("if (rsq::ld_agent(a.err) & (u32)rsq::ERR_HT_FULL) return;      // another lane found the table too small: this run is void");
         openScope("for (;;) {");
         line("u32 stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);");
@@ -879,11 +889,7 @@ struct Walker {
         for (size_t i = 0; i < keyVars.size(); i++)
             cond += (i ? " && " : "") + std::string("rsq::ld_agent(&a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s]) == " + keyVars[i];
         openScope("if (" + cond + ") {");
-        for (int w = 0; w < W; w++) {
-            std::string in = w == 0 ? "row" : "in" + std::to_string(w);
-            line("rsq::global_merge_always<" + std::to_string(q.accums[(size_t)w].merge) + ">(a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) +
-                 " * a." + T + "_cap + " + T + "_s, (u64)(" + in + "));");
-        }
+        line(T + "_found = true;");
         line("break;");
         closeScope();
         line(T + "_s = (" + T + "_s + 1) & " + T + "_mask;");
@@ -894,6 +900,45 @@ struct Walker {
         closeScope();
         line("else if (++" + T + "_spin > (1u << 22)) { atomicOr(a.err, (u32)rsq::ERR_STUCK); break; }   // a slot another wave is writing");
         closeScope();
+        // The updates, after the loop (the wave has reconverged): lanes of this wave that found the SAME slot are folded
+        // into one update by their first lane while such sets are large (a few groups in the whole input); as soon as the
+        // first set is small the group domain is wide and every lane updates its own slot.
+        auto updates = [&](const std::string& slot, const std::string& valueOf) {
+            for (int w = 0; w < W; w++) {
+                std::string in = w == 0 ? "row" : "in" + std::to_string(w);
+                const std::string op = std::to_string(q.accums[(size_t)w].merge);
+                std::string v = valueOf.empty() ? "(u64)(" + in + ")" : "rsq::subset_reduce<" + op + ">((u64)(" + in + "), " + valueOf + ")";
+                if (valueOf.empty())
+                    line("rsq::global_merge_always<" + op + ">(a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) + " * a." + T + "_cap + " + slot + ", " + v + ");");
+                else {
+                    line("{ const u64 r = " + v + "; if (wl_lane == wl_leader) rsq::global_merge_always<" + op + ">(a." + T + "_acc + " +
+                         std::to_string(q.accumSlot[(size_t)w]) + " * a." + T + "_cap + " + slot + ", r); }");
+                }
+            }
+        };
+        if (envInt("RSQ_WAVE_FOLD", 1, 0, 1)) {
+            openScope("{");
+            line("const int wl_lane = (int)(threadIdx.x & 63);");
+            line("bool wl_mine = " + T + "_found;");
+            line("u64 wl_todo = __ballot(wl_mine);");
+            openScope("while (wl_todo) {");
+            line("const int wl_leader = __ffsll((long long)wl_todo) - 1;");
+            line("const u64 wl_slot = rsq::readlane_u64(" + T + "_s, wl_leader);");
+            line("const u64 wl_set = __ballot(wl_mine && " + T + "_s == wl_slot);");
+            line("if (__popcll(wl_set) < 4) break;");
+            updates("wl_slot", "wl_set");
+            line("if (" + T + "_s == wl_slot) wl_mine = false;");
+            line("wl_todo &= ~wl_set;");
+            closeScope();
+            openScope("if (wl_mine) {");
+            updates(T + "_s", "");
+            closeScope();
+            closeScope();
+        } else {
+            openScope("if (" + T + "_found) {");
+            updates(T + "_s", "");
+            closeScope();
+        }
         closeScope();
         q.aggTable = ht->id;
         explainSteps.push_back("hash aggregation in " + T + " (" + std::to_string(ht->keys.size()) + " key word(s)) accumulators=" +

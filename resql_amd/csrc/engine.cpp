@@ -578,6 +578,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
             }
             q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
+            tracePoint(p);
             continue;
         }
         if (p.partitioned) runLargeDenseAggregation(q, p);

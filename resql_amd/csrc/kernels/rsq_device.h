@@ -134,6 +134,31 @@ RSQ_DEV void global_merge_always(u64* dst, u64 v) {
     else if (OP == M_MIN_I64) { if ((i64)v < peek_i64(dst)) atomicMin(reinterpret_cast<i64*>(dst), (i64)v); }
     else { if ((i64)v > peek_i64(dst)) atomicMax(reinterpret_cast<i64*>(dst), (i64)v); }
 }
+// Wave-level pre-aggregation for hash aggregation: the lanes of a wave that update the SAME table slot are folded
+// into one update by their first lane.  Atomics on one word serialise at the memory side (~11 ns each), so a group-by
+// with a handful of groups (TPC-H Q12: 2, Q5: 5) otherwise spends its time queueing on a few addresses.  The fold reads
+// the members' values with v_readlane (uniform lane index, members are active lanes by construction), no LDS, no
+// assumptions about inactive lanes.
+RSQ_DEV u64 readlane_u64(u64 v, int lane) {
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, lane);
+    const u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), lane);
+    return ((u64)hi << 32) | lo;
+}
+template <int OP>
+RSQ_DEV u64 subset_reduce(u64 v, u64 members) {
+    u64 acc = OP == M_SUM ? 0ull : OP == M_MIN_U64 ? ~0ull : OP == M_MIN_I64 ? 0x7fffffffffffffffull : 0x8000000000000000ull;
+    while (members) {
+        const int m = __ffsll((long long)members) - 1;
+        members &= members - 1;
+        const u64 x = readlane_u64(v, m);
+        if (OP == M_SUM) acc += x;
+        else if (OP == M_MIN_U64) acc = x < acc ? x : acc;
+        else if (OP == M_MIN_I64) acc = (i64)x < (i64)acc ? x : acc;
+        else acc = (i64)x > (i64)acc ? x : acc;
+    }
+    return acc;
+}
+
 RSQ_DEV u64 merge_identity(int op) {
     return op == M_SUM ? 0ull : op == M_MIN_U64 ? ~0ull : op == M_MIN_I64 ? 0x7fffffffffffffffull : 0x8000000000000000ull;
 }
@@ -188,6 +213,7 @@ RSQ_DEV i64 str_word(const Str& s, int n, int w) {
     for (int i = 0; i < 8; i++) { const int k = w * 8 + i; v |= (u64)(k < n ? (u8)s.p[k] : (u8)0) << (8 * i); }
     return (i64)v;
 }
+RSQ_DEV bool ends_with_space(const Str& s) { const int n = str_len_exact(s); return n > 0 && s.p[n - 1] == ' '; }
 RSQ_DEV i64 str_addr(const Str& s) { return (i64)(u64)reinterpret_cast<unsigned long long>(s.p); }
 RSQ_DEV Str str_from_addr(i64 w, int cap) { return str(reinterpret_cast<const char*>((unsigned long long)(u64)w), cap); }
 

@@ -30,7 +30,10 @@ if with_ref:
     shell = P.Plan(host); shell.root = 0
     ref_case = orc.write_case(shell, tmp)
 
+only = sys.argv[sys.argv.index("--only") + 1].split(",") if "--only" in sys.argv else None
 for name, sql in tpch_full.QUERIES.items():
+    if only and name not in only:
+        continue
     q = ctx.sql_compile(sql, tabs)
     best_k, best_e = 1e9, 1e9
     for _ in range(repeat):
