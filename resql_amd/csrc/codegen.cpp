@@ -577,6 +577,21 @@ struct Walker {
         // inside a kernel, so it is sized for twice the rows the build pipeline can deliver and re-run
         // at double size if it still overflows (engine.cpp).
         ht->capacity = 0;     // decided by the sizing pass at execute time (engine.cpp)
+        // One integer key word whose values can never be INT64_MIN: the key word itself is the slot's state.  A 64-bit CAS
+        // from the EMPTY sentinel claims the slot and publishes the key in one memory request (instead of a CAS on a state
+        // word plus a key store), a probe step reads one word instead of two dependent ones.  Scattered HBM requests are what
+        // a build costs.
+        if (keyVars.size() == 1 && o->exprs.size() == 1 && envInt("RSQ_KEY_CAS", 1, 0, 1)) {
+            Expr* l = o->exprs[0]->child;
+            const int tg = l->type.tag;
+            if (tg == RSQ_INT || tg == RSQ_DATE || tg == RSQ_BOOL || (tg == RSQ_CHAR && l->type.len == 1)) ht->keyCas = true;   // widened 32-bit / 8-bit values
+            else if ((tg == RSQ_BIGINT || tg == RSQ_DECIMAL) && l->tag == RSQ_E_ATTRIBUTE) {
+                auto org = symbolOrigin.find(l->symbol);
+                int ci = pipe.src->findCol(l->symbol);
+                if (org != symbolOrigin.end() && org->second == -1 && ci >= 0 && pipe.src->cols[(size_t)ci].stats.valid &&
+                    pipe.src->cols[(size_t)ci].stats.min > INT64_MIN) ht->keyCas = true;
+            }
+        }
         addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
         addArg(T + "_countonly", "u64", 0);
         // sizing pass: the same pipeline run once with countonly = 1 tells the host how many entries to expect
@@ -587,12 +602,18 @@ struct Walker {
         line("u64 " + T + "_n = 0;");
         openScope("for (;; " + T + "_n++) {");
         line("if (" + T + "_n > " + T + "_mask) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
-        line("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) break;");
+        if (ht->keyCas)
+            line("if (atomicCAS(reinterpret_cast<unsigned long long*>(&a." + T + "_words[" + T + "_s]), 0x8000000000000000ull, (unsigned long long)" +
+                 keyVars[0] + ") == 0x8000000000000000ull) break;");
+        else line("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) break;");
         line(T + "_s = (" + T + "_s + 1) & " + T + "_mask;");
         closeScope();
         openScope("if (" + T + "_n <= " + T + "_mask) {");
         int w = 0;
-        for (auto& kv : keyVars) line("a." + T + "_words[" + std::to_string(w++) + " * a." + T + "_cap + " + T + "_s] = " + kv + ";");
+        for (auto& kv : keyVars) {
+            if (!ht->keyCas) line("a." + T + "_words[" + std::to_string(w) + " * a." + T + "_cap + " + T + "_s] = " + kv + ";");
+            w++;
+        }
         for (auto& p : ht->payload)
             line("a." + T + "_words[" + std::to_string(w++) + " * a." + T + "_cap + " + T + "_s] = " + toWord(eg.symbols[p.name].var, p.type) + ";");
         line("st.n_" + T + "++;");
@@ -608,7 +629,8 @@ struct Walker {
         o->hashTable = ht->id;
         explainSteps.push_back("build hash table " + T + " (" + std::to_string(ht->keys.size()) + " key(s), " +
                                std::to_string(ht->payload.size()) + " payload word(s), sized by a counting pass" +
-                               (ht->hasBitmap ? ", key bitmap of " + std::to_string((long long)ht->bmBits) + " bits" : "") + ")");
+                               (ht->hasBitmap ? ", key bitmap of " + std::to_string((long long)ht->bmBits) + " bits" : "") +
+                               (ht->keyCas ? ", key word is the slot state" : "") + ")");
         q.hashTables.push_back(std::move(ht));
     }
 
@@ -664,10 +686,16 @@ struct Walker {
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
         line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
         openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
-        line("if (a." + T + "_state[" + T + "_s] == 0u) break;");
         std::string cond;
-        for (size_t i = 0; i < keyVars.size(); i++)
-            cond += (i ? " && " : "") + std::string("a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s] == " + keyVars[i];
+        if (ht.keyCas) {
+            line("const i64 " + T + "_kk = a." + T + "_words[" + T + "_s];");
+            line("if (" + T + "_kk == (i64)0x8000000000000000ull) break;");
+            cond = T + "_kk == " + keyVars[0];
+        } else {
+            line("if (a." + T + "_state[" + T + "_s] == 0u) break;");
+            for (size_t i = 0; i < keyVars.size(); i++)
+                cond += (i ? " && " : "") + std::string("a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s] == " + keyVars[i];
+        }
         openScope("if (" + cond + ") {");
         // the build side's values become symbols (hashjoin.h:146-147 / 204-205)
         int w = (int)ht.keys.size();

@@ -408,12 +408,13 @@ static void buildHashTable(Query& q, Pipeline& p) {
         RSQ_HIP(hipMemcpyAsync(&n, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         RSQ_HIP(hipStreamSynchronize(ctx.stream));
         h.capacity = nextPow2(std::max<int64_t>(1024, 2 * (int64_t)n));
-        h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
+        if (!h.keyCas) h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
         h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
         if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
         RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
     }
-    RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
+    if (h.keyCas) fillU64Async(ctx, (uint64_t*)h.dWords, (size_t)h.capacity, 0x8000000000000000ull);     // every key word = EMPTY
+    else RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
     if (h.hasBitmap) {
         const size_t bmBytes = ((size_t)h.bmBits + 31) / 32 * 4;
         if (!h.dBitmap) h.dBitmap = (uint32_t*)ctx.alloc(bmBytes);

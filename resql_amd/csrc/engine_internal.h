@@ -45,6 +45,8 @@ struct HashTable {
     std::vector<std::pair<Attr, int>> keyAlias;   // build-side attributes that ARE a key value: (attribute, key word) — not stored twice
     int64_t capacity = 0;
     bool unique = false;             // probed single-match
+    bool keyCas = false;             // one integer key word that is never INT64_MIN: the key word is the slot state
+                                     // (EMPTY = INT64_MIN, claimed and published by one 64-bit CAS); dState is unused
     uint32_t* dState = nullptr;
     int64_t* dWords = nullptr;
     int64_t* dAcc = nullptr;         // [nAccBlocks][capacity] when aggregated at the entry
