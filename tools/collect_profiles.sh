@@ -30,5 +30,12 @@ json.dump({"kernel": "rsq_pipeline (TPC-H Q1 SF10: scan 7 columns + filter + 6-g
            "algorithmic_bytes_per_launch": 38 * 59999996}, open(sys.argv[2], "w"), indent=1)
 print("pmc launches", n, "corrected bytes", kb * 1024 * 2)
 PY
+# TPC-H Q3 at SF10 (BASELINE config 3): kernel statistics of a few executions, and the eight SQL statements at SF1
+rm -rf /tmp/prof_q3
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q3 -- python3 $ROOT/tools/profile_case.py q3 10 12 > $OUT/${R}_q3_sf10_runs.log 2>&1
+cp "$(find /tmp/prof_q3 -name '*kernel_stats.csv' | head -1)" $OUT/${R}_q3_sf10_kernel_stats.csv
+timeout -s KILL 300 python3 $ROOT/tools/sql_bench.py 1 --reference > $OUT/${R}_sql_sf1.log 2>&1
+grep '^{' $OUT/${R}_sql_sf1.log > $OUT/${R}_sql_sf1.jsonl
 head -3 $OUT/${R}_q1_sf10_kernel_stats.csv | cut -c1-150
+head -4 $OUT/${R}_q3_sf10_kernel_stats.csv | cut -c1-150
 cut -c1-400 $OUT/${R}_bench_n1.json
