@@ -296,14 +296,14 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value) {
     RSQ_HIP(hipGetLastError());
 }
 
-// Each workgroup owns chunks of 256 x 16 consecutive slots.  All 16 first-row words of a thread are loaded up front
+// Each workgroup owns chunks of 256 x COMPACT_PER_THREAD consecutive slots.  All first-row words of a thread are loaded up front
 // (independent, coalesced across the workgroup), the occupied ones are counted, an LDS scan gives every thread its
 // offset and ONE global atomic per workgroup and chunk reserves the output rows: returning atomics on a single word
 // serialise at ~11 ns each on MI355X (MI355X_MICROARCH.md, "fanin"), so one per occupied slot — or one per wave and
 // round, 54 K of them for TPC-H Q3 at SF10 — cost 620 us.  The table's first-row block is read once (the earlier
-// count-then-write form read it twice with 32 dependent rounds per thread: 73 us for 4 M slots; this form: see DESIGN).
+// count-then-write form read it twice with 32 dependent rounds per thread: 73 us for 4 M slots; this form: 19 us).
 // Rows beyond `maxRows` are counted but not written (the host re-runs with a larger buffer).
-enum { COMPACT_PER_THREAD = 16 };
+template <int COMPACT_PER_THREAD>
 __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__ first, i64 cap, const i64* __restrict__ words, int nWords,
                                                          const i64* __restrict__ acc, int nAcc, i64* __restrict__ out, unsigned maxRows,
                                                          unsigned* count) {
@@ -311,6 +311,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ unsigned s_wave[4];
     __shared__ unsigned s_base;
+    __shared__ unsigned s_list[256 * COMPACT_PER_THREAD];      // chunk-relative indices of the occupied slots
     const i64 chunkSlots = 256 * COMPACT_PER_THREAD;
     for (i64 lo = (i64)blockIdx.x * chunkSlots; lo < cap; lo += (i64)gridDim.x * chunkSlots) {
         i64 f[COMPACT_PER_THREAD];
@@ -333,18 +334,23 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
         if (t == 0) s_base = total ? atomicAdd(count, total) : 0u;
         __syncthreads();
         if (total) {
-            unsigned pos = s_base + before + incl - mine;
+            // the occupied slots are sparse (a few per cent): gather them into an LDS list first so that the row copies run
+            // with every lane busy — copying straight from the per-thread slots executed the (divergent) copy body once per
+            // slot position of the wave, 13 of 16 times for Q3, each a chain of dependent loads and stores: 42 us
+            unsigned lp = before + incl - mine;
 #pragma unroll
-            for (int r = 0; r < COMPACT_PER_THREAD; r++) {
-                if (f[r] == 0x7fffffffffffffffll) continue;
-                if (pos < maxRows) {
-                    const i64 s = lo + r * 256 + t;
-                    i64* o = out + (size_t)pos * stride;
-                    o[0] = f[r];
-                    for (int w = 0; w < nWords; w++) o[1 + w] = words[(size_t)w * cap + s];
-                    for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
-                }
-                pos++;
+            for (int r = 0; r < COMPACT_PER_THREAD; r++)
+                if (f[r] != 0x7fffffffffffffffll) s_list[lp++] = (unsigned)(r * 256 + t);
+            __syncthreads();
+            const unsigned base = s_base;
+            for (unsigned i = (unsigned)t; i < total; i += 256u) {
+                const unsigned pos = base + i;
+                if (pos >= maxRows) continue;
+                const i64 s = lo + (i64)s_list[i];
+                i64* o = out + (size_t)pos * stride;
+                o[0] = first[s];
+                for (int w = 0; w < nWords; w++) o[1 + w] = words[(size_t)w * cap + s];
+                for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
             }
         }
         __syncthreads();          // s_wave / s_base are rewritten by the next chunk
@@ -353,10 +359,16 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
 
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count) {
-    const int64_t chunkSlots = 256 * COMPACT_PER_THREAD;
+    // slots per thread: every chunk costs one reservation atomic on the same word (they serialise), so large tables take
+    // large chunks; swept on the box through RSQ_COMPACT_PT for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us
+    static const int forced = getenv("RSQ_COMPACT_PT") ? atoi(getenv("RSQ_COMPACT_PT")) : 0;
+    const int perThread = forced ? forced : capacity >= (1 << 22) ? 64 : capacity >= (1 << 20) ? 32 : 16;
+    const int64_t chunkSlots = 256 * (int64_t)perThread;
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8 * (int64_t)ctx.numCUs, (capacity + chunkSlots - 1) / chunkSlots));
-    hipLaunchKernelGGL(k_compact_entries, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, (const i64*)words, nWords,
-                       (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count);
+#define RSQ_LAUNCH_COMPACT(PT) hipLaunchKernelGGL(k_compact_entries<PT>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, \
+                       (const i64*)words, nWords, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count)
+    if (perThread >= 64) RSQ_LAUNCH_COMPACT(64); else if (perThread >= 32) RSQ_LAUNCH_COMPACT(32); else RSQ_LAUNCH_COMPACT(16);
+#undef RSQ_LAUNCH_COMPACT
     RSQ_HIP(hipGetLastError());
 }
 
