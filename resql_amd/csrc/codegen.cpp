@@ -117,7 +117,10 @@ struct ExprGen {
                     failType("emitTypecastToDECIMAL(..) code generation not implemented for datatype");
                 }
                 if (to.tag == RSQ_BIGINT) {
-                    if (from.tag == RSQ_INT) return "((i64)(" + c + "))";
+                    // INT -> BIGINT is a 32 -> 64 sign extension (ExpressionsJitFlounder.h:818-824 `movsx`).  The reference's
+                    // asmjit back end encodes the 16-bit movsx for it, so its JIT extends the low 16
+                    // bits; RSQ_REFERENCE_INT16_CAST=1 reproduces exactly that for hosts that need the JIT's answers.
+                    if (from.tag == RSQ_INT) return envInt("RSQ_REFERENCE_INT16_CAST", 0, 0, 1) ? "((i64)(short)(" + c + "))" : "((i64)(" + c + "))";
                     if (from.tag == RSQ_DECIMAL) {
                         if (from.scale > 8) failType("typecast beyond the supported scale");
                         return "((i64)((" + c + ") / " + lit64(pow10(from.scale)) + "))";

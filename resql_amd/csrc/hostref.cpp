@@ -1,4 +1,5 @@
 // hostref.cpp — see hostref.h.
+#include <cstring>
 #include "hostref.h"
 
 #include <algorithm>
@@ -195,6 +196,42 @@ int compareTyped(const Type& t, const uint8_t* l, const uint8_t* r) {
         case RSQ_CHAR: case RSQ_VARCHAR: return (int)(int8_t)strcmp((const char*)l, (const char*)r);
         default: return 0;
     }
+}
+
+// Restated with indices like the device version (kernels/rsq_device.h like()): the prefix and the suffix of the pattern are
+// matched independently (they may overlap in the string), infixes are searched greedily left to right; reading index ==
+// length yields the NUL the reference reads there.
+bool refLike(const char* S, const char* L) {
+    const int sn = (int)strlen(S), ln = (int)strlen(L);
+    auto at = [](const char* p, int n, int i) -> char { return i >= 0 && i < n ? p[i] : '\0'; };
+    auto likeChar = [](char c, char l) { return c == l || l == '_'; };
+    int sPos = 0, lPos = 0;
+    int lInStart = 0, lInEnd = ln, sInStart = 0, sInEnd = sn;
+    if (at(L, ln, 0) != '%') {                                   // prefix
+        for (; lPos < ln && sPos < sn && at(L, ln, lPos) != '%'; ++lPos, ++sPos)
+            if (!likeChar(at(S, sn, sPos), at(L, ln, lPos))) return false;
+        lInStart = lPos; sInStart = sPos;
+    }
+    if (lInStart == ln) return sInStart == sn;                   // no '%' left
+    if (at(L, ln, ln - 1) != '%') {                              // suffix
+        sPos = sn - 1; lPos = ln - 1;
+        for (; lPos >= 0 && sPos >= 0 && at(L, ln, lPos) != '%'; --lPos, --sPos)
+            if (!likeChar(at(S, sn, sPos), at(L, ln, lPos))) return false;
+        lInEnd = lPos; sInEnd = sPos + 1;
+    }
+    if (lInStart < lInEnd) {                                     // infixes
+        lPos = lInStart + 1; sPos = sInStart;
+        while (sPos < sInEnd && lPos < lInEnd) {
+            int lTrace = lPos, sTrace = sPos;
+            while (likeChar(at(S, sn, sTrace), at(L, ln, lTrace)) && sTrace < sInEnd) {
+                ++lTrace;
+                if (at(L, ln, lTrace) == '%') { lPos = ++lTrace; sPos = sTrace; break; }
+                ++sTrace;
+            }
+            ++sPos;
+        }
+    }
+    return lPos >= lInEnd;
 }
 
 void refQuicksort(uint8_t* data, int64_t n, size_t ts, const std::vector<OrderRequest>& order) {

@@ -34,6 +34,10 @@ struct OrderRequest { int offset; Type type; bool asc; };
 int compareTyped(const Type& t, const uint8_t* l, const uint8_t* r);
 void refQuicksort(uint8_t* tuples, int64_t n, size_t tupleSize, const std::vector<OrderRequest>& order);
 
+// stringLikeCheck (reference src/qlib/scalar.h:49-118) on NUL-terminated strings: '%' any run, '_' any one character; the
+// host-side twin of rsq_device.h like() for LIKE expressions evaluated above an aggregation
+bool refLike(const char* s, const char* pattern);
+
 // packed tuple access (reference src/values.h:151-232)
 void storeValue(uint8_t* addr, Val v, const Type& t);      // strings by value, NUL terminated
 Val loadValue(const uint8_t* addr, const Type& t);

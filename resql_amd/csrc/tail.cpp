@@ -92,7 +92,8 @@ struct HostCompiler {
                 return h;
             case BINARY:
                 h.kind = 2; h.tag = e->tag; h.opType = e->child->type;
-                if (e->tag == RSQ_E_LIKE) failUnsupported("LIKE is not implemented by the GPU engine");
+                if (e->tag == RSQ_E_LIKE && (!e->child->type.isString() || !e->child->next->type.isString()))
+                    failType("LIKE on a CHAR(1) operand is undefined in the reference");
                 h.kids.push_back(compile(e->child));
                 h.kids.push_back(compile(e->child->next));
                 return h;
@@ -164,7 +165,10 @@ Val evalHost(const HostExpr& h, const std::vector<Val>& sym) {
                 } else if (from.tag == RSQ_BIGINT) r.i = (int64_t)((uint64_t)c.i * (uint64_t)pow10i(to.scale));
                 else failType("emitTypecastToDECIMAL(..) code generation not implemented for datatype");
             } else if (to.tag == RSQ_BIGINT) {
-                if (from.tag == RSQ_INT) r.i = (int64_t)(int32_t)c.i;
+                if (from.tag == RSQ_INT) {
+                    static const bool int16Cast = getenv("RSQ_REFERENCE_INT16_CAST") && atoi(getenv("RSQ_REFERENCE_INT16_CAST")) == 1;
+                    r.i = int16Cast ? (int64_t)(int16_t)c.i : (int64_t)(int32_t)c.i;      // see codegen.cpp emitUnary
+                }
                 else if (from.tag == RSQ_DECIMAL) r.i = sdiv(c.i, pow10i(from.scale));
                 else r = c;
             } else failType("emitTypecast(..) code generation not implemented for datatype");
@@ -192,6 +196,7 @@ Val evalHost(const HostExpr& h, const std::vector<Val>& sym) {
         case RSQ_E_GE: r.i = cmpVal(a, b, h.opType) >= 0; break;
         case RSQ_E_EQ: r.i = equalsVal(a, b, h.opType); break;
         case RSQ_E_NEQ: r.i = 1 - (int)equalsVal(a, b, h.opType); break;
+        case RSQ_E_LIKE: r.i = refLike(a.s, b.s) ? 1 : 0; break;
         default: failUnsupported(std::string("host evaluation of ") + exprTagNames[h.tag]);
     }
     return r;

@@ -80,6 +80,7 @@ PLAN_CASES = [
     "select l_quantity :: bigint, (l_extendedprice * 2) :: decimal(19,4) from lineitem where l_linenumber > 6",   # explicit casts
     "select n_nationkey :: bigint + -3 from nation where n_nationkey :: bigint > 20",
     "select l_orderkey from lineitem where l_orderkey < 3",              # INT -> BIGINT cast of keys beyond int16: see oracle g_narrowCasts
+    "select n_name, n_name like '%IA', count(*) as n from nation group by n_name order by n_name limit 9",      # LIKE above the aggregation (host tail)
     "select n_name :: int from nation",                                   # a cast the reference has no code for
     "select c_name from customer, nation",                                 # no equality: nested-loops join
     "select x from nosuchtable",

@@ -97,3 +97,18 @@ def test_statement_loop_create_load_select(gpu_ctx, tmp_path):
             db.execute("select n_name from nation where")
     finally:
         db.close()
+
+
+def test_reference_int16_cast_switch_reproduces_the_jit(gpu_ctx, small_db, monkeypatch):
+    """RSQ_REFERENCE_INT16_CAST=1: INT -> BIGINT casts extend the low 16 bits, as the reference's asmjit back end does
+     — the engine then returns the JIT's own answer for `l_orderkey < 3` (keys 32769.. included)"""
+    host, tabs = small_db
+    cases = [g for g in GOLD["results"].values() if "reference_text" in g]
+    assert cases
+    monkeypatch.setenv("RSQ_REFERENCE_INT16_CAST", "1")
+    for g in cases:
+        q = gpu_ctx.sql_compile(g["sql"], tabs)
+        q.execute()
+        got = q.result()
+        q.close()
+        assert got.text == g["reference_text"] and got.text != g["text"]

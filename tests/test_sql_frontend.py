@@ -159,3 +159,15 @@ def test_database_statement_loop_without_gpu(compile_ctx):
         db.execute("create table nation ( x int )")
     with pytest.raises(engine.EngineError, match="does not exist"):
         db.execute("bulk insert region from 'r.tbl'")
+
+
+def test_reference_int16_cast_switch_reproduces_the_jit(compile_ctx, database, monkeypatch):
+    """the reference's asmjit back end sign-extends INT -> BIGINT casts from 16 bits; with
+    RSQ_REFERENCE_INT16_CAST=1 the oracle (and the engine, tests/test_gpu_sql.py) give the JIT's own answer"""
+    host, tabs = database
+    cases = [g for g in GOLD["results"].values() if "reference_text" in g]
+    assert cases
+    monkeypatch.setenv("RSQ_REFERENCE_INT16_CAST", "1")
+    for g in cases:
+        res = orc.execute(compile_ctx.sql_plan(g["sql"], tabs, host))
+        assert res.text == g["reference_text"] and res.text != g["text"]
