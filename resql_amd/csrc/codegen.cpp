@@ -257,6 +257,7 @@ struct Walker {
     std::string body;                          // row function body
     std::string closers;                       // closing braces of the open scopes
     std::string stateDecl, stateInit, prologue, epilogue, fileScope;
+    std::string helperFns;                     // device functions behind Args / State, in front of the row function
     std::vector<std::string> explainSteps;
     int indent = 1;
     int matchSlotTable = -1;                   // innermost single-match probe whose slot variable is in scope
@@ -348,7 +349,7 @@ struct Walker {
         // 768: 0.367, 1024: 0.374, 2048: 0.395, 4096: 0.448 - a streaming kernel wants exactly 2 resident workgroups per CU
         pipe.maxGrid = (unsigned)envInt("RSQ_MAXGRID", 0, 0, 1 << 20);
         colTypes.clear(); colIsString.clear(); rowParams.clear(); rowArgsTail.clear(); rowArgsTailGuarded.clear();
-        body.clear(); stateDecl.clear(); stateInit.clear(); prologue.clear(); epilogue.clear(); fileScope.clear();
+        body.clear(); stateDecl.clear(); stateInit.clear(); prologue.clear(); epilogue.clear(); fileScope.clear(); helperFns.clear();
         explainSteps.clear(); indent = 1; matchSlotTable = -1; slotVar.clear(); symbolOrigin.clear(); symbolWord.clear();
         multiMatchAbove = false;
         selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
@@ -869,111 +870,194 @@ struct Walker {
         const int W = (int)q.accums.size();
         ht->nAccBlocks = W;
         std::vector<std::string> keyVars;
-        std::vector<std::string> spaceSuffixed;       // per CHAR(n) group value: "its bytes end with a space"
+        std::vector<std::pair<size_t, size_t>> charKeyWords;      // per CHAR(n) group value: [first, last] key word
         openScope("{");
         int k = 0;
         q.groupSource.clear();
         for (Expr* g : o->exprs2) {
             const size_t w0 = keyVars.size();
             q.groupSource.push_back((int)w0);           // first table word of this group value
-            for (auto& kv : keyWords(g, T + "_g" + std::to_string(k++), false, &spaceSuffixed)) keyVars.push_back(kv);
+            for (auto& kv : keyWords(g, T + "_g" + std::to_string(k++), false)) keyVars.push_back(kv);
+            if (g->type.tag == RSQ_CHAR && g->type.len > 1) charKeyWords.push_back({w0, keyVars.size() - 1});
             for (size_t w = w0; w < keyVars.size(); w++)
                 ht->keys.push_back({w == w0 ? expressionName(g) : expressionName(g) + "#" + std::to_string(w - w0), w == w0 && !g->type.isString() ? g->type : Type(RSQ_BIGINT)});
         }
         if (keyVars.empty()) failUnsupported("hash aggregation without group keys");
+        const int K = (int)keyVars.size();
         for (int w = 1; w < W; w++) line("const i64 in" + std::to_string(w) + " = " + q.accums[(size_t)w].input + ";");
         addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
         addArg(T + "_acc", "u64*", 0);
+
+        // ---- LDS front table (per workgroup) ------------------------------------------------------------------------
+        // Direct-mapped slots {state, key words, accumulators} in LDS (256 .. 1024, by their size) in front of the HBM table: a row whose group
+        // already owns its slot is aggregated with LDS atomics and never leaves the CU; a row that finds the slot taken by
+        // another group, or still being written, goes to the HBM table as before (no waiting, so no wave can block
+        // itself).  At the end of the kernel every occupied slot is merged into the HBM table by the same upsert.  With
+        // few groups (TPC-H Q12: 2, Q5: 5) nearly every row stays in LDS; with many, nearly every row pays one LDS probe.
+        const int slotBytes = 8 * (K + W) + 4;
+        int LS = envInt("RSQ_HASH_LDS_SLOTS", 0, 0, 4096);
+        if (LS == 0) LS = slotBytes * 1024 <= 48 * 1024 ? 1024 : slotBytes * 512 <= 48 * 1024 ? 512 : 256;
+        while (LS & (LS - 1)) LS &= LS - 1;           // power of two
+        const bool lds = envInt("RSQ_HASH_LDS", 1, 0, 1) && LS >= 64 && slotBytes * LS <= 48 * 1024;
+        if (lds) {
+            stateDecl += "    u32* lc_state;\n    i64* lc_key;\n    u64* lc_acc;\n";
+            prologue += "    __shared__ u32 s_lc_state[" + std::to_string(LS) + "];\n    __shared__ i64 s_lc_key[" + std::to_string(K * LS) +
+                        "];\n    __shared__ u64 s_lc_acc[" + std::to_string(W * LS) + "];\n";
+            prologue += "    st.lc_state = s_lc_state; st.lc_key = s_lc_key; st.lc_acc = s_lc_acc;\n";
+            prologue += "    for (int i = threadIdx.x; i < " + std::to_string(LS) + "; i += blockDim.x) s_lc_state[i] = 0u;\n    __syncthreads();\n";
+            pipe.extraLdsBytes += (8 * (K + W) + 4) * LS;
+            // flush (before the entry counter's flush below: the upserts count new entries)
+            std::string f = "    __syncthreads();\n    for (int i = threadIdx.x; i < " + std::to_string(LS) + "; i += blockDim.x) {\n";
+            f += "        if (st.lc_state[i] == 2u) " + T + "_upsert(a, st, (i64)st.lc_acc[i]";
+            for (int i = 0; i < K; i++) f += ", st.lc_key[" + std::to_string(i * LS) + " + i]";
+            for (int w = 1; w < W; w++) f += ", (i64)st.lc_acc[" + std::to_string(w * LS) + " + i]";
+            f += ");\n    }\n";
+            epilogue += f;
+        }
         countPerThread(T);
-        line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
-        line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
-        // Insert-or-find, written so that it cannot deadlock inside a wave: the lane that wins the CAS writes the keys and
-        // publishes state 2 in a plain if-block that is followed by code every lane runs (the reload), so the publish
-        // stays inside the loop body.  (With `if (won) {publish; hit} if (!hit) continue; ...; break;` the compiler threads
-        // the winner straight to the loop exit, the structurizer parks it there until the whole wave has left the loop,
-        // and the losers of the same wave spin on a slot that is never published.)
-        line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0; bool " + T + "_found = false;");
-        line("if (rsq::ld_agent(a.err) & (u32)rsq::ERR_HT_FULL) return;      // another lane found the table too small: this run is void");
-        openScope("for (;;) {");
-        line("u32 stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);");
-        openScope("if (stt == 0u) {");
-        openScope("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) {");
-        for (size_t i = 0; i < keyVars.size(); i++)
-            line("rsq::st_agent(&a." + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s], " + keyVars[i] + ");");
-        line("__threadfence();");
-        line("rsq::st_agent(&a." + T + "_state[" + T + "_s], 2u);");
-        line("st.n_" + T + "++;");
-        if (!spaceSuffixed.empty()) {
-            // Groups are keyed by the exact bytes; the reference's CHAR equality ignores trailing spaces, so the host merges
-            // such groups — which is only ever needed when some group value ends with a space.  The lane that creates a
-            // group tells the host (once per group, nearly never): without the flag the host skips the merge and may take
-            // the candidate path of ORDER BY ... LIMIT.
-            std::string any;
-            for (size_t i = 0; i < spaceSuffixed.size(); i++) any += (i ? " || " : "") + spaceSuffixed[i];
-            line("if (" + any + ") atomicOr(a.err, (u32)rsq::NOTE_CHAR_GROUP_ENDS_WITH_SPACE);");
-        }
-        closeScope();
-        line("stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);      // our own publish, or whoever won the slot");
-        closeScope();
-        openScope("if (stt == 2u) {");
-        std::string cond;
-        for (size_t i = 0; i < keyVars.size(); i++)
-            cond += (i ? " && " : "") + std::string("rsq::ld_agent(&a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s]) == " + keyVars[i];
-        openScope("if (" + cond + ") {");
-        line(T + "_found = true;");
-        line("break;");
-        closeScope();
-        line(T + "_s = (" + T + "_s + 1) & " + T + "_mask;");
-        // A probe sequence of thousands of slots means the table is (nearly) full: linear probing degrades to a scan of
-        // the table per row long before every slot is taken (1 M groups in 1 M slots: 90 ns per row, 2.2 s per 25 M rows).
-        // Report "full" early; the host re-runs with a four times larger table and keeps the load below one half.
-        line("if (++" + T + "_adv > (" + T + "_mask < 4096 ? " + T + "_mask : 4096)) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
-        closeScope();
-        line("else if (++" + T + "_spin > (1u << 22)) { atomicOr(a.err, (u32)rsq::ERR_STUCK); break; }   // a slot another wave is writing");
-        closeScope();
-        // The updates, after the loop (the wave has reconverged): lanes of this wave that found the SAME slot are folded
-        // into one update by their first lane while such sets are large (a few groups in the whole input); as soon as the
-        // first set is small the group domain is wide and every lane updates its own slot.
-        auto updates = [&](const std::string& slot, const std::string& valueOf) {
-            for (int w = 0; w < W; w++) {
-                std::string in = w == 0 ? "row" : "in" + std::to_string(w);
-                const std::string op = std::to_string(q.accums[(size_t)w].merge);
-                std::string v = valueOf.empty() ? "(u64)(" + in + ")" : "rsq::subset_reduce<" + op + ">((u64)(" + in + "), " + valueOf + ")";
-                if (valueOf.empty())
-                    line("rsq::global_merge_always<" + op + ">(a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) + " * a." + T + "_cap + " + slot + ", " + v + ");");
-                else {
-                    line("{ const u64 r = " + v + "; if (wl_lane == wl_leader) rsq::global_merge_always<" + op + ">(a." + T + "_acc + " +
-                         std::to_string(q.accumSlot[(size_t)w]) + " * a." + T + "_cap + " + slot + ", r); }");
+
+        // ---- the HBM table's insert-or-find + update, as a function of (first row, key words, accumulator inputs) ---
+        // Slot protocol: state 0 empty -> CAS to 1 (being written) -> keys stored -> fence -> 2 (ready); a lane that
+        // loses the CAS or meets state 1 looks at the slot again.
+        {
+            std::string savedBody = body; const int savedIndent = indent;
+            body.clear(); indent = 1;
+            std::vector<std::string> kp;
+            for (int i = 0; i < K; i++) kp.push_back("k" + std::to_string(i));
+            line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
+            line("u64 " + T + "_s = " + hashOf(kp) + " & " + T + "_mask;");
+            // Insert-or-find, written so that it cannot deadlock inside a wave: the lane that wins the CAS writes the keys and
+            // publishes state 2 in a plain if-block that is followed by code every lane runs (the reload), so the publish
+            // stays inside the loop body.  (With `if (won) {publish; hit} if (!hit) continue; ...; break;` the compiler threads
+            // the winner straight to the loop exit, the structurizer parks it there until the whole wave has left the loop,
+            // and the losers of the same wave spin on a slot that is never published.)
+            line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0; bool " + T + "_found = false;");
+            line("if (rsq::ld_agent(a.err) & (u32)rsq::ERR_HT_FULL) return;      // another lane found the table too small: this run is void");
+            openScope("for (;;) {");
+            line("u32 stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);");
+            openScope("if (stt == 0u) {");
+            openScope("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) {");
+            for (int i = 0; i < K; i++)
+                line("rsq::st_agent(&a." + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s], " + kp[(size_t)i] + ");");
+            line("__threadfence();");
+            line("rsq::st_agent(&a." + T + "_state[" + T + "_s], 2u);");
+            line("st.n_" + T + "++;");
+            if (!charKeyWords.empty()) {
+                // Groups are keyed by the exact bytes; the reference's CHAR equality ignores trailing spaces, so the host merges
+                // such groups — which is only ever needed when some group value ends with a space.  The lane that creates a
+                // group tells the host (once per group, nearly never): without the flag the host skips the merge and may take
+                // the candidate path of ORDER BY ... LIMIT.  The last character is the top non-zero byte of the value's last
+                // non-zero key word.
+                std::string any;
+                for (auto& r : charKeyWords) {
+                    std::string last = kp[r.first];
+                    for (size_t w = r.first + 1; w <= r.second; w++) last = "(" + kp[w] + " != 0 ? " + kp[w] + " : " + last + ")";
+                    any += (any.empty() ? "" : " || ") + std::string("rsq::top_byte_is_space(") + last + ")";
                 }
+                line("if (" + any + ") atomicOr(a.err, (u32)rsq::NOTE_CHAR_GROUP_ENDS_WITH_SPACE);");
             }
-        };
-        if (envInt("RSQ_WAVE_FOLD", 1, 0, 1)) {
-            openScope("{");
-            line("const int wl_lane = (int)(threadIdx.x & 63);");
-            line("bool wl_mine = " + T + "_found;");
-            line("u64 wl_todo = __ballot(wl_mine);");
-            openScope("while (wl_todo) {");
-            line("const int wl_leader = __ffsll((long long)wl_todo) - 1;");
-            line("const u64 wl_slot = rsq::readlane_u64(" + T + "_s, wl_leader);");
-            line("const u64 wl_set = __ballot(wl_mine && " + T + "_s == wl_slot);");
-            line("if (__popcll(wl_set) < 4) break;");
-            updates("wl_slot", "wl_set");
-            line("if (" + T + "_s == wl_slot) wl_mine = false;");
-            line("wl_todo &= ~wl_set;");
             closeScope();
-            openScope("if (wl_mine) {");
-            updates(T + "_s", "");
+            line("stt = rsq::ld_agent(&a." + T + "_state[" + T + "_s]);      // our own publish, or whoever won the slot");
             closeScope();
+            openScope("if (stt == 2u) {");
+            std::string cond;
+            for (int i = 0; i < K; i++)
+                cond += (i ? " && " : "") + std::string("rsq::ld_agent(&a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s]) == " + kp[(size_t)i];
+            openScope("if (" + cond + ") {");
+            line(T + "_found = true;");
+            line("break;");
             closeScope();
-        } else {
-            openScope("if (" + T + "_found) {");
-            updates(T + "_s", "");
+            line(T + "_s = (" + T + "_s + 1) & " + T + "_mask;");
+            // A probe sequence of thousands of slots means the table is (nearly) full: linear probing degrades to a scan of
+            // the table per row long before every slot is taken (1 M groups in 1 M slots: 90 ns per row, 2.2 s per 25 M rows).
+            // Report "full" early; the host re-runs with a four times larger table and keeps the load below one half.
+            line("if (++" + T + "_adv > (" + T + "_mask < 4096 ? " + T + "_mask : 4096)) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
             closeScope();
+            line("else if (++" + T + "_spin > (1u << 22)) { atomicOr(a.err, (u32)rsq::ERR_STUCK); break; }   // a slot another wave is writing");
+            closeScope();
+            // The updates, after the loop (the wave has reconverged): lanes of this wave that found the SAME slot are folded
+            // into one update by their first lane while such sets are large (a few groups in the whole input); as soon as the
+            // first set is small the group domain is wide and every lane updates its own slot.
+            auto updates = [&](const std::string& slot, const std::string& members) {
+                for (int w = 0; w < W; w++) {
+                    const std::string in = "x" + std::to_string(w);
+                    const std::string op = std::to_string(q.accums[(size_t)w].merge);
+                    const std::string dst = "a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) + " * a." + T + "_cap + " + slot;
+                    if (members.empty()) line("rsq::global_merge_always<" + op + ">(" + dst + ", (u64)" + in + ");");
+                    else line("{ const u64 r = rsq::subset_reduce<" + op + ">((u64)" + in + ", " + members + "); if (wl_lane == wl_leader) rsq::global_merge_always<" +
+                              op + ">(" + dst + ", r); }");
+                }
+            };
+            if (envInt("RSQ_WAVE_FOLD", 1, 0, 1)) {
+                line("const int wl_lane = (int)(threadIdx.x & 63);");
+                line("bool wl_mine = " + T + "_found;");
+                line("u64 wl_todo = __ballot(wl_mine);");
+                openScope("while (wl_todo) {");
+                line("const int wl_leader = __ffsll((long long)wl_todo) - 1;");
+                line("const u64 wl_slot = rsq::readlane_u64(" + T + "_s, wl_leader);");
+                line("const u64 wl_set = __ballot(wl_mine && " + T + "_s == wl_slot);");
+                line("if (__popcll(wl_set) < 4) break;");
+                updates("wl_slot", "wl_set");
+                line("if (" + T + "_s == wl_slot) wl_mine = false;");
+                line("wl_todo &= ~wl_set;");
+                closeScope();
+                openScope("if (wl_mine) {");
+                updates(T + "_s", "");
+                closeScope();
+            } else {
+                openScope("if (" + T + "_found) {");
+                updates(T + "_s", "");
+                closeScope();
+            }
+            std::string fn = "static RSQ_DEV void " + T + "_upsert(const Args& a, State& st, const i64 x0";
+            for (int i = 0; i < K; i++) fn += ", const i64 k" + std::to_string(i);
+            for (int w = 1; w < W; w++) fn += ", const i64 x" + std::to_string(w);
+            fn += ") {\n" + body + "}\n";
+            helperFns += fn;
+            body = savedBody; indent = savedIndent;
         }
+
+        // ---- the row: LDS front table first, the HBM table otherwise ---------------------------------------------------
+        std::string call = T + "_upsert(a, st, row";
+        for (int i = 0; i < K; i++) call += ", " + keyVars[(size_t)i];
+        for (int w = 1; w < W; w++) call += ", in" + std::to_string(w);
+        call += ");";
+        if (lds) {
+            line("bool " + T + "_done = false;");
+            openScope("{");
+            // up to four consecutive slots: two groups that map to the same slot would otherwise send one of them to the
+            // HBM table for good — with few groups that is a handful of HBM words taking every update of a hot group
+            // (64 groups, 1024 slots: 5.1 ms per 100 M rows against 2.9 ms for 1024 groups, before the probing)
+            line("u32 ls = (u32)(" + hashOf(keyVars) + " >> 44) & " + std::to_string(LS - 1) + "u;");
+            openScope("for (int lt = 0; lt < 4; lt++, ls = (ls + 1u) & " + std::to_string(LS - 1) + "u) {");
+            line("u32 lst = __hip_atomic_load(&st.lc_state[ls], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);");
+            openScope("if (lst == 0u && atomicCAS(&st.lc_state[ls], 0u, 1u) == 0u) {");
+            for (int i = 0; i < K; i++) line("st.lc_key[" + std::to_string(i * LS) + " + ls] = " + keyVars[(size_t)i] + ";");
+            for (int w = 0; w < W; w++) {
+                const int m = q.accums[(size_t)w].merge;
+                line("st.lc_acc[" + std::to_string(w * LS) + " + ls] = " + (m == 0 ? "0ull" : m == 2 ? "0x7fffffffffffffffull" : m == 3 ? "0x8000000000000000ull" : "~0ull") + ";");
+            }
+            line("__hip_atomic_store(&st.lc_state[ls], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);");
+            line("lst = 2u;");
+            closeScope();
+            line("if (lst != 2u) break;           // another lane is writing this slot: do not wait, take the HBM table");
+            std::string eq;
+            for (int i = 0; i < K; i++) eq += std::string(i ? " && " : "") + "st.lc_key[" + std::to_string(i * LS) + " + ls] == " + keyVars[(size_t)i];
+            openScope("if (" + eq + ") {");
+            for (int w = 0; w < W; w++)
+                line("rsq::lds_merge<" + std::to_string(q.accums[(size_t)w].merge) + ">(&st.lc_acc[" + std::to_string(w * LS) + " + ls], (u64)(" +
+                     (w == 0 ? std::string("row") : "in" + std::to_string(w)) + "));");
+            line(T + "_done = true;");
+            line("break;");
+            closeScope();
+            closeScope();
+            closeScope();
+            line("if (!" + T + "_done) " + call);
+        } else line(call);
         closeScope();
         q.aggTable = ht->id;
-        explainSteps.push_back("hash aggregation in " + T + " (" + std::to_string(ht->keys.size()) + " key word(s)) accumulators=" +
-                               std::to_string(W - 1) + " (of " + std::to_string(o->splitAgg.size()) + " in the reference)");
+        explainSteps.push_back("hash aggregation in " + T + " (" + std::to_string(ht->keys.size()) + " key word(s)" + (lds ? ", LDS front table" : "") +
+                               ") accumulators=" + std::to_string(W - 1) + " (of " + std::to_string(o->splitAgg.size()) + " in the reference)");
         q.hashTables.push_back(std::move(ht));
     }
 
@@ -1301,7 +1385,7 @@ struct Walker {
         const int NV = 1 + pipe.compactWords;       // the row index + the carried values
         if (cq) {
             // the queues take LDS: as many workgroups per CU as fit next to each other, at most the 8 of a random-access pipeline
-            const int ldsPerWG = (pipe.blockThreads / 64) * NV * QCAP * 8;
+            const int ldsPerWG = (pipe.blockThreads / 64) * NV * QCAP * 8 + pipe.extraLdsBytes;
             pipe.gridPerCU = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(8, (144 * 1024) / std::max(1, ldsPerWG))), 1, 16);
             stateDecl += "    int cq_n = 0;\n    i64* cq;\n";
             prologue += "    __shared__ i64 s_cq[(RSQ_BLOCK_THREADS / 64) * " + std::to_string(NV * QCAP) + "];\n";
@@ -1311,6 +1395,7 @@ struct Walker {
         s << "struct Args {\n";
         for (auto& a : pipe.args) s << "    " << a.ctype << " " << a.name << ";\n";
         s << "};\nstruct State {\n" << stateDecl << "};\n";
+        s << helperFns;
         if (cq) {
             // stage 2: everything behind the compaction point, called with dense lanes
             s << "static RSQ_DEV void stage2(const Args& a, State& st, const i64 row";

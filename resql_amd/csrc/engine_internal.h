@@ -111,6 +111,7 @@ struct Pipeline {
     int64_t bytesPerRow = 0;
     bool compact = false;            // wave-level selection compaction (codegen.cpp compactThen): carried 8-byte values
     int compactWords = 0;
+    int extraLdsBytes = 0;           // LDS a pipeline takes besides the compaction queues (hash aggregation's front table)
     int blockThreads = 256;
     int unroll = 2;
     unsigned maxGrid = 0;            // 256-thread workgroups per launch; 0 = gridPerCU per CU

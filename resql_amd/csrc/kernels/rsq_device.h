@@ -213,6 +213,13 @@ RSQ_DEV i64 str_word(const Str& s, int n, int w) {
     for (int i = 0; i < 8; i++) { const int k = w * 8 + i; v |= (u64)(k < n ? (u8)s.p[k] : (u8)0) << (8 * i); }
     return (i64)v;
 }
+// the last character of a string held as little-endian key words = the top non-zero byte of its last non-zero word
+RSQ_DEV bool top_byte_is_space(i64 w) {
+    const u64 v = (u64)w;
+    if (v == 0) return false;
+    const int top = (63 - __clzll((long long)v)) & ~7;
+    return ((v >> top) & 0xffull) == 0x20ull;
+}
 RSQ_DEV bool ends_with_space(const Str& s) { const int n = str_len_exact(s); return n > 0 && s.p[n - 1] == ' '; }
 RSQ_DEV i64 str_addr(const Str& s) { return (i64)(u64)reinterpret_cast<unsigned long long>(s.p); }
 RSQ_DEV Str str_from_addr(i64 w, int cap) { return str(reinterpret_cast<const char*>((unsigned long long)(u64)w), cap); }
