@@ -188,6 +188,21 @@ int  rsq_sql_compile(rsq_ctx* ctx, const char* sql, rsq_table* const* tables, in
  * firstrow lines).  Returns a malloc'ed string (rsq_free) or NULL with rsq_last_error set. */
 char* rsq_sql_describe(rsq_ctx* ctx, const char* sql, int32_t what);
 
+/* ---- statement loop: executeStatement (src/execute.h:508-545) over the engine ----------------
+ * A database handle keeps what the reference's `Database` keeps (src/dbdata.h: relations by name): schemas from CREATE TABLE
+ * (executeCreateTable, execute.h:263-281: "Table x already exists."), device-resident tables from BULK INSERT
+ * (executeBulkInsert, execute.h:332-388: "Table x does not exist.", field terminator = first character of
+ * `fieldterminator`, default ','), and runs SELECT statements through rsq_sql_compile + rsq_query_execute.
+ * rsq_db_execute: `result` may be NULL; for a SELECT it receives a view of the result relation that stays valid until the
+ * next statement on the same handle.  *kind receives 1 SELECT, 2 CREATE TABLE, 3 BULK INSERT (may be NULL).
+ * rsq_db_adopt_table hands an existing table (rsq_table_create / _generate / ...) to the database, which then owns it. */
+typedef struct rsq_db rsq_db;
+int  rsq_db_create(rsq_ctx* ctx, rsq_db** out);
+int  rsq_db_execute(rsq_db* db, const char* sql, int32_t* kind, rsq_result_view* result);
+int  rsq_db_adopt_table(rsq_db* db, rsq_table* table);
+int  rsq_db_report(const rsq_db* db, rsq_report* out);          /* of the last SELECT */
+void rsq_db_destroy(rsq_db* db);
+
 /* Sustained read-only streaming bandwidth of this GPU (grid-stride int64 sum over `bytes` of
  * resident memory): the measured roofline SURVEY.md §8(d) quotes fractions against. */
 int  rsq_measure_read_bandwidth(rsq_ctx* ctx, size_t bytes, int32_t iters, double* gb_per_s);

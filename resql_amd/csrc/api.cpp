@@ -1,6 +1,7 @@
 // api.cpp — the extern "C" surface of include/resql_hip.h.  No exception crosses it.
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <thread>
 
 #include "engine.h"
@@ -306,6 +307,113 @@ int rsq_sql_compile(rsq_ctx* ctx, const char* sqlText, rsq_table* const* tables,
     st = rsq_query_compile(ctx, &p->plan.desc, tables, n_tables, out);
     delete p;
     return st;
+}
+
+// ---- statement loop (executeStatement, execute.h:508-545) ----
+struct rsq_db {
+    Context* ctx = nullptr;
+    std::map<std::string, std::vector<std::pair<std::string, Type>>> schemas;      // CREATE TABLE
+    std::map<std::string, Table*> tables;                                          // name order = the planner's table order
+    rsq_query* last = nullptr;
+    rsq_report lastReport{};
+};
+
+int rsq_db_create(rsq_ctx* ctx, rsq_db** out) {
+    if (!ctx || !out) return RSQ_ERR_INVALID;
+    *out = new rsq_db();
+    (*out)->ctx = C(ctx);
+    return RSQ_OK;
+}
+
+void rsq_db_destroy(rsq_db* db) {
+    if (!db) return;
+    if (db->last) rsq_query_destroy(db->last);
+    for (auto& t : db->tables) delete t.second;
+    delete db;
+}
+
+int rsq_db_adopt_table(rsq_db* db, rsq_table* table) {
+    if (!db || !table) return RSQ_ERR_INVALID;
+    return guarded(db->ctx, [&] {
+        Table* t = T(table);
+        if (db->tables.count(t->name) || db->schemas.count(t->name)) failInvalid("Table " + t->name + " already exists.");
+        std::vector<std::pair<std::string, Type>> sch;
+        for (auto& c : t->cols) sch.emplace_back(c.name, c.type);
+        db->schemas[t->name] = sch;
+        db->tables[t->name] = t;
+    });
+}
+
+int rsq_db_report(const rsq_db* db, rsq_report* out) {
+    if (!db || !out) return RSQ_ERR_INVALID;
+    *out = db->lastReport;
+    return RSQ_OK;
+}
+
+int rsq_db_execute(rsq_db* db, const char* sqlText, int32_t* kind, rsq_result_view* result) {
+    if (!db || !sqlText) return RSQ_ERR_INVALID;
+    if (kind) *kind = 0;
+    rsq_ctx* cx = reinterpret_cast<rsq_ctx*>(db->ctx);
+    int selectStatus = RSQ_OK;
+    bool isSelect = false;
+    int st = guarded(db->ctx, [&] {
+        rsq::ExprPool pool;
+        rsq::sql::Statement stmt;
+        rsq::sql::parse(sqlText, pool, stmt);
+        if (kind) *kind = stmt.kind;
+        if (stmt.kind == rsq::sql::Statement::CREATE_TABLE) {
+            if (db->schemas.count(stmt.tableName)) failInvalid("Table " + stmt.tableName + " already exists.");
+            if (stmt.schema.empty()) failInvalid("Create table needs at least one schema element.");
+            db->schemas[stmt.tableName] = stmt.schema;
+            // an empty relation that can be scanned (db.relations.try_emplace(name, schema), execute.h:279)
+            static const uint8_t kEmpty[16] = {0};       // columns WITH data, of zero rows
+            std::vector<rsq_column> cols(stmt.schema.size());
+            for (size_t i = 0; i < cols.size(); i++) {
+                memset(&cols[i], 0, sizeof cols[i]);
+                snprintf(cols[i].name, RSQ_SYMBOL_MAX, "%s", stmt.schema[i].first.c_str());
+                cols[i].type = stmt.schema[i].second.toC();
+                cols[i].data = kEmpty;
+            }
+            rsq_table_desc d;
+            memset(&d, 0, sizeof d);
+            snprintf(d.name, RSQ_SYMBOL_MAX, "%s", stmt.tableName.c_str());
+            d.n_rows = 0; d.n_cols = (int32_t)cols.size(); d.cols = cols.data();
+            db->tables[stmt.tableName] = makeTable(*db->ctx, d, false);
+        } else if (stmt.kind == rsq::sql::Statement::BULK_INSERT) {
+            auto it = db->schemas.find(stmt.tableName);
+            if (it == db->schemas.end()) failInvalid("Table " + stmt.tableName + " does not exist.");
+            auto have = db->tables.find(stmt.tableName);
+            if (have != db->tables.end() && have->second->nRows > 0) failUnsupported("BULK INSERT into a table that already holds data");
+            if (stmt.fieldTerminator.empty()) failInvalid("empty field terminator");
+            std::vector<rsq_column> cols(it->second.size());
+            for (size_t i = 0; i < cols.size(); i++) {
+                memset(&cols[i], 0, sizeof cols[i]);
+                snprintf(cols[i].name, RSQ_SYMBOL_MAX, "%s", it->second[i].first.c_str());
+                cols[i].type = it->second[i].second.toC();
+            }
+            rsq_table_desc d;
+            memset(&d, 0, sizeof d);
+            snprintf(d.name, RSQ_SYMBOL_MAX, "%s", stmt.tableName.c_str());
+            d.n_cols = (int32_t)cols.size(); d.cols = cols.data();
+            rsq_table* t = nullptr;
+            int rc = rsq_table_load_tbl(cx, &d, stmt.fileName.c_str(), stmt.fieldTerminator[0], 0, &t);
+            if (rc != RSQ_OK) throw Error(rc, db->ctx->lastError);
+            if (have != db->tables.end()) delete have->second;
+            db->tables[stmt.tableName] = T(t);
+        } else isSelect = true;
+    });
+    if (st != RSQ_OK || !isSelect) return st;
+    // SELECT: executeSelect (execute.h:250-260)
+    if (db->last) { rsq_query_destroy(db->last); db->last = nullptr; }
+    std::vector<rsq_table*> arr;
+    for (auto& t : db->tables) arr.push_back(reinterpret_cast<rsq_table*>(t.second));
+    selectStatus = rsq_sql_compile(cx, sqlText, arr.data(), (int32_t)arr.size(), &db->last);
+    if (selectStatus != RSQ_OK) return selectStatus;
+    selectStatus = rsq_query_execute(db->last);
+    if (selectStatus != RSQ_OK) return selectStatus;
+    rsq_query_report(db->last, &db->lastReport);
+    if (result) return rsq_query_result(db->last, result);
+    return RSQ_OK;
 }
 
 char* rsq_sql_describe(rsq_ctx* ctx, const char* sqlText, int32_t what) {

@@ -107,6 +107,11 @@ def lib():
         L.rsq_sql_compile.argtypes = [vp, C.c_char_p, C.POINTER(vp), i32, C.POINTER(vp)]
         L.rsq_sql_describe.restype = vp
         L.rsq_sql_describe.argtypes = [vp, C.c_char_p, i32]
+        L.rsq_db_create.argtypes = [vp, C.POINTER(vp)]
+        L.rsq_db_execute.argtypes = [vp, C.c_char_p, C.POINTER(i32), C.POINTER(P.rsq_result_view)]
+        L.rsq_db_adopt_table.argtypes = [vp, vp]
+        L.rsq_db_report.argtypes = [vp, C.POINTER(rsq_report)]
+        L.rsq_db_destroy.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -120,6 +125,7 @@ EXPORTED_SYMBOLS = [
     "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
     "rsq_measure_read_bandwidth",
     "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
+    "rsq_db_create", "rsq_db_execute", "rsq_db_adopt_table", "rsq_db_report", "rsq_db_destroy",
 ]
 
 GEN_LINEITEM, GEN_ORDERS, GEN_CUSTOMER, GEN_SYNTHETIC = 0, 1, 2, 3
@@ -357,51 +363,38 @@ class Query:
 
 
 class Database:
-    """The statement loop of the reference's executeStatement (execute.h:508-545) over the engine: CREATE TABLE records
-    a schema, BULK INSERT loads a '.tbl' file into device columns (rsq_table_load_tbl), SELECT is parsed, planned,
-    compiled and executed.  Statements of a script are split at ';' like expandExecStatements (execute.h:470-505)."""
+    """The statement loop of the reference's executeStatement (execute.h:508-545) over the engine — the C ABI's rsq_db_*:
+    CREATE TABLE records a schema, BULK INSERT loads a '.tbl' file into device columns, SELECT is parsed, planned, compiled
+    and executed.  execute_script splits at ';' like expandExecStatements (execute.h:470-505)."""
+
+    KINDS = {1: "SELECT", 2: "CREATE_TABLE", 3: "BULK_INSERT"}
 
     def __init__(self, ctx: Context):
         self.ctx = ctx
-        self.schemas: dict = {}      # name -> P.Table without data (CREATE TABLE)
-        self.tables: dict = {}       # name -> DeviceTable
+        h = C.c_void_p()
+        ctx._check(ctx._L.rsq_db_create(ctx.h, C.byref(h)))
+        self.h = h
 
     def add_table(self, t: "DeviceTable"):
-        self.tables[t.name] = t
-
-    def _db(self):
-        return [self.tables[k] for k in sorted(self.tables)]
+        """hand a device table to the database (which owns it from now on)"""
+        self.ctx._check(self.ctx._L.rsq_db_adopt_table(self.h, t.h))
+        t.h = None
 
     def execute(self, sql: str):
         """returns a P.Result for a select, None otherwise"""
-        text = self.ctx.sql_describe(sql, 1)
-        lines = text.splitlines()
-        head = lines[0].split(" ")
-        if head[0] == "CREATE_TABLE":
-            name = head[1]
-            if name in self.schemas or name in self.tables:
-                raise EngineError(2, f"Table {name} already exists.")
-            cols = []
-            for l in lines[1:]:
-                _, cn, ty = l.split(" ", 2)
-                cols.append(P.Column(cn, P.parse_type(ty.replace("(", " ").replace(")", " ").replace(",", " ").split())))
-            self.schemas[name] = P.Table(name, cols, 0)
+        kind = C.c_int32(0)
+        v = P.rsq_result_view()
+        self.ctx._check(self.ctx._L.rsq_db_execute(self.h, sql.encode("latin1"), C.byref(kind), C.byref(v)))
+        if kind.value != 1:
             return None
-        if head[0] == "BULK_INSERT":
-            name = head[1]
-            if name not in self.schemas:
-                raise EngineError(2, f"Table {name} does not exist.")
-            fields = {l.split(" ", 1)[0]: l.split(" ", 1)[1] for l in lines[1:]}
-            if name in self.tables:
-                raise EngineError(3, "BULK INSERT into a table that already holds data")
-            self.tables[name] = self.ctx.load_tbl(self.schemas[name], fields["file"], fields["fieldterminator"])
-            return None
-        q = self.ctx.sql_compile(sql, self._db())
-        try:
-            q.execute()
-            return q.result()
-        finally:
-            q.close()
+        res = P.Result.from_view(v)
+        res.text = res.serialize()
+        return res
+
+    def report(self) -> rsq_report:
+        r = rsq_report()
+        self.ctx._check(self.ctx._L.rsq_db_report(self.h, C.byref(r)))
+        return r
 
     def execute_script(self, text: str):
         res = None
@@ -411,6 +404,6 @@ class Database:
         return res
 
     def close(self):
-        for t in self.tables.values():
-            t.close()
-        self.tables.clear()
+        if getattr(self, "h", None):
+            self.ctx._L.rsq_db_destroy(self.h)
+            self.h = None

@@ -83,9 +83,11 @@ def test_statement_loop_create_load_select(gpu_ctx, tmp_path):
             f.write(f"{reg.col('r_regionkey').data[i]}|{reg.col('r_name').data[i].decode()}|none|\n")
     db = engine.Database(gpu_ctx)
     try:
-        db.execute_script(f"""
+        db.execute_script("""
             create table nation ( n_nationkey int, n_name char(25), n_regionkey int, n_comment varchar(152) );
-            create table region ( r_regionkey int, r_name char(25), r_comment varchar(152) );
+            create table region ( r_regionkey int, r_name char(25), r_comment varchar(152) );""")
+        assert db.execute("select n_name from nation where n_nationkey < 3").n_rows == 0        # a created, still empty relation
+        db.execute_script(f"""
             bulk insert nation from "{tmp_path}/nation.tbl" with ( fieldterminator="|" );
             bulk insert region from "{tmp_path}/region.tbl" with ( fieldterminator="|" );
         """)
@@ -95,6 +97,14 @@ def test_statement_loop_create_load_select(gpu_ctx, tmp_path):
         assert res.text.splitlines()[1:] == ["GERMANY                  |about 7|", "CANADA                   |about 3|"]
         with pytest.raises(engine.EngineError, match="Syntax error."):
             db.execute("select n_name from nation where")
+        with pytest.raises(engine.EngineError, match="already holds data"):
+            db.execute(f'bulk insert region from "{tmp_path}/region.tbl" with ( fieldterminator="|" )')
+        assert db.report().num_kernels >= 1
+        # a generated table handed over to the database
+        li = gpu_ctx.generate(engine.GEN_LINEITEM, 60_000, 0.01, param=1)
+        db.add_table(li)
+        res = db.execute("select count(*) as n from lineitem where l_quantity < 26")
+        assert 25_000 < int(res.text.splitlines()[1].split("|")[0]) < 35_000
     finally:
         db.close()
 
