@@ -520,6 +520,19 @@ struct Walker {
         return out;
     }
 
+    // String join keys of different declared lengths.  The reference hashes each side with its own type: hashVarchar stops
+    // at the NUL, so VARCHAR(a) = VARCHAR(b) matches equal strings — both sides take the word count of the wider one, the
+    // narrower side's missing words are zero.  hashChar pads with spaces to the DECLARED length (qlib/hash.h:131-147), so
+    // CHAR(a) = CHAR(b), a != b, never has equal hashes and never matches: the two sides get pad words that differ.
+    // (CHAR against VARCHAR of another length stays refused.)
+    void padKeyWords(Expr* mine, Expr* other, size_t w0, std::vector<std::string>& keyVars, bool buildSide) {
+        if (!mine->type.isString() || !other->type.isString() || mine->type.len == other->type.len) return;
+        if (mine->type.tag != other->type.tag) failUnsupported("CHAR and VARCHAR join keys of different declared lengths");
+        const size_t want = (size_t)(std::max(mine->type.len, other->type.len) + 7) / 8 + (mine->type.tag == RSQ_CHAR ? 1 : 0);
+        const std::string pad = mine->type.tag == RSQ_CHAR && !buildSide ? "((i64)-1)" : "((i64)0)";
+        while (keyVars.size() - w0 < want) keyVars.push_back(pad);
+    }
+
     // ---- hash join build (hashjoin.h:226-256) ---------------------------------------------------
     std::string hashOf(const std::vector<std::string>& keyVars) {
         std::string h = "rsq::hash64((u64)" + keyVars[0] + ")";
@@ -548,6 +561,7 @@ struct Walker {
             size_t w0 = keyVars.size();
             keyFirstWord.push_back(l->type.isString() ? -1 : (int)w0);
             for (auto& kv : keyWords(l, T + "_k" + std::to_string(k++), true)) keyVars.push_back(kv);
+            padKeyWords(l, eq->child->next, w0, keyVars, true);
             for (size_t w = w0; w < keyVars.size(); w++)
                 ht->keys.push_back({w == w0 ? expressionName(l) : expressionName(l) + "#" + std::to_string(w - w0), w == w0 && !l->type.isString() ? l->type : Type(RSQ_BIGINT)});
         }
@@ -647,6 +661,7 @@ struct Walker {
             q.pool.addId(r);
             const size_t w0 = keyVars.size();
             for (auto& kv : keyWords(r, T + "_p" + std::to_string(k++), true)) keyVars.push_back(kv);
+            padKeyWords(r, eq->child, w0, keyVars, false);
             // (only a one-word key can stand in for the build key of the matched entry, see tryJoinEntry)
             probeKeyNames.push_back(keyVars.size() - w0 == 1 ? expressionName(r) : std::string());
             for (size_t w = w0 + 1; w < keyVars.size(); w++) probeKeyNames.push_back(std::string());

@@ -98,3 +98,24 @@ def test_hash_aggregation_on_computed_keys(gpu_ctx, n, groups):
     got, want = gpu_ctx.run(p), orc.execute(p)
     assert got.n_rows == want.n_rows
     assert got.text == want.text
+
+
+def test_string_join_keys_of_different_declared_lengths(gpu_ctx):
+    """VARCHAR(a) = VARCHAR(b): equal strings match (hashVarchar stops at the NUL); CHAR(a) = CHAR(b), a != b: never a match
+    in the reference (hashChar pads with spaces to the declared length, qlib/hash.h:131-147) — engine == oracle == reference"""
+    import numpy as np
+    from resql_amd import plan as P
+    for T in (P.TypeInit.VARCHAR, P.TypeInit.CHAR):
+        a = P.Table("a", [P.Column("ak", T(6), np.array([b"x1", b"x2 ", b"longer", b"q"], dtype="S6")),
+                          P.Column("av", P.TypeInit.BIGINT(), np.arange(4, dtype=np.int64))], 4)
+        b = P.Table("b", [P.Column("bk", T(12), np.array([b"x1  ", b"x2", b"longer", b"longerstill", b"x2 ", b"q"], dtype="S12")),
+                          P.Column("bv", P.TypeInit.BIGINT(), np.arange(6, dtype=np.int64) * 10)], 6)
+        p = P.Plan([a, b])
+        j = p.hashjoin([p.eq(p.attr("ak"), p.attr("bk"))], p.scan("a"), p.scan("b"))
+        plan = p.set_root(p.materialize(p.projection([p.attr("av"), p.attr("bv")], j)))
+        want = orc.execute(plan)
+        if orc.have_reference():
+            assert orc.run_reference(plan)[0] == want.text
+        got = gpu_ctx.run(plan)
+        assert got.text == want.text
+        assert (want.n_rows > 0) == (T is P.TypeInit.VARCHAR)
