@@ -453,23 +453,85 @@ struct Walker {
         compacted = true;
         pipe.compact = true;
         cqLive.assign(eg.symbols.begin(), eg.symbols.end());
-        line("cq_pass = true;");
-        for (size_t k = 0; k < cqLive.size(); k++) line("cq_" + std::to_string(k) + " = " + toWord(cqLive[k].second.var, cqLive[k].second.type) + ";");
-        // ---- everything downstream goes into stage 2, which sees the carried values as its parameters ----
-        std::string savedBody = body; int savedIndent = indent;
-        body.clear(); indent = 1;
-        for (size_t k = 0; k < cqLive.size(); k++) {
-            const Type& t = cqLive[k].second.type;
-            const std::string v = "q_" + std::to_string(k);
-            line("const " + ExprGen::ctype(t) + " " + v + " = " + fromWord("qw_" + std::to_string(k), t) + ";");
-            eg.symbols[cqLive[k].first] = Sym{v, t};
+        // Late column loads: a scanned (non-string) column that stage 1 never looked at is needed only by the rows that reach
+        // stage 2.  The kernel exists in two forms from one source: RSQ_LAZY 0 loads it with the tile and carries it in the
+        // queue; RSQ_LAZY 1 leaves it out of the tile loads and stage 2 reads it by row index.  The engine picks the lazy
+        // form when the previous execution sent fewer than 1/32 of the rows to stage 2 (TPC-H Q3: 1.6 % of lineitem need
+        // l_extendedprice and l_discount, 16 of the 24 bytes per row) — gathers for a few rows beat streaming for all, but
+        // only then: a row gathered costs a 64-byte request per column.
+        std::vector<int> lazyOf(cqLive.size(), -1);
+        if (envInt("RSQ_LAZY_COLUMNS", 1, 0, 1)) {
+            for (size_t k = 0; k < cqLive.size(); k++) {
+                const std::string& var = cqLive[k].second.var;
+                auto org = symbolOrigin.find(cqLive[k].first);
+                if (org == symbolOrigin.end() || org->second != -1 || cqLive[k].second.type.isString()) continue;
+                if (var.compare(0, 2, "v_") != 0) continue;
+                bool used = false;                      // does the stage-1 text mention the variable?
+                for (size_t pos = body.find(var); pos != std::string::npos && !used; pos = body.find(var, pos + 1)) {
+                    const size_t end = pos + var.size();
+                    const bool left = pos == 0 || !(isalnum((unsigned char)body[pos - 1]) || body[pos - 1] == '_');
+                    const bool right = end >= body.size() || !(isalnum((unsigned char)body[end]) || body[end] == '_');
+                    if (left && right) used = true;
+                }
+                if (!used) { lazyOf[k] = atoi(var.c_str() + 2); pipe.lazyCols.push_back(lazyOf[k]); }
+            }
         }
+        // ---- everything downstream goes into stage 2, which sees the carried values under the names q_<k> ----
+        const std::string stage1 = body; const int stage1Indent = indent;
+        body.clear(); indent = 1;
+        for (size_t k = 0; k < cqLive.size(); k++) eg.symbols[cqLive[k].first] = Sym{"q_" + std::to_string(k), cqLive[k].second.type};
         explainSteps.push_back("wave compaction");
         downstream();
         while (indent > 1) closeScope();
-        stage2Body = body;
-        body = savedBody; indent = savedIndent;
-        pipe.compactWords = (int)cqLive.size();
+        const std::string down = body;
+        // only the values stage 2 really reads travel through the queue (a date that was only filtered on does not); the
+        // late-loaded ones take the LAST slots, which exist in the RSQ_LAZY 0 form only: the lazy form's queues are
+        // smaller, more workgroups fit a CU, and a latency-bound pipeline (tile load, then the key bitmap's L2 load) gets
+        // twice the waves
+        auto mentions = [](const std::string& text, const std::string& var) {
+            for (size_t pos = text.find(var); pos != std::string::npos; pos = text.find(var, pos + 1)) {
+                const size_t end = pos + var.size();
+                const bool left = pos == 0 || !(isalnum((unsigned char)text[pos - 1]) || text[pos - 1] == '_');
+                const bool right = end >= text.size() || !(isalnum((unsigned char)text[end]) || text[end] == '_');
+                if (left && right) return true;
+            }
+            return false;
+        };
+        std::vector<int> slot(cqLive.size(), -1);
+        int nSlots = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (size_t k = 0; k < cqLive.size(); k++)
+                if ((lazyOf[k] >= 0) == (pass == 1) && mentions(down, "q_" + std::to_string(k))) slot[k] = nSlots++;
+        int nLazySlots = 0;
+        for (size_t k = 0; k < cqLive.size(); k++) if (slot[k] >= 0 && lazyOf[k] < 0) nLazySlots++;
+        // drop lazy columns nobody reads from the list of late loads (their tile loads can go in both forms... keep it simple:
+        // they stay eager in the RSQ_LAZY 0 form and are simply not loaded in the lazy one)
+        body.clear(); indent = 1;
+        for (size_t k = 0; k < cqLive.size(); k++) {
+            if (slot[k] < 0) continue;
+            const Type& t = cqLive[k].second.type;
+            const std::string v = "q_" + std::to_string(k);
+            const std::string carried = "const " + ExprGen::ctype(t) + " " + v + " = " + fromWord("qw_" + std::to_string(slot[k]), t) + ";";
+            if (lazyOf[k] < 0) line(carried);
+            else {
+                body += "#if RSQ_LAZY\n";
+                line("const " + ExprGen::ctype(t) + " " + v + " = a.c" + std::to_string(lazyOf[k]) + "[row - a.row0];");
+                body += "#else\n";
+                line(carried);
+                body += "#endif\n";
+            }
+        }
+        stage2Body = body + down;
+        body = stage1; indent = stage1Indent;
+        line("cq_pass = true;");
+        for (size_t k = 0; k < cqLive.size(); k++) {
+            if (slot[k] < 0) continue;
+            const std::string push = "cq_" + std::to_string(slot[k]) + " = " + toWord(cqLive[k].second.var, cqLive[k].second.type) + ";";
+            if (lazyOf[k] < 0) line(push);
+            else { body += "#if !RSQ_LAZY\n"; line(push); body += "#endif\n"; }
+        }
+        pipe.compactWords = nSlots;
+        pipe.compactWordsLazy = pipe.lazyCols.empty() ? nSlots : nLazySlots;
         return true;
     }
 
@@ -1398,14 +1460,25 @@ struct Walker {
         const bool cq = pipe.compact;
         const int QCAP = 192;                       // 63 left over + 128 pushed by one tile, rounded up
         const int NV = 1 + pipe.compactWords;       // the row index + the carried values
+        const int NVL = 1 + pipe.compactWordsLazy;  // ... in the RSQ_LAZY 1 form
+        const bool twoForms = !pipe.lazyCols.empty();
         if (cq) {
             // the queues take LDS: as many workgroups per CU as fit next to each other, at most the 8 of a random-access pipeline
             const int ldsPerWG = (pipe.blockThreads / 64) * NV * QCAP * 8 + pipe.extraLdsBytes;
+            const int ldsPerWGLazy = (pipe.blockThreads / 64) * NVL * QCAP * 8 + pipe.extraLdsBytes;
             pipe.gridPerCU = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(8, (144 * 1024) / std::max(1, ldsPerWG))), 1, 16);
-            stateDecl += "    int cq_n = 0;\n    i64* cq;\n";
-            prologue += "    __shared__ i64 s_cq[(RSQ_BLOCK_THREADS / 64) * " + std::to_string(NV * QCAP) + "];\n";
-            prologue += "    st.cq = s_cq + (threadIdx.x >> 6) * " + std::to_string(NV * QCAP) + ";\n";
+            pipe.gridPerCULazy = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(8, (144 * 1024) / std::max(1, ldsPerWGLazy))), 1, 16);
+            stateDecl += "    int cq_n = 0;\n    u32 cq_rows = 0;\n    i64* cq;\n";
+            // rows that reached stage 2, for the host's choice between the two forms of the kernel (see compactThen).  Only
+            // the first 64 workgroups report (tiles are dealt round-robin, so they are a fair sample; the host scales): every
+            // wave of the grid adding to one word cost 90 us — atomics on one address serialise
+            addArg("cq_total", "unsigned long long*", 0);
+            epilogue += "    if (blockIdx.x < 64) {\n        const u64 v = rsq::wave_sum((u64)st.cq_rows);\n        if ((threadIdx.x & 63) == 0 && v) atomicAdd(a.cq_total, (unsigned long long)v);\n    }\n";
+            const std::string nv = twoForms ? "RSQ_CQ_NV" : std::to_string(NV);
+            prologue += "    __shared__ i64 s_cq[(RSQ_BLOCK_THREADS / 64) * " + nv + " * " + std::to_string(QCAP) + "];\n";
+            prologue += "    st.cq = s_cq + (threadIdx.x >> 6) * " + nv + " * " + std::to_string(QCAP) + ";\n";
         }
+        if (twoForms) s << "#if RSQ_LAZY\n#define RSQ_CQ_NV " << NVL << "\n#else\n#define RSQ_CQ_NV " << NV << "\n#endif\n";
         s << "#ifndef RSQ_BLOCK_THREADS\n#define RSQ_BLOCK_THREADS " << pipe.blockThreads << "\n#endif\n";
         s << "struct Args {\n";
         for (auto& a : pipe.args) s << "    " << a.ctype << " " << a.name << ";\n";
@@ -1419,8 +1492,15 @@ struct Walker {
             s << "static RSQ_DEV void cq_drain(const Args& a, State& st, const int count) {\n";
             s << "    const int lane = threadIdx.x & 63;\n    const int i = st.cq_n - count + lane;\n";
             s << "    if (lane < count) {\n        stage2(a, st, st.cq[i]";
-            for (int k = 0; k < pipe.compactWords; k++) s << ", st.cq[" << (k + 1) * QCAP << " + i]";
-            s << ");\n    }\n    st.cq_n -= count;\n}\n";
+            for (int k = 0; k < pipe.compactWordsLazy; k++) s << ", st.cq[" << (k + 1) * QCAP << " + i]";
+            if (pipe.compactWords > pipe.compactWordsLazy) {
+                s << "\n#if RSQ_LAZY\n            ";
+                for (int k = pipe.compactWordsLazy; k < pipe.compactWords; k++) s << ", 0";
+                s << "\n#else\n            ";
+                for (int k = pipe.compactWordsLazy; k < pipe.compactWords; k++) s << ", st.cq[" << (k + 1) * QCAP << " + i]";
+                s << "\n#endif\n        ";
+            }
+            s << ");\n        st.cq_rows++;\n    }\n    st.cq_n -= count;\n}\n";
         }
         s << "static RSQ_DEV void row_fn(const Args& a, State& st, const i64 lr" << (cq ? ", const bool valid" : "") << rowParams << ") {\n";
         s << "    const i64 row = a.row0 + lr;\n";
@@ -1431,7 +1511,11 @@ struct Walker {
             // push: every lane of the wave is here (the callers keep the control flow wave-uniform)
             s << "    {\n        const int lane = threadIdx.x & 63;\n        const u64 m = __ballot(cq_pass);\n";
             s << "        if (cq_pass) {\n            const int s = st.cq_n + (int)__popcll(m & ((1ull << lane) - 1ull));\n            st.cq[s] = row;\n";
-            for (int k = 0; k < pipe.compactWords; k++) s << "            st.cq[" << (k + 1) * QCAP << " + s] = cq_" << k << ";\n";
+            for (int k = 0; k < pipe.compactWords; k++) {
+                if (k == pipe.compactWordsLazy && pipe.compactWords > pipe.compactWordsLazy) s << "#if !RSQ_LAZY\n";
+                s << "            st.cq[" << (k + 1) * QCAP << " + s] = cq_" << k << ";\n";
+            }
+            if (pipe.compactWords > pipe.compactWordsLazy) s << "#endif\n";
             s << "        }\n        st.cq_n += (int)__popcll(m);\n    }\n}\n";
         } else s << body << "}\n";
         s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) rsq_pipeline(Args a) {\n";
@@ -1449,7 +1533,12 @@ struct Walker {
             s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2];\n";
             s << "        if (tt" << u << " < ntiles) {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
-            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "            rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
+            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) {
+                const bool lazy = std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) != pipe.lazyCols.end();
+                if (lazy) s << "#if !RSQ_LAZY\n";
+                s << "            rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
+                if (lazy) s << "#else\n            t" << k << "_" << u << "[0] = t" << k << "_" << u << "[1] = 0;\n#endif\n";
+            }
             s << "        }\n";
         }
         for (int u = 0; u < U; u++) {
@@ -1481,6 +1570,7 @@ struct Walker {
         }
         s << epilogue << "}\n";
         pipe.source = s.str();
+        if (!pipe.lazyCols.empty()) pipe.source = "#define RSQ_LAZY 0\n" + pipe.source;
         if (mat) {   // two code objects from one source
             pipe.sourcePass1 = "#define RSQ_PASS 1\n" + pipe.source;
             pipe.source = "#define RSQ_PASS 2\n" + pipe.source;
@@ -1496,6 +1586,13 @@ struct Walker {
             pipe.sourcePartCount = "#define RSQ_AGG_VARIANT 1\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
             pipe.sourcePartScatter = "#define RSQ_AGG_VARIANT 2\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
             pipe.source = "#define RSQ_AGG_VARIANT 0\n" + pipe.source;
+        }
+        if (!pipe.lazyCols.empty()) {          // the late-load form of the full-execution kernel: same text, RSQ_LAZY 1
+            pipe.sourceLazy = pipe.source;
+            const std::string off = "#define RSQ_LAZY 0\n";
+            const size_t at = pipe.sourceLazy.find(off);
+            if (at == std::string::npos) pipe.sourceLazy.clear();
+            else pipe.sourceLazy.replace(at, off.size(), "#define RSQ_LAZY 1\n");
         }
         std::string ex = "pipeline " + std::to_string(q.pipelines.size()) + ": ";
         for (size_t i = 0; i < explainSteps.size(); i++) ex += (i ? " -> " : "") + explainSteps[i];

@@ -122,6 +122,7 @@ Query::~Query() {
     if (dScanTemp) ctx.free(dScanTemp);
     for (void* p : dMatCols) if (p) ctx.free(p);
     if (dGroupRows) ctx.free(dGroupRows);
+    if (dPipeStats) ctx.free(dPipeStats);
     if (dGroupCount) ctx.free(dGroupCount);
     if (dTopkImages) ctx.free(dTopkImages);
     if (dTopkHists) ctx.free(dTopkHists);
@@ -201,6 +202,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
             p.kernelPartAgg = &ctx.getKernel(p.sourcePartAgg, "rsq_part_agg");
         }
         p.kernel = &ctx.getKernel(p.source, p.entry);
+        if (!p.sourceLazy.empty() && ctx.device < 0) (void)ctx.getKernel(p.sourceLazy, p.entry);      // build(): warm the cache with both forms
         q->allSource += p.source + "\n";
         q->explainText += p.explain + "\n";
     }
@@ -228,7 +230,8 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
             h->dCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
         }
         if (q->aggMode == AggMode::AT_JOIN_ENTRY || q->aggMode == AggMode::HASH) q->dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
-        size_t pw = q->pinnedWords + 8;
+        q->dPipeStats = (uint64_t*)ctx.alloc(std::max<size_t>(1, q->pipelines.size()) * 8);
+        size_t pw = q->pinnedWords + 8 + q->pipelines.size();
         RSQ_HIP(hipHostMalloc((void**)&q->hPinned, pw * 8, hipHostMallocDefault));
     }
     q->report.compilation_time_ms = nowMs() - t0;
@@ -250,6 +253,7 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
     if (a.name == "rec") return q.dPartRecords.empty() ? 0 : (uint64_t)(uintptr_t)q.dPartRecords[0];
     (void)p;
+    if (a.name == "cq_total") return (uint64_t)(uintptr_t)(q.dPipeStats + (&p - q.pipelines.data()));
     if (a.name == "cnt") return (uint64_t)(uintptr_t)q.dMatCnt;
     if (a.name == "offs") return (uint64_t)(uintptr_t)q.dMatOffs;
     if (a.name == "out_limit") return (uint64_t)q.matLimit;
@@ -273,24 +277,31 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     return a.value;
 }
 
-static unsigned pipelineGrid(const Query& q, const Pipeline& p) {
+static unsigned pipelineGrid(const Query& q, const Pipeline& p, bool lazyForm = false) {
     const int64_t tiles = p.src->nRows >> 7;
     const int wavesPerBlock = p.blockThreads / 64;
     int64_t want = (tiles + (int64_t)wavesPerBlock * p.unroll - 1) / ((int64_t)wavesPerBlock * p.unroll);
-    const int64_t maxGrid = p.maxGrid ? (int64_t)p.maxGrid : (int64_t)p.gridPerCU * (int64_t)q.ctx.numCUs;
+    const int64_t maxGrid = p.maxGrid ? (int64_t)p.maxGrid : (int64_t)(lazyForm ? p.gridPerCULazy : p.gridPerCU) * (int64_t)q.ctx.numCUs;
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(maxGrid * 256 / p.blockThreads, want));
 }
 
 static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnlyTable, unsigned grid = 0, unsigned block = 0) {
     std::vector<uint64_t> args;
     for (auto& a : p.args) args.push_back(argValue(q, p, a, countOnlyTable));
-    launch(q.ctx, k, grid ? grid : pipelineGrid(q, p), block ? block : (unsigned)p.blockThreads, args);
+    p.lastGrid = grid ? grid : pipelineGrid(q, p);
+    launch(q.ctx, k, p.lastGrid, block ? block : (unsigned)p.blockThreads, args);
     q.report.num_kernels++;
 }
 
 static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
-    Kernel& k = pass1 ? *p.kernelPass1 : (q.flatRun && p.kernelFlat ? *p.kernelFlat : *p.kernel);
-    launchPipelineKernel(q, p, k, countOnlyTable);
+    Kernel* k = pass1 ? p.kernelPass1 : (q.flatRun && p.kernelFlat ? p.kernelFlat : p.kernel);
+    // late column loads (codegen.cpp compactThen): worth it when the previous execution sent few rows to stage 2
+    if (!pass1 && k == p.kernel && !p.sourceLazy.empty() && p.stage2Rows >= 0 && p.stage2Rows * 32 < p.src->nRows) {
+        if (!p.kernelLazy) p.kernelLazy = &q.ctx.getKernel(p.sourceLazy, p.entry);
+        launchPipelineKernel(q, p, *p.kernelLazy, countOnlyTable, pipelineGrid(q, p, true));
+        return;
+    }
+    launchPipelineKernel(q, p, *k, countOnlyTable);
 }
 
 // Aggregation into a large dense table (see emitDenseAggregation, DENSE_GLOBAL): pick, per execution, between HBM
@@ -519,6 +530,9 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     }
     if (denseMode(q)) enqueueTableInit(q);
     RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+    bool anyCompaction = false;
+    for (auto& p : q.pipelines) anyCompaction |= p.compact;
+    if (anyCompaction) RSQ_HIP(hipMemsetAsync(q.dPipeStats, 0, q.pipelines.size() * 8, ctx.stream));
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     const bool trace = getenv("RSQ_TRACE") != nullptr;      // per-pipeline wall time (synchronises after each one)
     double tPipe = nowMs();
@@ -643,6 +657,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     if (!partialOnly && denseMode(q)) enqueueTableReadback(q);
     if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH))
         RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+    if (anyCompaction) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 8, q.dPipeStats, q.pipelines.size() * 8, hipMemcpyDeviceToHost, ctx.stream));
     if (topkCapacity) {
         RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 2, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         RSQ_HIP(hipMemcpyAsync(q.hGroupRows, q.dCandRows, (size_t)topkSpec * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost, ctx.stream));
@@ -655,6 +670,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         return;
     }
     RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    if (anyCompaction)      // a build pipeline that also ran its counting pass reports both passes: only ever an over-estimate
+        for (size_t i = 0; i < q.pipelines.size(); i++) {
+            Pipeline& p = q.pipelines[i];           // the first 64 workgroups report: scale to the grid
+            if (p.compact) p.stage2Rows = (int64_t)((double)q.hPinned[words + 8 + i] * (double)std::max(1u, p.lastGrid) / (double)std::min(64u, std::max(1u, p.lastGrid)));
+        }
     float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
     q.report.kernel_time_ms = ms;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;

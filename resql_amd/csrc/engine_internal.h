@@ -111,6 +111,13 @@ struct Pipeline {
     int64_t bytesPerRow = 0;
     bool compact = false;            // wave-level selection compaction (codegen.cpp compactThen): carried 8-byte values
     int compactWords = 0;
+    int compactWordsLazy = 0;        // ... in the late-load form (its queues are smaller)
+    int gridPerCULazy = 2;
+    std::vector<int> lazyCols;       // scanned columns only stage 2 needs (codegen.cpp compactThen): RSQ_LAZY 1 reads them by row
+    std::string sourceLazy;
+    Kernel* kernelLazy = nullptr;    // compiled when first chosen
+    unsigned lastGrid = 0;           // workgroups of the most recent launch
+    int64_t stage2Rows = -1;         // rows the previous execution sent to stage 2 (-1: not known yet)
     int extraLdsBytes = 0;           // LDS a pipeline takes besides the compaction queues (hash aggregation's front table)
     int blockThreads = 256;
     int unroll = 2;
@@ -165,6 +172,8 @@ struct Query {
     std::vector<void*> dPartRecords;       // [0] keys (group-in-partition << 40 | row - row0), then one array per record input
     uint64_t partRecordCapacity = 0;
     int64_t partTileStep = 1;              // > 1: the counting pass samples every n-th tile (selectivity estimate)
+
+    uint64_t* dPipeStats = nullptr;        // per pipeline: rows that reached stage 2 (behind the wave compaction)
 
     // device-side materialisation (plans without aggregation)
     OpNode* matOp = nullptr;
