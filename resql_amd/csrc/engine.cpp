@@ -296,7 +296,8 @@ static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnly
 static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
     Kernel* k = pass1 ? p.kernelPass1 : (q.flatRun && p.kernelFlat ? p.kernelFlat : p.kernel);
     // late column loads (codegen.cpp compactThen): worth it when the previous execution sent few rows to stage 2
-    if (!pass1 && k == p.kernel && !p.sourceLazy.empty() && p.stage2Rows >= 0 && p.stage2Rows * 32 < p.src->nRows) {
+    static const int64_t lazyDen = getenv("RSQ_LAZY_THRESHOLD") ? std::max(1, atoi(getenv("RSQ_LAZY_THRESHOLD"))) : 32;
+    if (!pass1 && k == p.kernel && !p.sourceLazy.empty() && p.stage2Rows >= 0 && p.stage2Rows * lazyDen < p.src->nRows) {
         if (!p.kernelLazy) p.kernelLazy = &q.ctx.getKernel(p.sourceLazy, p.entry);
         launchPipelineKernel(q, p, *p.kernelLazy, countOnlyTable, pipelineGrid(q, p, true));
         return;
