@@ -1458,7 +1458,10 @@ struct Walker {
         s << "#include \"rsq_device.h\"\n";
         s << fileScope;
         const bool cq = pipe.compact;
-        const int QCAP = 192;                       // 63 left over + 128 pushed by one tile, rounded up
+        // 63 left over + 128 pushed by one tile, rounded up.  (RSQ_QCAP=128 drains after every row_fn call instead: smaller
+        // queues, 7 instead of 4 workgroups of a five-word pipeline per CU — measured slower: Q3's orders pipeline 0.24 ->
+        // 0.31 ms, its inserts do not want more waves.)
+        const int QCAP = envInt("RSQ_QCAP", 192, 128, 192);
         const int NV = 1 + pipe.compactWords;       // the row index + the carried values
         const int NVL = 1 + pipe.compactWordsLazy;  // ... in the RSQ_LAZY 1 form
         const bool twoForms = !pipe.lazyCols.empty();
@@ -1548,8 +1551,8 @@ struct Walker {
                 s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");
                 for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
                 s << ");\n";
+                if (cq && (QCAP < 192 || j == 1)) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";
             }
-            if (cq) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";
             if (mat) s << "#if RSQ_PASS == 1\n            a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
             s << "        }\n";
         }
