@@ -602,6 +602,21 @@ struct Walker {
         return h;
     }
 
+    // Home slot of a join key.  RSQ_BLOCKED_HASH=1 (off by default — measured and rejected) makes the hash of one integer key
+    // of known range BLOCKED: 128 consecutive key values share a hashed base slot and spread, in key order, over the slots
+    // behind it, so that tables clustered by the key insert and probe neighbouring slots from neighbouring rows.  On MI355X
+    // that is 2-13x SLOWER (Q3 SF10 0.51 -> 1.1 ms, Q14 SF1 0.09 -> 1.2 ms): the 64 CAS of a wave then land in a handful of
+    // cache lines, and atomics on one line serialise at the memory side just like atomics on one word.  Scattering the
+    // inserts over the table is what keeps them fast.
+    std::string slotOf(const HashTable& ht, const std::string& T, const std::vector<std::string>& keyVars) {
+        if (ht.hasBitmap && keyVars.size() == 1 && envInt("RSQ_BLOCKED_HASH", 0, 0, 1)) {
+            addArg(T + "_bmmin", "i64", (uint64_t)ht.bmMin);
+            addArg(T + "_hm", "u64", 0);
+            return "rsq::blocked_slot((u64)(" + keyVars[0] + " - a." + T + "_bmmin), a." + T + "_hm, " + T + "_mask)";
+        }
+        return hashOf(keyVars) + " & " + T + "_mask";
+    }
+
     void consumeBuild(OpNode* o, OpNode* from) {
         if (compactThen(o, [&] { consumeBuildBody(o, from); })) return;
         consumeBuildBody(o, from);
@@ -678,7 +693,7 @@ struct Walker {
         countPerThread(T);
         openScope("if (a." + T + "_countonly) { st.n_" + T + "++; } else {");
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
-        line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
+        line("u64 " + T + "_s = " + slotOf(*ht, T, keyVars) + ";");
         line("u64 " + T + "_n = 0;");
         openScope("for (;; " + T + "_n++) {");
         line("if (" + T + "_n > " + T + "_mask) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
@@ -765,7 +780,7 @@ struct Walker {
     void probeTable(OpNode* o, HashTable& ht, const std::string& T, const std::vector<std::string>& keyVars,
                     const std::vector<std::string>& probeKeyNames) {
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
-        line("u64 " + T + "_s = " + hashOf(keyVars) + " & " + T + "_mask;");
+        line("u64 " + T + "_s = " + slotOf(ht, T, keyVars) + ";");
         openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
         std::string cond;
         if (ht.keyCas) {

@@ -273,6 +273,12 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
         if (f == "acc") return (uint64_t)(uintptr_t)h.dAcc;
         if (f == "countonly") return id == countOnlyTable ? 1ull : 0ull;
         if (f == "bm") return (uint64_t)(uintptr_t)h.dBitmap;
+        if (f == "hm") {      // slots per key value as a 32.32 fixed-point number, at most 4 (small ranges in large tables)
+            if (h.bmBits <= 0) return 0;
+            unsigned __int128 m = (((unsigned __int128)(uint64_t)h.capacity) << 32) / (unsigned __int128)(uint64_t)h.bmBits;
+            const unsigned __int128 cap4 = ((unsigned __int128)4) << 32;
+            return (uint64_t)(m < cap4 ? m : cap4);
+        }
     }
     return a.value;
 }

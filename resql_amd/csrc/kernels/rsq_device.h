@@ -290,4 +290,7 @@ RSQ_DEV u64 hash64(u64 x) {     // splitmix64 finaliser; the engine's own table 
     return x;
 }
 
+// blocked hash of a join key with a known range: d = key - min, m = (capacity << 32) / range (see codegen.cpp slotOf)
+RSQ_DEV u64 blocked_slot(u64 d, u64 m, u64 mask) { return (hash64(d >> 7) + (((d & 127ull) * m) >> 32)) & mask; }
+
 }  // namespace rsq
