@@ -714,7 +714,8 @@ struct Walker {
         line("st.n_" + T + "++;");
         if (ht->hasBitmap) {
             addArg(T + "_bm", "u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht->bmMin);
-            line("{ const u64 d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin); atomicOr(&a." + T + "_bm[d >> 5], 1u << (d & 31)); }");
+            if (envInt("RSQ_DEBUG_NO_BITMAP_SET", 0, 0, 64) != ht->id + 1)      // (measurement only: table id + 1 builds no bitmap; its probes then find nothing)
+                line("{ const u64 d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin); atomicOr(&a." + T + "_bm[d >> 5], 1u << (d & 31)); }");
         }
         closeScope();
         closeScope();
