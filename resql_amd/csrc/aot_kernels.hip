@@ -305,8 +305,8 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value) {
 // Rows beyond `maxRows` are counted but not written (the host re-runs with a larger buffer).
 template <int COMPACT_PER_THREAD>
 __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__ first, i64 cap, const i64* __restrict__ words, int nWords,
-                                                         const i64* __restrict__ acc, int nAcc, i64* __restrict__ out, unsigned maxRows,
-                                                         unsigned* count) {
+                                                         int wordsAos, const i64* __restrict__ acc, int nAcc, i64* __restrict__ out,
+                                                         unsigned maxRows, unsigned* count) {
     const int stride = 1 + nWords + nAcc;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ unsigned s_wave[4];
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                 const i64 s = lo + (i64)s_list[i];
                 i64* o = out + (size_t)pos * stride;
                 o[0] = first[s];
-                for (int w = 0; w < nWords; w++) o[1 + w] = words[(size_t)w * cap + s];
+                for (int w = 0; w < nWords; w++) o[1 + w] = wordsAos ? words[(size_t)s * nWords + w] : words[(size_t)w * cap + s];
                 for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
             }
         }
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
     }
 }
 
-void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,
+void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count) {
     // slots per thread: every chunk costs one reservation atomic on the same word (they serialise), so large tables take
     // large chunks; swept on the box through RSQ_COMPACT_PT for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us
@@ -366,7 +366,7 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
     const int64_t chunkSlots = 256 * (int64_t)perThread;
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8 * (int64_t)ctx.numCUs, (capacity + chunkSlots - 1) / chunkSlots));
 #define RSQ_LAUNCH_COMPACT(PT) hipLaunchKernelGGL(k_compact_entries<PT>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, \
-                       (const i64*)words, nWords, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count)
+                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count)
     if (perThread >= 64) RSQ_LAUNCH_COMPACT(64); else if (perThread >= 32) RSQ_LAUNCH_COMPACT(32); else RSQ_LAUNCH_COMPACT(16);
 #undef RSQ_LAUNCH_COMPACT
     RSQ_HIP(hipGetLastError());

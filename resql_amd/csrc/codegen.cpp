@@ -602,6 +602,17 @@ struct Walker {
         return h;
     }
 
+    // Word w of the slot in `T_s` of a join table.  Join tables keep a slot's words next to each other (array of
+    // structures): the CAS on the key and the payload stores of an insert fall into one cache line, which the memory side
+    // then writes back once instead of read-modify-writing three lines; a probe that matches finds the payload in the line
+    // it already fetched for the key.  (The generic aggregation's tables stay structure-of-arrays: their key words are
+    // compared one array at a time and their accumulators live in separate blocks anyway.)
+    static std::string wordAt(const HashTable& ht, const std::string& T, int w) {
+        const int nw = std::max<int>(1, (int)(ht.keys.size() + ht.payload.size()));
+        if (ht.aos) return "a." + T + "_words[" + T + "_s * " + std::to_string(nw) + " + " + std::to_string(w) + "]";
+        return "a." + T + "_words[" + std::to_string(w) + " * a." + T + "_cap + " + T + "_s]";
+    }
+
     // Home slot of a join key.  RSQ_BLOCKED_HASH=1 (off by default — measured and rejected) makes the hash of one integer key
     // of known range BLOCKED: 128 consecutive key values share a hashed base slot and spread, in key order, over the slots
     // behind it, so that tables clustered by the key insert and probe neighbouring slots from neighbouring rows.  On MI355X
@@ -671,6 +682,7 @@ struct Walker {
         // capacity: the reference sizes its table lChild.getSize() * 5 / 3 and grows it; ours cannot grow
         // inside a kernel, so it is sized for twice the rows the build pipeline can deliver and re-run
         // at double size if it still overflows (engine.cpp).
+        ht->aos = envInt("RSQ_JOIN_AOS", 1, 0, 1) != 0;
         ht->capacity = 0;     // decided by the sizing pass at execute time (engine.cpp)
         // One integer key word whose values can never be INT64_MIN: the key word itself is the slot's state.  A 64-bit CAS
         // from the EMPTY sentinel claims the slot and publishes the key in one memory request (instead of a CAS on a state
@@ -698,7 +710,7 @@ struct Walker {
         openScope("for (;; " + T + "_n++) {");
         line("if (" + T + "_n > " + T + "_mask) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
         if (ht->keyCas)
-            line("if (atomicCAS(reinterpret_cast<unsigned long long*>(&a." + T + "_words[" + T + "_s]), 0x8000000000000000ull, (unsigned long long)" +
+            line("if (atomicCAS(reinterpret_cast<unsigned long long*>(&" + wordAt(*ht, T, 0) + "), 0x8000000000000000ull, (unsigned long long)" +
                  keyVars[0] + ") == 0x8000000000000000ull) break;");
         else line("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) break;");
         line(T + "_s = (" + T + "_s + 1) & " + T + "_mask;");
@@ -706,11 +718,11 @@ struct Walker {
         openScope("if (" + T + "_n <= " + T + "_mask) {");
         int w = 0;
         for (auto& kv : keyVars) {
-            if (!ht->keyCas) line("a." + T + "_words[" + std::to_string(w) + " * a." + T + "_cap + " + T + "_s] = " + kv + ";");
+            if (!ht->keyCas) line(wordAt(*ht, T, w) + " = " + kv + ";");
             w++;
         }
         for (auto& p : ht->payload)
-            line("a." + T + "_words[" + std::to_string(w++) + " * a." + T + "_cap + " + T + "_s] = " + toWord(eg.symbols[p.name].var, p.type) + ";");
+            line(wordAt(*ht, T, w++) + " = " + toWord(eg.symbols[p.name].var, p.type) + ";");
         line("st.n_" + T + "++;");
         if (ht->hasBitmap) {
             addArg(T + "_bm", "u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht->bmMin);
@@ -785,20 +797,20 @@ struct Walker {
         openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
         std::string cond;
         if (ht.keyCas) {
-            line("const i64 " + T + "_kk = a." + T + "_words[" + T + "_s];");
+            line("const i64 " + T + "_kk = " + wordAt(ht, T, 0) + ";");
             line("if (" + T + "_kk == (i64)0x8000000000000000ull) break;");
             cond = T + "_kk == " + keyVars[0];
         } else {
             line("if (a." + T + "_state[" + T + "_s] == 0u) break;");
             for (size_t i = 0; i < keyVars.size(); i++)
-                cond += (i ? " && " : "") + std::string("a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s] == " + keyVars[i];
+                cond += (i ? " && " : "") + wordAt(ht, T, (int)i) + " == " + keyVars[i];
         }
         openScope("if (" + cond + ") {");
         // the build side's values become symbols (hashjoin.h:146-147 / 204-205)
         int w = (int)ht.keys.size();
         for (auto& p : ht.payload) {
             std::string var = T + "_v" + std::to_string(w);
-            line("const " + ExprGen::ctype(p.type) + " " + var + " = " + fromWord("a." + T + "_words[" + std::to_string(w) + " * a." + T + "_cap + " + T + "_s]", p.type) + ";");
+            line("const " + ExprGen::ctype(p.type) + " " + var + " = " + fromWord(wordAt(ht, T, w), p.type) + ";");
             eg.symbols[p.name] = Sym{var, p.type};
             symbolOrigin[p.name] = ht.id; symbolWord[p.name] = w;
             w++;

@@ -431,7 +431,9 @@ static void buildHashTable(Query& q, Pipeline& p) {
         if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
         RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
     }
-    if (h.keyCas) fillU64Async(ctx, (uint64_t*)h.dWords, (size_t)h.capacity, 0x8000000000000000ull);     // every key word = EMPTY
+    // every key word = EMPTY; with a slot's words next to each other that is a fill of the whole table (the payload words are
+    // overwritten by the inserts)
+    if (h.keyCas) fillU64Async(ctx, (uint64_t*)h.dWords, (size_t)h.capacity * (h.aos ? std::max<size_t>(1, nWords) : 1), 0x8000000000000000ull);
     else RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
     if (h.hasBitmap) {
         const size_t bmBytes = ((size_t)h.bmBits + 31) / 32 * 4;
@@ -634,7 +636,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             q.hGroupRowsWords = need;
         }
         RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
-        compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.dAcc, h.nAccBlocks,
+        compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
                        q.dGroupRows, groupRowsAllocated, q.dGroupCount);
         q.report.num_kernels++;
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those

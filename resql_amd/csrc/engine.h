@@ -102,7 +102,7 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
 void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPartitions, uint64_t* totals, uint32_t* partStart, uint64_t* total);
 // gather the occupied entries (first-row word != INT64_MAX) of a hash table that carries aggregates into
 // packed rows [first row | table words | accumulator blocks]; *count receives the number of rows, at most maxRows are written
-void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords,
+void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count);
 // ORDER BY ... LIMIT pre-selection: the rows of `rows` ([*nRows][stride] words) whose word `keyWord` is among the `want`
 // leading values of the requested order (ties of the last one included) are copied to `cand`; *candCount counts them

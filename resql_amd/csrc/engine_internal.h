@@ -45,6 +45,7 @@ struct HashTable {
     std::vector<std::pair<Attr, int>> keyAlias;   // build-side attributes that ARE a key value: (attribute, key word) — not stored twice
     int64_t capacity = 0;
     bool unique = false;             // probed single-match
+    bool aos = false;                // join tables: words[slot][k] (a slot's words share a cache line) instead of words[k][slot]
     bool keyCas = false;             // one integer key word that is never INT64_MIN: the key word is the slot state
                                      // (EMPTY = INT64_MIN, claimed and published by one 64-bit CAS); dState is unused
     uint32_t* dState = nullptr;
