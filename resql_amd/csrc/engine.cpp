@@ -419,8 +419,8 @@ static void buildHashTable(Query& q, Pipeline& p) {
     Context& ctx = q.ctx;
     HashTable& h = *q.hashTables[(size_t)p.buildTable];
     const size_t nWords = h.keys.size() + h.payload.size();
-    RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
     if (h.capacity == 0) {
+        RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
         launchPipeline(q, p, h.id);                     // counting pass
         uint32_t n = 0;
         RSQ_HIP(hipMemcpyAsync(&n, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
@@ -429,17 +429,18 @@ static void buildHashTable(Query& q, Pipeline& p) {
         if (!h.keyCas) h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
         h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
         if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
-        RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
     }
-    // every key word = EMPTY; with a slot's words next to each other that is a fill of the whole table (the payload words are
-    // overwritten by the inserts)
-    if (h.keyCas) fillU64Async(ctx, (uint64_t*)h.dWords, (size_t)h.capacity * (h.aos ? std::max<size_t>(1, nWords) : 1), 0x8000000000000000ull);
-    else RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
+    size_t bmWords = 0;
     if (h.hasBitmap) {
-        const size_t bmBytes = ((size_t)h.bmBits + 31) / 32 * 4;
-        if (!h.dBitmap) h.dBitmap = (uint32_t*)ctx.alloc(bmBytes);
-        RSQ_HIP(hipMemsetAsync(h.dBitmap, 0, bmBytes, ctx.stream));
+        bmWords = ((size_t)h.bmBits + 31) / 32;
+        if (!h.dBitmap) h.dBitmap = (uint32_t*)ctx.alloc(bmWords * 4);
     }
+    // ONE launch readies the table: every key word = EMPTY (with a slot's words next to each other that is a fill of the whole
+    // table; the payload words are overwritten by the inserts) or the state words = 0, the key bitmap and the entry counter = 0
+    if (h.keyCas) prepareTableAsync(ctx, (uint64_t*)h.dWords, (size_t)h.capacity * (h.aos ? std::max<size_t>(1, nWords) : 1), 0x8000000000000000ull,
+                                    nullptr, 0, h.dBitmap, bmWords, h.dCount);
+    else prepareTableAsync(ctx, nullptr, 0, 0, h.dState, (size_t)h.capacity, h.dBitmap, bmWords, h.dCount);
+    q.report.num_kernels++;
     launchPipeline(q, p, -1);
     q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
 }

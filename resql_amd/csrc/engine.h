@@ -97,6 +97,9 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
 size_t scanTempBytes(int64_t n);
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
+// one launch: fill[0..nFill) = fillValue (u64), zeroA / zeroB cleared (u32 words), *count = 0 (any of them may be empty / null)
+void prepareTableAsync(Context& ctx, uint64_t* fill, size_t nFill, uint64_t fillValue, uint32_t* zeroA, size_t nZeroA, uint32_t* zeroB, size_t nZeroB,
+                       uint32_t* count);
 // partitioned aggregation: counts[workgroup][partition] -> exclusive prefix inside each partition (in place), partition
 // bounds partStart[0..P] and the record total
 void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPartitions, uint64_t* totals, uint32_t* partStart, uint64_t* total);
