@@ -719,6 +719,10 @@ static void deriveExpressionTypes(Ctx* c, Expr* e) {
         }
         case S_BINARY: {    /* expressions.h:1293-1351 */
             Expr* left = e->child;
+            /* A node shared by two parents loses its right sibling when a typecast is put above it under the first parent
+             * (insertUnaryBetweenParentAndChild sets child->next = nullptr): the second parent is a binary node with one
+             * operand.  The reference reads through the null pointer here and dies; the oracle reports it. */
+            if (!left || !left->next) fail("binary expression %s has lost an operand (shared node below two typecasts): the reference crashes here", exprTagNames[e->tag]);
             Expr* right = e->child->next;
             deriveExpressionTypes(c, left);
             deriveExpressionTypes(c, right);

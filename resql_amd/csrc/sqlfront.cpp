@@ -14,6 +14,7 @@
 // Behaviour that looks odd is the reference's and is kept (each place says so): results have to be identical.
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <set>
 #include <sstream>
@@ -725,6 +726,26 @@ void planSelect(Statement& st, ExprPool& pool, const std::vector<Table*>& db, Pl
         if (from.empty()) failInvalid("Need from-clause for 'select *'");
     }
     for (Expr* grp : groupby) for (size_t i = 0; i < select.size(); i++) select[i] = matchAndUnify(select[i], grp);
+    // matchAndUnify rewrites group->next at every match.  When a group-by expression is a select item of its own AND occurs
+    // inside another one (select k, max(k + 1) ... group by k), the node inside the arithmetic ends up linked to the next
+    // SELECT ITEM, which contains that arithmetic: a cycle.  The reference then recurses until its stack is gone
+    // (filterExpr, planner.h:36-51); here the statement is refused.
+    {
+        std::set<const Expr*> open, done;
+        std::function<bool(const Expr*)> cyclic = [&](const Expr* e) -> bool {
+            if (!e || done.count(e)) return false;
+            if (!open.insert(e).second) return true;
+            for (const Expr* c = e->child; c; c = c->next) {
+                if (open.count(c) && !done.count(c)) return true;
+                if (cyclic(c)) return true;
+            }
+            open.erase(e); done.insert(e);
+            return false;
+        };
+        for (Expr* sel : select)
+            if (cyclic(sel)) failUnsupported("a group-by expression is both a select item and part of another one: the reference's planner "
+                                             "links its expression tree into a cycle here (planner.h:13-33) and crashes");
+    }
     ExprVec aggregations;
     for (Expr* s : select) filterAggregations(s, aggregations);
 

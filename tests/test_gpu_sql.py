@@ -122,3 +122,31 @@ def test_reference_int16_cast_switch_reproduces_the_jit(gpu_ctx, small_db, monke
         got = q.result()
         q.close()
         assert got.text == g["reference_text"] and got.text != g["text"]
+
+
+def test_random_valid_statements(gpu_ctx, small_db):
+    """the first 60 statements of tests/sqlgen.py (the oracle's answers for all 160 are pinned on the reference by
+    tests/test_sql_frontend.py): engine == oracle byte for byte, a statement the reference dies on is refused by both"""
+    import sqlgen
+    host, tabs = small_db
+    with open(os.path.join(HERE, "golden", "sqlgen_reference.json")) as f:
+        gold = json.load(f)["seeds"]
+    ran = 0
+    for seed in range(60):
+        s = sqlgen.statement(seed)
+        if "refused" in gold[str(seed)]:
+            with pytest.raises(engine.EngineError):
+                q = gpu_ctx.sql_compile(s, tabs)
+                q.execute()
+            continue
+        want = orc.execute(gpu_ctx.sql_plan(s, tabs, host))
+        q = gpu_ctx.sql_compile(s, tabs)
+        try:
+            q.execute()
+            got = q.result()
+        finally:
+            q.close()
+        assert got.text == want.text, s
+        assert got.tuples == want.tuples, s
+        ran += 1
+    assert ran >= 55
