@@ -150,3 +150,33 @@ def test_random_valid_statements(gpu_ctx, small_db):
         assert got.tuples == want.tuples, s
         ran += 1
     assert ran >= 55
+
+
+def test_random_valid_statements_larger_and_repeated(gpu_ctx):
+    """25 further statements at SF 0.1 (600 K lineitem rows), each executed three times: the second and third execution
+    may take the late-load form of a pipeline (chosen from the first one's row counts) and reuse table capacities, entry
+    counts and the LDS front table paths — every execution must give the oracle's answer"""
+    import sqlgen
+    db = tpch_full.database(0.1)
+    host = [db[k] for k in sorted(db)]
+    tabs = [gpu_ctx.table(t) for t in host]
+    try:
+        ran = 0
+        for seed in range(200, 225):
+            s = sqlgen.statement(seed)
+            try:
+                want = orc.execute(gpu_ctx.sql_plan(s, tabs, host))
+            except orc.OracleError:
+                continue                      # a statement the reference dies on (see test_sql_frontend.py)
+            q = gpu_ctx.sql_compile(s, tabs)
+            try:
+                for _ in range(3):
+                    q.execute()
+                    assert q.result().text == want.text, s
+            finally:
+                q.close()
+            ran += 1
+        assert ran >= 20
+    finally:
+        for t in tabs:
+            t.close()
