@@ -36,3 +36,25 @@ g++ $FLAGS $ROOT/tools/sanitize/parse_driver.cpp $ROOT/resql_amd/csrc/sqlfront.c
 g++ $FLAGS $ROOT/tools/sanitize/plan_driver.cpp $ROOT/resql_amd/csrc/sqlfront.cpp $ROOT/resql_amd/csrc/expr.cpp -o $W/plan_driver
 $W/parse_driver $W/stmts.txt
 ASAN_OPTIONS=detect_leaks=0 $W/plan_driver $W/schema.txt $W/plans.txt     # (the tables are never freed: ~Table lives in the HIP part of the library)
+# '.tbl' ingest: well-formed files and damaged ones (missing / extra fields, bad numbers, no trailing newline, empty lines)
+g++ $FLAGS -pthread $ROOT/tools/sanitize/tbl_driver.cpp $ROOT/resql_amd/csrc/tbl.cpp $ROOT/resql_amd/csrc/expr.cpp -o $W/tbl_driver
+python3 - "$W" <<'PY'
+import random, sys
+w = sys.argv[1]
+r = random.Random(11)
+rows = [f"{i}|name {i}|{r.randrange(-99999, 999999) / 100:.2f}|19{r.randrange(92, 99)}-{r.randrange(1, 13):02d}-{r.randrange(1, 29):02d}|{'ab'[i % 2]}|" for i in range(20000)]
+open(w + "/good.tbl", "w").write("\n".join(rows) + "\n")
+open(w + "/nonl.tbl", "w").write("\n".join(rows[:100]))
+bad = list(rows[:3000])
+for k in range(300):
+    i = r.randrange(len(bad)); m = r.randrange(5)
+    f = bad[i].split("|")
+    if m == 0: del f[r.randrange(len(f) - 1)]
+    elif m == 1: f.insert(r.randrange(len(f)), "extra")
+    elif m == 2: f[0] = "12x" + f[0]
+    elif m == 3: f[2] = "1.2.3"
+    else: f = [""]
+    bad[i] = "|".join(f)
+    open(w + f"/bad{k % 6}.tbl", "w").write("\n".join(bad[max(0, i - 50):i + 50]) + "\n")
+PY
+for f in good nonl bad0 bad1 bad2 bad3 bad4 bad5; do $W/tbl_driver $W/$f.tbl '|' INT VARCHAR:12 DECIMAL:12:2 DATE CHAR:1 | tr '\n' ' '; echo; done
