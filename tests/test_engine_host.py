@@ -178,3 +178,21 @@ def test_plan_text_roundtrip():
     again = P.Plan.from_text(text, plan.tables)
     assert again.to_text() == text
     assert orc.execute(again).text == orc.execute(plan).text
+
+
+def test_plain_c_host_links_and_runs(tmp_path):
+    """integration/examples/sql_host.c: the public headers are valid C11 and a C program can drive the statement loop through the
+    C ABI alone (compile-only context here: a SELECT is parsed, planned and compiled, executing it needs a GPU)"""
+    import subprocess
+    exe = str(tmp_path / "sql_host")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "integration", "examples", "sql_host.c"), "-L" + os.path.join(ROOT, "resql_amd"),
+                           "-lresql_hip", "-Wl,-rpath," + os.path.join(ROOT, "resql_amd"), "-o", exe])
+    env = dict(os.environ, RSQ_DEVICE="-1")
+    pr = subprocess.run([exe, "create table t ( a int, b char(3) )", "create table t ( a int )", "select a from t where",
+                         "select a, count(*) from t group by a"], capture_output=True, text=True, env=env)
+    out = pr.stdout.splitlines()
+    assert out[0] == "create table ok"
+    assert "Table t already exists." in out[1]
+    assert "Syntax error." in out[2]
+    assert out[3].startswith("error") and pr.returncode == 1          # compile-only context: no device to execute on
