@@ -180,3 +180,24 @@ def test_random_valid_statements_larger_and_repeated(gpu_ctx):
     finally:
         for t in tabs:
             t.close()
+
+
+def test_plain_c_host_end_to_end(tmp_path):
+    """integration/examples/sql_host.c on the GPU: CREATE TABLE, BULK INSERT and SELECT through the C ABI from a C program"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    exe = str(tmp_path / "sql_host")
+    subprocess.check_call(["gcc", "-std=c11", "-I" + os.path.join(root, "include"), os.path.join(root, "integration", "examples", "sql_host.c"),
+                           "-L" + os.path.join(root, "resql_amd"), "-lresql_hip", "-Wl,-rpath," + os.path.join(root, "resql_amd"), "-o", exe])
+    nat = tpch_full.nation()
+    with open(tmp_path / "nation.tbl", "w") as f:
+        for i in range(nat.n_rows):
+            f.write(f"{nat.col('n_nationkey').data[i]}|{nat.col('n_name').data[i].decode()}|{nat.col('n_regionkey').data[i]}|c{i}|\n")
+    pr = subprocess.run([exe, "create table nation ( n_nationkey int, n_name char(25), n_regionkey int, n_comment varchar(152) )",
+                         f'bulk insert nation from "{tmp_path}/nation.tbl" with ( fieldterminator="|" )',
+                         "select n_name, n_comment from nation where n_regionkey = 2 order by n_name desc limit 3"],
+                        capture_output=True, text=True)
+    assert pr.returncode == 0, pr.stdout + pr.stderr
+    out = pr.stdout.splitlines()
+    assert out[:3] == ["create table ok", "bulk insert ok", "3 row(s)"]
+    assert out[3:] == ["VIETNAM                  |c21|", "JAPAN                    |c12|", "INDONESIA                |c9|"]
