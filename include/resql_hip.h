@@ -195,7 +195,8 @@ char* rsq_sql_describe(rsq_ctx* ctx, const char* sql, int32_t what);
  * `fieldterminator`, default ','), and runs SELECT statements through rsq_sql_compile + rsq_query_execute.
  * rsq_db_execute: `result` may be NULL; for a SELECT it receives a view of the result relation that stays valid until the
  * next statement on the same handle.  *kind receives 1 SELECT, 2 CREATE TABLE, 3 BULK INSERT (may be NULL).
- * rsq_db_adopt_table hands an existing table (rsq_table_create / _generate / ...) to the database, which then owns it. */
+ * rsq_db_adopt_table hands an existing table (rsq_table_create / _generate / ...) to the database, which then owns it.
+ * Destroy a database before the context it was created on (its tables live in that context's device memory). */
 typedef struct rsq_db rsq_db;
 int  rsq_db_create(rsq_ctx* ctx, rsq_db** out);
 int  rsq_db_execute(rsq_db* db, const char* sql, int32_t* kind, rsq_result_view* result);
