@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                 const i64 s = lo + (i64)s_list[i];
                 i64* o = out + (size_t)pos * stride;
                 o[0] = first[s];
-                for (int w = 0; w < nWords; w++) o[1 + w] = wordsAos ? words[(size_t)s * nWords + w] : words[(size_t)w * cap + s];
+                // (no word arrays: the one word is the slot index itself — dense aggregate tables, whose slot IS the group id)
+                for (int w = 0; w < nWords; w++) o[1 + w] = !words ? s : wordsAos ? words[(size_t)s * nWords + w] : words[(size_t)w * cap + s];
                 for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
             }
         }

@@ -662,10 +662,53 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             topkSpec = std::min<uint32_t>(topkCapacity, std::max<uint32_t>(q.topkWant + 64, 65536u / (uint32_t)(q.groupRowWords * 8)));
         }
     }
+    // ORDER BY ... LIMIT k over a large DENSE aggregate table: the groups present are compacted into rows [first row | group id |
+    // accumulator blocks] and go through the same candidate pre-selection; the table itself (tens of MB) is only read back
+    // when the candidates do not decide the answer
+    bool denseTopk = false;
+    if (!partialOnly && q.aggMode == AggMode::DENSE_GLOBAL && q.aggPad == 1 && q.denseGroups >= 65536 && q.denseGroups <= (1 << 21)) {
+        if (q.topkWord == -2) planDeviceTopK(q);
+        if (q.topkWord >= 0) {
+            const uint32_t D = (uint32_t)q.denseGroups;
+            const int W = (int)q.accums.size();
+            q.groupRowWords = 2 + W;
+            groupRowsAllocated = D;
+            const size_t need = (size_t)D * (size_t)q.groupRowWords;
+            if (q.hGroupRowsWords < need) {
+                if (q.dGroupRows) ctx.free(q.dGroupRows);
+                q.dGroupRows = (int64_t*)ctx.alloc(need * 8);
+                if (q.hGroupRows) (void)hipHostFree(q.hGroupRows);
+                q.hGroupRows = nullptr;
+                RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
+                q.hGroupRowsWords = need;
+            }
+            if (!q.dGroupCount) q.dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
+            RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
+            compactEntries(ctx, (const int64_t*)q.dAgg /* block 0 = first row */, (int64_t)D, nullptr, 1, false, (const int64_t*)q.dAgg, W,
+                           q.dGroupRows, D, q.dGroupCount);
+            topkCapacity = std::min<uint32_t>(D, std::max<uint32_t>(256, 4 * q.topkWant));
+            if (q.topkImageRows < D) {
+                if (q.dTopkImages) ctx.free(q.dTopkImages);
+                q.dTopkImages = (uint64_t*)ctx.alloc((size_t)D * 8);
+                q.topkImageRows = D;
+            }
+            if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = (uint32_t*)ctx.alloc(4); }
+            if (q.candCapacity < topkCapacity || q.candRowWords != q.groupRowWords) {
+                if (q.dCandRows) ctx.free(q.dCandRows);
+                q.dCandRows = (int64_t*)ctx.alloc((size_t)topkCapacity * (size_t)q.groupRowWords * 8);
+                q.candCapacity = topkCapacity; q.candRowWords = q.groupRowWords;
+            }
+            selectTopCandidates(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, D, q.topkWant,
+                                q.dTopkImages, q.dTopkHists, q.dCandRows, topkCapacity, q.dCandCount);
+            q.report.num_kernels += 8;
+            topkSpec = std::min<uint32_t>(topkCapacity, std::max<uint32_t>(q.topkWant + 64, 65536u / (uint32_t)(q.groupRowWords * 8)));
+            denseTopk = true;
+        }
+    }
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
-    if (!partialOnly && denseMode(q)) enqueueTableReadback(q);
-    if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH))
+    if (!partialOnly && denseMode(q) && !denseTopk) enqueueTableReadback(q);
+    if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH || denseTopk))
         RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
     if (anyCompaction) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 8, q.dPipeStats, q.pipelines.size() * 8, hipMemcpyDeviceToHost, ctx.stream));
     if (topkCapacity) {
@@ -691,6 +734,31 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     checkDeviceError((uint32_t)q.hPinned[words]);
     if (!partialOnly) {
         double t1 = nowMs();
+        if (denseTopk) {
+            const int64_t nGroups = (int64_t)(uint32_t)q.hPinned[words + 1];
+            const int64_t nCand = (int64_t)(uint32_t)q.hPinned[words + 2];
+            const size_t rowBytes = (size_t)q.groupRowWords * 8;
+            bool done = false;
+            if (nCand <= (int64_t)topkCapacity && nCand < nGroups) {
+                if (nCand > (int64_t)topkSpec)
+                    RSQ_HIP(hipMemcpy((char*)q.hGroupRows + (size_t)topkSpec * rowBytes, (char*)q.dCandRows + (size_t)topkSpec * rowBytes,
+                                      (size_t)(nCand - topkSpec) * rowBytes, hipMemcpyDeviceToHost));
+                q.candidateRun = true;
+                q.nGroupRows = nCand; q.totalGroups = nGroups;
+                runTail(q);
+                q.candidateRun = false;
+                done = !q.tailNeedsAllGroups;
+            }
+            if (!done) {            // the candidates do not decide it: the whole table after all
+                enqueueTableReadback(q);
+                RSQ_HIP(hipStreamSynchronize(ctx.stream));
+                tableFromPinned(q);
+                runTail(q);
+            }
+            q.report.finalize_time_ms = nowMs() - t1;
+            q.report.execution_time_ms = nowMs() - t0;
+            return;
+        }
         if (denseMode(q)) tableFromPinned(q);
         else if (q.matOp && !q.agg) {
             q.hMatCols.resize(q.matSchema.size());

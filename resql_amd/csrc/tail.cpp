@@ -251,6 +251,29 @@ Groups groupsFromDense(Query& q) {
     return G;
 }
 
+// candidate rows of a dense aggregate table (engine.cpp: ORDER BY ... LIMIT over a large dense table):
+// [first row | group id | accumulator blocks]
+Groups groupsFromDenseRows(Query& q) {
+    const size_t W = q.accums.size();
+    const size_t stride = (size_t)q.groupRowWords;
+    Groups G;
+    G.n = (size_t)q.nGroupRows; G.nKeys = q.denseKeys.size(); G.nAcc = W;
+    G.firstRow.resize(G.n); G.keyData.resize(G.n * G.nKeys); G.accData.resize(G.n * W);
+    for (size_t i = 0; i < G.n; i++) {
+        const int64_t* r = &q.hGroupRows[i * stride];
+        const int64_t g = r[1];
+        G.firstRow[i] = r[0];
+        size_t k = 0;
+        for (auto& dk : q.denseKeys) {
+            const int64_t rank = (g / dk.stride) % dk.card;
+            Val v; v.i = dk.byteSet ? (int64_t)dk.values[(size_t)rank] : dk.min + rank;
+            G.keyData[i * G.nKeys + k++] = v;
+        }
+        for (size_t w = 0; w < W; w++) G.accData[i * W + w] = r[2 + (size_t)q.accumSlot[w]];
+    }
+    return G;
+}
+
 Groups groupsFromJoinEntries(Query& q) {
     // rows compacted on the device: [firstrow | table words (keys, payload) | accumulator blocks]
     HashTable& ht = *q.hashTables[(size_t)q.aggTable];
@@ -405,7 +428,8 @@ void planDeviceTopK(Query& q) {
     const char* env = getenv("RSQ_DEVICE_TOPK");
     if (env && atoi(env) == 0) return;
     OpNode* agg = q.agg;
-    if (!agg || (q.aggMode != AggMode::AT_JOIN_ENTRY && q.aggMode != AggMode::HASH)) return;
+    const bool dense = q.aggMode == AggMode::DENSE_GLOBAL;         // candidate rows [first row | group id | accumulator blocks]
+    if (!agg || (q.aggMode != AggMode::AT_JOIN_ENTRY && q.aggMode != AggMode::HASH && !dense)) return;
     OpNode* mat = nullptr; OpNode* orderBy = nullptr;
     std::vector<OpNode*> projections;
     for (OpNode* o = agg->parent; o; o = o->parent) {
@@ -421,11 +445,11 @@ void planDeviceTopK(Query& q) {
     q.topkNeedsNoMerge = false;
     if (q.aggMode == AggMode::HASH)
         for (Expr* g : agg->exprs2) if (g->type.tag == RSQ_CHAR && g->type.len > 1) q.topkNeedsNoMerge = true;
-    const HashTable& ht = *q.hashTables[(size_t)q.aggTable];
-    const int nTab = (int)(ht.keys.size() + ht.payload.size());
+    const int nTab = dense ? 1 : (int)(q.hashTables[(size_t)q.aggTable]->keys.size() + q.hashTables[(size_t)q.aggTable]->payload.size());
     typedef std::pair<int, Type> Src;
     std::map<std::string, Src> src;
-    for (size_t k = 0; k < agg->exprs2.size(); k++) src[expressionName(agg->exprs2[k])] = Src(1 + q.groupSource[k], agg->exprs2[k]->type);
+    if (!dense)      // (the group values of a dense table are functions of the group id, not words of the row)
+        for (size_t k = 0; k < agg->exprs2.size(); k++) src[expressionName(agg->exprs2[k])] = Src(1 + q.groupSource[k], agg->exprs2[k]->type);
     {
         size_t si = 0;
         for (Expr* a : agg->exprs) {
@@ -479,7 +503,8 @@ void runTail(Query& q) {
         fprintf(stderr, "[rsq trace]     tail: %.3f ms  %s\n", t - tPhase, what);
         tPhase = t;
     };
-    Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) ? groupsFromJoinEntries(q) : groupsFromDense(q);
+    Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) ? groupsFromJoinEntries(q)
+             : q.candidateRun ? groupsFromDenseRows(q) : groupsFromDense(q);
     if (q.aggMode == AggMode::HASH) mergeSpaceEquivalentGroups(q, G);
     phase("groups from the device tables");
 

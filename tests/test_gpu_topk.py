@@ -125,3 +125,28 @@ def test_string_group_keys_take_the_candidate_path(gpu_ctx):
     node = p.projection([p.attr("name"), p.as_("s", s)], node)
     node = p.orderby([p.desc(p.attr("s")), p.attr("name")], node)
     run_both_ways(gpu_ctx, p.set_root(node, limit=7))
+
+
+def dense_plan(t, order, limit):
+    """select b, sum(c - 2^19) as s, min(d) as lo, count(*) as n from t where a < 2^30 group by b order by ... limit (b is a column with
+    statistics: a dense group id, the aggregate table lives in HBM)"""
+    p = P.Plan([t])
+    b = p.attr("b")
+    s = p.sum(p.sub(p.attr("c"), p.constant("524288", P.BIGINT)))
+    lo, n = p.min(p.attr("d")), p.count(p.star())
+    node = p.selection(p.lt(p.attr("a"), p.constant(str(1 << 30), P.BIGINT)), p.scan(t.name))
+    node = p.aggregation([s, lo, n], [b], node)
+    node = p.projection([b, p.as_("s", s), p.as_("lo", lo), p.as_("n", n)], node)
+    node = p.orderby(order(p), node)
+    return p.set_root(node, limit=limit)
+
+
+def test_large_dense_tables_take_the_candidate_path(gpu_ctx):
+    """200 K dense groups (about half of them present): ORDER BY an aggregate ... LIMIT reads back a few candidate rows instead of
+    the whole aggregate table; ties on all keys fall back to the table"""
+    t = tpch.synthetic_table(300_000, 200_000)
+    for order, limit in ((lambda p: [p.desc(p.attr("s")), p.attr("b")], 10), (lambda p: [p.attr("s"), p.desc(p.attr("b"))], 25),
+                         (lambda p: [p.desc(p.attr("n")), p.attr("lo"), p.attr("b")], 7), (lambda p: [p.attr("lo")], 5),
+                         (lambda p: [p.desc(p.attr("n"))], 5)):
+        want = run_both_ways(gpu_ctx, dense_plan(t, order, limit))
+        assert want.n_rows == limit
