@@ -1,32 +1,45 @@
 #!/usr/bin/env python3
 """bench.py — TPC-H Q1 rows/s at SF10 on MI355X through the engine's C ABI.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run,
-                                                          one rank per GPU, RCCL)
+  python bench.py --gpus N --steps K --warmup W
 
-One *step* = one execution of the compiled Q1 plan over the whole lineitem table that is already
-resident in HBM (device-generated, deterministic; H2D is not part of any timed region):
-scan 7 columns -> filter -> 6-group aggregation kernel -> group-by merge (RCCL all-reduce of the
-partial aggregate table when N > 1) -> host finalisation (AVG, projection, ORDER BY) to ReSQL's
-result relation.  `value` = lineitem rows of the whole job / wall time of the K steps (max over
-ranks).
+N > 1 needs one process per GPU.  Two ways in, same code path afterwards:
+  * under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`): RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* come from the environment;
+  * plain `python bench.py --gpus N`: this process — BEFORE it imports torch or touches a GPU — starts N fresh rank
+    processes of itself with those variables set (rendezvous on 127.0.0.1, a free port), relays rank 0's JSON line and
+    exits non-zero if any rank does.  (Mirrors the reference's execute(): one call fans out to all workers and joins
+    them, reference src/JitContextFlounder.h:459-487.)
 
-N > 1 shards the SF10 table by row range across the ranks ("morsel-sharded", BASELINE.json config 4):
-total work is fixed, so scaling is "strong".
+One *step* = one execution of the compiled Q1 plan over the whole lineitem table that is already resident in HBM
+(device-generated, deterministic; H2D is not part of any timed region): scan 7 columns -> filter -> 6-group aggregation
+kernel -> group-by merge (one RCCL all-gather of the 42-word partial tables + one fused merge kernel when N > 1) -> host
+finalisation (AVG, projection, ORDER BY) to ReSQL's result relation.  `value` = lineitem rows of the whole job / wall
+time of the K steps (max over ranks).
+
+N > 1 shards the SF10 table by row range across the ranks ("morsel-sharded", BASELINE.json config 4): total work is
+fixed, so scaling is "strong".
 
 Extra objects on the JSON line:
-  roofline     — the scan+aggregate kernel: ALGORITHMIC bytes (38 B/row x rows per launch, SURVEY.md
-                 §8d) / its average duration measured with HIP events on the engine's stream, against
-                 the 8 TB/s HBM3E peak of /opt/skills/guides/MI355X_MICROARCH.md.
-  cpu_baseline — the UNMODIFIED reference (oracle/_ref/ref_harness: ReSQL's asmjit path, threads=1;
-                 ReSQL's aggregation pipelines are single-threaded by construction) timed
-                 on this box's host cores on a bounded sample (SF1 Q1), rank 0, N = 1 only.
+  roofline     — the scan+aggregate kernel: ALGORITHMIC bytes (38 B/row x rows per launch) / its average
+                 duration measured with HIP events on the engine's stream, against the 8 TB/s HBM3E peak of
+                 /opt/skills/guides/MI355X_MICROARCH.md.  `traffic` is NOT measured by this run: it is the FETCH_SIZE
+                 figure of the committed rocprofv3 --pmc pass named in `traffic_source`, quoted only when this run has the
+                 same bytes per launch.
+  cpu_baseline — the UNMODIFIED reference (oracle/_ref/ref_harness: ReSQL's asmjit path, threads=1; ReSQL's aggregation
+                 pipelines are single-threaded by construction) timed on this box's host cores on the SAME
+                 rows the value is quoted on (SF10 lineitem read back from the device table), rank 0, N = 1 only.
+
+`--backend gloo --no-gpu` is a dry mode for machines without a GPU (the CPU test of the launch path): every rank takes a
+compile-only engine context, a deterministic stand-in partial table goes through the same sharding, layout check, merge
+and finalisation calls, and the line carries "dry_run": true instead of a measurement.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,14 +47,79 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
+PMC_PROFILE = "profiles/r02_q1_sf10_pmc.json"
 
 
-def cpu_baseline(sample_sf: float = 1.0, repeat: int = 3):
-    """time the reference itself (or, if its binary is absent, the C restatement) on a bounded sample"""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sf", type=float, default=10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-sf", type=float, default=None,
+                    help="scale factor of the reference's sample (default: --sf, i.e. the rows `value` is quoted on)")
+    ap.add_argument("--dist-path", action="store_true",
+                    help="take the multi-rank step (async partial + merge + finalize) even with one rank: lets a 1-GPU box "
+                         "exercise the exact code the N > 1 runs use")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the group-by merge (nccl = RCCL over xGMI; gloo only with --no-gpu)")
+    ap.add_argument("--no-gpu", action="store_true", help="dry mode, see the module docstring")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# self-launch: no torch, no HIP in this function or before it
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv) -> int:
+    """start n rank processes of this script, wait for all, relay rank 0's stdout; returns the exit code"""
+    port = _free_port()
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RSQ_BENCH_SELF_LAUNCHED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=(rank == 0) or None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return next(c for _, c in bad) or 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(sample_sf: float, device_table=None, repeat: int = 3):
+    """time the reference itself (or, if its binary is absent, the C restatement) on a bounded sample.
+    device_table: the resident lineitem table of the run — its columns are read back so that the reference scans exactly
+    the rows the GPU number is quoted on (the numpy generator makes the same bits, but takes minutes at SF10)."""
     from resql_amd import tpch, datagen
+    from resql_amd import plan as P
     from oracle import orc
+    import numpy as np
     n = datagen.n_lineitem(sample_sf)
-    li = tpch.lineitem_table(sample_sf, tpch.Q1_COLUMNS)
+    if device_table is not None and device_table.n_rows == n:
+        dt = {"l_quantity": np.int64, "l_extendedprice": np.int64, "l_discount": np.int64, "l_tax": np.int64,
+              "l_returnflag": np.uint8, "l_linestatus": np.uint8, "l_shipdate": np.uint32}
+        data = {c: device_table.read_column(c, dt[c]) for c in tpch.Q1_COLUMNS}
+        li = tpch.make_table("lineitem", tpch.LINEITEM_SCHEMA, data, n)
+        source = "read back from the device table"
+    else:
+        li = tpch.lineitem_table(sample_sf, tpch.Q1_COLUMNS)
+        source = "numpy generator (same bits as the device generator)"
     plan = tpch.q1_plan(li)
     cores = os.cpu_count() or 1
     if orc.have_reference():
@@ -55,36 +133,120 @@ def cpu_baseline(sample_sf: float = 1.0, repeat: int = 3):
         except Exception:
             many = ""
         return {"value": n / (ms * 1e-3), "unit": "rows/s", "cores": 1, "kind": "reference",
-                "sample": f"TPC-H Q1 over {n} synthetic lineitem rows (SF{sample_sf:g}), ReSQL asmjit path threads=1, "
-                          f"best of {repeat} `execute:` times ({ms:.1f} ms){many}; host has {cores} cores but ReSQL runs "
-                          f"aggregation pipelines on one thread (SingleThreadGuard)"}
+                "sample": f"TPC-H Q1 over {n} synthetic lineitem rows (SF{sample_sf:g}, {source}), ReSQL asmjit path "
+                          f"threads=1, best of {repeat} `execute:` times ({ms:.1f} ms){many}; host has {cores} cores but "
+                          f"ReSQL runs aggregation pipelines on one thread (SingleThreadGuard)"}
     t0 = time.time()
     orc.execute(plan)
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": f"TPC-H Q1 over {n} synthetic lineitem rows (SF{sample_sf:g}), oracle/resql_oracle.c, 1 thread"}
+    dt_s = time.time() - t0
+    return {"value": n / dt_s, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"TPC-H Q1 over {n} synthetic lineitem rows (SF{sample_sf:g}, {source}), oracle/resql_oracle.c, 1 thread"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--sf", type=float, default=10.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dist-path", action="store_true",
-                    help="take the multi-rank step (async partial + merge + finalize) even with one rank: lets a 1-GPU box "
-                         "exercise the exact code the N > 1 runs use")
-    args = ap.parse_args()
+def committed_traffic(bytes_per_launch: int):
+    """HBM bytes per launch of the Q1 kernel from the rocprofv3 --pmc pass committed under profiles/ (FETCH_SIZE,
+    collected in its own run and corrected as MI355X_MICROARCH.md prescribes for gfx950) — only for the configuration
+    it was measured on.  Returns (traffic, source)."""
+    for rel in (PMC_PROFILE, "profiles/r01_q1_sf10_pmc.json"):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                pmc = json.load(f)
+            if pmc.get("algorithmic_bytes_per_launch") == bytes_per_launch:
+                return pmc["hbm_read_bytes_per_launch_corrected"], f"{rel} (committed rocprofv3 --pmc FETCH_SIZE pass; not measured by this run)"
+        except Exception:
+            continue
+    return None, None
 
+
+# ------------------------------------------------------------------------------------------------------------------
+def dry_run(args, world: int, rank: int) -> int:
+    """--no-gpu: launch path, process group, sharding, layout check, merge and finalisation without a device"""
     import torch
+    import torch.distributed as dist
     from resql_amd import datagen, engine, tpch
+    from resql_amd.dist import PartialMerger, shard_rows
+    if os.environ.get("RSQ_BENCH_DRY_FAIL_RANK") == str(rank):     # test hook: a rank that dies before the rendezvous
+        print(f"rank {rank}: failing on request", file=sys.stderr)
+        return 3
+    if world > 1 or args.dist_path:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        grouped = True
+    else:
+        grouped = False
+    n_total = datagen.n_lineitem(args.sf)
+    row0, n_rows = shard_rows(n_total, world, rank)
+    ctx = engine.Context(device=-1)
+    schema_only = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
+    shard = ctx.table(tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=1024))   # statistics -> the 6-group layout
+    q = ctx.compile(tpch.q1_plan(schema_only), [shard])
+    n_min, n_max, n_sum = q.partial_layout()
+    words = n_min + n_max + n_sum
+    # stand-in partial table: first-row trackers = this shard's first rows, sums = (rank + 1) * (word index + 1)
+    partial = torch.empty(words, dtype=torch.int64)
+    partial[:n_min] = row0 + torch.arange(n_min)
+    partial[n_min:n_min + n_max] = rank
+    partial[n_min + n_max:] = (rank + 1) * (torch.arange(n_sum) + 1)
+    if grouped and world > 1:
+        layout = [l for l in q.explain.splitlines() if l.startswith("partial table:")]
+        every = [None] * world
+        dist.all_gather_object(every, layout)
+        if any(e != every[0] for e in every):
+            raise SystemExit(f"rank {rank}: shards disagree on the partial aggregate table layout: {every}")
+    merger = PartialMerger(dist if grouped else None, partial, n_min, n_max, n_sum, world)
+    for _ in range(args.warmup + args.steps):
+        mine = partial.clone()
+        merger.partial = mine
+        merger.merge()
+    if grouped:
+        dist.barrier()
+    if rank == 0:
+        q.finalize_host(mine.numpy())
+        res = q.result()
+        tri = world * (world + 1) // 2
+        expect_sum = [tri * (i + 1) for i in range(n_sum)]
+        ok = mine[:n_min].tolist() == list(range(n_min)) and mine[n_min + n_max:].tolist() == expect_sum
+        print(json.dumps({"metric": "TPC-H Q1 rows/s at SF10", "dry_run": True, "value": None, "unit": "rows/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"workload": "launch / merge / finalize plumbing only (no GPU)", "rows": n_total,
+                                     "world_size": dist.get_world_size() if grouped else 1,
+                                     "backend": dist.get_backend() if grouped else "none",
+                                     "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
+                                     "shards": [list(shard_rows(n_total, world, r)) for r in range(world)],
+                                     "merge": merger.strategy, "merged_ok": bool(ok), "result_groups": res.n_rows}}),
+              flush=True)
+        if not ok:
+            return 1
+    q.close()
+    shard.close()
+    ctx.close()
+    if grouped:
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.backend == "gloo" and not args.no_gpu:
+        raise SystemExit("--backend gloo exists for the --no-gpu dry mode only: the measured path merges over RCCL")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus, argv)              # nothing GPU-related has been imported yet
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.no_gpu:
+        return dry_run(args, world, rank)
+
+    import torch
+    from resql_amd import datagen, engine, tpch
+
     dist = None
     if world > 1 or args.dist_path:
         import torch.distributed as dist
@@ -126,7 +288,7 @@ def main():
         # single host synchronisation (inside finalize) per step on rank 0 and none on the other ranks
         torch.cuda.set_stream(torch.cuda.Stream(device))       # not the null stream: it serialises against every blocking stream
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        merger = PartialMerger(dist, partial, n_min, n_max, n_sum, world, always_collective=args.dist_path)
+        merger = PartialMerger(dist, partial, n_min, n_max, n_sum, world, always_collective=args.dist_path, query=q)
 
     def step():
         if not multi:
@@ -154,26 +316,19 @@ def main():
     elapsed = time.perf_counter() - t0
     if multi and rank != 0:
         q.finalize()                                  # the other ranks check their device error word once, untimed
+        kernel_ms = [q.report().kernel_time_ms]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    rc = 0
     if rank == 0:
         result = q.result()
-        # HBM traffic of this kernel from the PMC pass committed under profiles/ (FETCH_SIZE, collected in its own
-        # rocprofv3 --pmc run and corrected x2 as MI355X_MICROARCH.md prescribes for gfx950); only quoted for the
-        # configuration it was measured on
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_q1_sf10_pmc.json")) as f:
-                pmc = json.load(f)
-            if world == 1 and pmc.get("algorithmic_bytes_per_launch") == tpch.Q1_BYTES_PER_ROW * n_rows:
-                traffic = pmc["hbm_read_bytes_per_launch_corrected"]
-        except Exception:
-            traffic = None
+        bytes_per_launch = tpch.Q1_BYTES_PER_ROW * n_rows
+        traffic, traffic_source = committed_traffic(bytes_per_launch) if world == 1 else (None, None)
         avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = tpch.Q1_BYTES_PER_ROW * n_rows / (avg_kernel_ms * 1e-3) / 1e9
+        achieved = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
         # the read-only streaming roofline of THIS box, measured after the timed region with the access form the scan
         # uses (16 B per lane, non-temporal, 2 workgroups per CU): SURVEY.md §8d asks for the fraction against it too
         try:
@@ -195,22 +350,30 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"TPC-H Q1 over lineitem SF{args.sf:g} ({n_total} rows, 7 columns, 38 B/row) "
                                    f"resident in HBM, row-range sharded over {world} GPU(s)",
-                       "rows": n_total, "result_groups": result.n_rows,
+                       "rows": n_total, "rows_per_gpu": n_rows, "result_groups": result.n_rows,
+                       "world_size": dist.get_world_size() if dist is not None else 1,
+                       "backend": (dist.get_backend() + " (RCCL)") if dist is not None else "none (single process, single GPU)",
+                       "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
                        "parallelism": f"row-range shards x{world}, group-by merge over RCCL: {merger.strategy}"
                        if multi else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rsq_pipeline (scan+filter+dense aggregation)", "kernel_ms": avg_kernel_ms,
-                         "bytes_per_launch": tpch.Q1_BYTES_PER_ROW * n_rows,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "scan+filter+dense aggregation pipeline (rank 0's launches)", "kernel_ms": avg_kernel_ms,
+                         "bytes_per_launch": bytes_per_launch,
                          "measured_read_roofline": measured,
                          "frac_of_measured_read_roofline": (achieved / measured) if measured else None},
         }
         if world == 1 and not args.no_cpu_baseline:
+            want_sf = args.cpu_baseline_sf if args.cpu_baseline_sf is not None else args.sf
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(want_sf, table if want_sf == args.sf else None)
             except Exception as e:  # the baseline is a reported extra; never lose the bench line over it
-                out["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 0, "kind": "reference",
-                                       "sample": f"failed: {e}"}
+                try:
+                    out["cpu_baseline"] = cpu_baseline(1.0)
+                    out["cpu_baseline"]["sample"] += f" [SF{want_sf:g} sample failed: {e}]"
+                except Exception as e2:
+                    out["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 0, "kind": "reference",
+                                           "sample": f"failed: {e2}"}
         print(json.dumps(out), flush=True)
 
     q.close()
@@ -218,7 +381,8 @@ def main():
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -145,6 +145,10 @@ int  rsq_query_partial_layout(const rsq_query* q, int64_t* n_min_words, int64_t*
 /* Make the query keep its partial aggregate table in caller-owned device memory (e.g. a torch
  * tensor the host hands to RCCL) instead of its own allocation; `bytes` must cover all words. */
 int  rsq_query_bind_partial(rsq_query* q, void* dev_ptr, size_t bytes);
+/* The kernel behind the merge collective of small tables: `gathered_dev` holds the partial tables of `n_ranks` ranks back to
+ * back (the receive buffer of ONE all-gather, device memory); they are reduced segment by segment (min | max | sum) into this
+ * query's own partial table (the bound one).  Enqueued on the context's stream; no synchronisation. */
+int  rsq_query_merge_gathered(rsq_query* q, const void* gathered_dev, int32_t n_ranks);
 int  rsq_query_result(rsq_query* q, rsq_result_view* out);
 int  rsq_query_report(const rsq_query* q, rsq_report* out);
 /* Generated HIP source and pipeline description of the compiled query (debugging). */

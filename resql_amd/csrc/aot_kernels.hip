@@ -603,6 +603,33 @@ void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, i
 }
 
 // ------------------------------------------------------------------------------------------------
+// group-by merge of partial aggregate tables (multi-GPU): `parts` holds nParts tables of `words` int64 words, each laid
+// out [ nMin | nMax | nSum ] (include/resql_hip.h, rsq_query_execute_partial), either back to back (one all-gather
+// buffer: stride = words) or at `stride` words from each other.  out[w] = min / max / sum over the parts — the one
+// kernel behind the collective, instead of one reduction launch per segment.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_merge_partials(const i64* __restrict__ parts, int nParts, i64 stride, i64 nMin, i64 nMax, i64 nSum,
+                                                        i64* __restrict__ out) {
+    const i64 words = nMin + nMax + nSum;
+    for (i64 w = blockIdx.x * (i64)blockDim.x + threadIdx.x; w < words; w += (i64)gridDim.x * blockDim.x) {
+        i64 v = parts[w];
+        if (w < nMin) { for (int r = 1; r < nParts; r++) { i64 x = parts[(i64)r * stride + w]; v = x < v ? x : v; } }
+        else if (w < nMin + nMax) { for (int r = 1; r < nParts; r++) { i64 x = parts[(i64)r * stride + w]; v = x > v ? x : v; } }
+        else { u64 s = (u64)v; for (int r = 1; r < nParts; r++) s += (u64)parts[(i64)r * stride + w]; v = (i64)s; }
+        out[w] = v;
+    }
+}
+
+void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out) {
+    const int64_t words = nMin + nMax + nSum;
+    if (words <= 0 || nParts <= 0) return;
+    unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (words + 255) / 256));
+    hipLaunchKernelGGL(k_merge_partials, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)parts, nParts, (i64)stride, (i64)nMin, (i64)nMax, (i64)nSum,
+                       (i64*)out);
+    RSQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
 // streaming read bandwidth probe
 // ------------------------------------------------------------------------------------------------
 typedef i64 ll2 __attribute__((ext_vector_type(2)));

@@ -219,6 +219,11 @@ int rsq_query_bind_partial(rsq_query* q, void* dev_ptr, size_t bytes) {
     return guarded(QH(q)->ctx, [&] { bindPartial(*QH(q)->q, dev_ptr, bytes); });
 }
 
+int rsq_query_merge_gathered(rsq_query* q, const void* gathered_dev, int32_t n_ranks) {
+    if (!q) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] { mergeGathered(*QH(q)->q, gathered_dev, n_ranks); });
+}
+
 int rsq_query_finalize_host(rsq_query* q, const int64_t* words, int64_t n_words) {
     if (!q || !words || n_words < 0) return RSQ_ERR_INVALID;
     return guarded(QH(q)->ctx, [&] { finalizeQueryHost(*QH(q)->q, words, (size_t)n_words); });

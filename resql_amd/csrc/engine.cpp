@@ -841,6 +841,17 @@ void bindPartial(Query& q, void* dptr, size_t bytes) {
     q.dAggOwned = false;
 }
 
+// the kernel behind the merge collective: `gathered` = every rank's partial table back to back (one all-gather), reduced by
+// segment into this query's own partial table; enqueued on the context's stream, no synchronisation
+void mergeGathered(Query& q, const void* gathered, int nRanks) {
+    if (!denseMode(q)) failUnsupported("partial tables exist for dense aggregations only");
+    if (!gathered || nRanks < 1) failInvalid("merge needs the gathered tables of at least one rank");
+    if (q.ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
+    RSQ_HIP(hipSetDevice(q.ctx.device));
+    const int64_t G = q.denseGroups;
+    mergePartialsAsync(q.ctx, (const int64_t*)gathered, nRanks, (int64_t)q.tableWords, q.nMinBlocks * G, q.nMaxBlocks * G, q.nSumBlocks * G, (int64_t*)q.dAgg);
+}
+
 void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum) {
     if (!denseMode(q)) failUnsupported("partial tables exist for dense aggregations only");
     *dptr = q.dAgg;

@@ -97,6 +97,8 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
 size_t scanTempBytes(int64_t n);
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
+// multi-GPU group-by merge: out[w] = min | max | sum over nParts partial tables (`stride` words apart) by segment
+void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out);
 // one launch: fill[0..nFill) = fillValue (u64), zeroA / zeroB cleared (u32 words), *count = 0 (any of them may be empty / null)
 void prepareTableAsync(Context& ctx, uint64_t* fill, size_t nFill, uint64_t fillValue, uint32_t* zeroA, size_t nZeroA, uint32_t* zeroB, size_t nZeroB,
                        uint32_t* count);
@@ -125,6 +127,7 @@ void executeQuery(Query& q, bool partialOnly, bool async = false);
 void finalizeQuery(Query& q);
 void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords);
 void bindPartial(Query& q, void* dptr, size_t bytes);
+void mergeGathered(Query& q, const void* gathered, int nRanks);
 void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum);
 void queryResult(Query& q, rsq_result_view* out);
 void queryReport(const Query& q, rsq_report* out);

@@ -41,19 +41,25 @@ def allreduce_partial(dist, partial, n_min: int, n_max: int, n_sum: int) -> None
 
 class PartialMerger:
     """Merges `partial` (this rank's table, a 1-D int64 tensor that stays bound to the query) across all ranks, in
-    place.  Everything is enqueued on the current stream of `partial`'s device: no host synchronisation here."""
+    place.  Everything is enqueued on the current stream of `partial`'s device: no host synchronisation here.
+    With `query` (an engine.Query whose partial table is bound to `partial`, on a GPU) the small-table strategy is
+    ONE all-gather + ONE fused merge kernel of the engine (rsq_query_merge_gathered, on the context's stream — which
+    must be the current torch stream); without it (CPU tests over gloo) the segment reductions are torch ops."""
 
-    def __init__(self, dist, partial, n_min: int, n_max: int, n_sum: int, world: int, always_collective: bool = False):
+    def __init__(self, dist, partial, n_min: int, n_max: int, n_sum: int, world: int, always_collective: bool = False,
+                 query=None):
         import torch
         self.dist, self.partial = dist, partial
         self.n_min, self.n_max, self.n_sum, self.world = n_min, n_max, n_sum, world
         words = n_min + n_max + n_sum
         assert partial.numel() == words and partial.dtype == torch.int64
-        self.collective = world > 1 or always_collective       # always_collective: run the exchange even with one rank (tests)
+        self.collective = dist is not None and (world > 1 or always_collective)   # always_collective: run the exchange even with one rank (tests)
         self.gather = self.collective and words <= GATHER_LIMIT_WORDS
+        self.query = query if (query is not None and partial.is_cuda) else None
         self.all = torch.empty((world, words), dtype=torch.int64, device=partial.device) if self.gather else None
-        self.strategy = "single rank" if not self.collective else ("one all-gather + local segment reductions" if self.gather
-                                                         else "one all-reduce per segment (min | max | sum)")
+        self.strategy = "single rank" if not self.collective else (
+            ("one all-gather + one fused merge kernel" if self.query is not None else "one all-gather + local segment reductions")
+            if self.gather else "one all-reduce per segment (min | max | sum)")
 
     def merge(self) -> None:
         import torch
@@ -63,6 +69,9 @@ class PartialMerger:
             allreduce_partial(self.dist, self.partial, self.n_min, self.n_max, self.n_sum)
             return
         self.dist.all_gather_into_tensor(self.all.view(-1), self.partial)
+        if self.query is not None:
+            self.query.merge_gathered(self.all.data_ptr(), self.world)
+            return
         a, b = self.n_min, self.n_min + self.n_max
         if self.n_min:
             torch.amin(self.all[:, :a], dim=0, out=self.partial[:a])

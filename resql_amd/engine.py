@@ -83,6 +83,7 @@ def lib():
         L.rsq_ctx_set_stream.argtypes = [vp, vp, i32]
         L.rsq_query_finalize.argtypes = [vp]
         L.rsq_query_bind_partial.argtypes = [vp, vp, C.c_size_t]
+        L.rsq_query_merge_gathered.argtypes = [vp, vp, i32]
         L.rsq_query_finalize_host.argtypes = [vp, C.POINTER(i64), i64]
         L.rsq_query_partial_layout.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.rsq_query_result.argtypes = [vp, C.POINTER(P.rsq_result_view)]
@@ -121,7 +122,7 @@ EXPORTED_SYMBOLS = [
     "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
-    "rsq_query_finalize", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
+    "rsq_query_finalize", "rsq_query_merge_gathered", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
     "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
     "rsq_measure_read_bandwidth",
     "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
@@ -326,6 +327,10 @@ class Query:
 
     def bind_partial(self, dev_ptr: int, nbytes: int):
         self.ctx._check(self.ctx._L.rsq_query_bind_partial(self.h, dev_ptr, nbytes))
+
+    def merge_gathered(self, gathered_dev_ptr: int, n_ranks: int):
+        """reduce the gathered partial tables of n_ranks ranks (device memory, back to back) into the bound partial table"""
+        self.ctx._check(self.ctx._L.rsq_query_merge_gathered(self.h, gathered_dev_ptr, n_ranks))
 
     def partial_layout(self):
         """(n_min_words, n_max_words, n_sum_words) of the partial aggregate table"""

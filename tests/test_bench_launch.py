@@ -1,0 +1,71 @@
+"""bench.py's own way into N > 1 ranks, on CPU: `python bench.py --gpus 2` (no launcher) must start two fresh rank
+processes itself, rendezvous them, run the sharding / layout check / merge / finalize plumbing and relay rank 0's JSON
+line; the same under torch.distributed.run (how the driver launches N > 1); a failing rank must fail the whole call.
+`--backend gloo --no-gpu` is bench.py's dry mode: same code path up to the device work (see its docstring)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _line(stdout: str) -> dict:
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def _check(rec: dict, world: int, self_launched: bool):
+    assert rec["dry_run"] is True and rec["n_gpus"] == world
+    cfg = rec["config"]
+    assert cfg["world_size"] == world and cfg["backend"] == "gloo" and cfg["self_launched"] is self_launched
+    assert cfg["merged_ok"] is True and cfg["result_groups"] == 6
+    shards = cfg["shards"]
+    assert shards[0][0] == 0 and sum(n for _, n in shards) == cfg["rows"] == 59_999_996
+    for (a0, an), (b0, _) in zip(shards, shards[1:]):
+        assert a0 + an == b0 and b0 % 128 == 0
+
+
+def test_bench_starts_its_own_ranks():
+    pr = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--no-gpu", "--steps", "3", "--warmup", "1"],
+                        env=_env(), capture_output=True, text=True, timeout=240)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    _check(_line(pr.stdout), 2, True)
+
+
+def test_bench_under_torch_distributed_run():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    pr = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH,
+                         "--gpus", "2", "--backend", "gloo", "--no-gpu", "--steps", "2", "--warmup", "1"],
+                        env=_env(), capture_output=True, text=True, timeout=240)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    _check(_line(pr.stdout), 2, False)
+
+
+def test_a_failing_rank_fails_the_call():
+    env = _env()
+    env["RSQ_BENCH_DRY_FAIL_RANK"] = "1"
+    pr = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--no-gpu", "--steps", "1", "--warmup", "0"],
+                        env=env, capture_output=True, text=True, timeout=240)
+    assert pr.returncode != 0
+    assert not [l for l in pr.stdout.splitlines() if l.startswith("{")]
+
+
+def test_world_size_mismatch_is_refused():
+    env = _env()
+    env.update({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    pr = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--backend", "gloo", "--no-gpu"], env=env, capture_output=True, text=True, timeout=120)
+    assert pr.returncode != 0 and "WORLD_SIZE=2" in pr.stderr
