@@ -208,6 +208,51 @@ int  rsq_db_adopt_table(rsq_db* db, rsq_table* table);
 int  rsq_db_report(const rsq_db* db, rsq_report* out);          /* of the last SELECT */
 void rsq_db_destroy(rsq_db* db);
 
+/* ---- one host process, N GPUs ------------------------------------------------------------------
+ * JitContextFlounder::execute() fans ONE compiled function out to config.numThreads workers that pull morsels from a shared
+ * iterator and joins them (reference src/JitContextFlounder.h:459-487).  The multi-GPU form of that call: a host process
+ * (ReSQL's executeSelectPlan, src/execute.h:213-247, unchanged in shape) holds one handle over N GPUs; the morsels are
+ * row-range shards of the scanned table, one per GPU and resident in its HBM; rsq_multi_query_execute runs the same compiled
+ * pipelines on every GPU and merges the partial aggregate tables with ONE exchange step — an RCCL reduce over xGMI to the
+ * root GPU (ncclReduce per [min | max | sum] segment, all segments and GPUs in one ncclGroup; communicators from
+ * ncclCommInitAll; librccl is dlopen'ed by rsq_multi_create) — then finalises on the root.  Integer min / max / sum:
+ * the result is bit-identical to the single-GPU one.
+ *
+ * Plans that do not end in a dense partial table (joins with many groups, hash aggregation, materialisation) run whole on
+ * every shard concurrently; the caller shards the probe-side table on a boundary of the group key and gives every shard the
+ * full build-side tables, and the merge is the host-side ordered merge of the shards' (LIMIT-ed) rows.
+ *
+ * devices may list a GPU more than once (shards that share a GPU: how a one-GPU box runs N shards); RCCL cannot hold a device
+ * twice, so such handles — and any handle created with RSQ_MERGE_PEER_COPY — move the partial tables with peer copies to
+ * the root and reduce them with the engine's merge kernel. */
+enum rsq_merge_mode { RSQ_MERGE_AUTO = 0, RSQ_MERGE_RCCL = 1, RSQ_MERGE_PEER_COPY = 2 };
+typedef struct rsq_multi_config {
+    rsq_config base;            /* per-GPU context settings; base.device is ignored */
+    const int32_t* devices;     /* HIP device ordinals, one shard each; devices[0] is the root */
+    int32_t n_devices;
+    int32_t merge;              /* rsq_merge_mode; AUTO = RCCL when the devices are distinct */
+} rsq_multi_config;
+typedef struct rsq_multi rsq_multi;
+typedef struct rsq_multi_query rsq_multi_query;
+int  rsq_multi_create(const rsq_multi_config* cfg, rsq_multi** out);
+void rsq_multi_destroy(rsq_multi* m);                            /* after its queries and tables */
+const char* rsq_multi_last_error(const rsq_multi* m);            /* m == NULL: of rsq_multi_create */
+int32_t rsq_multi_devices(const rsq_multi* m);
+rsq_ctx* rsq_multi_ctx(rsq_multi* m, int32_t shard);             /* the shard's context: create its tables on it */
+const char* rsq_multi_merge_name(const rsq_multi* m);
+/* rows [*row0, *row0 + *n_rows) of shard `shard` of n_shards: equal shards on 128-row tile boundaries, remainder to the last */
+void rsq_multi_shard_rows(int64_t n_total, int32_t n_shards, int32_t shard, int64_t* row0, int64_t* n_rows);
+/* rsq_table_generate over all shards: out_tables[i] = rows of shard i of an n_rows_total table, on GPU i */
+int  rsq_multi_table_generate(rsq_multi* m, int32_t kind, int64_t n_rows_total, double scale_factor, int64_t param, uint64_t seed,
+                              rsq_table** out_tables /* [n_devices] */);
+/* tables[shard * n_tables + t] is table t of the plan on that shard's context */
+int  rsq_multi_query_compile(rsq_multi* m, const rsq_plan_desc* plan, rsq_table* const* tables, int32_t n_tables, rsq_multi_query** out);
+int  rsq_multi_query_execute(rsq_multi_query* q);                /* blocking, like JitContextFlounder::execute() */
+int  rsq_multi_query_result(rsq_multi_query* q, rsq_result_view* out);
+/* kernel_time_ms = the slowest shard's; shard_kernel_ms (may be NULL) receives every shard's */
+int  rsq_multi_query_report(const rsq_multi_query* q, rsq_report* out, double* shard_kernel_ms /* [n_devices] */);
+void rsq_multi_query_destroy(rsq_multi_query* q);
+
 /* Sustained read-only streaming bandwidth of this GPU (grid-stride int64 sum over `bytes` of
  * resident memory): the measured roofline SURVEY.md §8(d) quotes fractions against. */
 int  rsq_measure_read_bandwidth(rsq_ctx* ctx, size_t bytes, int32_t iters, double* gb_per_s);

@@ -241,8 +241,8 @@ int rsq_query_result(rsq_query* q, rsq_result_view* out) {
 
 int rsq_query_report(const rsq_query* q, rsq_report* out) {
     if (!q || !out) return RSQ_ERR_INVALID;
-    queryReport(*reinterpret_cast<const QueryHandle*>(q)->q, out);
-    return RSQ_OK;
+    const QueryHandle* h = reinterpret_cast<const QueryHandle*>(q);
+    return guarded(h->ctx, [&] { queryReport(*h->q, out); });
 }
 
 const char* rsq_query_source(const rsq_query* q) { return q ? querySource(*reinterpret_cast<const QueryHandle*>(q)->q) : ""; }

@@ -1262,6 +1262,33 @@ struct Walker {
             // memory-side atomics serialise per line, and the 42 cells of TPC-H Q1 otherwise share six lines.
             q.aggPad = envInt("RSQ_AGG_PAD", 8, 1, 16);
             emitGlobalFlush(ep, std::to_string((long long)(W * D)), "s_acc[i]", D, q.aggPad);
+            // The step in ONE launch (engine.cpp runFusedStep): the workgroup that flushes last hands the finished table to
+            // the host — plain stores into host-mapped pinned memory (a full execution) or into the partial table the
+            // group-by merge reads (a multi-GPU step) — together with the device error word, and puts the working table,
+            // the error word and the ticket back to their identities for the next execution.  That replaces the D2D
+            // copy that readied the table, the error-word memset and the two read-back copies of every step.
+            // Order: a thread waits until its flush atomics have been performed (s_waitcnt vmcnt(0): device-scope atomics are
+            // coherent across the XCDs once performed) before the workgroup takes its ticket, so the holder of the last ticket
+            // finds every cell final; it reads with agent-scope exchanges, which execute where the flush atomics did.  A
+            // release fence instead (__threadfence: buffer_wbl2 + buffer_inv in every wave) cost 30 us per launch — more than
+            // the copies it was meant to save.
+            addArg("fin_out", "u64*", 0);
+            addArg("fin_err", "u64*", 0);
+            addArg("fin_ticket", "u32*", 0);
+            addArg("fin_seq", "u64", 0);
+            ep << "    if (a.fin_out) {\n        __shared__ u32 s_last;\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        __syncthreads();\n";
+            ep << "        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;\n        __syncthreads();\n";
+            ep << "        if (s_last) {\n";
+            ep << "            for (int i = threadIdx.x; i < " << W * D << "; i += blockDim.x) {\n                const int blk = i / " << D << ";\n";
+            ep << "                const u64 idv = " << blockIdentityExpr("blk") << ";\n";
+            ep << "                a.fin_out[i] = __hip_atomic_exchange(a.out + i" << (q.aggPad > 1 ? " * RSQ_OUT_STRIDE" : "") << ", idv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n            }\n";
+            ep << "            if (threadIdx.x == 0) {\n                a.fin_err[0] = (u64)atomicExch(a.err, 0u);\n";
+            ep << "                __hip_atomic_store(a.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n            }\n";
+            // a full execution is announced to the polling host by a sequence number behind the table: written after every
+            // thread's table stores have been acknowledged, with a system-scope release (one wave, once per launch)
+            ep << "            if (a.fin_seq) {\n                asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n                __syncthreads();\n";
+            ep << "                if (threadIdx.x == 0) __hip_atomic_store(a.fin_err + 1, a.fin_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n            }\n";
+            ep << "        }\n    }\n";
             // One 512-thread workgroup per CU: the same 8 waves per CU as 2 x 256, but half as many workgroups flush.
             // The flush is 42 atomics per workgroup (TPC-H Q1) onto six 64-byte lines, where they serialise: going from
             // 512 to 256 workgroups took 8 us off the 352 us SF10 kernel and 9 off the 67 us SF1 kernel (1024 and 2048

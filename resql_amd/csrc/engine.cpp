@@ -1,6 +1,7 @@
 // engine.cpp — describe -> compile -> execute -> retrieve for one query
 // (the call sequence of the reference's executeSelectPlan, reference src/execute.h:213-247).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <sstream>
@@ -114,7 +115,7 @@ Query::~Query() {
     if (dAggWorkInit) ctx.free(dAggWorkInit);
     if (hPinned) (void)hipHostFree(hPinned);
     if (hGroupRows) (void)hipHostFree(hGroupRows);
-    if (graphExec) (void)hipGraphExecDestroy(graphExec);
+    if (dFinTicket) ctx.free(dFinTicket);
     if (gev0) (void)hipEventDestroy(gev0);
     if (gev1) (void)hipEventDestroy(gev1);
     if (dMatCnt) ctx.free(dMatCnt);
@@ -233,6 +234,15 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         q->dPipeStats = (uint64_t*)ctx.alloc(std::max<size_t>(1, q->pipelines.size()) * 8);
         size_t pw = q->pinnedWords + 8 + q->pipelines.size();
         RSQ_HIP(hipHostMalloc((void**)&q->hPinned, pw * 8, hipHostMallocDefault));
+        memset(q->hPinned, 0, pw * 8);
+        if (q->aggMode == AggMode::DENSE_REG && q->aggPad > 1) {
+            void* dv = nullptr;
+            if (hipHostGetDevicePointer(&dv, q->hPinned, 0) == hipSuccess && dv) {
+                q->dFinHost = (uint64_t*)dv;
+                q->dFinTicket = (uint32_t*)ctx.alloc(sizeof(uint32_t));
+                RSQ_HIP(hipMemset(q->dFinTicket, 0, sizeof(uint32_t)));
+            } else (void)hipGetLastError();
+        }
     }
     q->report.compilation_time_ms = nowMs() - t0;
     q->report.jit_cache_hits = ctx.jitCacheHits - hits0;
@@ -246,8 +256,11 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
 // execute
 // ================================================================================================
 static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTable) {
-    if (a.name == "err" && q.errInTable) return (uint64_t)(uintptr_t)(q.dAggWork + q.padWords);
     if (a.name == "out") return (uint64_t)(uintptr_t)(q.aggPad > 1 && !q.flatRun ? q.dAggWork : q.dAgg);
+    if (a.name == "fin_out") return (uint64_t)(uintptr_t)q.finOut;
+    if (a.name == "fin_err") return (uint64_t)(uintptr_t)q.finErr;
+    if (a.name == "fin_seq") return q.finOut ? q.finSeq : 0;
+    if (a.name == "fin_ticket") return (uint64_t)(uintptr_t)(q.finOut ? q.dFinTicket : nullptr);
     if (a.name == "part_counts") return (uint64_t)(uintptr_t)q.dPartCounts;
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
@@ -291,11 +304,12 @@ static unsigned pipelineGrid(const Query& q, const Pipeline& p, bool lazyForm = 
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>(maxGrid * 256 / p.blockThreads, want));
 }
 
-static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnlyTable, unsigned grid = 0, unsigned block = 0) {
+static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnlyTable, unsigned grid = 0, unsigned block = 0,
+                                 hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     std::vector<uint64_t> args;
     for (auto& a : p.args) args.push_back(argValue(q, p, a, countOnlyTable));
     p.lastGrid = grid ? grid : pipelineGrid(q, p);
-    launch(q.ctx, k, p.lastGrid, block ? block : (unsigned)p.blockThreads, args);
+    launch(q.ctx, k, p.lastGrid, block ? block : (unsigned)p.blockThreads, args, start, stop);
     q.report.num_kernels++;
 }
 
@@ -455,16 +469,36 @@ static void checkDeviceError(uint32_t err) {
 
 // the dense aggregate table at the start / end of an execution: register-mode kernels work on the padded copy
 static void enqueueTableInit(Query& q) {
-    if (q.aggPad > 1 && !q.flatRun) RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, (q.padWords + (q.errInTable ? 1 : 0)) * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
+    q.fusedReady = false;          // the plain path leaves the working table as the kernels left it
+    if (q.aggPad > 1 && !q.flatRun) RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
     else RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, q.tableWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
 }
 static void enqueueTableReadback(Query& q) {
-    if (q.aggPad > 1) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAggWork, (q.padWords + (q.errInTable ? 1 : 0)) * 8, hipMemcpyDeviceToHost, q.ctx.stream));
+    if (q.aggPad > 1) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAggWork, q.padWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
     else RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
 }
 static void tableFromPinned(Query& q) {
     if (q.aggPad > 1) for (size_t i = 0; i < q.tableWords; i++) q.hAgg[i] = q.hPinned[i * (size_t)q.aggPad];
     else memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
+}
+
+// kernel time of a fused step: its events are read when somebody asks (the report) or before they are recorded again
+void resolveKernelTime(Query& q) {
+    if (!q.kernelTimePending || q.pendingAsync) return;
+    q.kernelTimePending = false;
+    RSQ_HIP(hipSetDevice(q.ctx.device));
+    RSQ_HIP(hipEventSynchronize(q.gev1));
+    float ms = 0;
+    RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1));
+    q.report.kernel_time_ms = ms;
+    q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
+}
+
+// a single register-mode pipeline: its kernel carries the whole step (codegen.cpp, "The step in ONE launch")
+static bool fusedEligible(const Query& q) {
+    static const bool off = getenv("RSQ_FUSED_STEP") && atoi(getenv("RSQ_FUSED_STEP")) == 0;
+    return !off && q.aggMode == AggMode::DENSE_REG && q.pipelines.size() == 1 && q.pipelines[0].sink == SinkKind::AGGREGATE &&
+           !q.pipelines[0].partitioned && q.dFinTicket != nullptr;
 }
 
 void executeQuery(Query& q, bool partialOnly, bool async) {
@@ -480,65 +514,74 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     const size_t words = q.pinnedWords;
     q.report.num_kernels = 0; q.report.bytes_read = 0;
     q.flatRun = partialOnly && q.aggPad > 1;
-    q.errInTable = false;
     const bool trace0 = getenv("RSQ_TRACE") != nullptr;
-    const char* genv = getenv("RSQ_GRAPH");
     uint32_t topkCapacity = 0, topkSpec = 0;      // > 0: this execution pre-selects ORDER BY ... LIMIT candidates on the device
     uint32_t groupRowsAllocated = 0;              // rows the group-row buffers of this execution can take
-    // ---- graph path: one plain pipeline into a dense table, on the context's own stream ----
-    if (denseMode(q) && q.pipelines.size() == 1 && q.pipelines[0].sink == SinkKind::AGGREGATE && !q.pipelines[0].partitioned &&
-        !trace0 && !q.graphFailed && ctx.stream == ctx.ownStream && !(genv && atoi(genv) == 0)) {
+    // ---- the step in one launch: a single register-mode pipeline whose last workgroup publishes the table ----
+    if (fusedEligible(q) && !trace0) {
         Pipeline& p = q.pipelines[0];
-        // full executions of register-mode queries keep the error word behind the padded table: the init copy clears it
-        // and the read-back fetches it, so a replay is {copy, kernel, copy}
-        q.errInTable = q.aggPad > 1 && !partialOnly;
-        if (!q.graphExec || q.graphAggPtr != (void*)q.dAgg || q.graphPartial != partialOnly) {
-            if (q.graphExec) { (void)hipGraphExecDestroy(q.graphExec); q.graphExec = nullptr; }
-            hipGraph_t g = nullptr;
-            bool ok = hipStreamBeginCapture(ctx.stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-            if (ok) {
-                try {
-                    enqueueTableInit(q);
-                    if (!q.errInTable) RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
-                    // the graph's own pair of events: an event that is also recorded outside a graph (the context's pair,
-                    // by multi-pipeline queries) keeps reporting that recording after a replay
-                    if (!q.gev0) { RSQ_HIP(hipEventCreate(&q.gev0)); RSQ_HIP(hipEventCreate(&q.gev1)); }
-                    RSQ_HIP(hipEventRecord(q.gev0, ctx.stream));
-                    launchPipeline(q, p, -1);
-                    RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
-                    if (!q.errInTable) RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
-                    if (!partialOnly) enqueueTableReadback(q);
-                } catch (...) { ok = false; }
-                if (hipStreamEndCapture(ctx.stream, &g) != hipSuccess) ok = false;
-            }
-            if (ok && hipGraphInstantiate(&q.graphExec, g, nullptr, nullptr, 0) != hipSuccess) { ok = false; q.graphExec = nullptr; }
-            if (g) (void)hipGraphDestroy(g);
-            (void)hipGetLastError();
-            if (!ok) { q.graphFailed = true; q.errInTable = false; }
-            else { q.graphAggPtr = (void*)q.dAgg; q.graphPartial = partialOnly; }
+        // the kernel leaves its working table, the error word and the ticket at their identities; make them so the first
+        // time, after an execution that did not come back (an exception between launch and synchronisation), and whenever
+        // another query of this context may have left the shared error word set
+        if (!q.fusedReady || !ctx.errWordClean) {
+            RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, ctx.stream));
+            RSQ_HIP(hipMemsetAsync(q.dFinTicket, 0, 4, ctx.stream));
+            RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+            ctx.errWordClean = true;
         }
-        if (q.graphExec) {
-            RSQ_HIP(hipGraphLaunch(q.graphExec, ctx.stream));
-            q.report.num_kernels = 1;
-            q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
-            if (async && partialOnly) { q.pendingAsync = true; q.pendingGraph = true; q.report.execution_time_ms = nowMs() - t0; return; }
-            RSQ_HIP(hipStreamSynchronize(ctx.stream));
-            float gms = 0;
-            if (hipEventElapsedTime(&gms, q.gev0, q.gev1) != hipSuccess) { (void)hipGetLastError(); q.graphFailed = true; gms = 0; }
-            q.report.kernel_time_ms = gms;
-            q.report.hbm_gbps = gms > 0 ? (double)q.report.bytes_read / (gms * 1e-3) / 1e9 : 0;
-            checkDeviceError((uint32_t)q.hPinned[words]);
-            if (!partialOnly) {
-                double t1 = nowMs();
-                tableFromPinned(q);
-                runTail(q);
-                q.report.finalize_time_ms = nowMs() - t1;
-            }
-            q.report.execution_time_ms = nowMs() - t0;
-            return;
+        resolveKernelTime(q);                                  // the previous step's events, before they are recorded again
+        q.fusedReady = false;
+        q.flatRun = false;                                     // always the padded kernel: the last workgroup unpads
+        static const bool pollOk = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
+        const bool poll = pollOk && !partialOnly;
+        const uint64_t seq = poll ? ++q.finSeqCounter : 0;
+        q.finSeq = seq;
+        q.finOut = partialOnly ? q.dAgg : q.dFinHost;          // device partial table | host-mapped pinned read-back buffer
+        q.finErr = q.dFinHost + q.pinnedWords;
+        if (!q.gev0) { RSQ_HIP(hipEventCreate(&q.gev0)); RSQ_HIP(hipEventCreate(&q.gev1)); }
+        static const bool extEvents = !(getenv("RSQ_EXT_EVENTS") && atoi(getenv("RSQ_EXT_EVENTS")) == 0);
+        if (extEvents) launchPipelineKernel(q, p, *p.kernel, -1, 0, 0, q.gev0, q.gev1);
+        else {
+            RSQ_HIP(hipEventRecord(q.gev0, ctx.stream));
+            launchPipelineKernel(q, p, *p.kernel, -1);
+            RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
         }
+        q.finOut = nullptr;
+        q.finSeq = 0;
+        q.kernelTimePending = true;
+        q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
+        if (async && partialOnly) { q.pendingAsync = true; q.pendingFused = true; q.report.execution_time_ms = nowMs() - t0; return; }
+        if (poll) {
+            // the finished table is in host memory as soon as the last workgroup's stores have landed: watch the sequence
+            // number instead of waiting for the stream's completion signal (saves the interrupt path, ~8 us per step);
+            // hipStreamQuery now and then notices a failed launch, and a kernel that takes long is waited for properly
+            volatile uint64_t* flag = q.hPinned + q.pinnedWords + 1;
+            const double deadline = nowMs() + 5.0;
+            unsigned spins = 0;
+            while (*flag != seq) {
+                if ((++spins & 1023u) == 0) {
+                    hipError_t e = hipStreamQuery(ctx.stream);
+                    if (e != hipSuccess && e != hipErrorNotReady) RSQ_HIP(e);
+                    if (e == hipSuccess || nowMs() > deadline) { RSQ_HIP(hipStreamSynchronize(ctx.stream)); break; }
+                }
+                __builtin_ia32_pause();
+            }
+            if (*flag != seq) failRuntime("internal error: the fused step finished without publishing its table");
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        q.fusedReady = true;
+        checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
+        if (!partialOnly) {
+            double t1 = nowMs();
+            memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
+            runTail(q);
+            q.report.finalize_time_ms = nowMs() - t1;
+        }
+        q.report.execution_time_ms = nowMs() - t0;
+        return;
     }
     if (denseMode(q)) enqueueTableInit(q);
+    ctx.errWordClean = false;      // until this execution has read the word back as 0
     RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
     bool anyCompaction = false;
     for (auto& p : q.pipelines) anyCompaction |= p.compact;
@@ -718,7 +761,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     if (async && partialOnly) {
         // everything is enqueued; the caller orders its own work (the group-by merge collective) behind it on the same
         // stream and finalizeQuery() does the one host synchronisation of the step
-        q.pendingAsync = true; q.pendingGraph = false;
+        q.pendingAsync = true; q.pendingFused = false;
         q.report.execution_time_ms = nowMs() - t0;
         return;
     }
@@ -731,6 +774,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
     q.report.kernel_time_ms = ms;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
+    ctx.errWordClean = (uint32_t)q.hPinned[words] == 0;
     checkDeviceError((uint32_t)q.hPinned[words]);
     if (!partialOnly) {
         double t1 = nowMs();
@@ -813,15 +857,76 @@ void finalizeQuery(Query& q) {
     if (q.pendingAsync) {         // the step was enqueued by rsq_query_execute_partial_async: account for it now
         q.pendingAsync = false;
         float ms = 0;
-        if (q.pendingGraph) RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1));
+        if (q.pendingFused) { RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.fusedReady = true; q.kernelTimePending = false; }
         else RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
         q.report.kernel_time_ms = ms;
         q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
+        if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;
         checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
     }
     memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
     runTail(q);
     q.report.finalize_time_ms = nowMs() - t1;
+}
+
+// a rank of a multi-GPU step that does not finalise (only the root reads the merged table back): wait for its enqueued
+// step, account for the kernel time, check its device error word
+void settleAsync(Query& q) {
+    Context& ctx = q.ctx;
+    if (!q.pendingAsync) return;
+    RSQ_HIP(hipSetDevice(ctx.device));
+    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    q.pendingAsync = false;
+    float ms = 0;
+    if (q.pendingFused) { RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.fusedReady = true; q.kernelTimePending = false; }
+    else RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+    q.report.kernel_time_ms = ms;
+    q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
+    if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;
+    checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
+}
+
+// Results of the same plan over disjoint shards (every group lives in exactly one shard: the caller shards on the group key)
+// become one result in `into`: the rows of all parts in part order, then the root's ORDER BY (multi-key, typed compare as
+// the reference's Quicksorter, types.h:264-353; ties keep part order) and its LIMIT (orderby.h:87-93; materialize.h:197-206).
+void mergeShardResults(Query& into, const std::vector<Query*>& parts) {
+    const Schema& sch = into.resultSchema;
+    const size_t ts = (size_t)schemaTupleSize(sch);
+    std::vector<uint8_t> all;
+    int64_t rows = 0;
+    for (Query* p : parts) {
+        if ((size_t)schemaTupleSize(p->resultSchema) != ts) failInvalid("shard results have different schemas");
+        all.insert(all.end(), p->resultTuples.begin(), p->resultTuples.begin() + (size_t)p->resultRows * ts);
+        rows += p->resultRows;
+    }
+    OpNode* root = into.root;
+    if (root && root->tag == RSQ_OP_ORDERBY) {
+        std::vector<OrderRequest> reqs;
+        for (Expr* e : root->exprs) {
+            const std::string& nm = e->child->symbol;
+            bool found = false;
+            for (auto& a : sch) if (a.name == nm) { reqs.push_back({schemaOffset(sch, nm), a.type, e->tag != RSQ_E_DESC}); found = true; break; }
+            if (!found) failType("Order By attribute not found.");
+        }
+        std::vector<int64_t> idx((size_t)rows);
+        for (int64_t i = 0; i < rows; i++) idx[(size_t)i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
+            const uint8_t* l = all.data() + (size_t)a * ts; const uint8_t* r = all.data() + (size_t)b * ts;
+            for (const auto& o : reqs) {
+                int c = compareTyped(o.type, l + o.offset, r + o.offset);
+                if (c) return o.asc ? c < 0 : c > 0;
+            }
+            return false;
+        });
+        if (root->hasLimit && rows > root->limit) rows = std::max<int64_t>(root->limit, 0);
+        into.resultTuples.resize((size_t)rows * ts);
+        for (int64_t i = 0; i < rows; i++) memcpy(&into.resultTuples[(size_t)i * ts], all.data() + (size_t)idx[(size_t)i] * ts, ts);
+    } else {
+        if (root && root->hasLimit) rows = std::min<int64_t>(rows, std::max<int64_t>(root->limit, 1));
+        all.resize((size_t)rows * ts);
+        into.resultTuples.swap(all);
+    }
+    into.resultRows = rows;
 }
 
 void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords) {
@@ -880,7 +985,22 @@ void queryResult(Query& q, rsq_result_view* out) {
     out->tuples = q.resultTuples.data();
 }
 
-void queryReport(const Query& q, rsq_report* out) { *out = q.report; }
+void queryReport(const Query& q, rsq_report* out) {
+    resolveKernelTime(const_cast<Query&>(q));
+    *out = q.report;
+}
+bool queryIsDense(const Query& q) { return denseMode(q); }
+void queryDenseLayout(const Query& q, int64_t* nMin, int64_t* nMax, int64_t* nSum, void** dptr) {
+    if (!denseMode(q)) failUnsupported("partial tables exist for dense aggregations only");
+    *dptr = q.dAgg;
+    *nMin = q.nMinBlocks * q.denseGroups; *nMax = q.nMaxBlocks * q.denseGroups; *nSum = q.nSumBlocks * q.denseGroups;
+}
+std::string queryPartialLayoutText(const Query& q) {
+    size_t at = q.explainText.find("partial table:");
+    if (at == std::string::npos) return "";
+    size_t end = q.explainText.find('\n', at);
+    return q.explainText.substr(at, end == std::string::npos ? std::string::npos : end - at);
+}
 const char* querySource(const Query& q) { return q.allSource.c_str(); }
 const char* queryExplain(const Query& q) { return q.explainText.c_str(); }
 void destroyQuery(Query* q) { delete q; }

@@ -73,6 +73,7 @@ struct Context {
     uint32_t* dErr = nullptr;                  // device error word
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int jitCompiles = 0, jitCacheHits = 0;
+    bool errWordClean = false;                 // *dErr is known to be 0 (fused steps reset it themselves and rely on that)
 
     explicit Context(const rsq_config& c);
     ~Context();
@@ -88,7 +89,9 @@ struct Context {
 };
 
 // launch helper: kernel takes one struct of 8-byte slots by value
-void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::vector<uint64_t>& args);
+// start / stop (optional): events that take the kernel's own begin and end (hipExtModuleLaunchKernel)
+void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::vector<uint64_t>& args, hipEvent_t start = nullptr,
+            hipEvent_t stop = nullptr);
 
 // AOT kernels (aot_kernels.hip)
 void computeColumnStats(Context& ctx, Table& t);
@@ -126,6 +129,12 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
 void executeQuery(Query& q, bool partialOnly, bool async = false);
 void finalizeQuery(Query& q);
 void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords);
+void settleAsync(Query& q);
+void resolveKernelTime(Query& q);
+void mergeShardResults(Query& into, const std::vector<Query*>& parts);
+bool queryIsDense(const Query& q);              // its aggregation ends in a dense partial table ([min | max | sum] words)
+void queryDenseLayout(const Query& q, int64_t* nMin, int64_t* nMax, int64_t* nSum, void** dptr);
+std::string queryPartialLayoutText(const Query& q);   // the "partial table: ..." line of explain (same on every mergeable shard)
 void bindPartial(Query& q, void* dptr, size_t bytes);
 void mergeGathered(Query& q, const void* gathered, int nRanks);
 void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum);

@@ -156,7 +156,6 @@ struct Query {
     uint64_t* dAggWorkInit = nullptr;
     size_t padWords = 0;                   // cells * aggPad
     bool flatRun = false;                  // this execution is partial: kernels flush straight into dAgg
-    bool errInTable = false;               // graph path: the error word is the word behind the padded table (one init copy, one read-back)
     size_t tableWords = 0;                 // accumulators * dense groups (the [block][group] table)
     bool dAggOwned = true;
     uint64_t* dAgg = nullptr;              // dense modes: [blocks][denseGroups]
@@ -225,13 +224,19 @@ struct Query {
     std::vector<int32_t> rvOffsets;
 
     rsq_report report{};
-    // single-pipeline dense aggregations replay one captured HIP graph per execution (init copy, error word reset,
-    // kernel between two event records, read-back): one submission instead of six
-    hipGraphExec_t graphExec = nullptr;
-    hipEvent_t gev0 = nullptr, gev1 = nullptr;   // recorded only inside the graph, around the kernel
-    void* graphAggPtr = nullptr;
-    bool graphPartial = false, graphFailed = false;
-    bool pendingGraph = false;             // ... and it was a graph replay (its kernel time is between gev0 and gev1)
+    // a single register-mode pipeline carries the whole step in its one launch (engine.cpp, the fused step): the last
+    // workgroup writes the finished table to finOut (host-mapped pinned memory, or the device partial table of a multi-GPU
+    // step) and the error word to finErr, and resets the working table and the ticket
+    uint32_t* dFinTicket = nullptr;
+    uint64_t* dFinHost = nullptr;          // device-side address of hPinned
+    uint64_t* finOut = nullptr;            // set around the launch; null: the kernel skips the hand-over
+    uint64_t* finErr = nullptr;
+    bool fusedReady = false;               // working table, ticket and error word are at their identities
+    uint64_t finSeq = 0;                   // > 0 around a launch the host polls for: the number the last workgroup writes behind the error word
+    uint64_t finSeqCounter = 0;
+    bool kernelTimePending = false;        // the fused step's events have not been read yet (resolveKernelTime)
+    hipEvent_t gev0 = nullptr, gev1 = nullptr;   // start / stop of the fused step's kernel (hipExtModuleLaunchKernel)
+    bool pendingFused = false;             // the enqueued asynchronous step was a fused one
     bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
     std::string allSource, explainText;
 

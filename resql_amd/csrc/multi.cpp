@@ -1,0 +1,338 @@
+// multi.cpp — one host process, N GPUs: the rsq_multi_* part of include/resql_hip.h.
+//
+// The reference's execute() fans one compiled function out to config.numThreads worker threads that pull morsels from a
+// shared iterator, and joins them (reference src/JitContextFlounder.h:459-487); its aggregation state is one hash table
+// all workers reach.  Across GPUs the morsels are row-range shards resident in each GPU's HBM, every GPU runs the same
+// compiled pipelines to a partial aggregate table, and the one exchange step is the group-by merge of those tables:
+// an RCCL reduce over xGMI to the root GPU — ncclReduce per [min | max | sum] segment, grouped into one launch per GPU —
+// issued from this process through communicators made by ncclCommInitAll.  librccl is loaded with dlopen when the first
+// multi-GPU handle is created, so that hosts with one GPU (and machines without RCCL) never need it.
+//
+// A second merge path moves the partial tables with peer copies into the root GPU and reduces them with the engine's own
+// merge kernel (no RCCL): chosen with rsq_multi_config.merge = RSQ_MERGE_PEER_COPY, and the only one possible when a device
+// ordinal is listed twice — which is how a box with ONE GPU exercises N-shard execution end to end (tests).
+//
+// Plans that do not end in a dense partial table (joins with many groups, hash aggregation, plain materialisation) run
+// whole on every shard in parallel host threads; the shards must then be disjoint in the group key (the caller shards the
+// probe-side table on a key boundary and replicates the build sides), and the merge is a host-side ordered
+// merge of the (LIMIT-ed) result rows.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <set>
+#include <thread>
+
+#include "engine.h"
+
+using namespace rsq;
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi& rccl() {
+    static RcclApi api;
+    if (api.handle) return api;
+    // a process that already has an RCCL (PyTorch brings its own) keeps using that one: same SONAME, same handle
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) throw Error(RSQ_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) throw Error(RSQ_ERR_DEVICE, std::string("librccl lacks ") + n); return p; };
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.Reduce = (decltype(api.Reduce))sym("ncclReduce");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.handle = h;
+    return api;
+}
+
+#define RSQ_NCCL(call)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t _r = (call);                                                                               \
+        if (_r != ncclSuccess) throw Error(RSQ_ERR_DEVICE, std::string(#call) + ": " + rccl().GetErrorString(_r)); \
+    } while (0)
+
+thread_local std::string g_multiCreateError;
+
+}  // namespace
+
+struct rsq_multi {
+    std::vector<Context*> ctxs;
+    std::vector<int> devices;
+    bool sharedDevice = false;          // a device ordinal is listed more than once (tests on one GPU)
+    int merge = RSQ_MERGE_RCCL;
+    std::vector<ncclComm_t> comms;      // RCCL mode, one per device
+    std::string lastError;
+    ~rsq_multi() {
+        for (ncclComm_t c : comms) if (c) (void)rccl().CommDestroy(c);
+        for (Context* c : ctxs) delete c;
+    }
+};
+
+struct rsq_multi_query {
+    rsq_multi* m = nullptr;
+    std::vector<Query*> qs;             // one compiled query per device, same plan
+    bool dense = false;
+    int64_t nMin = 0, nMax = 0, nSum = 0;
+    int64_t* gathered = nullptr;        // peer-copy mode: [n][words] on the root device
+    std::vector<hipEvent_t> ready;      // peer-copy mode: shard i's partial table is complete
+    rsq_report report{};
+    std::vector<double> shardKernelMs;
+    ~rsq_multi_query() {
+        if (gathered && m && !m->ctxs.empty()) { (void)hipSetDevice(m->ctxs[0]->device); m->ctxs[0]->free(gathered); }
+        for (size_t i = 0; i < ready.size(); i++) if (ready[i]) { (void)hipSetDevice(m->ctxs[i]->device); (void)hipEventDestroy(ready[i]); }
+        for (Query* q : qs) destroyQuery(q);
+    }
+};
+
+namespace {
+
+template <typename F>
+int guardedM(rsq_multi* m, F&& f) {
+    try { f(); return RSQ_OK; }
+    catch (const Error& e) { if (m) m->lastError = e.what(); else g_multiCreateError = e.what(); return e.status; }
+    catch (const std::bad_alloc&) { if (m) m->lastError = "out of host memory"; return RSQ_ERR_NOMEM; }
+    catch (const std::exception& e) { if (m) m->lastError = e.what(); else g_multiCreateError = e.what(); return RSQ_ERR_INVALID; }
+}
+
+// the group-by merge of one step, enqueued behind every shard's kernels; returns after enqueueing
+void enqueueMerge(rsq_multi_query& mq) {
+    rsq_multi& m = *mq.m;
+    const int n = (int)m.ctxs.size();
+    const int64_t words = mq.nMin + mq.nMax + mq.nSum;
+    if (n == 1 && m.comms.empty()) return;          // (a one-GPU handle made with RSQ_MERGE_RCCL still runs its collective)
+    std::vector<int64_t*> part((size_t)n);
+    for (int i = 0; i < n; i++) { int64_t a, b, c; void* p; queryDenseLayout(*mq.qs[(size_t)i], &a, &b, &c, &p); part[(size_t)i] = (int64_t*)p; }
+    if (m.merge == RSQ_MERGE_RCCL) {
+        // one reduce per non-empty segment to the root (device 0, in place), all of them for all GPUs in ONE group:
+        // RCCL launches a single kernel per GPU for the group.  Integer min / max / sum: bit-exact in any order.
+        RcclApi& R = rccl();
+        const int64_t off[3] = {0, mq.nMin, mq.nMin + mq.nMax};
+        const int64_t cnt[3] = {mq.nMin, mq.nMax, mq.nSum};
+        const ncclRedOp_t op[3] = {ncclMin, ncclMax, ncclSum};
+        RSQ_NCCL(R.GroupStart());
+        for (int i = 0; i < n; i++)
+            for (int s = 0; s < 3; s++)
+                if (cnt[s] > 0)
+                    RSQ_NCCL(R.Reduce(part[(size_t)i] + off[s], part[(size_t)i] + off[s], (size_t)cnt[s], ncclInt64, op[s], 0, m.comms[(size_t)i],
+                                      m.ctxs[(size_t)i]->stream));
+        RSQ_NCCL(R.GroupEnd());
+        return;
+    }
+    // peer copies: every shard's table -> root's gather buffer (ordered behind the shard's kernels by an event), then the
+    // engine's merge kernel on the root's stream
+    Context& root = *m.ctxs[0];
+    for (int i = 0; i < n; i++) {
+        Context& c = *m.ctxs[(size_t)i];
+        if (i > 0) {
+            RSQ_HIP(hipSetDevice(c.device));
+            RSQ_HIP(hipEventRecord(mq.ready[(size_t)i], c.stream));
+            RSQ_HIP(hipSetDevice(root.device));
+            RSQ_HIP(hipStreamWaitEvent(root.stream, mq.ready[(size_t)i], 0));
+        }
+        RSQ_HIP(hipSetDevice(root.device));
+        if (c.device == root.device)
+            RSQ_HIP(hipMemcpyAsync(mq.gathered + (size_t)i * (size_t)words, part[(size_t)i], (size_t)words * 8, hipMemcpyDeviceToDevice, root.stream));
+        else
+            RSQ_HIP(hipMemcpyPeerAsync(mq.gathered + (size_t)i * (size_t)words, root.device, part[(size_t)i], c.device, (size_t)words * 8, root.stream));
+    }
+    mergePartialsAsync(root, mq.gathered, n, words, mq.nMin, mq.nMax, mq.nSum, part[0]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsq_multi_create(const rsq_multi_config* cfg, rsq_multi** out) {
+    if (!out || !cfg || cfg->n_devices < 1 || !cfg->devices) return RSQ_ERR_INVALID;
+    *out = nullptr;
+    return guardedM(nullptr, [&] {
+        std::unique_ptr<rsq_multi> m(new rsq_multi());
+        std::set<int> distinct;
+        for (int i = 0; i < cfg->n_devices; i++) {
+            if (cfg->devices[i] < 0) failInvalid("rsq_multi_create needs device ordinals (a compile-only context has no shards to run)");
+            m->devices.push_back(cfg->devices[i]);
+            distinct.insert(cfg->devices[i]);
+        }
+        m->sharedDevice = (int)distinct.size() != cfg->n_devices;
+        m->merge = cfg->merge == RSQ_MERGE_AUTO ? (m->sharedDevice ? RSQ_MERGE_PEER_COPY : RSQ_MERGE_RCCL) : cfg->merge;
+        if (m->merge != RSQ_MERGE_RCCL && m->merge != RSQ_MERGE_PEER_COPY) failInvalid("unknown merge mode");
+        if (m->merge == RSQ_MERGE_RCCL && m->sharedDevice)
+            failInvalid("an RCCL communicator cannot hold the same device twice: use RSQ_MERGE_PEER_COPY for shards that share a GPU");
+        for (int i = 0; i < cfg->n_devices; i++) {
+            rsq_config c = cfg->base;
+            c.device = cfg->devices[i];
+            m->ctxs.push_back(new Context(c));
+        }
+        if (m->merge == RSQ_MERGE_PEER_COPY && !m->sharedDevice)
+            for (int i = 1; i < cfg->n_devices; i++) {
+                int can = 0;
+                RSQ_HIP(hipDeviceCanAccessPeer(&can, m->devices[0], m->devices[(size_t)i]));
+                if (can) { RSQ_HIP(hipSetDevice(m->devices[0])); hipError_t e = hipDeviceEnablePeerAccess(m->devices[(size_t)i], 0); if (e != hipSuccess) (void)hipGetLastError(); }
+            }
+        if (m->merge == RSQ_MERGE_RCCL && (cfg->n_devices > 1 || cfg->merge == RSQ_MERGE_RCCL)) {
+            m->comms.assign((size_t)cfg->n_devices, nullptr);
+            RSQ_NCCL(rccl().CommInitAll(m->comms.data(), cfg->n_devices, m->devices.data()));
+        }
+        *out = m.release();
+    });
+}
+
+void rsq_multi_destroy(rsq_multi* m) { delete m; }
+
+const char* rsq_multi_last_error(const rsq_multi* m) { return m ? m->lastError.c_str() : g_multiCreateError.c_str(); }
+
+int32_t rsq_multi_devices(const rsq_multi* m) { return m ? (int32_t)m->ctxs.size() : 0; }
+
+rsq_ctx* rsq_multi_ctx(rsq_multi* m, int32_t shard) {
+    if (!m || shard < 0 || shard >= (int32_t)m->ctxs.size()) return nullptr;
+    return reinterpret_cast<rsq_ctx*>(m->ctxs[(size_t)shard]);
+}
+
+const char* rsq_multi_merge_name(const rsq_multi* m) {
+    if (!m) return "";
+    if (m->ctxs.size() == 1) return "single GPU (no exchange)";
+    return m->merge == RSQ_MERGE_RCCL ? "RCCL reduce to the root GPU, one grouped launch (min | max | sum segments)"
+                                      : "peer copies to the root GPU + merge kernel";
+}
+
+void rsq_multi_shard_rows(int64_t n_total, int32_t n_shards, int32_t shard, int64_t* row0, int64_t* n_rows) {
+    // equal shards on 128-row tile boundaries (the scan's vector loads want 16-byte aligned column offsets); the last
+    // shard takes the remainder — resql_amd/dist.py shard_rows, same numbers
+    const int64_t tile = 128;
+    const int64_t per = n_shards > 0 ? (n_total / (tile * n_shards)) * tile : 0;
+    if (row0) *row0 = (int64_t)shard * per;
+    if (n_rows) *n_rows = shard < n_shards - 1 ? per : n_total - per * (n_shards - 1);
+}
+
+int rsq_multi_table_generate(rsq_multi* m, int32_t kind, int64_t n_rows_total, double scale_factor, int64_t param, uint64_t seed,
+                             rsq_table** out_tables) {
+    if (!m || !out_tables || n_rows_total < 0) return RSQ_ERR_INVALID;
+    const int n = (int)m->ctxs.size();
+    for (int i = 0; i < n; i++) out_tables[i] = nullptr;
+    return guardedM(m, [&] {
+        for (int i = 0; i < n; i++) {
+            int64_t r0, nr;
+            rsq_multi_shard_rows(n_rows_total, n, i, &r0, &nr);
+            std::unique_ptr<Table> t(new Table());
+            generateTable(*m->ctxs[(size_t)i], *t, kind, r0, nr, scale_factor, param, seed);
+            out_tables[i] = reinterpret_cast<rsq_table*>(t.release());
+        }
+    });
+}
+
+int rsq_multi_query_compile(rsq_multi* m, const rsq_plan_desc* plan, rsq_table* const* tables, int32_t n_tables, rsq_multi_query** out) {
+    if (!m || !plan || !out || n_tables < 0 || (n_tables > 0 && !tables)) return RSQ_ERR_INVALID;
+    *out = nullptr;
+    return guardedM(m, [&] {
+        const int n = (int)m->ctxs.size();
+        std::unique_ptr<rsq_multi_query> mq(new rsq_multi_query());
+        mq->m = m;
+        for (int i = 0; i < n; i++) {
+            for (int t = 0; t < n_tables; t++) {
+                const Table* tb = reinterpret_cast<const Table*>(tables[(size_t)i * (size_t)n_tables + (size_t)t]);
+                if (!tb) failInvalid("null table");
+                if (tb->ctx != m->ctxs[(size_t)i]) failInvalid("table " + tb->name + " of shard " + std::to_string(i) + " does not live on that shard's context");
+            }
+            mq->qs.push_back(compileQuery(*m->ctxs[(size_t)i], *plan, tables + (size_t)i * (size_t)n_tables, n_tables));
+        }
+        mq->dense = queryIsDense(*mq->qs[0]);
+        if (mq->dense) {
+            // mergeable only if every shard derived the same dense group layout from its column statistics
+            const std::string l0 = queryPartialLayoutText(*mq->qs[0]);
+            for (int i = 1; i < n; i++)
+                if (!queryIsDense(*mq->qs[(size_t)i]) || queryPartialLayoutText(*mq->qs[(size_t)i]) != l0)
+                    failUnsupported("shards disagree on the partial aggregate table layout: shard 0 has \"" + l0 + "\", shard " + std::to_string(i) +
+                                    " has \"" + queryPartialLayoutText(*mq->qs[(size_t)i]) + "\"");
+            void* p;
+            queryDenseLayout(*mq->qs[0], &mq->nMin, &mq->nMax, &mq->nSum, &p);
+            if (n > 1 && m->merge == RSQ_MERGE_PEER_COPY) {
+                Context& root = *m->ctxs[0];
+                mq->gathered = (int64_t*)root.alloc((size_t)n * (size_t)(mq->nMin + mq->nMax + mq->nSum) * 8);
+                mq->ready.assign((size_t)n, nullptr);
+                for (int i = 1; i < n; i++) { RSQ_HIP(hipSetDevice(m->ctxs[(size_t)i]->device)); RSQ_HIP(hipEventCreateWithFlags(&mq->ready[(size_t)i], hipEventDisableTiming)); }
+            }
+        } else {
+            for (int i = 1; i < n; i++) if (queryIsDense(*mq->qs[(size_t)i])) failUnsupported("shards disagree on the aggregation strategy");
+        }
+        mq->shardKernelMs.assign((size_t)n, 0.0);
+        *out = mq.release();
+    });
+}
+
+int rsq_multi_query_execute(rsq_multi_query* mq) {
+    if (!mq) return RSQ_ERR_INVALID;
+    rsq_multi* m = mq->m;
+    return guardedM(m, [&] {
+        const int n = (int)m->ctxs.size();
+        const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        if (mq->dense) {
+            // fan out: enqueue every shard's pipelines (no host synchronisation), then the merge behind them, then ONE
+            // synchronising read-back on the root
+            for (int i = 0; i < n; i++) executeQuery(*mq->qs[(size_t)i], true, true);
+            enqueueMerge(*mq);
+            finalizeQuery(*mq->qs[0]);
+            for (int i = 1; i < n; i++) settleAsync(*mq->qs[(size_t)i]);
+        } else {
+            std::vector<std::string> errs((size_t)n);
+            std::vector<int> status((size_t)n, RSQ_OK);
+            std::vector<std::thread> th;
+            for (int i = 0; i < n; i++)
+                th.emplace_back([&, i] {
+                    try { executeQuery(*mq->qs[(size_t)i], false); }
+                    catch (const Error& e) { status[(size_t)i] = e.status; errs[(size_t)i] = e.what(); }
+                    catch (const std::exception& e) { status[(size_t)i] = RSQ_ERR_RUNTIME; errs[(size_t)i] = e.what(); }
+                });
+            for (auto& t : th) t.join();
+            for (int i = 0; i < n; i++) if (status[(size_t)i] != RSQ_OK) throw Error(status[(size_t)i], "shard " + std::to_string(i) + ": " + errs[(size_t)i]);
+            double t1 = now();
+            if (n > 1) mergeShardResults(*mq->qs[0], mq->qs);
+            mq->report.finalize_time_ms = now() - t1;
+        }
+        // report: the slowest shard's kernel time (the shards run concurrently), bytes of all shards
+        rsq_report r0; queryReport(*mq->qs[0], &r0);
+        rsq_report rep = r0;
+        rep.bytes_read = 0; rep.num_kernels = 0; rep.kernel_time_ms = 0;
+        for (int i = 0; i < n; i++) {
+            rsq_report r; queryReport(*mq->qs[(size_t)i], &r);
+            rep.bytes_read += r.bytes_read; rep.num_kernels += r.num_kernels;
+            rep.kernel_time_ms = std::max(rep.kernel_time_ms, r.kernel_time_ms);
+            rep.compilation_time_ms = std::max(rep.compilation_time_ms, r.compilation_time_ms);
+            mq->shardKernelMs[(size_t)i] = r.kernel_time_ms;
+        }
+        if (!mq->dense && n > 1) rep.finalize_time_ms = r0.finalize_time_ms + mq->report.finalize_time_ms;
+        rep.execution_time_ms = now() - t0;
+        rep.hbm_gbps = rep.kernel_time_ms > 0 ? (double)rep.bytes_read / (rep.kernel_time_ms * 1e-3) / 1e9 : 0;
+        mq->report = rep;
+    });
+}
+
+int rsq_multi_query_result(rsq_multi_query* mq, rsq_result_view* out) {
+    if (!mq || !out) return RSQ_ERR_INVALID;
+    return guardedM(mq->m, [&] { queryResult(*mq->qs[0], out); });
+}
+
+int rsq_multi_query_report(const rsq_multi_query* mq, rsq_report* out, double* shard_kernel_ms) {
+    if (!mq || !out) return RSQ_ERR_INVALID;
+    *out = mq->report;
+    if (shard_kernel_ms) for (size_t i = 0; i < mq->shardKernelMs.size(); i++) shard_kernel_ms[i] = mq->shardKernelMs[i];
+    return RSQ_OK;
+}
+
+void rsq_multi_query_destroy(rsq_multi_query* mq) { delete mq; }
+
+}  // extern "C"

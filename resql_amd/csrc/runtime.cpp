@@ -7,6 +7,7 @@
 #include "engine.h"
 
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -184,11 +185,17 @@ Kernel& Context::getKernel(const std::string& source, const std::string& entry) 
     return kernels.emplace(key, k).first->second;
 }
 
-void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::vector<uint64_t>& args) {
+void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::vector<uint64_t>& args, hipEvent_t start, hipEvent_t stop) {
     if (!k.fn) throw Error(RSQ_ERR_DEVICE, "kernel not loaded (context without device)");
     size_t size = args.size() * sizeof(uint64_t);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, (void*)args.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &size,
                       HIP_LAUNCH_PARAM_END};
+    if (start || stop) {
+        // the events take the timestamps of this dispatch itself: no marker packets around the kernel
+        // (the extended launch counts the GLOBAL size in work-items, not workgroups)
+        RSQ_HIP(hipExtModuleLaunchKernel(k.fn, grid * block, 1, 1, block, 1, 1, 0, ctx.stream, nullptr, config, start, stop, 0));
+        return;
+    }
     RSQ_HIP(hipModuleLaunchKernel(k.fn, grid, 1, 1, block, 1, 1, 0, ctx.stream, nullptr, config));
 }
 

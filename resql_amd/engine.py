@@ -34,6 +34,13 @@ class rsq_report(C.Structure):
                 ("jit_cache_hits", C.c_int32), ("jit_compiles", C.c_int32)]
 
 
+class rsq_multi_config(C.Structure):
+    _fields_ = [("base", rsq_config), ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_int32), ("merge", C.c_int32)]
+
+
+MERGE_AUTO, MERGE_RCCL, MERGE_PEER_COPY = 0, 1, 2
+
+
 class EngineError(RuntimeError):
     def __init__(self, status: int, message: str):
         super().__init__(f"[{STATUS.get(status, status)}] {message}")
@@ -113,6 +120,24 @@ def lib():
         L.rsq_db_adopt_table.argtypes = [vp, vp]
         L.rsq_db_report.argtypes = [vp, C.POINTER(rsq_report)]
         L.rsq_db_destroy.argtypes = [vp]
+        L.rsq_multi_create.argtypes = [C.POINTER(rsq_multi_config), C.POINTER(vp)]
+        L.rsq_multi_destroy.argtypes = [vp]
+        L.rsq_multi_last_error.restype = C.c_char_p
+        L.rsq_multi_last_error.argtypes = [vp]
+        L.rsq_multi_devices.restype = i32
+        L.rsq_multi_devices.argtypes = [vp]
+        L.rsq_multi_ctx.restype = vp
+        L.rsq_multi_ctx.argtypes = [vp, i32]
+        L.rsq_multi_merge_name.restype = C.c_char_p
+        L.rsq_multi_merge_name.argtypes = [vp]
+        L.rsq_multi_shard_rows.restype = None
+        L.rsq_multi_shard_rows.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+        L.rsq_multi_table_generate.argtypes = [vp, i32, i64, C.c_double, i64, C.c_uint64, C.POINTER(vp)]
+        L.rsq_multi_query_compile.argtypes = [vp, C.POINTER(P.rsq_plan_desc), C.POINTER(vp), i32, C.POINTER(vp)]
+        L.rsq_multi_query_execute.argtypes = [vp]
+        L.rsq_multi_query_result.argtypes = [vp, C.POINTER(P.rsq_result_view)]
+        L.rsq_multi_query_report.argtypes = [vp, C.POINTER(rsq_report), C.POINTER(C.c_double)]
+        L.rsq_multi_query_destroy.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -127,6 +152,9 @@ EXPORTED_SYMBOLS = [
     "rsq_measure_read_bandwidth",
     "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
     "rsq_db_create", "rsq_db_execute", "rsq_db_adopt_table", "rsq_db_report", "rsq_db_destroy",
+    "rsq_multi_create", "rsq_multi_destroy", "rsq_multi_last_error", "rsq_multi_devices", "rsq_multi_ctx", "rsq_multi_merge_name",
+    "rsq_multi_shard_rows", "rsq_multi_table_generate", "rsq_multi_query_compile", "rsq_multi_query_execute",
+    "rsq_multi_query_result", "rsq_multi_query_report", "rsq_multi_query_destroy",
 ]
 
 GEN_LINEITEM, GEN_ORDERS, GEN_CUSTOMER, GEN_SYNTHETIC = 0, 1, 2, 3
@@ -134,6 +162,17 @@ GEN_LINEITEM, GEN_ORDERS, GEN_CUSTOMER, GEN_SYNTHETIC = 0, 1, 2, 3
 
 class Context:
     """one engine context per GPU (device=-1: compile-only, no GPU needed)"""
+
+    @classmethod
+    def borrowed(cls, handle, device: int) -> "Context":
+        """a context owned by someone else (a MultiContext's shard): close() does not destroy it"""
+        self = cls.__new__(cls)
+        self._L = lib()
+        self._cache = None
+        self.h = C.c_void_p(handle)
+        self.device = device
+        self._borrowed = True
+        return self
 
     def __init__(self, device: int = 0, cache_dir: Optional[str] = None, print_source: bool = False):
         self._L = lib()
@@ -157,7 +196,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self._L.rsq_ctx_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self._L.rsq_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -411,4 +451,84 @@ class Database:
     def close(self):
         if getattr(self, "h", None):
             self.ctx._L.rsq_db_destroy(self.h)
+            self.h = None
+
+
+class MultiContext:
+    """one host process, N GPUs (include/resql_hip.h rsq_multi_*): shard contexts + the RCCL (or peer-copy) group-by merge"""
+
+    def __init__(self, devices: Sequence[int], merge: int = MERGE_AUTO, cache_dir: Optional[str] = None):
+        self._L = lib()
+        self._devs = (C.c_int32 * len(devices))(*devices)
+        self._cache = cache_dir.encode() if cache_dir else None
+        cfg = rsq_multi_config(rsq_config(0, 0, 0, 1, 1, 0, 0, self._cache), self._devs, len(devices), merge)
+        h = C.c_void_p()
+        rc = self._L.rsq_multi_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, self._L.rsq_multi_last_error(None).decode())
+        self.h = h
+        self.n = len(devices)
+        self.shards = [Context.borrowed(self._L.rsq_multi_ctx(h, i), devices[i]) for i in range(self.n)]
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(rc, self._L.rsq_multi_last_error(self.h).decode())
+
+    @property
+    def merge_name(self) -> str:
+        return self._L.rsq_multi_merge_name(self.h).decode()
+
+    def shard_rows(self, n_total: int, shard: int):
+        a, b = C.c_int64(), C.c_int64()
+        self._L.rsq_multi_shard_rows(n_total, self.n, shard, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def generate(self, kind: int, n_rows_total: int, sf: float, param: int = 0, seed: int = 20240613) -> List["DeviceTable"]:
+        arr = (C.c_void_p * self.n)()
+        self._check(self._L.rsq_multi_table_generate(self.h, kind, n_rows_total, sf, param, seed, arr))
+        name = ["lineitem", "orders", "customer", "t"][kind]
+        return [DeviceTable(self.shards[i], C.c_void_p(arr[i]), name) for i in range(self.n)]
+
+    def compile(self, plan: P.Plan, tables_per_shard: Sequence[Sequence["DeviceTable"]]) -> "MultiQuery":
+        keep: list = []
+        d = plan.to_c(keep)
+        nt = len(tables_per_shard[0])
+        flat = [t.h for shard in tables_per_shard for t in shard]
+        arr = (C.c_void_p * max(1, len(flat)))(*flat)
+        h = C.c_void_p()
+        self._check(self._L.rsq_multi_query_compile(self.h, C.byref(d), arr, nt, C.byref(h)))
+        return MultiQuery(self, h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            for s in self.shards:
+                s.close()
+            self._L.rsq_multi_destroy(self.h)
+            self.h = None
+
+
+class MultiQuery:
+    def __init__(self, m: MultiContext, h):
+        self.m, self.h = m, h
+
+    def execute(self):
+        self.m._check(self.m._L.rsq_multi_query_execute(self.h))
+
+    def result(self) -> P.Result:
+        v = P.rsq_result_view()
+        self.m._check(self.m._L.rsq_multi_query_result(self.h, C.byref(v)))
+        res = P.Result.from_view(v)
+        res.text = res.serialize()
+        return res
+
+    def report(self):
+        """(rsq_report, [kernel ms of every shard])"""
+        r = rsq_report()
+        k = (C.c_double * self.m.n)()
+        self.m._check(self.m._L.rsq_multi_query_report(self.h, C.byref(r), k))
+        return r, list(k)
+
+    def close(self):
+        if self.h:
+            self.m._L.rsq_multi_query_destroy(self.h)
             self.h = None
