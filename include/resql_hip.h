@@ -198,12 +198,22 @@ char* rsq_sql_describe(rsq_ctx* ctx, const char* sql, int32_t what);
  * (executeBulkInsert, execute.h:332-388: "Table x does not exist.", field terminator = first character of
  * `fieldterminator`, default ','), and runs SELECT statements through rsq_sql_compile + rsq_query_execute.
  * rsq_db_execute: `result` may be NULL; for a SELECT it receives a view of the result relation that stays valid until the
- * next statement on the same handle.  *kind receives 1 SELECT, 2 CREATE TABLE, 3 BULK INSERT (may be NULL).
+ * next statement on the same handle.  *kind receives 1 SELECT, 2 CREATE TABLE, 3 BULK INSERT, 4 CONTROL (may be NULL).
+ * A second BULK INSERT into a table appends, as the reference's does.
  * rsq_db_adopt_table hands an existing table (rsq_table_create / _generate / ...) to the database, which then owns it.
  * Destroy a database before the context it was created on (its tables live in that context's device memory). */
 typedef struct rsq_db rsq_db;
 int  rsq_db_create(rsq_ctx* ctx, rsq_db** out);
 int  rsq_db_execute(rsq_db* db, const char* sql, int32_t* kind, rsq_result_view* result);
+/* Control statements (processControl, execute.h:454-474; *kind receives 4): `name=value` or the bare name (prints the value)
+ * for showplan, tofile, threads, showperf, showasm, showfln, optimize, emitmc — spaces are ignored and, as in the reference,
+ * the name may stand anywhere in the line — and `tables`.  Effects on later SELECTs: showplan puts the operator tree,
+ * showperf the `compile:` / `execute:` lines of showReport (JitContextFlounder.h:132-150) plus the device figures, showasm the
+ * generated HIP source, showfln the pipeline description into the message; tofile=true writes the result to "qres.tbl"
+ * (serializeRelation format, execute.h:203-210, 243-245); threads / optimize / emitmc are stored and reported only.
+ * rsq_db_message: what the reference's printQueryResult prints for the last statement in front of the relation
+ * (execute.h:173-200): the control statement's answer, "Created table x", "Inserted n tuples", or plan + report. */
+const char* rsq_db_message(const rsq_db* db);
 int  rsq_db_adopt_table(rsq_db* db, rsq_table* table);
 int  rsq_db_report(const rsq_db* db, rsq_report* out);          /* of the last SELECT */
 void rsq_db_destroy(rsq_db* db);

@@ -6,6 +6,9 @@
  *              'bulk insert nation from "nation.tbl" with ( fieldterminator="|" )' \
  *              'select n_name from nation where n_regionkey = 2 order by n_name'
  *
+ * Control statements of the reference's processControl (execute.h:454-474) work as arguments too: 'showperf=true',
+ * 'showplan=true', 'tofile=true', 'threads=4', 'tables', ...
+ *
  * RSQ_DEVICE=-1 in the environment selects a compile-only context (no GPU: statements are parsed, planned and compiled for
  * gfx950, executing a SELECT then fails with RSQ_ERR_DEVICE) — which is how the CPU test suite links and runs this file. */
 #include <stdio.h>
@@ -29,10 +32,14 @@ int main(int argc, char** argv) {
         int st = rsq_db_execute(db, argv[i], &kind, &view);
         if (st != RSQ_OK) { printf("error %d: %s\n", st, rsq_last_error(ctx)); failed++; continue; }
         if (kind == 1) {
+            /* printQueryResult (execute.h:178-183): plan line and report first (empty unless showplan / showperf / ... are set) */
+            const char* msg = rsq_db_message(db);
+            if (msg[0] && strcmp(msg, "\n") != 0) printf("%s", msg);
             char* text = rsq_result_serialize(&view);
             printf("%lld row(s)\n%s", (long long)view.n_rows, text ? text : "");
             rsq_free(text);
-        } else printf("%s ok\n", kind == 2 ? "create table" : "bulk insert");
+        } else if (kind == 4) printf("%s", rsq_db_message(db));            /* control statement: its answer, if any */
+        else printf("%s ok\n", kind == 2 ? "create table" : "bulk insert");
     }
     rsq_db_destroy(db);
     rsq_ctx_destroy(ctx);

@@ -19,17 +19,20 @@ typedef unsigned long long u64;
 // statistics
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) k_minmax(const T* __restrict__ p, i64 n, i64* out /* [min,max] */) {
+__global__ void __launch_bounds__(256) k_minmax(const T* __restrict__ p, i64 n, i64* out /* [min, max, descents] */) {
     i64 mn = 0x7fffffffffffffffll, mx = (i64)0x8000000000000000ull;
+    u64 desc = 0;          // rows smaller than the row before them: 0 = the column is in ascending order
     for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
         i64 v = (i64)p[i];
         mn = v < mn ? v : mn; mx = v > mx ? v : mx;
+        if (i > 0 && v < (i64)p[i - 1]) desc++;
     }
     for (int m = 32; m >= 1; m >>= 1) {
         i64 a = __shfl_xor(mn, m, 64), b = __shfl_xor(mx, m, 64);
         mn = a < mn ? a : mn; mx = b > mx ? b : mx;
+        desc += (u64)__shfl_xor((long long)desc, m, 64);
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); if (desc) atomicAdd(reinterpret_cast<u64*>(&out[2]), desc); }
 }
 
 __global__ void __launch_bounds__(256) k_byteset(const unsigned char* __restrict__ p, i64 n, unsigned* out /* 8 words */) {
@@ -61,13 +64,16 @@ static void hostStats(Table& t) {
             c.stats.valid = true;
         } else if (w == 4 || w == 8) {
             if (c.type.isString()) continue;
-            int64_t mn = INT64_MAX, mx = INT64_MIN;
+            int64_t mn = INT64_MAX, mx = INT64_MIN, prev = INT64_MIN;
+            bool asc = true;
             for (int64_t i = 0; i < t.nRows; i++) {
                 int64_t v = (w == 8) ? ((const int64_t*)c.dptr)[i]
                           : (c.type.tag == RSQ_DATE ? (int64_t)((const uint32_t*)c.dptr)[i] : (int64_t)((const int32_t*)c.dptr)[i]);
                 mn = std::min(mn, v); mx = std::max(mx, v);
+                if (v < prev) asc = false;
+                prev = v;
             }
-            c.stats.min = mn; c.stats.max = mx; c.stats.valid = true;
+            c.stats.min = mn; c.stats.max = mx; c.stats.valid = true; c.stats.ascending = asc;
         }
     }
 }
@@ -76,7 +82,7 @@ void computeColumnStats(Context& ctx, Table& t) {
     if (ctx.device < 0) { hostStats(t); return; }
     if (t.nRows == 0) return;
     RSQ_HIP(hipSetDevice(ctx.device));
-    i64* dmm = (i64*)ctx.alloc(2 * sizeof(i64));
+    i64* dmm = (i64*)ctx.alloc(3 * sizeof(i64));
     unsigned* dset = (unsigned*)ctx.alloc(8 * sizeof(unsigned));
     const unsigned grid = 1024;
     for (auto& c : t.cols) {
@@ -90,15 +96,15 @@ void computeColumnStats(Context& ctx, Table& t) {
             for (int v = 0; v < 256; v++) if (h[v >> 5] & (1u << (v & 31))) c.stats.distinctBytes.push_back((uint8_t)v);
             if (!c.stats.distinctBytes.empty()) { c.stats.min = c.stats.distinctBytes.front(); c.stats.max = c.stats.distinctBytes.back(); c.stats.valid = true; }
         } else if (!c.type.isString()) {
-            i64 init[2] = {0x7fffffffffffffffll, (i64)0x8000000000000000ull};
-            RSQ_HIP(hipMemcpyAsync(dmm, init, 16, hipMemcpyHostToDevice, ctx.stream));
+            i64 init[3] = {0x7fffffffffffffffll, (i64)0x8000000000000000ull, 0};
+            RSQ_HIP(hipMemcpyAsync(dmm, init, 24, hipMemcpyHostToDevice, ctx.stream));
             if (c.type.tag == RSQ_INT) hipLaunchKernelGGL(k_minmax<int>, dim3(grid), dim3(256), 0, ctx.stream, (const int*)c.dptr, (i64)t.nRows, dmm);
             else if (c.type.tag == RSQ_DATE) hipLaunchKernelGGL(k_minmax<unsigned>, dim3(grid), dim3(256), 0, ctx.stream, (const unsigned*)c.dptr, (i64)t.nRows, dmm);
             else hipLaunchKernelGGL(k_minmax<i64>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)c.dptr, (i64)t.nRows, dmm);
-            i64 h[2];
-            RSQ_HIP(hipMemcpyAsync(h, dmm, 16, hipMemcpyDeviceToHost, ctx.stream));
+            i64 h[3];
+            RSQ_HIP(hipMemcpyAsync(h, dmm, 24, hipMemcpyDeviceToHost, ctx.stream));
             RSQ_HIP(hipStreamSynchronize(ctx.stream));
-            c.stats.min = h[0]; c.stats.max = h[1]; c.stats.valid = true;
+            c.stats.min = h[0]; c.stats.max = h[1]; c.stats.valid = true; c.stats.ascending = h[2] == 0;
         }
     }
     ctx.free(dmm); ctx.free(dset);
@@ -334,7 +340,7 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value) {
 template <int COMPACT_PER_THREAD>
 __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__ first, i64 cap, const i64* __restrict__ words, int nWords,
                                                          int wordsAos, const i64* __restrict__ acc, int nAcc, i64* __restrict__ out,
-                                                         unsigned maxRows, unsigned* count) {
+                                                         unsigned maxRows, unsigned* count, int unmix) {
     const int stride = 1 + nWords + nAcc;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ unsigned s_wave[4];
@@ -378,7 +384,20 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                 i64* o = out + (size_t)pos * stride;
                 o[0] = first[s];
                 // (no word arrays: the one word is the slot index itself — dense aggregate tables, whose slot IS the group id)
-                for (int w = 0; w < nWords; w++) o[1 + w] = !words ? s : wordsAos ? words[(size_t)s * nWords + w] : words[(size_t)w * cap + s];
+                // (rank dictionaries keep the aggregates of entry r at rank_mix(r), kernels/rsq_device.h: the entry of accumulator
+                // slot s is the inverse — the same steps backwards, with the multipliers' inverses modulo 2^64)
+                i64 e = s;
+                if (unmix) {
+                    const u64 mask = (u64)cap - 1;
+                    const int k = 63 - __builtin_clzll((u64)cap), h = (k + 1) >> 1;
+                    u64 x = (u64)s;
+                    x ^= x >> h;
+                    x = (x * 0x96DE1B173F119089ull) & mask;          // (0xBF58476D1CE4E5B9)^-1 mod 2^64
+                    x ^= x >> h;
+                    x = (x * 0xF1DE83E19937733Dull) & mask;          // (0x9E3779B97F4A7C15)^-1 mod 2^64
+                    e = (i64)x;
+                }
+                for (int w = 0; w < nWords; w++) o[1 + w] = !words ? s : wordsAos ? words[(size_t)e * nWords + w] : words[(size_t)w * cap + e];
                 for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
             }
         }
@@ -387,7 +406,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
 }
 
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
-                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count) {
+                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix) {
     // slots per thread: every chunk costs one reservation atomic on the same word (they serialise), so large tables take
     // large chunks; swept on the box through RSQ_COMPACT_PT for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us
     static const int forced = getenv("RSQ_COMPACT_PT") ? atoi(getenv("RSQ_COMPACT_PT")) : 0;
@@ -395,7 +414,7 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
     const int64_t chunkSlots = 256 * (int64_t)perThread;
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8 * (int64_t)ctx.numCUs, (capacity + chunkSlots - 1) / chunkSlots));
 #define RSQ_LAUNCH_COMPACT(PT) hipLaunchKernelGGL(k_compact_entries<PT>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, \
-                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count)
+                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0)
     if (perThread >= 64) RSQ_LAUNCH_COMPACT(64); else if (perThread >= 32) RSQ_LAUNCH_COMPACT(32); else RSQ_LAUNCH_COMPACT(16);
 #undef RSQ_LAUNCH_COMPACT
     RSQ_HIP(hipGetLastError());
@@ -600,6 +619,109 @@ void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, i
     if (n > 0x7fffffff) throw Error(RSQ_ERR_UNSUPPORTED, "materialisation of more than 2^31 lane slots");
     hipcub::TransformInputIterator<u64, CastU64, const unsigned*> in((const unsigned*)counts, CastU64());
     RSQ_HIP(hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, in, (u64*)offs, (int)n, ctx.stream));
+}
+
+// ------------------------------------------------------------------------------------------------
+// bitmap-rank dictionary (kernels/rsq_device.h rank_of): prefix arrays over a join table's key bitmap, and the placement
+// of the build pipeline's records (appended in arrival order) at the rank of their key.  The bitmap is allocated in whole
+// 256-bit blocks.  Input that is clustered by the key (TPC-H orders by o_orderkey) arrives nearly in rank order, so the
+// placement writes walk the entry array almost sequentially; input in random order is still placed correctly.
+// ------------------------------------------------------------------------------------------------
+#define RANK_CHUNK_BLOCKS 4096          /* = RSQ_RANK_CHUNK_BLOCKS: 256-bit blocks per workgroup */
+__global__ void __launch_bounds__(256) k_rank_blocks(const unsigned* __restrict__ bm, i64 nBlocks, unsigned* __restrict__ blockRank,
+                                                     unsigned* __restrict__ chunkTotal) {
+    __shared__ unsigned s_tot[256];
+    const i64 b0 = (i64)blockIdx.x * RANK_CHUNK_BLOCKS + (i64)threadIdx.x * 16;
+    unsigned c[16];
+    unsigned mine = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        unsigned n = 0;
+        if (b0 + j < nBlocks) {
+            const uint4* w = reinterpret_cast<const uint4*>(bm + (b0 + j) * 8);
+            const uint4 lo = w[0], hi = w[1];
+            n = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+        }
+        c[j] = n; mine += n;
+    }
+    s_tot[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                  // inclusive scan of the thread totals
+        unsigned v = threadIdx.x >= (unsigned)off ? s_tot[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_tot[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = s_tot[threadIdx.x] - mine;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { if (b0 + j < nBlocks) blockRank[b0 + j] = run; run += c[j]; }
+    if (threadIdx.x == 255) chunkTotal[blockIdx.x] = s_tot[255];
+}
+
+__global__ void __launch_bounds__(1024) k_rank_chunks(const unsigned* __restrict__ chunkTotal, int nChunks, unsigned* __restrict__ chunkBase /* [nChunks + 1] */) {
+    __shared__ unsigned s[1024];
+    unsigned carry = 0;
+    for (int base = 0; base < nChunks; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const unsigned v = i < nChunks ? chunkTotal[i] : 0u;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            unsigned t = threadIdx.x >= (unsigned)off ? s[threadIdx.x - off] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nChunks) chunkBase[i] = carry + s[threadIdx.x] - v;
+        carry += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) chunkBase[nChunks] = carry;          // number of distinct keys
+}
+
+__global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp, const unsigned* __restrict__ used, unsigned nWaves, unsigned region,
+                                                    const unsigned* __restrict__ nRecords, int nWords,
+                                                    const unsigned* __restrict__ bm, i64 bmMin, const unsigned* __restrict__ blockRank,
+                                                    const unsigned* __restrict__ chunkBase, int nChunks, i64* __restrict__ words, i64 capacity,
+                                                    unsigned* __restrict__ err) {
+    // as many records as distinct keys, and no more than the table was sized for — anything else means the build side changed
+    // since the sizing pass (two rows with one key, more rows): the host then falls back to the hash table
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (*nRecords != chunkBase[nChunks] || (i64)*nRecords > capacity)) atomicOr(err, 64u);
+    const i64 slots = (i64)nWaves * region;          // the build pipeline's waves own `region` slots each, used[wave] of them filled
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < slots; i += (i64)gridDim.x * blockDim.x) {
+        const unsigned w = (unsigned)(i / region), o = (unsigned)(i % region);
+        if (o >= used[w]) continue;
+        const i64* rec = temp + i * nWords;
+        const u64 d = (u64)(rec[0] - bmMin);
+        const unsigned* blk = bm + ((d >> 8) << 3);
+        const unsigned wi = (unsigned)(d >> 5) & 7u, bit = (unsigned)d & 31u;
+        unsigned r = chunkBase[d >> 20] + blockRank[d >> 8];
+        for (unsigned j = 0; j < 8; j++) {
+            const unsigned x = blk[j];
+            r += j < wi ? __popc(x) : (j == wi ? __popc(x & ((1u << bit) - 1u)) : 0u);
+        }
+        if ((i64)r < capacity) for (int k = 0; k < nWords; k++) words[(i64)r * nWords + k] = rec[k];
+    }
+}
+
+void rankTableIndex(Context& ctx, const uint32_t* bitmap, int64_t nBlocks, uint32_t* blockRank, uint32_t* chunkTotal, uint32_t* chunkBase) {
+    const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
+    hipLaunchKernelGGL(k_rank_blocks, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (const unsigned*)bitmap, (i64)nBlocks, (unsigned*)blockRank, (unsigned*)chunkTotal);
+    hipLaunchKernelGGL(k_rank_chunks, dim3(1), dim3(1024), 0, ctx.stream, (const unsigned*)chunkTotal, nChunks, (unsigned*)chunkBase);
+    RSQ_HIP(hipGetLastError());
+}
+
+void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uint32_t nWaves, uint32_t region, const uint32_t* nRecords, int nWords,
+                    const uint32_t* bitmap, int64_t bmMin, const uint32_t* blockRank, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
+                    int64_t capacity) {
+    const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
+    const int64_t slots = (int64_t)nWaves * region;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8 * (int64_t)ctx.numCUs, (slots + 255) / 256));
+    hipLaunchKernelGGL(k_rank_place, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)temp, (const unsigned*)used, (unsigned)nWaves, (unsigned)region,
+                       (const unsigned*)nRecords, nWords,
+                       (const unsigned*)bitmap, (i64)bmMin, (const unsigned*)blockRank, (const unsigned*)chunkBase, nChunks, (i64*)words, (i64)capacity,
+                       (unsigned*)ctx.dErr);
+    RSQ_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,4 +1,5 @@
 // api.cpp — the extern "C" surface of include/resql_hip.h.  No exception crosses it.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -90,6 +91,7 @@ int rsq_table_create_device(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table*
 int rsq_table_from_rowstore(rsq_ctx* ctx, const rsq_table_desc* schema, const uint8_t* const* blocks,
                             const size_t* content_size, int32_t n_blocks, rsq_table** out) {
     if (!ctx || !schema || !out || n_blocks < 0) return RSQ_ERR_INVALID;
+    if (schema->n_cols <= 0 || (n_blocks > 0 && (!blocks || !content_size))) return RSQ_ERR_INVALID;
     return guarded(C(ctx), [&] {
         // transpose packed ReSQL tuples (strings by value, schema.h:76-106 offsets) into columns on the host,
         // then upload: the bridge is ingest, not the hot path
@@ -321,7 +323,150 @@ struct rsq_db {
     std::map<std::string, Table*> tables;                                          // name order = the planner's table order
     rsq_query* last = nullptr;
     rsq_report lastReport{};
+    // DBConfig / JitConfig as the control variables set them (execute.h:23-27, JitContextFlounder.h:86-109)
+    bool showPlan = false, writeResultsToFile = false;
+    uint16_t numThreads = 1;
+    bool printPerformance = false, printAssembly = false, printFlounder = false, optimizeFlounder = false, emitMachineCode = false;
+    std::string message;          // what the reference's printQueryResult would print in front of the relation (execute.h:173-200)
 };
+
+}  // extern "C"
+
+namespace {
+
+// setBoolVar / setIntVar (execute.h:407-451): spaces are removed from the line, the variable name may stand anywhere in it
+// (rfind), the line is either the bare name (prints the value) or name=value
+bool controlVar(std::string cmd, const std::string& name, std::string& value, bool& bare) {
+    cmd.erase(std::remove(cmd.begin(), cmd.end(), ' '), cmd.end());
+    if (cmd.rfind(name) == std::string::npos) return false;
+    bare = cmd.length() == name.length();
+    if (bare) return true;
+    if (cmd.at(name.length()) != '=') failInvalid("Expected varname=value");
+    value = cmd.substr(name.length() + 1);
+    return true;
+}
+void boolVar(const std::string& line, const char* name, bool& var, bool& done, std::string& out) {
+    std::string v; bool bare = false;
+    if (!controlVar(line, name, v, bare)) return;
+    done = true;
+    if (bare) { out += var ? "true\n" : "false\n"; return; }
+    if (v == "true") var = true;
+    else if (v == "false") var = false;
+    else failInvalid("Expected true or false");
+}
+void intVar(const std::string& line, const char* name, uint16_t& var, bool& done, std::string& out) {
+    std::string v; bool bare = false;
+    if (!controlVar(line, name, v, bare)) return;
+    done = true;
+    if (bare) { out += std::to_string(var) + "\n"; return; }
+    // std::stoi semantics (leading blanks, sign, digits; trailing characters ignored) without its exceptions: the reference lets
+    // std::invalid_argument escape executeStatement (it catches runtime_error and ResqlError only) and dies
+    size_t i = 0;
+    bool neg = false;
+    if (i < v.size() && (v[i] == '+' || v[i] == '-')) neg = v[i++] == '-';
+    if (i >= v.size() || !isdigit((unsigned char)v[i])) failInvalid("Expected an integer value");
+    long long x = 0;
+    for (; i < v.size() && isdigit((unsigned char)v[i]); i++) { x = x * 10 + (v[i] - '0'); if (x > 0x7fffffffLL) failInvalid("Integer value out of range"); }
+    var = (uint16_t)(int)(neg ? -x : x);
+}
+
+// printStringTable (dbdata.h:578-626): cells are right-aligned in columns two wider than their longest string
+std::string stringTable(const std::vector<std::string>& cells, int nCols, int headerRows, const std::string& subTitle) {
+    std::vector<size_t> w((size_t)nCols, 0);
+    for (size_t i = 0; i < cells.size(); i++) w[i % (size_t)nCols] = std::max(w[i % (size_t)nCols], cells[i].size() + 2);
+    auto rule = [&](const char* l, const char* m, const char* x, const char* r) {
+        std::string o = l;
+        for (int c = 0; c < nCols; c++) { if (c) o += x; for (size_t k = 0; k < w[(size_t)c]; k++) o += m; }
+        return o + r + "\n";
+    };
+    auto row = [&](size_t at) {
+        std::string o;
+        for (int c = 0; c < nCols; c++) {
+            std::string cell = " " + cells[at + (size_t)c] + " ";
+            o += "\xe2\x94\x82" + std::string(w[(size_t)c] > cell.size() ? w[(size_t)c] - cell.size() : 0, ' ') + cell;
+        }
+        return o + "\xe2\x94\x82\n";
+    };
+    std::string out = rule("\xe2\x94\x8c", "\xe2\x94\x80", "\xe2\x94\xac", "\xe2\x94\x90");
+    size_t at = 0;
+    for (int h = 0; h < headerRows; h++, at += (size_t)nCols) out += row(at);
+    out += rule("\xe2\x94\x9c", "\xe2\x94\x80", "\xe2\x94\xbc", "\xe2\x94\xa4");
+    for (; at < cells.size(); at += (size_t)nCols) out += row(at);
+    out += rule("\xe2\x94\x94", "\xe2\x94\x80", "\xe2\x94\xb4", "\xe2\x94\x98");
+    if (!subTitle.empty()) {
+        size_t width = (size_t)nCols;
+        for (size_t x : w) width += x;
+        out += std::string(width > subTitle.size() ? width - subTitle.size() : 0, ' ') + subTitle + "\n";
+    }
+    return out;
+}
+
+// processControl (execute.h:454-474): every variable is tried in the reference's order; "tables" must be the whole line
+bool processControl(rsq_db& db, const std::string& line, std::string& out) {
+    bool done = false;
+    boolVar(line, "showplan", db.showPlan, done, out);
+    boolVar(line, "tofile", db.writeResultsToFile, done, out);
+    intVar(line, "threads", db.numThreads, done, out);
+    boolVar(line, "showperf", db.printPerformance, done, out);
+    boolVar(line, "showasm", db.printAssembly, done, out);
+    boolVar(line, "showfln", db.printFlounder, done, out);
+    boolVar(line, "optimize", db.optimizeFlounder, done, out);
+    boolVar(line, "emitmc", db.emitMachineCode, done, out);
+    if (line == "tables") {          // showTables (execute.h:390-404); std::map order = by name
+        std::vector<std::string> cells = {"Table name", "Number of attributes", "Number of tuples"};
+        for (auto& t : db.tables) { cells.push_back(t.first); cells.push_back(std::to_string(t.second->cols.size())); cells.push_back(std::to_string(t.second->nRows)); }
+        out += stringTable(cells, 3, 1, std::to_string(db.tables.size()) + " tables");
+        done = true;
+    }
+    return done;
+}
+
+// showReport (JitContextFlounder.h:132-150) for this engine: the code (HIP source for showasm, the pipeline description for
+// showfln), then the performance lines in the reference's format plus the device-side figures
+std::string reportText(const rsq_db& db, rsq_query* q, const rsq_report& r) {
+    std::string o;
+    if (db.printFlounder) { o += rsq_query_explain(q); }
+    if (db.printAssembly) { o += rsq_query_source(q); }
+    if (db.printPerformance) {
+        char b[256];
+        snprintf(b, sizeof b, "Launched %llu kernels (%d compiled by hiprtc, %d from the code-object cache). \n", (unsigned long long)r.num_kernels, r.jit_compiles, r.jit_cache_hits);
+        o += b;
+        snprintf(b, sizeof b, "compile: %.3f ms\n", r.compilation_time_ms); o += b;
+        snprintf(b, sizeof b, "execute: %.3f ms\n", r.execution_time_ms); o += b;
+        snprintf(b, sizeof b, "device:  %.3f ms, %llu bytes scanned, %.1f GB/s\n", r.kernel_time_ms, (unsigned long long)r.bytes_read, r.hbm_gbps); o += b;
+    }
+    return o;
+}
+
+// concatenate `more` behind `t` (BULK INSERT appends, execute.h:332-388): new device columns, statistics recomputed
+void appendTable(Context& ctx, Table& t, Table& more) {
+    if (t.cols.size() != more.cols.size()) failInvalid("append: different schemas");
+    const int64_t n0 = t.nRows, n1 = more.nRows;
+    for (size_t c = 0; c < t.cols.size(); c++) {
+        TableColumn& a = t.cols[c]; TableColumn& b = more.cols[c];
+        const size_t w = (size_t)columnWidth(a.type);
+        if (ctx.device >= 0) {
+            char* nu = (char*)ctx.alloc((size_t)(n0 + n1) * w);
+            if (n0 && a.dptr) RSQ_HIP(hipMemcpy(nu, a.dptr, (size_t)n0 * w, hipMemcpyDeviceToDevice));
+            if (n1 && b.dptr) RSQ_HIP(hipMemcpy(nu + (size_t)n0 * w, b.dptr, (size_t)n1 * w, hipMemcpyDeviceToDevice));
+            if (a.owned && a.dptr) ctx.free(a.dptr);
+            a.dptr = nu; a.owned = true;
+        } else {
+            char* nu = (char*)malloc(std::max<size_t>(1, (size_t)(n0 + n1) * w));
+            if (!nu) throw std::bad_alloc();
+            if (n0 && a.dptr) memcpy(nu, a.dptr, (size_t)n0 * w);
+            if (n1 && b.dptr) memcpy(nu + (size_t)n0 * w, b.dptr, (size_t)n1 * w);
+            if (a.owned && a.dptr) ::free(a.dptr);
+            a.dptr = nu; a.owned = true;
+        }
+    }
+    t.nRows = n0 + n1;
+    computeColumnStats(ctx, t);
+}
+
+}  // namespace
+
+extern "C" {
 
 int rsq_db_create(rsq_ctx* ctx, rsq_db** out) {
     if (!ctx || !out) return RSQ_ERR_INVALID;
@@ -355,13 +500,19 @@ int rsq_db_report(const rsq_db* db, rsq_report* out) {
     return RSQ_OK;
 }
 
+const char* rsq_db_message(const rsq_db* db) { return db ? db->message.c_str() : ""; }
+
 int rsq_db_execute(rsq_db* db, const char* sqlText, int32_t* kind, rsq_result_view* result) {
     if (!db || !sqlText) return RSQ_ERR_INVALID;
     if (kind) *kind = 0;
+    db->message.clear();
     rsq_ctx* cx = reinterpret_cast<rsq_ctx*>(db->ctx);
     int selectStatus = RSQ_OK;
     bool isSelect = false;
     int st = guarded(db->ctx, [&] {
+        // control statements first (executeStatement, execute.h:512-516)
+        std::string ctl;
+        if (processControl(*db, sqlText, ctl)) { db->message = ctl; if (kind) *kind = 4; return; }
         rsq::ExprPool pool;
         rsq::sql::Statement stmt;
         rsq::sql::parse(sqlText, pool, stmt);
@@ -384,12 +535,13 @@ int rsq_db_execute(rsq_db* db, const char* sqlText, int32_t* kind, rsq_result_vi
             snprintf(d.name, RSQ_SYMBOL_MAX, "%s", stmt.tableName.c_str());
             d.n_rows = 0; d.n_cols = (int32_t)cols.size(); d.cols = cols.data();
             db->tables[stmt.tableName] = makeTable(*db->ctx, d, false);
+            db->message = "Created table " + stmt.tableName + "\n";
         } else if (stmt.kind == rsq::sql::Statement::BULK_INSERT) {
             auto it = db->schemas.find(stmt.tableName);
             if (it == db->schemas.end()) failInvalid("Table " + stmt.tableName + " does not exist.");
-            auto have = db->tables.find(stmt.tableName);
-            if (have != db->tables.end() && have->second->nRows > 0) failUnsupported("BULK INSERT into a table that already holds data");
+            if (stmt.fieldTerminator.length() > 1) failInvalid("Bulk insert only supports single-character field terminators.");
             if (stmt.fieldTerminator.empty()) failInvalid("empty field terminator");
+            auto have = db->tables.find(stmt.tableName);
             std::vector<rsq_column> cols(it->second.size());
             for (size_t i = 0; i < cols.size(); i++) {
                 memset(&cols[i], 0, sizeof cols[i]);
@@ -403,8 +555,16 @@ int rsq_db_execute(rsq_db* db, const char* sqlText, int32_t* kind, rsq_result_vi
             rsq_table* t = nullptr;
             int rc = rsq_table_load_tbl(cx, &d, stmt.fileName.c_str(), stmt.fieldTerminator[0], 0, &t);
             if (rc != RSQ_OK) throw Error(rc, db->ctx->lastError);
-            if (have != db->tables.end()) delete have->second;
-            db->tables[stmt.tableName] = T(t);
+            const int64_t inserted = T(t)->nRows;
+            if (have != db->tables.end() && have->second->nRows > 0) {
+                // the reference appends to the relation (AppendIterator on the existing table, execute.h:348-350)
+                std::unique_ptr<Table> more(T(t));
+                appendTable(*db->ctx, *have->second, *more);
+            } else {
+                if (have != db->tables.end()) delete have->second;
+                db->tables[stmt.tableName] = T(t);
+            }
+            db->message = "Inserted " + std::to_string(inserted) + " tuples\n";
         } else isSelect = true;
     });
     if (st != RSQ_OK || !isSelect) return st;
@@ -412,12 +572,36 @@ int rsq_db_execute(rsq_db* db, const char* sqlText, int32_t* kind, rsq_result_vi
     if (db->last) { rsq_query_destroy(db->last); db->last = nullptr; }
     std::vector<rsq_table*> arr;
     for (auto& t : db->tables) arr.push_back(reinterpret_cast<rsq_table*>(t.second));
+    std::string planText;
+    if (db->showPlan) {            // root->print(plan) before anything else (execute.h:217-220)
+        rsq_sql_plan* p = nullptr;
+        selectStatus = rsq_sql_plan_select(cx, sqlText, arr.data(), (int32_t)arr.size(), &p);
+        if (selectStatus != RSQ_OK) return selectStatus;
+        char* txt = rsq_sql_plan_text(p);
+        if (txt) { planText = txt; free(txt); }
+        rsq_sql_plan_destroy(p);
+    }
     selectStatus = rsq_sql_compile(cx, sqlText, arr.data(), (int32_t)arr.size(), &db->last);
     if (selectStatus != RSQ_OK) return selectStatus;
     selectStatus = rsq_query_execute(db->last);
     if (selectStatus != RSQ_OK) return selectStatus;
     rsq_query_report(db->last, &db->lastReport);
-    if (result) return rsq_query_result(db->last, result);
+    rsq_result_view view;
+    selectStatus = rsq_query_result(db->last, &view);
+    if (selectStatus != RSQ_OK) return selectStatus;
+    if (db->writeResultsToFile) {            // writeRelationToFile(*rel, "qres.tbl") (execute.h:203-210, 243-245)
+        selectStatus = guarded(db->ctx, [&] {
+            FILE* f = fopen("qres.tbl", "w");
+            if (!f) failInvalid("Could not open file qres.tbl");
+            std::string text = serializeResultView(view);
+            fwrite(text.data(), 1, text.size(), f);
+            fclose(f);
+        });
+        if (selectStatus != RSQ_OK) return selectStatus;
+    }
+    // printQueryResult (execute.h:178-183): the plan line, then showReport
+    db->message = planText + "\n" + reportText(*db, db->last, db->lastReport);
+    if (result) *result = view;
     return RSQ_OK;
 }
 

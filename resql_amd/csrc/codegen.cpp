@@ -254,6 +254,9 @@ struct Walker {
     std::vector<std::string> colTypes;        // device type per scanned (vector-loadable) column
     std::vector<int> colIsString;
     std::string rowParams, rowArgsTail, rowArgsTailGuarded;
+    // key-bitmap words fetched for both rows of a lane (and all tiles in flight) before the first row is processed:
+    // (table name, scanned column index) — see consumeProbe
+    std::vector<std::pair<std::string, int>> bitmapPrefetch;
     std::string body;                          // row function body
     std::string closers;                       // closing braces of the open scopes
     std::string stateDecl, stateInit, prologue, epilogue, fileScope;
@@ -348,7 +351,7 @@ struct Walker {
         // workgroups (of 256 threads) per launch; 0 = 2 per CU.  Measured on MI355X (Q1 SF10): 512 workgroups 0.348 ms,
         // 768: 0.367, 1024: 0.374, 2048: 0.395, 4096: 0.448 - a streaming kernel wants exactly 2 resident workgroups per CU
         pipe.maxGrid = (unsigned)envInt("RSQ_MAXGRID", 0, 0, 1 << 20);
-        colTypes.clear(); colIsString.clear(); rowParams.clear(); rowArgsTail.clear(); rowArgsTailGuarded.clear();
+        colTypes.clear(); colIsString.clear(); rowParams.clear(); rowArgsTail.clear(); rowArgsTailGuarded.clear(); bitmapPrefetch.clear();
         body.clear(); stateDecl.clear(); stateInit.clear(); prologue.clear(); epilogue.clear(); fileScope.clear(); helperFns.clear();
         explainSteps.clear(); indent = 1; matchSlotTable = -1; slotVar.clear(); symbolOrigin.clear(); symbolWord.clear();
         multiMatchAbove = false;
@@ -699,16 +702,73 @@ struct Walker {
                     pipe.src->cols[(size_t)ci].stats.min > INT64_MIN) ht->keyCas = true;
             }
         }
+        // Bitmap-rank dictionary (HashTable::rankCapable, kernels/rsq_device.h rank_of): a table that is probed single-match over
+        // one integer key with a key bitmap needs no hashing when its build keys prove unique.  The same kernel carries both
+        // forms behind a uniform branch on a.<T>_rank; the host decides once, from the sizing pass.
+        ht->rankCapable = ht->unique && ht->hasBitmap && ht->keyCas && ht->aos && keyVars.size() == 1 && envInt("RSQ_JOIN_RANK", 1, 0, 1) != 0;
+        const std::string bitSet = ht->hasBitmap ? "const u64 d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin); " : "";
         addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
         addArg(T + "_countonly", "u64", 0);
-        // sizing pass: the same pipeline run once with countonly = 1 tells the host how many entries to expect
+        if (ht->hasBitmap) { addArg(T + "_bm", "u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht->bmMin); }
+        // sizing pass: the same pipeline run once with countonly = 1 tells the host how many entries to expect — and, for a
+        // table that could be a rank dictionary, whether two build rows share a key (a bit that is already set)
         countPerThread(T);
+        if (ht->rankCapable) {
+            addArg(T + "_rank", "u64", 0); addArg(T + "_temp", "i64*", 0);
+            openScope("if (a." + T + "_countonly) {");
+            line("st.n_" + T + "++;");
+            line("{ " + bitSet + "const u32 b = 1u << (d & 31); if (atomicOr(&a." + T + "_bm[d >> 5], b) & b) atomicOr(a.err, (u32)rsq::NOTE_BUILD_KEYS_NOT_UNIQUE); }");
+            closeScope();
+            openScope("else if (a." + T + "_rank) {");
+            // The record goes to the arrival-order buffer, into the region of the wave that produced it: a.<T>_treg records
+            // per wave (the host sizes the regions at four times the mean from the sizing pass; tiles are dealt to the waves
+            // round-robin, so every wave sees an even sample of the table).  No atomics: a returning atomic on ONE counter word
+            // serialises at ~11 ns, and even one reservation per wave and 256 records made this pipeline 2x slower.  A wave's
+            // fill count lives in LDS, because the lanes of a wave reach this point in diverged groups; it is written to
+            // a.<T>_tused[wave] at the end, where the placement kernel finds it.  A wave that overflows its region says so
+            // (the host then keeps the hash form).
+            line("{ " + bitSet + "atomicOr(&a." + T + "_bm[d >> 5], 1u << (d & 31)); }");
+            addArg(T + "_treg", "u64", 0); addArg(T + "_tused", "u32*", 0);
+            stateDecl += "    u32* tch_" + T + ";\n";
+            prologue += "    __shared__ u32 s_tch_" + T + "[RSQ_BLOCK_THREADS / 64];\n    st.tch_" + T + " = s_tch_" + T + " + (threadIdx.x >> 6);\n" +
+                        "    if ((threadIdx.x & 63) == 0) st.tch_" + T + "[0] = 0u;\n";
+            const int nw = 1 + (int)ht->payload.size();
+            const std::string NW = std::to_string(nw);
+            line("u64 " + T + "_t;");
+            openScope("{");
+            line("const u64 act = __ballot(1);");
+            line("const int ln = (int)(threadIdx.x & 63), leader = __ffsll((long long)act) - 1;");
+            line("const u32 pos = st.tch_" + T + "[0];");
+            line(T + "_t = (u64)pos + (u64)__popcll(act & ((1ull << ln) - 1ull));");
+            line("if (ln == leader) st.tch_" + T + "[0] = pos + (u32)__popcll(act);");
+            closeScope();
+            {
+                openScope("if (" + T + "_t < a." + T + "_treg) {");
+                line("i64* rec = a." + T + "_temp + (((u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a." + T + "_treg + " + T + "_t) * " + NW + ";");
+                line("rec[0] = " + keyVars[0] + ";");
+                int tw = 1;
+                for (auto& p : ht->payload)
+                    line("rec[" + std::to_string(tw++) + "] = " + toWord(eg.symbols[p.name].var, p.type) + ";");
+                closeScope();
+                line("else atomicOr(a.err, (u32)rsq::NOTE_BUILD_KEYS_NOT_UNIQUE);      // the region is full: this table is not for the dictionary");
+            }
+            epilogue += "    if (a." + T + "_rank && !a." + T + "_countonly && (threadIdx.x & 63) == 0) {\n        const u32 used = st.tch_" + T + "[0];\n" +
+                        "        a." + T + "_tused[(u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = used < a." + T + "_treg ? used : (u32)a." + T + "_treg;\n    }\n";
+            line("st.n_" + T + "++;");
+            closeScope();
+            openScope("else {");
+        } else
         openScope("if (a." + T + "_countonly) { st.n_" + T + "++; } else {");
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
         line("u64 " + T + "_s = " + slotOf(*ht, T, keyVars) + ";");
         line("u64 " + T + "_n = 0;");
+        // (measurement only, wrong results: 1 no payload stores, 2 a plain store into the home slot instead of the CAS loop,
+        // 4 no insert at all — to see what each part of an insert costs)
+        const int dbgBuild = envInt("RSQ_DEBUG_BUILD", 0, 0, 7);
         openScope("for (;; " + T + "_n++) {");
         line("if (" + T + "_n > " + T + "_mask) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
+        if (dbgBuild & 4) line("break;");
+        else if ((dbgBuild & 2) && ht->keyCas) line(wordAt(*ht, T, 0) + " = " + keyVars[0] + "; break;");
         if (ht->keyCas)
             line("if (atomicCAS(reinterpret_cast<unsigned long long*>(&" + wordAt(*ht, T, 0) + "), 0x8000000000000000ull, (unsigned long long)" +
                  keyVars[0] + ") == 0x8000000000000000ull) break;");
@@ -721,13 +781,14 @@ struct Walker {
             if (!ht->keyCas) line(wordAt(*ht, T, w) + " = " + kv + ";");
             w++;
         }
-        for (auto& p : ht->payload)
+        for (auto& p : ht->payload) {
+            if (dbgBuild & 5) { w++; continue; }
             line(wordAt(*ht, T, w++) + " = " + toWord(eg.symbols[p.name].var, p.type) + ";");
+        }
         line("st.n_" + T + "++;");
         if (ht->hasBitmap) {
-            addArg(T + "_bm", "u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht->bmMin);
             if (envInt("RSQ_DEBUG_NO_BITMAP_SET", 0, 0, 64) != ht->id + 1)      // (measurement only: table id + 1 builds no bitmap; its probes then find nothing)
-                line("{ const u64 d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin); atomicOr(&a." + T + "_bm[d >> 5], 1u << (d & 31)); }");
+                line("{ " + bitSet + "atomicOr(&a." + T + "_bm[d >> 5], 1u << (d & 31)); }");
         }
         closeScope();
         closeScope();
@@ -738,7 +799,8 @@ struct Walker {
         explainSteps.push_back("build hash table " + T + " (" + std::to_string(ht->keys.size()) + " key(s), " +
                                std::to_string(ht->payload.size()) + " payload word(s), sized by a counting pass" +
                                (ht->hasBitmap ? ", key bitmap of " + std::to_string((long long)ht->bmBits) + " bits" : "") +
-                               (ht->keyCas ? ", key word is the slot state" : "") + ")");
+                               (ht->keyCas ? ", key word is the slot state" : "") +
+                               (ht->rankCapable ? "; a bitmap-rank dictionary instead when the build keys prove unique" : "") + ")");
         q.hashTables.push_back(std::move(ht));
     }
 
@@ -774,6 +836,35 @@ struct Walker {
             // keys outside the build side's [min, max] or with a clear bit cannot match: skip the table altogether
             addArg(T + "_bm", "const u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht.bmMin); addArg(T + "_bmbits", "u64", (uint64_t)ht.bmBits);
             line("const u64 " + T + "_d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin);");
+            // When the probe key is a column of this pipeline's scan, its bitmap word is fetched by the scan skeleton for BOTH
+            // rows of the lane (and every tile in flight) before the first row is processed, and handed to the row function:
+            // the two row functions of a lane otherwise run one after the other, each with its own dependent load — a cache
+            // round trip per row that nothing overlaps (TPC-H Q3's lineitem pipeline spent a quarter of its time there).
+            int pfCol = -1;
+            {
+                Expr* r = o->exprs[0]->child->next;
+                auto org = r->tag == RSQ_E_ATTRIBUTE ? symbolOrigin.find(r->symbol) : symbolOrigin.end();
+                auto sym = r->tag == RSQ_E_ATTRIBUTE ? eg.symbols.find(r->symbol) : eg.symbols.end();
+                // ... worth it when the table is clustered by the key (column statistics): the 64 lanes of a wave then read one or
+                // two cache lines.  For keys in random order (orders.o_custkey) a wave's load touches 64 lines, and fetching for
+                // the rows the filter in front would have dropped made TPC-H Q3's orders pipeline 30 % slower.
+                if (!compacted && o->exprs.size() == 1 && org != symbolOrigin.end() && org->second == -1 && sym != eg.symbols.end() &&
+                    sym->second.var.compare(0, 2, "v_") == 0 && !r->type.isString()) {
+                    const int ci = pipe.src->findCol(r->symbol);
+                    const int mode = envInt("RSQ_BITMAP_PREFETCH", 1, 0, 2);       // 0 never, 1 clustered keys, 2 always
+                    if (ci >= 0 && (mode == 2 || (mode == 1 && pipe.src->cols[(size_t)ci].stats.valid && pipe.src->cols[(size_t)ci].stats.ascending)))
+                        pfCol = atoi(sym->second.var.c_str() + 2);
+                }
+                for (auto& pf : bitmapPrefetch) if (pf.first == T) pfCol = -1;        // (one probe per table and pipeline)
+            }
+            if (pfCol >= 0) {
+                bitmapPrefetch.push_back({T, pfCol});
+                const std::string call = "rsq::bm_word(a." + T + "_bm, a." + T + "_bmmin, a." + T + "_bmbits, (i64)";
+                rowParams += ", const u32 pf_" + T;
+                rowArgsTail += ", " + call + "a.c" + std::to_string(pfCol) + "[r])";
+                rowArgsTailGuarded += ", (valid ? " + call + "a.c" + std::to_string(pfCol) + "[r]) : 0u)";
+                openScope("if (" + T + "_d < a." + T + "_bmbits && ((pf_" + T + " >> (" + T + "_d & 31)) & 1u)) {");
+            } else
             openScope("if (" + T + "_d < a." + T + "_bmbits && ((a." + T + "_bm[" + T + "_d >> 5] >> (" + T + "_d & 31)) & 1u)) {");
             selective = true;
         }
@@ -790,23 +881,9 @@ struct Walker {
         closeScope();
     }
 
-    void probeTable(OpNode* o, HashTable& ht, const std::string& T, const std::vector<std::string>& keyVars,
-                    const std::vector<std::string>& probeKeyNames) {
-        line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
-        line("u64 " + T + "_s = " + slotOf(ht, T, keyVars) + ";");
-        openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
-        std::string cond;
-        if (ht.keyCas) {
-            line("const i64 " + T + "_kk = " + wordAt(ht, T, 0) + ";");
-            line("if (" + T + "_kk == (i64)0x8000000000000000ull) break;");
-            cond = T + "_kk == " + keyVars[0];
-        } else {
-            line("if (a." + T + "_state[" + T + "_s] == 0u) break;");
-            for (size_t i = 0; i < keyVars.size(); i++)
-                cond += (i ? " && " : "") + wordAt(ht, T, (int)i) + " == " + keyVars[i];
-        }
-        openScope("if (" + cond + ") {");
-        // the build side's values become symbols (hashjoin.h:146-147 / 204-205)
+    // what a match exposes: the build side's values become symbols (hashjoin.h:146-147 / 204-205), then the parent consumes
+    void consumeMatch(OpNode* o, HashTable& ht, const std::string& T, const std::vector<std::string>& keyVars,
+                      const std::vector<std::string>& probeKeyNames) {
         int w = (int)ht.keys.size();
         for (auto& p : ht.payload) {
             std::string var = T + "_v" + std::to_string(w);
@@ -833,6 +910,61 @@ struct Walker {
         selective = true;                       // whatever follows a join probe sees only the matching rows
         consume(o->parent, o);
         matchSlotTable = prevMatch; multiMatchAbove = prevMulti;
+    }
+
+    void probeTable(OpNode* o, HashTable& ht, const std::string& T, const std::vector<std::string>& keyVars,
+                    const std::vector<std::string>& probeKeyNames) {
+        if (ht.rankCapable && o->singleMatch) {
+            // both forms of the table behind a uniform branch: the entry of a key whose bit is set (tested above) is entry
+            // number rank(key) of the dictionary — or the first key-equal slot of the hash walk when the host kept the hash form
+            addArg(T + "_rank", "u64", 0); addArg(T + "_brank", "const u32*", 0); addArg(T + "_cbase", "const u32*", 0);
+            line("u64 " + T + "_s = 0; bool " + T + "_hit = false;");
+            openScope("if (a." + T + "_rank) {");
+            {
+                const int dbgRank = envInt("RSQ_DEBUG_RANK", 0, 0, 8);      // (measurement only, wrong results: 1 no rank at all, 2 prefix arrays only, 3 block popcount only)
+                const std::string dd = "(u64)(" + keyVars[0] + " - a." + T + "_bmmin)";
+                if (dbgRank == 1) line(T + "_s = " + dd + " & (a." + T + "_cap - 1);");
+                else if (dbgRank == 2) line(T + "_s = ((u64)a." + T + "_cbase[" + dd + " >> 20] + (u64)a." + T + "_brank[" + dd + " >> 8]) & (a." + T + "_cap - 1);");
+                else if (dbgRank == 5) line(T + "_s = (" + dd + " & (a." + T + "_cap - 1)) ^ (rsq::rank_of(a." + T + "_bm, a." + T + "_brank, a." + T + "_cbase, " + dd + ") & (" + dd + " >> 40));");
+                else if (dbgRank == 6) line(T + "_s = rsq::hash64(rsq::rank_of(a." + T + "_bm, a." + T + "_brank, a." + T + "_cbase, " + dd + ")) & (a." + T + "_cap - 1);");
+                else if (dbgRank == 7) line(T + "_s = ((u64)a." + T + "_cbase[" + dd + " >> 20] + " + dd + ") & (a." + T + "_cap - 1);");
+                else if (dbgRank == 8) line(T + "_s = ((u64)a." + T + "_brank[" + dd + " >> 8] + " + dd + ") & (a." + T + "_cap - 1);");
+                else if (dbgRank == 4) line(T + "_s = rsq::hash64(" + dd + ") & (a." + T + "_cap - 1);");
+                else if (dbgRank == 3) line(T + "_s = ((u64)rsq::rank_in_block(a." + T + "_bm, " + dd + ") + " + dd + ") & (a." + T + "_cap - 1);");
+                else
+                line(T + "_s = rsq::rank_of(a." + T + "_bm, a." + T + "_brank, a." + T + "_cbase, (u64)(" + keyVars[0] + " - a." + T + "_bmmin));");
+            }
+            line(T + "_hit = true;");
+            closeScope();
+            openScope("else {");
+            line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
+            line(T + "_s = " + slotOf(ht, T, keyVars) + ";");
+            openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
+            line("const i64 " + T + "_kk = " + wordAt(ht, T, 0) + ";");
+            line("if (" + T + "_kk == (i64)0x8000000000000000ull) break;");
+            line("if (" + T + "_kk == " + keyVars[0] + ") { " + T + "_hit = true; break; }");
+            closeScope();
+            closeScope();
+            openScope("if (" + T + "_hit) {");
+            consumeMatch(o, ht, T, keyVars, probeKeyNames);
+            closeScope();
+            return;
+        }
+        line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
+        line("u64 " + T + "_s = " + slotOf(ht, T, keyVars) + ";");
+        openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
+        std::string cond;
+        if (ht.keyCas) {
+            line("const i64 " + T + "_kk = " + wordAt(ht, T, 0) + ";");
+            line("if (" + T + "_kk == (i64)0x8000000000000000ull) break;");
+            cond = T + "_kk == " + keyVars[0];
+        } else {
+            line("if (a." + T + "_state[" + T + "_s] == 0u) break;");
+            for (size_t i = 0; i < keyVars.size(); i++)
+                cond += (i ? " && " : "") + wordAt(ht, T, (int)i) + " == " + keyVars[i];
+        }
+        openScope("if (" + cond + ") {");
+        consumeMatch(o, ht, T, keyVars, probeKeyNames);
         if (o->singleMatch) line("break;");
         closeScope();
         closeScope();
@@ -1443,10 +1575,20 @@ struct Walker {
         const int W = (int)q.accums.size();
         ht.nAccBlocks = W;
         addArg(T + "_acc", "u64*", 0);
+        // Entries of a rank dictionary are in key order, and rows clustered by the key update neighbouring entries: their
+        // atomics would queue on a handful of cache lines.  The accumulators of entry r therefore live at rsq::rank_mix(r), a
+        // bijection of [0, capacity) (rsq_device.h; the capacity of a dictionary that carries aggregates is a power of two).
+        std::string accIdx = slotVar[ht.id];
+        if (ht.rankCapable && envInt("RSQ_RANK_SCRAMBLE", 1, 0, 1)) {
+            line("const u64 " + T + "_ai = a." + T + "_rank ? rsq::rank_mix(" + slotVar[ht.id] + ", a." + T + "_cap) : " + slotVar[ht.id] + ";");
+            accIdx = T + "_ai";
+        }
+        const int dbgAcc = envInt("RSQ_DEBUG_ENTRY_ACC", 0, 0, 3);      // (measurement only: 1 no first-row tracker, 2 no aggregates, 3 neither)
         for (int w = 0; w < W; w++) {
+            if ((w == 0 && (dbgAcc & 1)) || (w > 0 && (dbgAcc & 2))) continue;
             std::string in = w == 0 ? "row" : q.accums[(size_t)w].input;
             line("rsq::global_merge_always<" + std::to_string(q.accums[(size_t)w].merge) + ">(a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) +
-                 " * a." + T + "_cap + " + slotVar[ht.id] + ", (u64)(" + in + "));");
+                 " * a." + T + "_cap + " + accIdx + ", (u64)(" + in + "));");
         }
         explainSteps.push_back("aggregation at the matched entry of " + T + " accumulators=" + std::to_string(W - 1) + " (of " +
                                std::to_string(o->splitAgg.size()) + " in the reference)");
@@ -1576,7 +1718,16 @@ struct Walker {
             if (pipe.compactWords > pipe.compactWordsLazy) s << "#endif\n";
             s << "        }\n        st.cq_n += (int)__popcll(m);\n    }\n}\n";
         } else s << body << "}\n";
-        s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) rsq_pipeline(Args a) {\n";
+        // one kernel name per pipeline — rsq_p<index>_<scanned table>_<sink> — so that a kernel trace (rocprofv3
+        // --kernel-trace --stats) splits a multi-pipeline query into its phases
+        {
+            std::string tn;
+            for (char c : pipe.src->name) tn += (isalnum((unsigned char)c) ? c : '_');
+            const char* sk = pipe.sink == SinkKind::BUILD ? "build" : pipe.sink == SinkKind::MATERIALIZE ? "materialize" : "aggregate";
+            pipe.entry = "rsq_p" + std::to_string(q.pipelines.size()) + "_" + tn + "_" + sk;
+            if (pipe.sink == SinkKind::BUILD) pipe.entry += "_ht" + std::to_string(pipe.buildTable);
+        }
+        s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n";
         s << "    State st;\n" << prologue;
         s << "    const int lane = threadIdx.x & 63;\n";
         s << "    const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n";
@@ -1599,12 +1750,22 @@ struct Walker {
             }
             s << "        }\n";
         }
+        for (int u = 0; u < U; u++)
+            for (auto& pf : bitmapPrefetch) {
+                s << "        u32 pf_" << pf.first << "_" << u << "[2] = {0u, 0u};\n";
+                s << "        if (tt" << u << " < ntiles) {\n";
+                for (int j = 0; j < 2; j++)
+                    s << "            pf_" << pf.first << "_" << u << "[" << j << "] = rsq::bm_word(a." << pf.first << "_bm, a." << pf.first << "_bmmin, a." << pf.first
+                      << "_bmbits, (i64)t" << pf.second << "_" << u << "[" << j << "]);\n";
+                s << "        }\n";
+            }
         for (int u = 0; u < U; u++) {
             s << "        if (tt" << u << " < ntiles) {\n";
             if (mat) s << "            const i64 slot = tt" << u << " * 64 + lane;\n#if RSQ_PASS == 2\n            st.pos = a.offs[slot];\n#endif\n";
             for (int j = 0; j < 2; j++) {
                 s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");
                 for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
+                for (auto& pf : bitmapPrefetch) s << ", pf_" << pf.first << "_" << u << "[" << j << "]";
                 s << ");\n";
                 if (cq && (QCAP < 192 || j == 1)) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";
             }

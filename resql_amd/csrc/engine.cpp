@@ -13,6 +13,8 @@ namespace rsq {
 namespace {
 
 int64_t nextPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
+// multiplicative inverse of an odd number modulo 2^64 (Newton: every step doubles the correct low bits)
+uint64_t inverseOdd64(uint64_t a) { uint64_t x = a; for (int i = 0; i < 6; i++) x *= 2 - a * x; return x; }
 
 // ================================================================================================
 // plan construction + typing
@@ -139,6 +141,11 @@ Query::~Query() {
         if (h->dAcc) ctx.free(h->dAcc);
         if (h->dCount) ctx.free(h->dCount);
         if (h->dBitmap) ctx.free(h->dBitmap);
+        if (h->dTemp) ctx.free(h->dTemp);
+        if (h->dTempUsed) ctx.free(h->dTempUsed);
+        if (h->dBlockRank) ctx.free(h->dBlockRank);
+        if (h->dChunkTotal) ctx.free(h->dChunkTotal);
+        if (h->dChunkBase) ctx.free(h->dChunkBase);
     }
 }
 
@@ -286,6 +293,12 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
         if (f == "acc") return (uint64_t)(uintptr_t)h.dAcc;
         if (f == "countonly") return id == countOnlyTable ? 1ull : 0ull;
         if (f == "bm") return (uint64_t)(uintptr_t)h.dBitmap;
+        if (f == "rank") return h.rank ? 1ull : 0ull;
+        if (f == "temp") return (uint64_t)(uintptr_t)h.dTemp;
+        if (f == "treg") return (uint64_t)h.tempRegion;
+        if (f == "tused") return (uint64_t)(uintptr_t)h.dTempUsed;
+        if (f == "brank") return (uint64_t)(uintptr_t)h.dBlockRank;
+        if (f == "cbase") return (uint64_t)(uintptr_t)h.dChunkBase;
         if (f == "hm") {      // slots per key value as a 32.32 fixed-point number, at most 4 (small ranges in large tables)
             if (h.bmBits <= 0) return 0;
             unsigned __int128 m = (((unsigned __int128)(uint64_t)h.capacity) << 32) / (unsigned __int128)(uint64_t)h.bmBits;
@@ -320,9 +333,11 @@ static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1
     if (!pass1 && k == p.kernel && !p.sourceLazy.empty() && p.stage2Rows >= 0 && p.stage2Rows * lazyDen < p.src->nRows) {
         if (!p.kernelLazy) p.kernelLazy = &q.ctx.getKernel(p.sourceLazy, p.entry);
         launchPipelineKernel(q, p, *p.kernelLazy, countOnlyTable, pipelineGrid(q, p, true));
+        if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     %s: late-load form, %u workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(), p.lastGrid, (long long)p.stage2Rows);
         return;
     }
     launchPipelineKernel(q, p, *k, countOnlyTable);
+    if (getenv("RSQ_TRACE") && p.compact) fprintf(stderr, "[rsq trace]     %s: %u workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(), p.lastGrid, (long long)p.stage2Rows);
 }
 
 // Aggregation into a large dense table (see emitDenseAggregation, DENSE_GLOBAL): pick, per execution, between HBM
@@ -428,26 +443,68 @@ static void materializePipeline(Query& q, Pipeline& p) {
     q.report.bytes_read += 2 * (uint64_t)(p.bytesPerRow * p.src->nRows);
 }
 
-// size (by a counting pass of the same pipeline), allocate and clear a join hash table, then build it
+// size (by a counting pass of the same pipeline), allocate and clear a join table, then build it
 static void buildHashTable(Query& q, Pipeline& p) {
     Context& ctx = q.ctx;
     HashTable& h = *q.hashTables[(size_t)p.buildTable];
     const size_t nWords = h.keys.size() + h.payload.size();
-    if (h.capacity == 0) {
-        RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
-        launchPipeline(q, p, h.id);                     // counting pass
-        uint32_t n = 0;
-        RSQ_HIP(hipMemcpyAsync(&n, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
-        RSQ_HIP(hipStreamSynchronize(ctx.stream));
-        h.capacity = nextPow2(std::max<int64_t>(1024, 2 * (int64_t)n));
-        if (!h.keyCas) h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
-        h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
-        if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
-    }
     size_t bmWords = 0;
     if (h.hasBitmap) {
-        bmWords = ((size_t)h.bmBits + 31) / 32;
+        // whole 256-bit blocks (the rank dictionary's unit, kernels/rsq_device.h)
+        h.bmBlocks = (h.bmBits + 255) / 256;
+        bmWords = (size_t)h.bmBlocks * 8;
         if (!h.dBitmap) h.dBitmap = (uint32_t*)ctx.alloc(bmWords * 4);
+    }
+    if (h.capacity == 0) {
+        // sizing pass.  For a table that could be a rank dictionary the pass also sets the key bits and notes a bit that was
+        // already set (two build rows with one key): only then does the table stay a hash table.
+        if (h.rankCapable) prepareTableAsync(ctx, nullptr, 0, 0, nullptr, 0, h.dBitmap, bmWords, h.dCount);
+        else RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
+        launchPipeline(q, p, h.id);                     // counting pass
+        uint32_t n = 0, err = 0;
+        RSQ_HIP(hipMemcpyAsync(&n, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+        RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        h.rank = h.rankCapable && !(err & 64u);
+        if (err & 64u) { err &= ~64u; RSQ_HIP(hipMemcpy(ctx.dErr, &err, 4, hipMemcpyHostToDevice)); }
+        if (h.rank) {
+            // a dictionary that carries aggregates scatters them with a multiplicative bijection: power-of-two capacity
+            const int64_t capMul = getenv("RSQ_DEBUG_RANK_CAP") ? std::max(1, atoi(getenv("RSQ_DEBUG_RANK_CAP"))) : 1;      // (measurement only)
+            h.capacity = q.aggTable == h.id ? nextPow2(std::max<int64_t>(64, (int64_t)n * capMul)) : std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);
+            const int64_t nChunks = (h.bmBlocks + 4095) / 4096;
+            // arrival-order buffer: one region per wave of the largest grid this pipeline launches, four times the mean
+            // number of records per wave of the smallest one
+            const int64_t wpb = p.blockThreads / 64;
+            const int64_t wavesMax = (int64_t)std::max(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
+            const int64_t wavesMin = (int64_t)std::min(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
+            h.tempWaves = wavesMax;
+            h.tempRegion = ((4 * (int64_t)n / std::max<int64_t>(1, wavesMin) + 64 + 63) / 64) * 64;
+            h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
+            h.dTemp = (int64_t*)ctx.alloc((size_t)h.tempWaves * (size_t)h.tempRegion * 8 * std::max<size_t>(1, nWords));
+            h.dTempUsed = (uint32_t*)ctx.alloc((size_t)h.tempWaves * 4);
+            h.dBlockRank = (uint32_t*)ctx.alloc((size_t)h.bmBlocks * 4);
+            h.dChunkTotal = (uint32_t*)ctx.alloc((size_t)nChunks * 4);
+            h.dChunkBase = (uint32_t*)ctx.alloc((size_t)(nChunks + 1) * 4);
+        } else {
+            h.capacity = nextPow2(std::max<int64_t>(1024, 2 * (int64_t)n));
+            if (!h.keyCas) h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
+            h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
+        }
+        if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
+        if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.rank ? "bitmap-rank dictionary" : "hash table", n);
+    }
+    if (h.rank) {
+        // ONE launch clears the bitmap and both counters' words; the records then arrive in the append buffer, the bitmap
+        // becomes the index, the records move to their entries
+        prepareTableAsync(ctx, nullptr, 0, 0, h.dTempUsed, (size_t)h.tempWaves, h.dBitmap, bmWords, h.dCount);
+        q.report.num_kernels++;
+        launchPipeline(q, p, -1);
+        rankTableIndex(ctx, h.dBitmap, h.bmBlocks, h.dBlockRank, h.dChunkTotal, h.dChunkBase);
+        rankTablePlace(ctx, h.dTemp, h.dTempUsed, (uint32_t)h.tempWaves, (uint32_t)h.tempRegion, h.dCount, (int)std::max<size_t>(1, nWords), h.dBitmap, h.bmMin,
+                       h.dBlockRank, h.dChunkBase, h.bmBlocks, h.dWords, h.capacity);
+        q.report.num_kernels += 3;
+        q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
+        return;
     }
     // ONE launch readies the table: every key word = EMPTY (with a slot's words next to each other that is a fill of the whole
     // table; the payload words are overwritten by the inserts) or the state words = 0, the key bitmap and the entry counter = 0
@@ -460,7 +517,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
 }
 
 static void checkDeviceError(uint32_t err) {
-    err &= ~32u;          // NOTE_CHAR_GROUP_ENDS_WITH_SPACE is information for the host tail, not an error
+    err &= ~(32u | 64u);  // NOTE_CHAR_GROUP_ENDS_WITH_SPACE / NOTE_BUILD_KEYS_NOT_UNIQUE are information for the host, not errors
     if (err & 1) failRuntime("Division by zero");
     if (err & 2) failRuntime("Hash table full");
     if (err & 16) failRuntime("internal error: a hash-table slot stayed in the 'being written' state");
@@ -681,7 +738,8 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
         RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
-                       q.dGroupRows, groupRowsAllocated, q.dGroupCount);
+                       q.dGroupRows, groupRowsAllocated, q.dGroupCount,
+                       h.rank && !(getenv("RSQ_RANK_SCRAMBLE") && atoi(getenv("RSQ_RANK_SCRAMBLE")) == 0));
         q.report.num_kernels++;
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
         if (q.topkWord == -2) planDeviceTopK(q);
@@ -775,6 +833,21 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     q.report.kernel_time_ms = ms;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
     ctx.errWordClean = (uint32_t)q.hPinned[words] == 0;
+    if (((uint32_t)q.hPinned[words] & 64u) && !async) {
+        // a rank dictionary met build rows it was not sized for (two rows with one key, or more rows than the sizing pass saw:
+        // the build side's data changed): its tables go back to the hash form and the execution starts over
+        bool any = false;
+        for (auto& hp : q.hashTables) {
+            HashTable& h = *hp;
+            if (!h.rank) continue;
+            any = true;
+            ctx.free(h.dWords); ctx.free(h.dTemp); ctx.free(h.dTempUsed); ctx.free(h.dBlockRank); ctx.free(h.dChunkTotal); ctx.free(h.dChunkBase);
+            if (h.dAcc) ctx.free(h.dAcc);
+            h.dWords = h.dTemp = nullptr; h.dAcc = nullptr; h.dTempUsed = h.dBlockRank = h.dChunkTotal = h.dChunkBase = nullptr;
+            h.rank = false; h.rankCapable = false; h.capacity = 0; h.lastCount = 0;
+        }
+        if (any) { executeQuery(q, partialOnly, async); return; }
+    }
     checkDeviceError((uint32_t)q.hPinned[words]);
     if (!partialOnly) {
         double t1 = nowMs();

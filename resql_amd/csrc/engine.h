@@ -26,6 +26,7 @@ namespace rsq {
 struct ColumnStats {
     bool valid = false;
     int64_t min = 0, max = 0;                  // numeric / date columns
+    bool ascending = false;                    // ... and no row is smaller than the row before it (the table is clustered by this column)
     std::vector<uint8_t> distinctBytes;        // 1-byte columns (CHAR(1), BOOL): sorted distinct values
 };
 
@@ -100,6 +101,12 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
 size_t scanTempBytes(int64_t n);
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
+// bitmap-rank dictionary (aot_kernels.hip): prefix arrays over a key bitmap of nBlocks 256-bit blocks (blockRank[nBlocks],
+// chunkTotal / chunkBase[ceil(nBlocks / 4096) (+ 1)]), and the placement of appended build records at the rank of their key
+void rankTableIndex(Context& ctx, const uint32_t* bitmap, int64_t nBlocks, uint32_t* blockRank, uint32_t* chunkTotal, uint32_t* chunkBase);
+void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uint32_t nWaves, uint32_t region, const uint32_t* nRecords, int nWords,
+                    const uint32_t* bitmap, int64_t bmMin, const uint32_t* blockRank, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
+                    int64_t capacity);
 // multi-GPU group-by merge: out[w] = min | max | sum over nParts partial tables (`stride` words apart) by segment
 void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out);
 // one launch: fill[0..nFill) = fillValue (u64), zeroA / zeroB cleared (u32 words), *count = 0 (any of them may be empty / null)
@@ -111,7 +118,7 @@ void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPart
 // gather the occupied entries (first-row word != INT64_MAX) of a hash table that carries aggregates into
 // packed rows [first row | table words | accumulator blocks]; *count receives the number of rows, at most maxRows are written
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
-                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count);
+                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix = false);
 // ORDER BY ... LIMIT pre-selection: the rows of `rows` ([*nRows][stride] words) whose word `keyWord` is among the `want`
 // leading values of the requested order (ties of the last one included) are copied to `cand`; *candCount counts them
 size_t topkHistBytes();

@@ -60,6 +60,21 @@ struct HashTable {
     bool hasBitmap = false;
     int64_t bmMin = 0, bmBits = 0;
     uint32_t* dBitmap = nullptr;
+    // Bitmap-rank dictionary (kernels/rsq_device.h rank_of): a table probed single-match over one integer key with a bitmap
+    // can skip hashing altogether when its build keys are unique — decided by the sizing pass of the first execution, which
+    // sets the key bits and notices a bit that was already set.  The build pipeline then appends {key, payload} records in
+    // arrival order (dTemp), two tiny kernels turn the bitmap into rank prefixes and a placement kernel writes every record to
+    // entry number rank(key): no CAS, no scattered read-modify-writes, nearly sequential stores for input clustered by the key.
+    // `capacity` is then the number of entries; words[entry][k] and acc[block][entry] as for the hash form.
+    bool rankCapable = false;
+    bool rank = false;
+    int64_t* dTemp = nullptr;        // arrival-order buffer: [wave of the build grid][tempRegion] records
+    uint32_t* dTempUsed = nullptr;   // [wave] records the wave appended
+    int64_t tempWaves = 0, tempRegion = 0;
+    uint32_t* dBlockRank = nullptr;  // [bitmap blocks]
+    uint32_t* dChunkTotal = nullptr; // [chunks]
+    uint32_t* dChunkBase = nullptr;  // [chunks + 1]
+    int64_t bmBlocks = 0;            // 256-bit blocks the bitmap is allocated in
 };
 
 // one accumulator the aggregation keeps per group

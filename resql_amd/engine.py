@@ -118,6 +118,8 @@ def lib():
         L.rsq_db_create.argtypes = [vp, C.POINTER(vp)]
         L.rsq_db_execute.argtypes = [vp, C.c_char_p, C.POINTER(i32), C.POINTER(P.rsq_result_view)]
         L.rsq_db_adopt_table.argtypes = [vp, vp]
+        L.rsq_db_message.restype = C.c_char_p
+        L.rsq_db_message.argtypes = [vp]
         L.rsq_db_report.argtypes = [vp, C.POINTER(rsq_report)]
         L.rsq_db_destroy.argtypes = [vp]
         L.rsq_multi_create.argtypes = [C.POINTER(rsq_multi_config), C.POINTER(vp)]
@@ -151,7 +153,7 @@ EXPORTED_SYMBOLS = [
     "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
     "rsq_measure_read_bandwidth",
     "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
-    "rsq_db_create", "rsq_db_execute", "rsq_db_adopt_table", "rsq_db_report", "rsq_db_destroy",
+    "rsq_db_create", "rsq_db_execute", "rsq_db_message", "rsq_db_adopt_table", "rsq_db_report", "rsq_db_destroy",
     "rsq_multi_create", "rsq_multi_destroy", "rsq_multi_last_error", "rsq_multi_devices", "rsq_multi_ctx", "rsq_multi_merge_name",
     "rsq_multi_shard_rows", "rsq_multi_table_generate", "rsq_multi_query_compile", "rsq_multi_query_execute",
     "rsq_multi_query_result", "rsq_multi_query_report", "rsq_multi_query_destroy",
@@ -381,11 +383,12 @@ class Query:
     def finalize(self):
         self.ctx._check(self.ctx._L.rsq_query_finalize(self.h))
 
-    def result(self) -> P.Result:
+    def result(self, text: bool = True) -> P.Result:
+        """text=False skips the (pure Python) serialisation — for results with millions of rows"""
         v = P.rsq_result_view()
         self.ctx._check(self.ctx._L.rsq_query_result(self.h, C.byref(v)))
         res = P.Result.from_view(v)
-        res.text = res.serialize()
+        res.text = res.serialize() if text else None
         return res
 
     def report(self) -> rsq_report:
@@ -412,7 +415,7 @@ class Database:
     CREATE TABLE records a schema, BULK INSERT loads a '.tbl' file into device columns, SELECT is parsed, planned, compiled
     and executed.  execute_script splits at ';' like expandExecStatements (execute.h:470-505)."""
 
-    KINDS = {1: "SELECT", 2: "CREATE_TABLE", 3: "BULK_INSERT"}
+    KINDS = {1: "SELECT", 2: "CREATE_TABLE", 3: "BULK_INSERT", 4: "CONTROL"}
 
     def __init__(self, ctx: Context):
         self.ctx = ctx
@@ -430,11 +433,17 @@ class Database:
         kind = C.c_int32(0)
         v = P.rsq_result_view()
         self.ctx._check(self.ctx._L.rsq_db_execute(self.h, sql.encode("latin1"), C.byref(kind), C.byref(v)))
+        self.last_kind = self.KINDS.get(kind.value)
         if kind.value != 1:
             return None
         res = P.Result.from_view(v)
         res.text = res.serialize()
         return res
+
+    @property
+    def message(self) -> str:
+        """what the reference's printQueryResult prints for the last statement in front of the relation"""
+        return self.ctx._L.rsq_db_message(self.h).decode("utf8", "replace")
 
     def report(self) -> rsq_report:
         r = rsq_report()

@@ -1,10 +1,22 @@
-"""BASELINE.json's full sizes (SF10: 59 999 996 lineitem rows, 15 M orders, 1.5 M customers; device-generated), checked
-through size-independent properties — the oracle cannot run these sizes in seconds:
+"""BASELINE.json's full sizes (SF1 and SF10: 59 999 996 lineitem rows, 15 M orders, 1.5 M customers; device-generated).
+
+DIRECT parity first: the engine's Q1 / Q6 / Q3 answers over the device-generated SF1 and SF10 tables are compared byte for
+byte with the answers of the UNMODIFIED reference on the same rows (tests/golden/ref_full_*.tbl, made in the build
+container by tests/golden/make_fullsize_golden.py from the numpy twin of the generator — the two generators are proven
+bit-identical at small sizes in tests/test_gpu_tpch.py, and at SF1 here by a column checksum), the way the reference's
+own test/test_queries.h:5-60 compares with test/reference/q*.tbl.  BASELINE config 5's 1.25 B-row shards are checked
+against checksums computed independently with numpy (tests/golden/synth_shard_checksums.json).
+
+Then size-independent properties:
   * linearity: Q1 over the whole table == finalize(merge of the partial tables of two row-range shards), bit for bit;
   * a checksum of checksums: the per-group counts / sums of Q1 add up to an UNGROUPED aggregate with the same
     predicate, which runs through a different kernel shape;
   * Q3: the key-aligned two-shard run merges to exactly the unsharded top-10; revenue is sorted; repeatable.
 Small-size parity against the oracle and the reference's goldens is in the other test files."""
+import hashlib
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -13,6 +25,18 @@ from resql_amd.dist import merge_ordered_results, shard_rows, shard_rows_on_key
 
 pytestmark = pytest.mark.gpu
 SF = 10.0
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _golden(name):
+    with open(os.path.join(GOLDEN, f"ref_full_{name}.tbl")) as f:
+        return f.read()
+
+
+@pytest.fixture(scope="module")
+def full_index():
+    with open(os.path.join(GOLDEN, "ref_full_index.json")) as f:
+        return json.load(f)
 
 
 @pytest.fixture(scope="module")
@@ -21,6 +45,75 @@ def big(gpu_ctx):
     li = gpu_ctx.generate(engine.GEN_LINEITEM, n, SF, param=1)
     yield n, li
     li.close()
+
+
+@pytest.mark.parametrize("sf", [1.0, 10.0])
+def test_q1_q6_q3_equal_the_reference_at_full_size(gpu_ctx, big, full_index, sf):
+    """TPC-H Q1 (BASELINE config 2 at SF1, the headline configuration at SF10), Q6 and Q3 (config 3 at SF10) against the
+    reference's own answers, byte for byte — result rows, scales, order"""
+    if sf == SF:
+        n, li = big
+        own = False
+    else:
+        n = datagen.n_lineitem(sf)
+        li = gpu_ctx.generate(engine.GEN_LINEITEM, n, sf, param=1)
+        own = True
+    tag = f"sf{sf:g}"
+    assert full_index[f"q1_{tag}"]["lineitem_rows"] == n
+    cu = gpu_ctx.generate(engine.GEN_CUSTOMER, datagen.n_customer(sf), sf)
+    od = gpu_ctx.generate(engine.GEN_ORDERS, datagen.n_orders(sf), sf)
+    try:
+        if sf == 1.0:
+            # the device generator against its numpy twin at this size: one checksum per Q1 column
+            host = datagen.lineitem_columns(0, n, sf, columns=set(tpch.Q1_COLUMNS))
+            for name, dt in (("l_quantity", np.int64), ("l_extendedprice", np.int64), ("l_discount", np.int64), ("l_tax", np.int64),
+                             ("l_returnflag", np.uint8), ("l_linestatus", np.uint8), ("l_shipdate", np.uint32)):
+                dev = li.read_column(name, dt)
+                assert np.array_equal(dev, host[name]), name
+        schema_q1 = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
+        for name, plan, tabs in (("q1", tpch.q1_plan(schema_q1), [li]), ("q6", tpch.q6_plan(schema_q1), [li]),
+                                 ("q3", tpch.q3_plan(tpch.customer_table(0.001), tpch.orders_table(0.001),
+                                                     tpch.lineitem_table(0.001, tpch.Q3_LINEITEM_COLUMNS, n_rows=0)), [cu, od, li])):
+            q = gpu_ctx.compile(plan, tabs)
+            try:
+                for _ in range(2):                       # the second execution reuses table capacities / the late-load forms
+                    q.execute()
+                    assert q.result().text == _golden(f"{name}_{tag}"), f"{name} at SF{sf:g} differs from the reference"
+            finally:
+                q.close()
+    finally:
+        cu.close(); od.close()
+        if own:
+            li.close()
+
+
+def _synth_cases():
+    with open(os.path.join(GOLDEN, "synth_shard_checksums.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", sorted(_synth_cases()))
+def test_synthetic_10b_shards_against_numpy_checksums(gpu_ctx, case):
+    """BASELINE config 5: one 1.25 B-row shard (40 GB, device-generated) of the 10 B-row table per case — group counts 8
+    (register accumulators) and 2^20 (HBM table: atomics at 1 %, partitioned at 10 % / 50 %) — against the independently
+    computed answer: number of groups, totals, and the SHA-256 of the sorted serialised rows"""
+    g = _synth_cases()[case]
+    shard = gpu_ctx.generate(engine.GEN_SYNTHETIC, g["rows"], 1.0, row0=g["row0"], param=g["groups"])
+    try:
+        q = gpu_ctx.compile(tpch.synthetic_plan(tpch.synthetic_table(16, g["groups"]), g["threshold"]), [shard])
+        try:
+            q.execute()
+            res = q.result(text=False)
+        finally:
+            q.close()
+    finally:
+        shard.close()
+    assert res.names == ["b", "sum_c", "sum_d", "cnt"] and res.tuple_size == 32      # four BIGINTs per packed tuple
+    rows = np.frombuffer(res.tuples, dtype=np.int64).reshape(-1, 4)
+    assert rows.shape[0] == res.n_rows == g["result_groups"]
+    assert [int(rows[:, 1].sum()), int(rows[:, 2].sum()), int(rows[:, 3].sum())] == [g["sum_c"], g["sum_d"], g["cnt"]]
+    lines = sorted(f"{b}|{sc}|{sd}|{c}|" for b, sc, sd, c in rows.tolist())            # serializeRelation's format for BIGINTs
+    assert hashlib.sha256(("\n".join(lines) + "\n").encode()).hexdigest() == g["sha256_sorted_lines"]
 
 
 def _ungrouped_q1(table):
@@ -38,7 +131,7 @@ def test_q1_sf10_linearity_and_checksums(gpu_ctx, big):
     q = gpu_ctx.compile(tpch.q1_plan(schema_only), [li])
     q.execute()
     whole = q.result()
-    assert whole.n_rows == 4 and q.report().kernel_time_ms < 1.0          # the headline kernel: 0.35 ms on MI355X
+    assert whole.n_rows == 4 and q.report().kernel_time_ms < 0.45         # the headline kernel: 0.34-0.36 ms on MI355X
     # ---- linearity: two shards, partial tables merged as the multi-GPU path merges them ----
     n_min, n_max, n_sum = q.partial_layout()
     merged = None

@@ -97,8 +97,13 @@ def test_statement_loop_create_load_select(gpu_ctx, tmp_path):
         assert res.text.splitlines()[1:] == ["GERMANY                  |about 7|", "CANADA                   |about 3|"]
         with pytest.raises(engine.EngineError, match="Syntax error."):
             db.execute("select n_name from nation where")
-        with pytest.raises(engine.EngineError, match="already holds data"):
-            db.execute(f'bulk insert region from "{tmp_path}/region.tbl" with ( fieldterminator="|" )')
+        with pytest.raises(engine.EngineError, match="single-character field terminators"):          # execute.h:340-342
+            db.execute(f'bulk insert region from "{tmp_path}/region.tbl" with ( fieldterminator="||" )')
+        # a second BULK INSERT appends, as the reference's does (AppendIterator on the existing relation, execute.h:348-350)
+        before = db.execute("select count(*) as n from region").text.splitlines()[1]
+        db.execute(f'bulk insert region from "{tmp_path}/region.tbl" with ( fieldterminator="|" )')
+        after = db.execute("select count(*) as n from region").text.splitlines()[1]
+        assert int(after.rstrip("|")) == 2 * int(before.rstrip("|"))
         assert db.report().num_kernels >= 1
         # a generated table handed over to the database
         li = gpu_ctx.generate(engine.GEN_LINEITEM, 60_000, 0.01, param=1)
@@ -195,9 +200,52 @@ def test_plain_c_host_end_to_end(tmp_path):
             f.write(f"{nat.col('n_nationkey').data[i]}|{nat.col('n_name').data[i].decode()}|{nat.col('n_regionkey').data[i]}|c{i}|\n")
     pr = subprocess.run([exe, "create table nation ( n_nationkey int, n_name char(25), n_regionkey int, n_comment varchar(152) )",
                          f'bulk insert nation from "{tmp_path}/nation.tbl" with ( fieldterminator="|" )',
-                         "select n_name, n_comment from nation where n_regionkey = 2 order by n_name desc limit 3"],
+                         "select n_name, n_comment from nation where n_regionkey = 2 order by n_name desc limit 3",
+                         "showperf", "showperf=true", "tables",
+                         "select count(*) as n from nation"],
                         capture_output=True, text=True)
     assert pr.returncode == 0, pr.stdout + pr.stderr
     out = pr.stdout.splitlines()
     assert out[:3] == ["create table ok", "bulk insert ok", "3 row(s)"]
-    assert out[3:] == ["VIETNAM                  |c21|", "JAPAN                    |c12|", "INDONESIA                |c9|"]
+    assert out[3:6] == ["VIETNAM                  |c21|", "JAPAN                    |c12|", "INDONESIA                |c9|"]
+    # control statements through the same C entry point (processControl, execute.h:454-474)
+    assert out[6] == "false"
+    assert out[7].startswith("┌") and any("nation" in l and " 25 " in l for l in out[8:14])
+    rest = out[out.index(next(l for l in out if l.endswith("1 tables"))) + 1:]
+    assert [l.split()[0] for l in rest if l.startswith(("compile:", "execute:", "device:"))] == ["compile:", "execute:", "device:"]
+    assert rest[-2:] == ["1 row(s)", "25|"]
+
+
+def test_control_variables_shape_what_a_select_returns(gpu_ctx, tmp_path, monkeypatch):
+    """processControl's variables (execute.h:454-474) and what executeSelectPlan / printQueryResult do with them
+    (execute.h:213-247, 173-200; showReport JitContextFlounder.h:132-150): showplan, showperf, showasm, showfln, tofile"""
+    monkeypatch.chdir(tmp_path)                                   # tofile writes "qres.tbl" into the working directory
+    nat = tpch_full.nation()
+    db = engine.Database(gpu_ctx)
+    try:
+        db.add_table(gpu_ctx.table(nat))
+        sql = "select n_regionkey, count(*) as c from nation group by n_regionkey order by n_regionkey"
+        plain = db.execute(sql)
+        assert db.last_kind == "SELECT" and db.message == "\n" and not os.path.exists("qres.tbl")
+        for stmt in ("showperf=true", "showplan = true", "tofile=true", "threads=8"):
+            assert db.execute(stmt) is None and db.last_kind == "CONTROL"
+        res = db.execute(sql)
+        assert res.text == plain.text
+        msg = db.message.splitlines()
+        assert any("AGGREGATION" in l.upper() for l in msg) and any("SCAN" in l.upper() for l in msg)        # the operator tree
+        perf = [l for l in msg if l.startswith(("compile: ", "execute: ", "device:  "))]
+        assert [l.split()[0] for l in perf] == ["compile:", "execute:", "device:"] and all(l.split()[2] == "ms" or l.split()[2] == "ms," for l in perf)
+        assert float(perf[1].split()[1]) > 0
+        with open("qres.tbl") as f:                                # serializeRelation's format (dbdata.h:688-701)
+            assert f.read() == "".join(l + "\n" for l in plain.text.splitlines() if not l.startswith("#"))
+        db.execute("showplan=false"); db.execute("showperf=false"); db.execute("tofile=false")
+        db.execute("showasm=true")
+        db.execute(sql)
+        assert "__global__" in db.message and "rsq_device.h" in db.message                                   # the generated HIP source
+        db.execute("showasm=false"); db.execute("showfln=true")
+        db.execute(sql)
+        assert "pipeline 0:" in db.message and "__global__" not in db.message                                # the pipeline description
+        db.execute("threads")
+        assert db.message == "8\n"
+    finally:
+        db.close()
