@@ -337,11 +337,35 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value) {
 // round, 54 K of them for TPC-H Q3 at SF10 — cost 620 us.  The table's first-row block is read once (the earlier
 // count-then-write form read it twice with 32 dependent rounds per thread: 73 us for 4 M slots; this form: 19 us).
 // Rows beyond `maxRows` are counted but not written (the host re-runs with a larger buffer).
+// order-preserving unsigned image of a sort key ("earlier in the requested order" = "larger"), see the top-k section below
+__device__ __forceinline__ u64 topk_image(i64 w, int is32, int desc) {
+    const i64 v = is32 ? (i64)(int)(unsigned)w : w;
+    const u64 u = (u64)v ^ 0x8000000000000000ull;
+    return desc ? u : ~u;
+}
+
+// inverse of rsq::rank_mix (kernels/rsq_device.h — keep the two in lock step): the Feistel rounds backwards
+__device__ inline u64 rank_mix_round(u64 v, u64 key) {
+    v = (v + key) * 0x9E3779B97F4A7C15ull; v ^= v >> 29; v *= 0xBF58476D1CE4E5B9ull; v ^= v >> 32;
+    return v;
+}
+__device__ inline u64 rank_unmix(u64 x, u64 cap) {
+    const int k = 63 - __builtin_clzll(cap), lo = k - (k >> 1), hi = k >> 1;
+    const u64 mlo = (1ull << lo) - 1, mhi = (1ull << hi) - 1;
+    u64 L = (x >> lo) & mhi, R = x & mlo;
+    L ^= rank_mix_round(R, 3) & mhi;
+    R ^= rank_mix_round(L, 2) & mlo;
+    L ^= rank_mix_round(R, 1) & mhi;
+    return (L << lo) | R;
+}
+
 template <int COMPACT_PER_THREAD>
 __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__ first, i64 cap, const i64* __restrict__ words, int nWords,
                                                          int wordsAos, const i64* __restrict__ acc, int nAcc, i64* __restrict__ out,
-                                                         unsigned maxRows, unsigned* count, int unmix) {
+                                                         unsigned maxRows, unsigned* count, int unmix, int keyWord, int keyIs32, int keyDesc,
+                                                         u64* __restrict__ imageRange) {
     const int stride = 1 + nWords + nAcc;
+    u64 imgMax = 0, imgMaxInv = 0;      // range of the sort-key images of the rows written (keyWord >= 0): max(u), max(~u)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ unsigned s_wave[4];
     __shared__ unsigned s_base;
@@ -385,28 +409,35 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                 o[0] = first[s];
                 // (no word arrays: the one word is the slot index itself — dense aggregate tables, whose slot IS the group id)
                 // (rank dictionaries keep the aggregates of entry r at rank_mix(r), kernels/rsq_device.h: the entry of accumulator
-                // slot s is the inverse — the same steps backwards, with the multipliers' inverses modulo 2^64)
+                // slot s is the inverse)
                 i64 e = s;
-                if (unmix) {
-                    const u64 mask = (u64)cap - 1;
-                    const int k = 63 - __builtin_clzll((u64)cap), h = (k + 1) >> 1;
-                    u64 x = (u64)s;
-                    x ^= x >> h;
-                    x = (x * 0x96DE1B173F119089ull) & mask;          // (0xBF58476D1CE4E5B9)^-1 mod 2^64
-                    x ^= x >> h;
-                    x = (x * 0xF1DE83E19937733Dull) & mask;          // (0x9E3779B97F4A7C15)^-1 mod 2^64
-                    e = (i64)x;
-                }
+                if (unmix) e = (i64)rank_unmix((u64)s, (u64)cap);
                 for (int w = 0; w < nWords; w++) o[1 + w] = !words ? s : wordsAos ? words[(size_t)e * nWords + w] : words[(size_t)w * cap + e];
                 for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
+                if (keyWord >= 0) { const u64 u = topk_image(o[keyWord], keyIs32, keyDesc); imgMax = u > imgMax ? u : imgMax; imgMaxInv = ~u > imgMaxInv ? ~u : imgMaxInv; }
             }
         }
         __syncthreads();          // s_wave / s_base are rewritten by the next chunk
     }
+    if (keyWord >= 0) {          // one pair of atomics per workgroup (atomics on one word serialise)
+        __shared__ u64 s_img[8];
+        for (int m = 32; m >= 1; m >>= 1) {
+            const u64 a = (u64)__shfl_xor((long long)imgMax, m, 64), b = (u64)__shfl_xor((long long)imgMaxInv, m, 64);
+            imgMax = a > imgMax ? a : imgMax; imgMaxInv = b > imgMaxInv ? b : imgMaxInv;
+        }
+        if (lane == 0) { s_img[wave] = imgMax; s_img[4 + wave] = imgMaxInv; }
+        __syncthreads();
+        if (t == 0) {
+            u64 a = 0, b = 0;
+            for (int w = 0; w < 4; w++) { a = s_img[w] > a ? s_img[w] : a; b = s_img[4 + w] > b ? s_img[4 + w] : b; }
+            if (a | b) { atomicMax(&imageRange[0], a); atomicMax(&imageRange[1], b); }
+        }
+    }
 }
 
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
-                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix) {
+                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix, int keyWord, bool keyIs32,
+                    bool keyDesc, uint64_t* imageRange) {
     // slots per thread: every chunk costs one reservation atomic on the same word (they serialise), so large tables take
     // large chunks; swept on the box through RSQ_COMPACT_PT for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us
     static const int forced = getenv("RSQ_COMPACT_PT") ? atoi(getenv("RSQ_COMPACT_PT")) : 0;
@@ -414,7 +445,7 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
     const int64_t chunkSlots = 256 * (int64_t)perThread;
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8 * (int64_t)ctx.numCUs, (capacity + chunkSlots - 1) / chunkSlots));
 #define RSQ_LAUNCH_COMPACT(PT) hipLaunchKernelGGL(k_compact_entries<PT>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, \
-                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0)
+                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0, imageRange ? keyWord : -1, keyIs32 ? 1 : 0, keyDesc ? 1 : 0, (u64*)imageRange)
     if (perThread >= 64) RSQ_LAUNCH_COMPACT(64); else if (perThread >= 32) RSQ_LAUNCH_COMPACT(32); else RSQ_LAUNCH_COMPACT(16);
 #undef RSQ_LAUNCH_COMPACT
     RSQ_HIP(hipGetLastError());
@@ -431,12 +462,6 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
 enum { TOPK_PASSES = 6, TOPK_BINS = 2048 };
 __device__ __forceinline__ int topk_shift(int p) { return p < 5 ? 53 - 11 * p : 0; }
 __device__ __forceinline__ int topk_bits(int p) { return p < 5 ? 11 : 9; }
-
-__device__ __forceinline__ u64 topk_image(i64 w, int is32, int desc) {
-    const i64 v = is32 ? (i64)(int)(unsigned)w : w;
-    const u64 u = (u64)v ^ 0x8000000000000000ull;
-    return desc ? u : ~u;
-}
 
 // Replays the digit choices of passes [0, upto): returns the chosen prefix (the top bits of T, right-aligned) and, in
 // *remOut, how many rows with exactly that prefix are still wanted.  *allOut is set when fewer than `want` rows exist
@@ -531,14 +556,105 @@ __global__ void __launch_bounds__(256) k_topk_gather(const i64* __restrict__ row
     }
 }
 
-size_t topkHistBytes() { return (size_t)TOPK_PASSES * TOPK_BINS * sizeof(unsigned); }
+// ---- the short form: ONE histogram over the images' actual range ------------------------------------------------
+// With the smallest and largest image known (the compaction kernel collects them while it writes the rows), the images are
+// stretched to that range, so the very first 11-bit digit already tells rows apart: the bin that holds the `want`-th
+// largest image and the bins above it together hold the candidates — a few dozen rows for TPC-H Q3's 114 K groups — and the
+// remaining five digit passes are not needed: two launches instead of seven.  The candidates are a superset of the exact
+// selection's (every row at or above the `want`-th largest image is among them); should they not fit the candidate buffer,
+// the host runs the exact selection.
+__device__ __forceinline__ unsigned topk_range_digit(u64 u, u64 lo, int shift) { return (unsigned)(((u - lo) << shift) >> 53); }
+
+__global__ void __launch_bounds__(256) k_topk_range_hist(const i64* __restrict__ rows, int stride, int keyWord, int is32, int desc,
+                                                         const unsigned* __restrict__ nRows, unsigned maxRows, const u64* __restrict__ imageRange,
+                                                         unsigned* __restrict__ hist) {
+    __shared__ unsigned s_hist[TOPK_BINS];
+    for (int b = threadIdx.x; b < TOPK_BINS; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    const u64 hi = imageRange[0], lo = ~imageRange[1];
+    const int shift = hi > lo ? __builtin_clzll(hi - lo) : 0;
+    const unsigned n = *nRows < maxRows ? *nRows : maxRows;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        atomicAdd(&s_hist[topk_range_digit(topk_image(rows[(size_t)i * stride + keyWord], is32, desc), lo, shift)], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < TOPK_BINS; b += 256) { const unsigned c = s_hist[b]; if (c) atomicAdd(&hist[b], c); }
+}
+
+__global__ void __launch_bounds__(256) k_topk_range_gather(const i64* __restrict__ rows, int stride, int keyWord, int is32, int desc,
+                                                           const unsigned* __restrict__ nRows, unsigned maxRows, const u64* __restrict__ imageRange,
+                                                           const unsigned* __restrict__ hist, unsigned want, i64* __restrict__ cand, unsigned capacity,
+                                                           unsigned* candCount) {
+    // the lowest bin that still belongs to the candidates: the highest b with (rows in bins >= b) >= want
+    __shared__ unsigned s_above[256];
+    __shared__ unsigned s_bin;
+    const int t = threadIdx.x;
+    unsigned c[8], local = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) { c[b] = hist[t * 8 + b]; local += c[b]; }
+    if (t == 0) s_bin = 0;                                  // fewer than `want` rows in all: every row qualifies
+    s_above[t] = local;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                     // inclusive suffix sums over the threads
+        const unsigned v = t + d < 256 ? s_above[t + d] : 0u;
+        __syncthreads();
+        s_above[t] += v;
+        __syncthreads();
+    }
+    unsigned running = s_above[t] - local;                  // rows in bins above this thread's eight
+#pragma unroll
+    for (int b = 7; b >= 0; b--) {
+        if (running < want && want <= running + c[b]) s_bin = (unsigned)(t * 8 + b);
+        running += c[b];
+    }
+    __syncthreads();
+    const unsigned bin = s_bin;
+    const u64 hi = imageRange[0], lo = ~imageRange[1];
+    const int shift = hi > lo ? __builtin_clzll(hi - lo) : 0;
+    const unsigned n = *nRows < maxRows ? *nRows : maxRows;
+    const int lane = threadIdx.x & 63;
+    const unsigned rounds = (n + gridDim.x * 256u - 1) / (gridDim.x * 256u);
+    for (unsigned r = 0; r < rounds; r++) {
+        const unsigned i = (r * gridDim.x + blockIdx.x) * 256u + threadIdx.x;
+        const bool take = i < n && topk_range_digit(topk_image(rows[(size_t)i * stride + keyWord], is32, desc), lo, shift) >= bin;
+        const unsigned long long vote = __ballot(take);
+        if (vote == 0) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(candCount, (unsigned)__popcll(vote));
+        base = (unsigned)__shfl((int)base, 0, 64);
+        if (!take) continue;
+        const unsigned pos = base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull));
+        if (pos >= capacity) continue;
+        const i64* src = rows + (size_t)i * stride;
+        i64* dst = cand + (size_t)pos * stride;
+        for (int w = 0; w < stride; w++) dst[w] = src[w];
+    }
+}
+
+// scratch of both forms: [image range: 2 x u64][candidate count: u32][pad: u32][TOPK_PASSES histograms]
+size_t topkHistBytes() { return 24 + (size_t)TOPK_PASSES * TOPK_BINS * sizeof(unsigned); }
+
+// to be enqueued BEFORE the compaction that collects the image range: clears range, candidate count and the histogram
+void prepareTopCandidatesRange(Context& ctx, void* scratch) { RSQ_HIP(hipMemsetAsync(scratch, 0, 24 + TOPK_BINS * sizeof(unsigned), ctx.stream)); }
+
+void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
+                              uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* cand, uint32_t capacity) {
+    const u64* range = (const u64*)scratch;
+    unsigned* candCount = (unsigned*)((char*)scratch + 16);
+    unsigned* hist = (unsigned*)((char*)scratch + 24);
+    const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx.numCUs, (rowsUpperBound + 2047) / 2048));
+    hipLaunchKernelGGL(k_topk_range_hist, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
+                       (const unsigned*)nRows, (unsigned)rowsUpperBound, range, hist);
+    hipLaunchKernelGGL(k_topk_range_gather, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
+                       (const unsigned*)nRows, (unsigned)rowsUpperBound, range, (const unsigned*)hist, (unsigned)want, (i64*)cand, (unsigned)capacity, candCount);
+    RSQ_HIP(hipGetLastError());
+}
 
 void selectTopCandidates(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
-                         uint32_t rowsUpperBound, uint32_t want, uint64_t* images, uint32_t* hists, int64_t* cand, uint32_t capacity,
-                         uint32_t* candCount) {
+                         uint32_t rowsUpperBound, uint32_t want, uint64_t* images, void* scratch, int64_t* cand, uint32_t capacity) {
+    unsigned* candCount = (unsigned*)((char*)scratch + 16);
+    unsigned* hists = (unsigned*)((char*)scratch + 24);
     const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx.numCUs, (rowsUpperBound + 2047) / 2048));
-    RSQ_HIP(hipMemsetAsync(hists, 0, topkHistBytes(), ctx.stream));
-    RSQ_HIP(hipMemsetAsync(candCount, 0, 4, ctx.stream));
+    RSQ_HIP(hipMemsetAsync(scratch, 0, topkHistBytes(), ctx.stream));
     for (int p = 0; p < TOPK_PASSES; p++)
         hipLaunchKernelGGL(k_topk_hist, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
                            (const unsigned*)nRows, (unsigned)rowsUpperBound, (u64*)images, (unsigned*)hists, p, (unsigned)want);
@@ -627,9 +743,9 @@ void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, i
 // 256-bit blocks.  Input that is clustered by the key (TPC-H orders by o_orderkey) arrives nearly in rank order, so the
 // placement writes walk the entry array almost sequentially; input in random order is still placed correctly.
 // ------------------------------------------------------------------------------------------------
-#define RANK_CHUNK_BLOCKS 4096          /* = RSQ_RANK_CHUNK_BLOCKS: 256-bit blocks per workgroup */
-__global__ void __launch_bounds__(256) k_rank_blocks(const unsigned* __restrict__ bm, i64 nBlocks, unsigned* __restrict__ blockRank,
-                                                     unsigned* __restrict__ chunkTotal) {
+#define RANK_CHUNK_BLOCKS 4096          /* = RSQ_RANK_CHUNK_BLOCKS: 32-byte blocks per workgroup */
+// blocks are [rank word | 7 bitmap words]; this pass writes every block's rank relative to its chunk of 4096 blocks
+__global__ void __launch_bounds__(256) k_rank_blocks(unsigned* __restrict__ bm, i64 nBlocks, unsigned* __restrict__ chunkTotal) {
     __shared__ unsigned s_tot[256];
     const i64 b0 = (i64)blockIdx.x * RANK_CHUNK_BLOCKS + (i64)threadIdx.x * 16;
     unsigned c[16];
@@ -640,7 +756,7 @@ __global__ void __launch_bounds__(256) k_rank_blocks(const unsigned* __restrict_
         if (b0 + j < nBlocks) {
             const uint4* w = reinterpret_cast<const uint4*>(bm + (b0 + j) * 8);
             const uint4 lo = w[0], hi = w[1];
-            n = __popc(lo.x) + __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+            n = __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
         }
         c[j] = n; mine += n;
     }
@@ -654,7 +770,7 @@ __global__ void __launch_bounds__(256) k_rank_blocks(const unsigned* __restrict_
     }
     unsigned run = s_tot[threadIdx.x] - mine;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { if (b0 + j < nBlocks) blockRank[b0 + j] = run; run += c[j]; }
+    for (int j = 0; j < 16; j++) { if (b0 + j < nBlocks) bm[(b0 + j) * 8] = run; run += c[j]; }
     if (threadIdx.x == 255) chunkTotal[blockIdx.x] = s_tot[255];
 }
 
@@ -695,7 +811,7 @@ __global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp
         const u64 d = (u64)(rec[0] - bmMin);
         const unsigned* blk = bm + ((d >> 8) << 3);
         const unsigned wi = (unsigned)(d >> 5) & 7u, bit = (unsigned)d & 31u;
-        unsigned r = chunkBase[d >> 20] + blockRank[d >> 8];
+        unsigned r = blockRank[d >> 8];
         for (unsigned j = 0; j < 8; j++) {
             const unsigned x = blk[j];
             r += j < wi ? __popc(x) : (j == wi ? __popc(x & ((1u << bit) - 1u)) : 0u);
@@ -704,23 +820,50 @@ __global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp
     }
 }
 
-void rankTableIndex(Context& ctx, const uint32_t* bitmap, int64_t nBlocks, uint32_t* blockRank, uint32_t* chunkTotal, uint32_t* chunkBase) {
+// the rank words become absolute (chunk base added): a probe then needs nothing but the block it tested
+__global__ void __launch_bounds__(256) k_rank_absolute(unsigned* __restrict__ bm, i64 nBlocks, const unsigned* __restrict__ chunkBase) {
+    for (i64 b = blockIdx.x * (i64)blockDim.x + threadIdx.x; b < nBlocks; b += (i64)gridDim.x * blockDim.x) bm[b * 8] += chunkBase[b / RANK_CHUNK_BLOCKS];
+}
+
+void rankTableIndex(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chunkTotal, uint32_t* chunkBase) {
     const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
-    hipLaunchKernelGGL(k_rank_blocks, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (const unsigned*)bitmap, (i64)nBlocks, (unsigned*)blockRank, (unsigned*)chunkTotal);
+    hipLaunchKernelGGL(k_rank_blocks, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (unsigned*)bitmap, (i64)nBlocks, (unsigned*)chunkTotal);
     hipLaunchKernelGGL(k_rank_chunks, dim3(1), dim3(1024), 0, ctx.stream, (const unsigned*)chunkTotal, nChunks, (unsigned*)chunkBase);
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (nBlocks + 255) / 256));
+    hipLaunchKernelGGL(k_rank_absolute, dim3(grid), dim3(256), 0, ctx.stream, (unsigned*)bitmap, (i64)nBlocks, (const unsigned*)chunkBase);
     RSQ_HIP(hipGetLastError());
 }
 
+// One workgroup per wave of the build pipeline: its region of the arrival-order buffer holds used[wave] records.
+__global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp, const unsigned* __restrict__ used, unsigned region,
+                                                    const unsigned* __restrict__ nRecords, int nWords, const unsigned* __restrict__ bm, i64 bmMin,
+                                                    const unsigned* __restrict__ chunkBase, int nChunks, i64* __restrict__ words, i64 capacity,
+                                                    unsigned* __restrict__ err) {
+    // as many records as distinct keys, and no more than the table was sized for — anything else means the build side changed
+    // since the sizing pass (two rows with one key, more rows): the host then falls back to the hash table
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (*nRecords != chunkBase[nChunks] || (i64)*nRecords > capacity)) atomicOr(err, 64u);
+    const unsigned n = used[blockIdx.x];
+    const i64* base = temp + (i64)blockIdx.x * region * nWords;
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
+        const i64* rec = base + (i64)i * nWords;
+        const u64 d = (u64)(rec[0] - bmMin);
+        const unsigned w = (unsigned)(d >> 5), blkI = w / 7u, wi = 1u + (w % 7u), bit = (unsigned)d & 31u;
+        const unsigned* blk = bm + (i64)blkI * 8;
+        unsigned r = blk[0];
+        for (unsigned j = 1; j < 8; j++) {
+            const unsigned x = blk[j];
+            r += j < wi ? __popc(x) : (j == wi ? __popc(x & ((1u << bit) - 1u)) : 0u);
+        }
+        if ((i64)r < capacity) for (int k = 0; k < nWords; k++) words[(i64)r * nWords + k] = rec[k];
+    }
+}
+
 void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uint32_t nWaves, uint32_t region, const uint32_t* nRecords, int nWords,
-                    const uint32_t* bitmap, int64_t bmMin, const uint32_t* blockRank, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
-                    int64_t capacity) {
+                    const uint32_t* bitmap, int64_t bmMin, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words, int64_t capacity) {
     const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
-    const int64_t slots = (int64_t)nWaves * region;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8 * (int64_t)ctx.numCUs, (slots + 255) / 256));
-    hipLaunchKernelGGL(k_rank_place, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)temp, (const unsigned*)used, (unsigned)nWaves, (unsigned)region,
-                       (const unsigned*)nRecords, nWords,
-                       (const unsigned*)bitmap, (i64)bmMin, (const unsigned*)blockRank, (const unsigned*)chunkBase, nChunks, (i64*)words, (i64)capacity,
-                       (unsigned*)ctx.dErr);
+    hipLaunchKernelGGL(k_rank_place, dim3(std::max(1u, nWaves)), dim3(256), 0, ctx.stream, (const i64*)temp, (const unsigned*)used, (unsigned)region,
+                       (const unsigned*)nRecords, nWords, (const unsigned*)bitmap, (i64)bmMin, (const unsigned*)chunkBase, nChunks, (i64*)words,
+                       (i64)capacity, (unsigned*)ctx.dErr);
     RSQ_HIP(hipGetLastError());
 }
 

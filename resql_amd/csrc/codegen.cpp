@@ -256,7 +256,8 @@ struct Walker {
     std::string rowParams, rowArgsTail, rowArgsTailGuarded;
     // key-bitmap words fetched for both rows of a lane (and all tiles in flight) before the first row is processed:
     // (table name, scanned column index) — see consumeProbe
-    std::vector<std::pair<std::string, int>> bitmapPrefetch;
+    struct BitmapPrefetch { std::string first; int second; bool interleaved; };
+    std::vector<BitmapPrefetch> bitmapPrefetch;
     std::string body;                          // row function body
     std::string closers;                       // closing braces of the open scopes
     std::string stateDecl, stateInit, prologue, epilogue, fileScope;
@@ -706,6 +707,9 @@ struct Walker {
         // one integer key with a key bitmap needs no hashing when its build keys prove unique.  The same kernel carries both
         // forms behind a uniform branch on a.<T>_rank; the host decides once, from the sizing pass.
         ht->rankCapable = ht->unique && ht->hasBitmap && ht->keyCas && ht->aos && keyVars.size() == 1 && envInt("RSQ_JOIN_RANK", 1, 0, 1) != 0;
+        // (a table that may become a rank dictionary keeps its bitmap in the interleaved layout, rsq_device.h bmi_word)
+        ht->bmInterleaved = ht->rankCapable;
+        const std::string bmw = ht->bmInterleaved ? "rsq::bmi_word(d)" : "d >> 5";
         const std::string bitSet = ht->hasBitmap ? "const u64 d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin); " : "";
         addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
         addArg(T + "_countonly", "u64", 0);
@@ -717,7 +721,7 @@ struct Walker {
             addArg(T + "_rank", "u64", 0); addArg(T + "_temp", "i64*", 0);
             openScope("if (a." + T + "_countonly) {");
             line("st.n_" + T + "++;");
-            line("{ " + bitSet + "const u32 b = 1u << (d & 31); if (atomicOr(&a." + T + "_bm[d >> 5], b) & b) atomicOr(a.err, (u32)rsq::NOTE_BUILD_KEYS_NOT_UNIQUE); }");
+            line("{ " + bitSet + "const u32 b = 1u << (d & 31); if (atomicOr(&a." + T + "_bm[" + bmw + "], b) & b) atomicOr(a.err, (u32)rsq::NOTE_BUILD_KEYS_NOT_UNIQUE); }");
             closeScope();
             openScope("else if (a." + T + "_rank) {");
             // The record goes to the arrival-order buffer, into the region of the wave that produced it: a.<T>_treg records
@@ -727,7 +731,7 @@ struct Walker {
             // fill count lives in LDS, because the lanes of a wave reach this point in diverged groups; it is written to
             // a.<T>_tused[wave] at the end, where the placement kernel finds it.  A wave that overflows its region says so
             // (the host then keeps the hash form).
-            line("{ " + bitSet + "atomicOr(&a." + T + "_bm[d >> 5], 1u << (d & 31)); }");
+            line("{ " + bitSet + "atomicOr(&a." + T + "_bm[" + bmw + "], 1u << (d & 31)); }");
             addArg(T + "_treg", "u64", 0); addArg(T + "_tused", "u32*", 0);
             stateDecl += "    u32* tch_" + T + ";\n";
             prologue += "    __shared__ u32 s_tch_" + T + "[RSQ_BLOCK_THREADS / 64];\n    st.tch_" + T + " = s_tch_" + T + " + (threadIdx.x >> 6);\n" +
@@ -788,7 +792,7 @@ struct Walker {
         line("st.n_" + T + "++;");
         if (ht->hasBitmap) {
             if (envInt("RSQ_DEBUG_NO_BITMAP_SET", 0, 0, 64) != ht->id + 1)      // (measurement only: table id + 1 builds no bitmap; its probes then find nothing)
-                line("{ " + bitSet + "atomicOr(&a." + T + "_bm[d >> 5], 1u << (d & 31)); }");
+                line("{ " + bitSet + "atomicOr(&a." + T + "_bm[" + bmw + "], 1u << (d & 31)); }");
         }
         closeScope();
         closeScope();
@@ -858,14 +862,14 @@ struct Walker {
                 for (auto& pf : bitmapPrefetch) if (pf.first == T) pfCol = -1;        // (one probe per table and pipeline)
             }
             if (pfCol >= 0) {
-                bitmapPrefetch.push_back({T, pfCol});
-                const std::string call = "rsq::bm_word(a." + T + "_bm, a." + T + "_bmmin, a." + T + "_bmbits, (i64)";
+                bitmapPrefetch.push_back({T, pfCol, ht.bmInterleaved});
+                const std::string call = std::string(ht.bmInterleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") + T + "_bm, a." + T + "_bmmin, a." + T + "_bmbits, (i64)";
                 rowParams += ", const u32 pf_" + T;
                 rowArgsTail += ", " + call + "a.c" + std::to_string(pfCol) + "[r])";
                 rowArgsTailGuarded += ", (valid ? " + call + "a.c" + std::to_string(pfCol) + "[r]) : 0u)";
                 openScope("if (" + T + "_d < a." + T + "_bmbits && ((pf_" + T + " >> (" + T + "_d & 31)) & 1u)) {");
             } else
-            openScope("if (" + T + "_d < a." + T + "_bmbits && ((a." + T + "_bm[" + T + "_d >> 5] >> (" + T + "_d & 31)) & 1u)) {");
+            openScope("if (" + T + "_d < a." + T + "_bmbits && ((a." + T + "_bm[" + (ht.bmInterleaved ? "rsq::bmi_word(" + T + "_d)" : T + "_d >> 5") + "] >> (" + T + "_d & 31)) & 1u)) {");
             selective = true;
         }
         // the table walk (dependent random accesses) runs behind the wave compaction when the pipeline is selective
@@ -917,22 +921,16 @@ struct Walker {
         if (ht.rankCapable && o->singleMatch) {
             // both forms of the table behind a uniform branch: the entry of a key whose bit is set (tested above) is entry
             // number rank(key) of the dictionary — or the first key-equal slot of the hash walk when the host kept the hash form
-            addArg(T + "_rank", "u64", 0); addArg(T + "_brank", "const u32*", 0); addArg(T + "_cbase", "const u32*", 0);
+            addArg(T + "_rank", "u64", 0);
             line("u64 " + T + "_s = 0; bool " + T + "_hit = false;");
             openScope("if (a." + T + "_rank) {");
             {
-                const int dbgRank = envInt("RSQ_DEBUG_RANK", 0, 0, 8);      // (measurement only, wrong results: 1 no rank at all, 2 prefix arrays only, 3 block popcount only)
+                const int dbgRank = envInt("RSQ_DEBUG_RANK", 0, 0, 2);      // (measurement only, wrong results: 1 the key offset, 2 its hash instead of the rank)
                 const std::string dd = "(u64)(" + keyVars[0] + " - a." + T + "_bmmin)";
                 if (dbgRank == 1) line(T + "_s = " + dd + " & (a." + T + "_cap - 1);");
-                else if (dbgRank == 2) line(T + "_s = ((u64)a." + T + "_cbase[" + dd + " >> 20] + (u64)a." + T + "_brank[" + dd + " >> 8]) & (a." + T + "_cap - 1);");
-                else if (dbgRank == 5) line(T + "_s = (" + dd + " & (a." + T + "_cap - 1)) ^ (rsq::rank_of(a." + T + "_bm, a." + T + "_brank, a." + T + "_cbase, " + dd + ") & (" + dd + " >> 40));");
-                else if (dbgRank == 6) line(T + "_s = rsq::hash64(rsq::rank_of(a." + T + "_bm, a." + T + "_brank, a." + T + "_cbase, " + dd + ")) & (a." + T + "_cap - 1);");
-                else if (dbgRank == 7) line(T + "_s = ((u64)a." + T + "_cbase[" + dd + " >> 20] + " + dd + ") & (a." + T + "_cap - 1);");
-                else if (dbgRank == 8) line(T + "_s = ((u64)a." + T + "_brank[" + dd + " >> 8] + " + dd + ") & (a." + T + "_cap - 1);");
-                else if (dbgRank == 4) line(T + "_s = rsq::hash64(" + dd + ") & (a." + T + "_cap - 1);");
-                else if (dbgRank == 3) line(T + "_s = ((u64)rsq::rank_in_block(a." + T + "_bm, " + dd + ") + " + dd + ") & (a." + T + "_cap - 1);");
+                else if (dbgRank == 2) line(T + "_s = rsq::hash64(" + dd + ") & (a." + T + "_cap - 1);");
                 else
-                line(T + "_s = rsq::rank_of(a." + T + "_bm, a." + T + "_brank, a." + T + "_cbase, (u64)(" + keyVars[0] + " - a." + T + "_bmmin));");
+                line(T + "_s = rsq::rank_of(a." + T + "_bm, (u64)(" + keyVars[0] + " - a." + T + "_bmmin));");
             }
             line(T + "_hit = true;");
             closeScope();
@@ -1755,7 +1753,7 @@ struct Walker {
                 s << "        u32 pf_" << pf.first << "_" << u << "[2] = {0u, 0u};\n";
                 s << "        if (tt" << u << " < ntiles) {\n";
                 for (int j = 0; j < 2; j++)
-                    s << "            pf_" << pf.first << "_" << u << "[" << j << "] = rsq::bm_word(a." << pf.first << "_bm, a." << pf.first << "_bmmin, a." << pf.first
+                    s << "            pf_" << pf.first << "_" << u << "[" << j << "] = " << (pf.interleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") << pf.first << "_bm, a." << pf.first << "_bmmin, a." << pf.first
                       << "_bmbits, (i64)t" << pf.second << "_" << u << "[" << j << "]);\n";
                 s << "        }\n";
             }

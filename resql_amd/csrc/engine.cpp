@@ -130,7 +130,6 @@ Query::~Query() {
     if (dTopkImages) ctx.free(dTopkImages);
     if (dTopkHists) ctx.free(dTopkHists);
     if (dCandRows) ctx.free(dCandRows);
-    if (dCandCount) ctx.free(dCandCount);
     if (dPartCounts) ctx.free(dPartCounts);
     if (dPartStart) ctx.free(dPartStart);
     if (dPartTotals) ctx.free(dPartTotals);
@@ -143,7 +142,6 @@ Query::~Query() {
         if (h->dBitmap) ctx.free(h->dBitmap);
         if (h->dTemp) ctx.free(h->dTemp);
         if (h->dTempUsed) ctx.free(h->dTempUsed);
-        if (h->dBlockRank) ctx.free(h->dBlockRank);
         if (h->dChunkTotal) ctx.free(h->dChunkTotal);
         if (h->dChunkBase) ctx.free(h->dChunkBase);
     }
@@ -297,8 +295,6 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
         if (f == "temp") return (uint64_t)(uintptr_t)h.dTemp;
         if (f == "treg") return (uint64_t)h.tempRegion;
         if (f == "tused") return (uint64_t)(uintptr_t)h.dTempUsed;
-        if (f == "brank") return (uint64_t)(uintptr_t)h.dBlockRank;
-        if (f == "cbase") return (uint64_t)(uintptr_t)h.dChunkBase;
         if (f == "hm") {      // slots per key value as a 32.32 fixed-point number, at most 4 (small ranges in large tables)
             if (h.bmBits <= 0) return 0;
             unsigned __int128 m = (((unsigned __int128)(uint64_t)h.capacity) << 32) / (unsigned __int128)(uint64_t)h.bmBits;
@@ -450,8 +446,8 @@ static void buildHashTable(Query& q, Pipeline& p) {
     const size_t nWords = h.keys.size() + h.payload.size();
     size_t bmWords = 0;
     if (h.hasBitmap) {
-        // whole 256-bit blocks (the rank dictionary's unit, kernels/rsq_device.h)
-        h.bmBlocks = (h.bmBits + 255) / 256;
+        // whole 32-byte blocks: 256 bits, or [rank word | 224 bits] for a table that may become a rank dictionary
+        h.bmBlocks = h.bmInterleaved ? (h.bmBits + 223) / 224 : (h.bmBits + 255) / 256;
         bmWords = (size_t)h.bmBlocks * 8;
         if (!h.dBitmap) h.dBitmap = (uint32_t*)ctx.alloc(bmWords * 4);
     }
@@ -482,7 +478,6 @@ static void buildHashTable(Query& q, Pipeline& p) {
             h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
             h.dTemp = (int64_t*)ctx.alloc((size_t)h.tempWaves * (size_t)h.tempRegion * 8 * std::max<size_t>(1, nWords));
             h.dTempUsed = (uint32_t*)ctx.alloc((size_t)h.tempWaves * 4);
-            h.dBlockRank = (uint32_t*)ctx.alloc((size_t)h.bmBlocks * 4);
             h.dChunkTotal = (uint32_t*)ctx.alloc((size_t)nChunks * 4);
             h.dChunkBase = (uint32_t*)ctx.alloc((size_t)(nChunks + 1) * 4);
         } else {
@@ -499,10 +494,10 @@ static void buildHashTable(Query& q, Pipeline& p) {
         prepareTableAsync(ctx, nullptr, 0, 0, h.dTempUsed, (size_t)h.tempWaves, h.dBitmap, bmWords, h.dCount);
         q.report.num_kernels++;
         launchPipeline(q, p, -1);
-        rankTableIndex(ctx, h.dBitmap, h.bmBlocks, h.dBlockRank, h.dChunkTotal, h.dChunkBase);
+        rankTableIndex(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase);
         rankTablePlace(ctx, h.dTemp, h.dTempUsed, (uint32_t)h.tempWaves, (uint32_t)h.tempRegion, h.dCount, (int)std::max<size_t>(1, nWords), h.dBitmap, h.bmMin,
-                       h.dBlockRank, h.dChunkBase, h.bmBlocks, h.dWords, h.capacity);
-        q.report.num_kernels += 3;
+                       h.dChunkBase, h.bmBlocks, h.dWords, h.capacity);
+        q.report.num_kernels += 4;
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
         return;
     }
@@ -573,6 +568,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     q.flatRun = partialOnly && q.aggPad > 1;
     const bool trace0 = getenv("RSQ_TRACE") != nullptr;
     uint32_t topkCapacity = 0, topkSpec = 0;      // > 0: this execution pre-selects ORDER BY ... LIMIT candidates on the device
+    bool topkRange = false;                       // ... with the short form (one histogram over the images' range)
     uint32_t groupRowsAllocated = 0;              // rows the group-row buffers of this execution can take
     // ---- the step in one launch: a single register-mode pipeline whose last workgroup publishes the table ----
     if (fusedEligible(q) && !trace0) {
@@ -736,29 +732,32 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
             q.hGroupRowsWords = need;
         }
-        RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
-        compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
-                       q.dGroupRows, groupRowsAllocated, q.dGroupCount,
-                       h.rank && !(getenv("RSQ_RANK_SCRAMBLE") && atoi(getenv("RSQ_RANK_SCRAMBLE")) == 0));
-        q.report.num_kernels++;
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
         if (q.topkWord == -2) planDeviceTopK(q);
-        if (q.topkWord >= 0 && nEntries >= 2048 && (uint64_t)nEntries > 4ull * q.topkWant && !(q.topkNeedsNoMerge && q.charGroupsNeedMerge)) {
-            topkCapacity = std::min<uint32_t>(nEntries, std::max<uint32_t>(256, 4 * q.topkWant));
-            if (q.topkImageRows < nEntries) {
-                if (q.dTopkImages) ctx.free(q.dTopkImages);
-                q.dTopkImages = (uint64_t*)ctx.alloc((size_t)nEntries * 8);
-                q.topkImageRows = nEntries;
-            }
-            if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = (uint32_t*)ctx.alloc(4); }
+        const bool preselect = q.topkWord >= 0 && nEntries >= 2048 && (uint64_t)nEntries > 4ull * q.topkWant && !(q.topkNeedsNoMerge && q.charGroupsNeedMerge);
+        if (preselect) {
+            topkCapacity = std::min<uint32_t>(nEntries, std::max<uint32_t>(1024, 4 * q.topkWant));
+            if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = q.dTopkHists + 4; }
             if (q.candCapacity < topkCapacity || q.candRowWords != q.groupRowWords) {
                 if (q.dCandRows) ctx.free(q.dCandRows);
                 q.dCandRows = (int64_t*)ctx.alloc((size_t)topkCapacity * (size_t)q.groupRowWords * 8);
                 q.candCapacity = topkCapacity; q.candRowWords = q.groupRowWords;
             }
-            selectTopCandidates(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated, q.topkWant,
-                                q.dTopkImages, q.dTopkHists, q.dCandRows, topkCapacity, q.dCandCount);
-            q.report.num_kernels += 7;
+            prepareTopCandidatesRange(ctx, q.dTopkHists);
+        }
+        RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
+        compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
+                       q.dGroupRows, groupRowsAllocated, q.dGroupCount,
+                       h.rank && !(getenv("RSQ_RANK_SCRAMBLE") && atoi(getenv("RSQ_RANK_SCRAMBLE")) == 0),
+                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr);
+        q.report.num_kernels++;
+        if (preselect) {
+            // the short form: the compaction collected the range of the sort key's images, ONE histogram over that range finds
+            // the candidates (aot_kernels.hip); the exact radix select runs only if they overflow the buffer (below)
+            selectTopCandidatesRange(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated, q.topkWant,
+                                     q.dTopkHists, q.dCandRows, topkCapacity);
+            q.report.num_kernels += 2;
+            topkRange = true;
             // the leading candidates travel with the same synchronisation as the counts (usually that is all of them)
             topkSpec = std::min<uint32_t>(topkCapacity, std::max<uint32_t>(q.topkWant + 64, 65536u / (uint32_t)(q.groupRowWords * 8)));
         }
@@ -784,24 +783,21 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 q.hGroupRowsWords = need;
             }
             if (!q.dGroupCount) q.dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
-            RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
-            compactEntries(ctx, (const int64_t*)q.dAgg /* block 0 = first row */, (int64_t)D, nullptr, 1, false, (const int64_t*)q.dAgg, W,
-                           q.dGroupRows, D, q.dGroupCount);
-            topkCapacity = std::min<uint32_t>(D, std::max<uint32_t>(256, 4 * q.topkWant));
-            if (q.topkImageRows < D) {
-                if (q.dTopkImages) ctx.free(q.dTopkImages);
-                q.dTopkImages = (uint64_t*)ctx.alloc((size_t)D * 8);
-                q.topkImageRows = D;
-            }
-            if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = (uint32_t*)ctx.alloc(4); }
+            topkCapacity = std::min<uint32_t>(D, std::max<uint32_t>(1024, 4 * q.topkWant));
+            if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = q.dTopkHists + 4; }
             if (q.candCapacity < topkCapacity || q.candRowWords != q.groupRowWords) {
                 if (q.dCandRows) ctx.free(q.dCandRows);
                 q.dCandRows = (int64_t*)ctx.alloc((size_t)topkCapacity * (size_t)q.groupRowWords * 8);
                 q.candCapacity = topkCapacity; q.candRowWords = q.groupRowWords;
             }
-            selectTopCandidates(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, D, q.topkWant,
-                                q.dTopkImages, q.dTopkHists, q.dCandRows, topkCapacity, q.dCandCount);
-            q.report.num_kernels += 8;
+            prepareTopCandidatesRange(ctx, q.dTopkHists);
+            RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
+            compactEntries(ctx, (const int64_t*)q.dAgg /* block 0 = first row */, (int64_t)D, nullptr, 1, false, (const int64_t*)q.dAgg, W,
+                           q.dGroupRows, D, q.dGroupCount, false, q.topkWord, q.topkIs32, q.topkDesc, (uint64_t*)q.dTopkHists);
+            selectTopCandidatesRange(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, D, q.topkWant,
+                                     q.dTopkHists, q.dCandRows, topkCapacity);
+            topkRange = true;
+            q.report.num_kernels += 3;
             topkSpec = std::min<uint32_t>(topkCapacity, std::max<uint32_t>(q.topkWant + 64, 65536u / (uint32_t)(q.groupRowWords * 8)));
             denseTopk = true;
         }
@@ -841,19 +837,35 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             HashTable& h = *hp;
             if (!h.rank) continue;
             any = true;
-            ctx.free(h.dWords); ctx.free(h.dTemp); ctx.free(h.dTempUsed); ctx.free(h.dBlockRank); ctx.free(h.dChunkTotal); ctx.free(h.dChunkBase);
+            ctx.free(h.dWords); ctx.free(h.dTemp); ctx.free(h.dTempUsed); ctx.free(h.dChunkTotal); ctx.free(h.dChunkBase);
             if (h.dAcc) ctx.free(h.dAcc);
-            h.dWords = h.dTemp = nullptr; h.dAcc = nullptr; h.dTempUsed = h.dBlockRank = h.dChunkTotal = h.dChunkBase = nullptr;
+            h.dWords = h.dTemp = nullptr; h.dAcc = nullptr; h.dTempUsed = h.dChunkTotal = h.dChunkBase = nullptr;
             h.rank = false; h.rankCapable = false; h.capacity = 0; h.lastCount = 0;
         }
         if (any) { executeQuery(q, partialOnly, async); return; }
     }
     checkDeviceError((uint32_t)q.hPinned[words]);
+    // the short candidate selection overflowed its buffer (many rows share the leading bin): the exact radix select, now
+    auto exactCandidates = [&](uint32_t rowsBound) -> int64_t {
+        if (q.topkImageRows < rowsBound) {
+            if (q.dTopkImages) ctx.free(q.dTopkImages);
+            q.dTopkImages = (uint64_t*)ctx.alloc((size_t)rowsBound * 8);
+            q.topkImageRows = rowsBound;
+        }
+        selectTopCandidates(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, rowsBound, q.topkWant, q.dTopkImages,
+                            q.dTopkHists, q.dCandRows, topkCapacity);
+        uint32_t n = 0;
+        RSQ_HIP(hipMemcpyAsync(&n, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        if (n <= topkCapacity) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dCandRows, (size_t)n * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost));
+        return (int64_t)n;
+    };
     if (!partialOnly) {
         double t1 = nowMs();
         if (denseTopk) {
             const int64_t nGroups = (int64_t)(uint32_t)q.hPinned[words + 1];
-            const int64_t nCand = (int64_t)(uint32_t)q.hPinned[words + 2];
+            int64_t nCand = (int64_t)(uint32_t)q.hPinned[words + 2];
+            if (topkRange && nCand > (int64_t)topkCapacity) { nCand = exactCandidates(groupRowsAllocated); topkSpec = topkCapacity; }
             const size_t rowBytes = (size_t)q.groupRowWords * 8;
             bool done = false;
             if (nCand <= (int64_t)topkCapacity && nCand < nGroups) {
@@ -893,7 +905,8 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 executeQuery(q, partialOnly, async);
                 return;
             }
-            const int64_t nCand = topkCapacity ? (int64_t)(uint32_t)q.hPinned[words + 2] : 0;
+            int64_t nCand = topkCapacity ? (int64_t)(uint32_t)q.hPinned[words + 2] : 0;
+            if (topkRange && nCand > (int64_t)topkCapacity) { nCand = exactCandidates(groupRowsAllocated); topkSpec = topkCapacity; }
             const size_t rowBytes = (size_t)q.groupRowWords * 8;
             q.candidateRun = false;
             if (topkCapacity && nCand <= (int64_t)topkCapacity && nCand < nGroups) {

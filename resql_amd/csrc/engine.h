@@ -101,12 +101,12 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
 size_t scanTempBytes(int64_t n);
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
-// bitmap-rank dictionary (aot_kernels.hip): prefix arrays over a key bitmap of nBlocks 256-bit blocks (blockRank[nBlocks],
-// chunkTotal / chunkBase[ceil(nBlocks / 4096) (+ 1)]), and the placement of appended build records at the rank of their key
-void rankTableIndex(Context& ctx, const uint32_t* bitmap, int64_t nBlocks, uint32_t* blockRank, uint32_t* chunkTotal, uint32_t* chunkBase);
+// bitmap-rank dictionary (aot_kernels.hip): the rank words of a bitmap laid out in nBlocks 32-byte blocks [rank | 224 bits]
+// (chunkTotal / chunkBase[ceil(nBlocks / 4096) (+ 1)] are scratch), and the placement of appended build records at the rank of
+// their key
+void rankTableIndex(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chunkTotal, uint32_t* chunkBase);
 void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uint32_t nWaves, uint32_t region, const uint32_t* nRecords, int nWords,
-                    const uint32_t* bitmap, int64_t bmMin, const uint32_t* blockRank, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
-                    int64_t capacity);
+                    const uint32_t* bitmap, int64_t bmMin, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words, int64_t capacity);
 // multi-GPU group-by merge: out[w] = min | max | sum over nParts partial tables (`stride` words apart) by segment
 void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out);
 // one launch: fill[0..nFill) = fillValue (u64), zeroA / zeroB cleared (u32 words), *count = 0 (any of them may be empty / null)
@@ -118,13 +118,21 @@ void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPart
 // gather the occupied entries (first-row word != INT64_MAX) of a hash table that carries aggregates into
 // packed rows [first row | table words | accumulator blocks]; *count receives the number of rows, at most maxRows are written
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
-                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix = false);
+                    const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix = false,
+                    // optional: while writing the rows, collect the range of the images of row word `keyWord` (a sort key) into
+                    // imageRange[0] = max(image), imageRange[1] = max(~image) — both must be 0 before the launch
+                    int keyWord = -1, bool keyIs32 = false, bool keyDesc = false, uint64_t* imageRange = nullptr);
 // ORDER BY ... LIMIT pre-selection: the rows of `rows` ([*nRows][stride] words) whose word `keyWord` is among the `want`
-// leading values of the requested order (ties of the last one included) are copied to `cand`; *candCount counts them
+// leading values of the requested order (ties of the last one included) are copied to `cand`.  `scratch` (topkHistBytes() bytes)
+// holds [image range: 2 x u64][candidate count: u32][pad][histograms]; the candidate count is read from scratch + 16.
+// selectTopCandidates is the exact radix select (7 launches); selectTopCandidatesRange needs the image range collected by
+// compactEntries (prepareTopCandidatesRange before that compaction) and selects a superset in 2 launches.
 size_t topkHistBytes();
 void selectTopCandidates(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
-                         uint32_t rowsUpperBound, uint32_t want, uint64_t* images, uint32_t* hists, int64_t* cand, uint32_t capacity,
-                         uint32_t* candCount);
+                         uint32_t rowsUpperBound, uint32_t want, uint64_t* images, void* scratch, int64_t* cand, uint32_t capacity);
+void prepareTopCandidatesRange(Context& ctx, void* scratch);
+void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
+                              uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* cand, uint32_t capacity);
 
 // tbl.cpp: '.tbl' text -> columns with the reference's BULK INSERT semantics (execute.h:332-388)
 void parseTblFile(const std::string& path, const std::vector<Type>& types, char terminator, int nThreads,

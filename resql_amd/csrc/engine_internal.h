@@ -67,14 +67,14 @@ struct HashTable {
     // entry number rank(key): no CAS, no scattered read-modify-writes, nearly sequential stores for input clustered by the key.
     // `capacity` is then the number of entries; words[entry][k] and acc[block][entry] as for the hash form.
     bool rankCapable = false;
+    bool bmInterleaved = false;      // the bitmap's layout: 32-byte blocks of [rank word | 7 words = 224 bits] (rank-capable tables)
     bool rank = false;
     int64_t* dTemp = nullptr;        // arrival-order buffer: [wave of the build grid][tempRegion] records
     uint32_t* dTempUsed = nullptr;   // [wave] records the wave appended
     int64_t tempWaves = 0, tempRegion = 0;
-    uint32_t* dBlockRank = nullptr;  // [bitmap blocks]
     uint32_t* dChunkTotal = nullptr; // [chunks]
     uint32_t* dChunkBase = nullptr;  // [chunks + 1]
-    int64_t bmBlocks = 0;            // 256-bit blocks the bitmap is allocated in
+    int64_t bmBlocks = 0;            // 32-byte blocks the bitmap is allocated in (256 bits, or 224 bits + the rank word)
 };
 
 // one accumulator the aggregation keeps per group
