@@ -129,3 +129,12 @@ def test_engine_gives_the_reference_answers(gpu_ctx, tbl_dir):
             assert res2.text == res.text
     finally:
         db.close()
+
+
+@pytest.mark.skipif(not orc.have_reference(), reason="needs the compiled reference (oracle/_ref, build container only)")
+@pytest.mark.parametrize("q", ["q1", "q3", "q12"])
+def test_the_reference_itself_reproduces_its_answers_on_the_generated_data(host_database, q):
+    """closing the loop: ReSQL's own grammar, planner and asmjit JIT (oracle/_ref/ref_harness), fed the regenerated tables,
+    return what its repository records as known answers"""
+    ctx, host, dev = host_database
+    _check(q, orc.run_reference_sql(host, ctx.sql_describe(tpch_full.QUERIES[q], 0)))
