@@ -87,7 +87,11 @@ const char* rsq_last_error(const rsq_ctx* ctx);
  * planner uses (row count as Relation::tupleNum(), min/max, byte-value sets) are gathered here. */
 int  rsq_table_create(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out);
 /* Adopt columns that already live in this GPU's memory (e.g. torch tensors): `data` pointers are
- * device pointers, not copied, and must outlive the table. */
+ * device pointers, not copied, and must outlive the table.  Their CONTENT must not change while the table exists: the
+ * column statistics gathered here (min / max, byte-value sets) shape the kernels compiled against the table (dense group
+ * ids, key bitmaps).  Kernels range-check what they derive from the statistics — a value outside them makes the
+ * execution fail with RSQ_ERR_RUNTIME instead of touching memory it should not — but an in-range change goes unnoticed
+ * where a byte-set or a uniqueness assumption was baked in: create a new table after changing the data. */
 int  rsq_table_create_device(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out);
 /* Transpose a ReSQL row store (reference src/dbdata.h: DataBlocks of packed tuples, strings by
  * value) into device columns: the bridge for a host that keeps ReSQL's own Relation objects. */

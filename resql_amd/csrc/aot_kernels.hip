@@ -837,8 +837,8 @@ void rankTableIndex(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* c
 // One workgroup per wave of the build pipeline: its region of the arrival-order buffer holds used[wave] records.
 __global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp, const unsigned* __restrict__ used, unsigned region,
                                                     const unsigned* __restrict__ nRecords, int nWords, const unsigned* __restrict__ bm, i64 bmMin,
-                                                    const unsigned* __restrict__ chunkBase, int nChunks, i64* __restrict__ words, i64 capacity,
-                                                    unsigned* __restrict__ err) {
+                                                    u64 bmBits, const unsigned* __restrict__ chunkBase, int nChunks, i64* __restrict__ words,
+                                                    i64 capacity, unsigned* __restrict__ err) {
     // as many records as distinct keys, and no more than the table was sized for — anything else means the build side changed
     // since the sizing pass (two rows with one key, more rows): the host then falls back to the hash table
     if (blockIdx.x == 0 && threadIdx.x == 0 && (*nRecords != chunkBase[nChunks] || (i64)*nRecords > capacity)) atomicOr(err, 64u);
@@ -847,6 +847,7 @@ __global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
         const i64* rec = base + (i64)i * nWords;
         const u64 d = (u64)(rec[0] - bmMin);
+        if (d >= bmBits) continue;          // a key outside the bitmap's domain (the build kernel has raised ERR_GROUP_OVERFLOW for it)
         const unsigned w = (unsigned)(d >> 5), blkI = w / 7u, wi = 1u + (w % 7u), bit = (unsigned)d & 31u;
         const unsigned* blk = bm + (i64)blkI * 8;
         unsigned r = blk[0];
@@ -859,11 +860,12 @@ __global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp
 }
 
 void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uint32_t nWaves, uint32_t region, const uint32_t* nRecords, int nWords,
-                    const uint32_t* bitmap, int64_t bmMin, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words, int64_t capacity) {
+                    const uint32_t* bitmap, int64_t bmMin, int64_t bmBits, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
+                    int64_t capacity) {
     const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
     hipLaunchKernelGGL(k_rank_place, dim3(std::max(1u, nWaves)), dim3(256), 0, ctx.stream, (const i64*)temp, (const unsigned*)used, (unsigned)region,
-                       (const unsigned*)nRecords, nWords, (const unsigned*)bitmap, (i64)bmMin, (const unsigned*)chunkBase, nChunks, (i64*)words,
-                       (i64)capacity, (unsigned*)ctx.dErr);
+                       (const unsigned*)nRecords, nWords, (const unsigned*)bitmap, (i64)bmMin, (u64)bmBits, (const unsigned*)chunkBase, nChunks,
+                       (i64*)words, (i64)capacity, (unsigned*)ctx.dErr);
     RSQ_HIP(hipGetLastError());
 }
 

@@ -710,10 +710,12 @@ struct Walker {
         // (a table that may become a rank dictionary keeps its bitmap in the interleaved layout, rsq_device.h bmi_word)
         ht->bmInterleaved = ht->rankCapable;
         const std::string bmw = ht->bmInterleaved ? "rsq::bmi_word(d)" : "d >> 5";
-        const std::string bitSet = ht->hasBitmap ? "const u64 d = (u64)(" + keyVars[0] + " - a." + T + "_bmmin); " : "";
+        // (a key outside the range the statistics promised sets no bit and raises ERR_GROUP_OVERFLOW: the host fails the execution)
+        const std::string bitSet = ht->hasBitmap ? "const u64 d0 = (u64)(" + keyVars[0] + " - a." + T + "_bmmin); if (d0 >= a." + T +
+                                   "_bmbits) atomicOr(a.err, (u32)rsq::ERR_GROUP_OVERFLOW); const u64 d = d0 < a." + T + "_bmbits ? d0 : 0; " : "";
         addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
         addArg(T + "_countonly", "u64", 0);
-        if (ht->hasBitmap) { addArg(T + "_bm", "u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht->bmMin); }
+        if (ht->hasBitmap) { addArg(T + "_bm", "u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht->bmMin); addArg(T + "_bmbits", "u64", (uint64_t)ht->bmBits); }
         // sizing pass: the same pipeline run once with countonly = 1 tells the host how many entries to expect — and, for a
         // table that could be a rank dictionary, whether two build rows share a key (a bit that is already set)
         countPerThread(T);
@@ -1296,24 +1298,34 @@ struct Walker {
         q.hashTables.push_back(std::move(ht));
     }
 
+    // Dense group id from the column statistics the table was created with.  The statistics are a promise about the data,
+    // not a guarantee (rsq_table_create_device adopts caller-owned memory): every rank is checked, a value outside its
+    // column's recorded domain raises ERR_GROUP_OVERFLOW and is counted into group 0 — no access leaves the table, and the
+    // host fails the execution.
     std::string groupIdExpr() {
         std::string gid = "0";
         for (size_t ki = 0; ki < q.denseKeys.size(); ki++) {
             DenseKey& k = q.denseKeys[ki];
             std::string v = eg.emit(k.expr), rank;
+            const std::string rv = "gk" + std::to_string(ki);
             if (k.byteSet) {
                 rank = "0";
-                for (size_t d = 1; d < k.values.size(); d++) {
+                std::string member;
+                for (size_t d = 0; d < k.values.size(); d++) {
                     std::string an = "k" + std::to_string(ki) + "_" + std::to_string(d);
                     addArg(an, "u64", k.values[d]);
-                    rank += " + (int)((u8)(" + v + ") >= (u8)a." + an + ")";
+                    if (d) rank += " + (int)((u8)(" + v + ") >= (u8)a." + an + ")";
+                    member += std::string(d ? " | " : "") + "(int)((u8)(" + v + ") == (u8)a." + an + ")";
                 }
+                line("int " + rv + " = " + rank + ";");
+                line("if (!(" + (member.empty() ? std::string("1") : member) + ")) { atomicOr(a.err, (u32)rsq::ERR_GROUP_OVERFLOW); " + rv + " = 0; }");
             } else {
                 std::string an = "k" + std::to_string(ki) + "_min";
                 addArg(an, "i64", (uint64_t)k.min);
-                rank = "(int)((i64)(" + v + ") - a." + an + ")";
+                line("int " + rv + " = (int)((i64)(" + v + ") - a." + an + ");");
+                line("if ((u64)((i64)(" + v + ") - a." + an + ") >= " + std::to_string((long long)k.card) + "ull) { atomicOr(a.err, (u32)rsq::ERR_GROUP_OVERFLOW); " + rv + " = 0; }");
             }
-            gid += " + (" + rank + ") * " + std::to_string((long long)k.stride);
+            gid += " + " + rv + " * " + std::to_string((long long)k.stride);
         }
         return gid;
     }

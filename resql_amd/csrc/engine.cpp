@@ -496,7 +496,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
         launchPipeline(q, p, -1);
         rankTableIndex(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase);
         rankTablePlace(ctx, h.dTemp, h.dTempUsed, (uint32_t)h.tempWaves, (uint32_t)h.tempRegion, h.dCount, (int)std::max<size_t>(1, nWords), h.dBitmap, h.bmMin,
-                       h.dChunkBase, h.bmBlocks, h.dWords, h.capacity);
+                       h.bmBits, h.dChunkBase, h.bmBlocks, h.dWords, h.capacity);
         q.report.num_kernels += 4;
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
         return;
@@ -516,6 +516,8 @@ static void checkDeviceError(uint32_t err) {
     if (err & 1) failRuntime("Division by zero");
     if (err & 2) failRuntime("Hash table full");
     if (err & 16) failRuntime("internal error: a hash-table slot stayed in the 'being written' state");
+    if (err & 8) failRuntime("a key lies outside the column statistics the query was compiled with: the table's data changed after the table was created "
+                             "(adopted device columns must stay immutable, see rsq_table_create_device)");
     if (err) failRuntime("device error word " + std::to_string(err));
 }
 
@@ -725,6 +727,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         size_t need = (size_t)groupRowsAllocated * (size_t)q.groupRowWords;
         if (q.hGroupRowsWords < need) {
             if (q.dGroupRows) ctx.free(q.dGroupRows);
+            q.dGroupRows = nullptr; q.hGroupRowsWords = 0;          // (nothing dangles if an allocation below throws)
             q.dGroupRows = (int64_t*)ctx.alloc(need * 8);
             if (q.hGroupRows) (void)hipHostFree(q.hGroupRows);
             q.hGroupRows = nullptr;

@@ -106,7 +106,8 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
 // their key
 void rankTableIndex(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chunkTotal, uint32_t* chunkBase);
 void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uint32_t nWaves, uint32_t region, const uint32_t* nRecords, int nWords,
-                    const uint32_t* bitmap, int64_t bmMin, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words, int64_t capacity);
+                    const uint32_t* bitmap, int64_t bmMin, int64_t bmBits, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
+                    int64_t capacity);
 // multi-GPU group-by merge: out[w] = min | max | sum over nParts partial tables (`stride` words apart) by segment
 void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out);
 // one launch: fill[0..nFill) = fillValue (u64), zeroA / zeroB cleared (u32 words), *count = 0 (any of them may be empty / null)

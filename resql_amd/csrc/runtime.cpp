@@ -66,6 +66,7 @@ Context::~Context() {
         (void)hipSetDevice(device);
         for (auto& kv : kernels) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
         for (auto& e : scratchFreeList) (void)hipFree(e.first);
+        for (auto& e : scratchLive) (void)hipFree(e.first);
         if (dErr) (void)hipFree(dErr);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -132,12 +133,16 @@ static bool readFile(const std::string& path, std::string& out) {
     return true;
 }
 
+static const char* const kHiprtcArch = "--offload-arch=gfx950";
+static const char* const kHiprtcOpt = "-O3";
+static const char* const kHiprtcStd = "-std=c++17";
+
 static std::string compileWithHiprtc(Context& ctx, const std::string& source) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, source.c_str(), "rsq_pipeline.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         throw Error(RSQ_ERR_DEVICE, "hiprtcCreateProgram failed");
     std::string inc = "-I" + ctx.includeDir;
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", inc.c_str()};
+    const char* opts[] = {kHiprtcArch, kHiprtcOpt, kHiprtcStd, inc.c_str()};
     hiprtcResult r = hiprtcCompileProgram(prog, 4, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
@@ -157,7 +162,15 @@ Kernel& Context::getKernel(const std::string& source, const std::string& entry) 
     // the key covers the generated source AND the hand-written header it includes
     if (headerText.empty() && !readFile(includeDir + "/rsq_device.h", headerText))
         throw Error(RSQ_ERR_DEVICE, "cannot read " + includeDir + "/rsq_device.h");
-    char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)(fnv1a(source) ^ (fnv1a(headerText) * 0x9E3779B97F4A7C15ull)));
+    // ... and what turns them into a code object: compiler version, target, options (a cache that survives a toolchain upgrade
+    // must not hand back the old compiler's code)
+    static const std::string toolchain = [] {
+        int major = 0, minor = 0;
+        (void)hiprtcVersion(&major, &minor);
+        return std::string("hiprtc ") + std::to_string(major) + "." + std::to_string(minor) + " " + kHiprtcArch + " " + kHiprtcOpt + " " + kHiprtcStd;
+    }();
+    char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)(fnv1a(source) ^ (fnv1a(headerText) * 0x9E3779B97F4A7C15ull) ^
+                                                                               (fnv1a(toolchain) * 0xBF58476D1CE4E5B9ull)));
     std::string key(hex);
     auto it = kernels.find(key);
     if (it != kernels.end()) return it->second;
@@ -165,8 +178,9 @@ Kernel& Context::getKernel(const std::string& source, const std::string& entry) 
     std::string path = cacheDir + "/" + key + ".hsaco";
     std::string code;
     Kernel k;
-    if (readFile(path, code) && !code.empty()) {
-        k.fromCache = true;
+    std::string storedSource;
+    if (readFile(path, code) && !code.empty() && (!readFile(cacheDir + "/" + key + ".hip", storedSource) || storedSource == source)) {
+        k.fromCache = true;              // (the source stored beside the code object is compared: a key collision compiles afresh)
         jitCacheHits++;
     } else {
         code = compileWithHiprtc(*this, source);

@@ -196,8 +196,20 @@ class Context:
         torch.cuda.current_stream().cuda_stream), or None to go back to the context's own stream"""
         self._check(self._L.rsq_ctx_set_stream(self.h, hip_stream or None, 0 if hip_stream is None else 1))
 
+    def _adopt(self, child):
+        """queries, tables and databases hold device memory of this context: they are closed before it is destroyed"""
+        import weakref
+        if not hasattr(self, "_children"):
+            self._children = weakref.WeakSet()
+        self._children.add(child)
+
     def close(self):
         if getattr(self, "h", None):
+            for child in list(getattr(self, "_children", ())):
+                try:
+                    child.close()
+                except Exception:
+                    pass
             if not getattr(self, "_borrowed", False):
                 self._L.rsq_ctx_destroy(self.h)
             self.h = None
@@ -328,6 +340,7 @@ class Context:
 class DeviceTable:
     def __init__(self, ctx: Context, h, name: str):
         self.ctx, self.h, self.name = ctx, h, name
+        ctx._adopt(self)
 
     @property
     def n_rows(self) -> int:
@@ -348,6 +361,7 @@ class DeviceTable:
 class Query:
     def __init__(self, ctx: Context, h):
         self.ctx, self.h = ctx, h
+        ctx._adopt(self)
 
     def execute(self):
         self.ctx._check(self.ctx._L.rsq_query_execute(self.h))
@@ -422,6 +436,7 @@ class Database:
         h = C.c_void_p()
         ctx._check(ctx._L.rsq_db_create(ctx.h, C.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def add_table(self, t: "DeviceTable"):
         """hand a device table to the database (which owns it from now on)"""
