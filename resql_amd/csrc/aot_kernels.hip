@@ -8,7 +8,7 @@
 #include <algorithm>
 #include <cstring>
 
-#include "engine.h"
+#include "engine_internal.h"
 
 namespace rsq {
 
@@ -893,6 +893,151 @@ void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t 
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (words + 255) / 256));
     hipLaunchKernelGGL(k_merge_partials, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)parts, nParts, (i64)stride, (i64)nMin, (i64)nMax, (i64)nSum,
                        (i64*)out);
+    RSQ_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------------
+// the pre-compiled generic pipeline: scan -> filter -> dense aggregation, interpreted (generic.cpp builds the program).
+// Registers live in LDS, [register][thread] (conflict-free: a wave's 64 accesses to one register are 64 consecutive words);
+// the program is read through uniform loads.  Values are int64: INT / DATE columns sign-extend from 32 bits (the reference
+// compares dates as signed 32-bit values), BOOL / CHAR(1) zero-extend from a byte.  Arithmetic wraps, division truncates and
+// flags /0 like rsq::div, AND / OR are bit-wise on 0 / 1 values (no short circuit, as in the reference).
+// Group ranks are checked against the statistics (ERR_GROUP_OVERFLOW) like the specialised kernels'.  Small aggregate tables
+// are kept per workgroup in LDS and flushed once; larger ones take HBM atomics.
+// ------------------------------------------------------------------------------------------------
+struct GenericArgs {
+    const void* col[G_MAX_COLS]; int colKind[G_MAX_COLS];
+    const GenericInstr* code; int nInstr;
+    int nKeys; int keyReg[G_MAX_KEYS]; int keyByteSet[G_MAX_KEYS]; i64 keyMin[G_MAX_KEYS]; i64 keyCard[G_MAX_KEYS]; i64 keyStride[G_MAX_KEYS];
+    unsigned char keyValues[G_MAX_KEYS][G_MAX_SET]; int keyNValues[G_MAX_KEYS];
+    int nAccs; int accReg[G_MAX_ACCS]; int accMerge[G_MAX_ACCS]; i64 accBlock[G_MAX_ACCS];
+    i64 nRows, row0, groups, tableWords;
+    u64* table; unsigned* err;
+    int ldsTable;            // the [block][group] table fits the workgroup's LDS copy
+};
+#define GENERIC_LDS_TABLE_WORDS 3072
+
+__device__ __forceinline__ void generic_merge_lds(u64* p, u64 v, int merge) {
+    if (merge == 0) atomicAdd(p, v);
+    else if (merge == 2) atomicMin(reinterpret_cast<i64*>(p), (i64)v);
+    else atomicMax(reinterpret_cast<i64*>(p), (i64)v);
+}
+__device__ __forceinline__ void generic_merge_global(u64* p, u64 v, int merge) {
+    if (merge == 0) { if (v) atomicAdd(p, v); }
+    else if (merge == 2) { if ((i64)v < (i64)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(reinterpret_cast<i64*>(p), (i64)v); }
+    else { if ((i64)v > (i64)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(reinterpret_cast<i64*>(p), (i64)v); }
+}
+
+__global__ void __launch_bounds__(256) k_generic_aggregate(GenericArgs a) {
+    __shared__ i64 s_reg[G_REGS * 256];
+    __shared__ u64 s_tab[GENERIC_LDS_TABLE_WORDS];
+    i64* reg = s_reg + threadIdx.x;            // register r of this thread: reg[r * 256]
+    if (a.ldsTable) {
+        for (i64 i = threadIdx.x; i < a.tableWords; i += 256) {
+            const i64 blk = i / a.groups;
+            int merge = 0;
+            for (int w = 0; w < a.nAccs; w++) if (a.accBlock[w] == blk) merge = a.accMerge[w];
+            s_tab[i] = merge == 0 ? 0ull : merge == 2 ? 0x7fffffffffffffffull : 0x8000000000000000ull;
+        }
+        __syncthreads();
+    }
+    for (i64 base = (i64)blockIdx.x * 256; base < a.nRows; base += (i64)gridDim.x * 256) {
+        const i64 r = base + threadIdx.x;
+        bool alive = r < a.nRows;
+        for (int pc = 0; pc < a.nInstr; pc++) {
+            const GenericInstr in = a.code[pc];
+            i64 x = reg[(int)in.a * 256], y = reg[(int)in.b * 256], v = 0;
+            switch (in.op) {
+                case G_COL: {
+                    const int k = a.colKind[in.a];
+                    if (alive) {
+                        if (k == 3) v = reinterpret_cast<const i64*>(a.col[in.a])[r];
+                        else if (k == 2) v = (i64)reinterpret_cast<const int*>(a.col[in.a])[r];
+                        else v = (i64)reinterpret_cast<const unsigned char*>(a.col[in.a])[r];
+                    }
+                    break;
+                }
+                case G_CONST: v = in.imm; break;
+                case G_ADD: v = (i64)((u64)x + (u64)y); break;
+                case G_SUB: v = (i64)((u64)x - (u64)y); break;
+                case G_MUL: v = (i64)((u64)x * (u64)y); break;
+                case G_DIV:
+                    if (y == 0 || (x == (i64)0x8000000000000000ull && y == -1)) { if (alive) atomicOr(a.err, 1u); v = 0; }
+                    else v = x / y;
+                    break;
+                case G_LT: v = x < y; break;
+                case G_LE: v = x <= y; break;
+                case G_GT: v = x > y; break;
+                case G_GE: v = x >= y; break;
+                case G_EQ: v = x == y; break;
+                case G_NE: v = x != y; break;
+                case G_AND: v = (x & y) & 0xff; break;
+                case G_OR: v = (x | y) & 0xff; break;
+                case G_MULI: v = (i64)((u64)x * (u64)in.imm); break;
+                case G_DIVI: v = x / in.imm; break;
+                case G_SELECT: v = x ? y : reg[(int)in.c * 256]; break;
+                case G_FILTER: alive = alive && x != 0; break;
+                default: break;
+            }
+            if (in.op != G_FILTER) reg[(int)in.dst * 256] = v;
+            else if (!__any(alive)) break;                 // the whole wave is filtered out
+        }
+        if (!alive) continue;
+        i64 gid = 0;
+        for (int k = 0; k < a.nKeys; k++) {
+            const i64 v = reg[a.keyReg[k] * 256];
+            i64 rank = 0;
+            bool ok;
+            if (a.keyByteSet[k]) {
+                ok = false;
+                for (int d = 0; d < a.keyNValues[k]; d++) {
+                    if (d && (unsigned char)v >= a.keyValues[k][d]) rank++;
+                    ok = ok || (unsigned char)v == a.keyValues[k][d];
+                }
+            } else { rank = v - a.keyMin[k]; ok = (u64)rank < (u64)a.keyCard[k]; }
+            if (!ok) { atomicOr(a.err, 8u); rank = 0; }
+            gid += rank * a.keyStride[k];
+        }
+        for (int w = 0; w < a.nAccs; w++) {
+            const int rg = a.accReg[w];
+            const u64 v = rg == -1 ? (u64)(a.row0 + r) : rg == -2 ? 1ull : (u64)reg[rg * 256];
+            const i64 cell = a.accBlock[w] * a.groups + gid;
+            if (a.ldsTable) generic_merge_lds(&s_tab[cell], v, a.accMerge[w]);
+            else generic_merge_global(a.table + cell, v, a.accMerge[w]);
+        }
+    }
+    if (a.ldsTable) {
+        __syncthreads();
+        for (i64 i = threadIdx.x; i < a.tableWords; i += 256) {
+            const i64 blk = i / a.groups;
+            int merge = 0;
+            for (int w = 0; w < a.nAccs; w++) if (a.accBlock[w] == blk) merge = a.accMerge[w];
+            const u64 v = s_tab[i];
+            const u64 idv = merge == 0 ? 0ull : merge == 2 ? 0x7fffffffffffffffull : 0x8000000000000000ull;
+            if (v != idv) generic_merge_global(a.table + i, v, merge);
+        }
+    }
+}
+
+void launchGenericAggregate(Context& ctx, const GenericProgram& prog, const GenericInstr* dCode, int64_t nRows, int64_t row0, uint64_t* dTable,
+                            int64_t denseGroups, int64_t tableWords) {
+    GenericArgs a;
+    memset(&a, 0, sizeof a);
+    for (size_t i = 0; i < prog.cols.size(); i++) { a.col[i] = prog.cols[i].ptr; a.colKind[i] = prog.cols[i].kind; }
+    a.code = dCode; a.nInstr = (int)prog.code.size();
+    a.nKeys = (int)prog.keys.size();
+    for (size_t k = 0; k < prog.keys.size(); k++) {
+        a.keyReg[k] = prog.keys[k].reg; a.keyByteSet[k] = prog.keys[k].byteSet; a.keyMin[k] = prog.keys[k].min; a.keyCard[k] = prog.keys[k].card;
+        a.keyStride[k] = prog.keys[k].stride; a.keyNValues[k] = prog.keys[k].nValues;
+        memcpy(a.keyValues[k], prog.keys[k].values, G_MAX_SET);
+    }
+    a.nAccs = (int)prog.accs.size();
+    for (size_t w = 0; w < prog.accs.size(); w++) { a.accReg[w] = prog.accs[w].reg; a.accMerge[w] = prog.accs[w].merge; a.accBlock[w] = prog.accs[w].block; }
+    a.nRows = nRows; a.row0 = row0; a.groups = denseGroups; a.tableWords = tableWords;
+    a.table = (u64*)dTable; a.err = (unsigned*)ctx.dErr;
+    a.ldsTable = tableWords <= GENERIC_LDS_TABLE_WORDS ? 1 : 0;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)ctx.numCUs, (nRows + 255) / 256));
+    hipLaunchKernelGGL(k_generic_aggregate, dim3(grid), dim3(256), 0, ctx.stream, a);
     RSQ_HIP(hipGetLastError());
 }
 

@@ -981,15 +981,15 @@ struct Walker {
         for (Expr* s : o->splitAgg) {
             Accum ac; ac.kind = s->tag; ac.type = s->type;
             switch (s->tag) {
-                case RSQ_E_COUNT: ac.key = "COUNT"; ac.input = eg.emit(s); ac.merge = 0; break;
+                case RSQ_E_COUNT: ac.key = "COUNT"; ac.input = eg.emit(s); ac.merge = 0; ac.inputExpr = nullptr; break;
                 case RSQ_E_SUM:
                     if (s->type.tag != RSQ_DECIMAL && s->type.tag != RSQ_BIGINT) failType("ADD code generation not implemented for datatype");
-                    ac.key = "SUM" + structuralKey(s->child); ac.input = eg.emit(s); ac.merge = 0; break;
+                    ac.key = "SUM" + structuralKey(s->child); ac.input = eg.emit(s); ac.merge = 0; ac.inputExpr = s->child; break;
                 case RSQ_E_MIN: case RSQ_E_MAX:
                     if (s->type.tag != RSQ_DECIMAL && s->type.tag != RSQ_BIGINT && s->type.tag != RSQ_DATE)
                         failType("LESS_THAN code generation not implemented for datatype");
                     ac.key = std::string(s->tag == RSQ_E_MIN ? "MIN" : "MAX") + structuralKey(s->child);
-                    ac.input = "((i64)(" + eg.emit(s) + "))"; ac.merge = s->tag == RSQ_E_MIN ? 2 : 3; break;
+                    ac.input = "((i64)(" + eg.emit(s) + "))"; ac.merge = s->tag == RSQ_E_MIN ? 2 : 3; ac.inputExpr = s->child; break;
                 default: failType("Aggregation type not implemented in updateAggregates(..).");
             }
             int found = -1;

@@ -111,6 +111,8 @@ uint64_t opSize(OpNode* o) {   // getSize() estimates (reference src/operators/*
 }
 
 Query::~Query() {
+    if (bgCompiler.joinable()) bgCompiler.join();
+    if (dGenericCode) ctx.free(dGenericCode);
     if (dAgg && dAggOwned) ctx.free(dAgg);
     if (dAggInit) ctx.free(dAggInit);
     if (dAggWork) ctx.free(dAggWork);
@@ -184,6 +186,32 @@ static void prepareDenseBuffers(Query& q) {
     }
 }
 
+// every kernel source a query's execution may need right away (lazily chosen forms are compiled when first chosen)
+static std::vector<std::string> kernelSources(const Query& q) {
+    std::vector<std::string> v;
+    for (auto& p : q.pipelines) {
+        if (!p.sourcePass1.empty()) v.push_back(p.sourcePass1);
+        if (!p.sourceFlat.empty()) v.push_back(p.sourceFlat);
+        if (p.partitioned) { v.push_back(p.sourcePartCount); v.push_back(p.sourcePartScatter); v.push_back(p.sourcePartAgg); }
+        v.push_back(p.source);
+    }
+    return v;
+}
+static void resolveKernels(Query& q) {
+    Context& ctx = q.ctx;
+    for (auto& p : q.pipelines) {
+        if (!p.sourcePass1.empty()) p.kernelPass1 = &ctx.getKernel(p.sourcePass1, p.entry);
+        if (!p.sourceFlat.empty()) p.kernelFlat = &ctx.getKernel(p.sourceFlat, p.entry);
+        if (p.partitioned) {
+            p.kernelPartCount = &ctx.getKernel(p.sourcePartCount, p.entry);
+            p.kernelPartScatter = &ctx.getKernel(p.sourcePartScatter, p.entry);
+            p.kernelPartAgg = &ctx.getKernel(p.sourcePartAgg, "rsq_part_agg");
+        }
+        p.kernel = &ctx.getKernel(p.source, p.entry);
+        if (!p.sourceLazy.empty() && ctx.device < 0) (void)ctx.getKernel(p.sourceLazy, p.entry);      // build(): warm the cache with both forms
+    }
+}
+
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables) {
     double t0 = nowMs();
     std::unique_ptr<Query> q(new Query(ctx));
@@ -199,16 +227,35 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     buildOps(*q, plan);
     defineAndDerive(*q, q->root);
     buildPipelines(*q);
-    for (auto& p : q->pipelines) {
-        if (!p.sourcePass1.empty()) p.kernelPass1 = &ctx.getKernel(p.sourcePass1, p.entry);
-        if (!p.sourceFlat.empty()) p.kernelFlat = &ctx.getKernel(p.sourceFlat, p.entry);
-        if (p.partitioned) {
-            p.kernelPartCount = &ctx.getKernel(p.sourcePartCount, p.entry);
-            p.kernelPartScatter = &ctx.getKernel(p.sourcePartScatter, p.entry);
-            p.kernelPartAgg = &ctx.getKernel(p.sourcePartAgg, "rsq_part_agg");
+    // A plan shape whose specialised kernels are not in the code-object cache starts on the pre-compiled generic pipeline
+    // (generic.cpp) while hiprtc builds them on a host thread; RSQ_FORCE_GENERIC=1 keeps every eligible plan there (tests),
+    // RSQ_GENERIC=0 restores the blocking compile.
+    const bool forceGeneric = getenv("RSQ_FORCE_GENERIC") && atoi(getenv("RSQ_FORCE_GENERIC")) != 0;
+    const bool allowGeneric = ctx.device >= 0 && !(getenv("RSQ_GENERIC") && atoi(getenv("RSQ_GENERIC")) == 0);
+    bool cached = true;
+    if (allowGeneric) for (const std::string& src : kernelSources(*q)) cached = cached && ctx.kernelCached(src);
+    if (allowGeneric && (forceGeneric || !cached)) {
+        std::string why;
+        if (buildGenericProgram(*q, q->generic, why)) {
+            q->genericActive = true; q->genericForced = forceGeneric;
+            q->dGenericCode = (GenericInstr*)ctx.alloc(std::max<size_t>(1, q->generic.code.size()) * sizeof(GenericInstr));
+            RSQ_HIP(hipMemcpy(q->dGenericCode, q->generic.code.data(), q->generic.code.size() * sizeof(GenericInstr), hipMemcpyHostToDevice));
+            q->explainText += "generic pre-compiled pipeline (" + std::to_string(q->generic.code.size()) + " instructions, " + std::to_string(q->generic.cols.size()) +
+                              " columns)" + (forceGeneric ? " forced" : " until hiprtc has built the specialised kernel") + "\n";
+            if (!cached) {
+                (void)ctx.cacheKey("");            // fills the header text the compiler thread reads
+                const std::vector<std::string> sources = kernelSources(*q);
+                Query* qp = q.get();
+                q->bgState = 1;
+                q->bgCompiler = std::thread([qp, sources] {
+                    try { for (const std::string& src : sources) if (!qp->ctx.kernelCachedOnDisk(src)) qp->ctx.compileToCache(src); qp->bgState = 2; }
+                    catch (const std::exception& e) { qp->bgError = e.what(); qp->bgState = 3; }
+                });
+            }
         }
-        p.kernel = &ctx.getKernel(p.source, p.entry);
-        if (!p.sourceLazy.empty() && ctx.device < 0) (void)ctx.getKernel(p.sourceLazy, p.entry);      // build(): warm the cache with both forms
+    }
+    if (!q->genericActive) resolveKernels(*q);
+    for (auto& p : q->pipelines) {
         q->allSource += p.source + "\n";
         q->explainText += p.explain + "\n";
     }
@@ -567,6 +614,45 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     double t0 = nowMs();
     const size_t words = q.pinnedWords;
     q.report.num_kernels = 0; q.report.bytes_read = 0;
+    if (q.genericActive) {
+        if (!q.genericForced && q.bgState.load() >= 2) {
+            // the specialised kernels are in the code-object cache now (or their compilation failed): switch over
+            if (q.bgCompiler.joinable()) q.bgCompiler.join();
+            if (q.bgState.load() == 3) throw Error(RSQ_ERR_DEVICE, q.bgError);
+            resolveKernels(q);
+            q.genericActive = false;
+            q.report.jit_compiles = (int32_t)kernelSources(q).size();       // built by the compiler thread since rsq_query_compile returned
+        } else {
+            // ---- the generic pipeline: table init, ONE interpreter launch, read-back ----
+            Pipeline& p = q.pipelines[0];
+            q.fusedReady = false;
+            ctx.errWordClean = false;
+            RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, q.tableWords * 8, hipMemcpyDeviceToDevice, ctx.stream));
+            RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+            RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+            launchGenericAggregate(ctx, q.generic, q.dGenericCode, p.src->nRows, p.src->row0, q.dAgg, q.denseGroups, (int64_t)q.tableWords);
+            RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+            q.report.num_kernels = 1;
+            q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
+            RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+            if (!partialOnly) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, ctx.stream));
+            if (async && partialOnly) { q.pendingAsync = true; q.pendingFused = false; q.report.execution_time_ms = nowMs() - t0; return; }
+            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            float gms = 0; RSQ_HIP(hipEventElapsedTime(&gms, ctx.ev0, ctx.ev1));
+            q.report.kernel_time_ms = gms;
+            q.report.hbm_gbps = gms > 0 ? (double)q.report.bytes_read / (gms * 1e-3) / 1e9 : 0;
+            ctx.errWordClean = (uint32_t)q.hPinned[words] == 0;
+            checkDeviceError((uint32_t)q.hPinned[words]);
+            if (!partialOnly) {
+                double t1 = nowMs();
+                memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
+                runTail(q);
+                q.report.finalize_time_ms = nowMs() - t1;
+            }
+            q.report.execution_time_ms = nowMs() - t0;
+            return;
+        }
+    }
     q.flatRun = partialOnly && q.aggPad > 1;
     const bool trace0 = getenv("RSQ_TRACE") != nullptr;
     uint32_t topkCapacity = 0, topkSpec = 0;      // > 0: this execution pre-selects ORDER BY ... LIMIT candidates on the device

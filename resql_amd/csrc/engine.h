@@ -79,6 +79,12 @@ struct Context {
     explicit Context(const rsq_config& c);
     ~Context();
     Kernel& getKernel(const std::string& source, const std::string& entry);
+    // is the code object of `source` at hand (loaded, or in the on-disk cache) — i.e. would getKernel return without compiling?
+    bool kernelCached(const std::string& source);
+    bool kernelCachedOnDisk(const std::string& source);      // (no access to the table of loaded kernels: for the compiler thread)
+    // compile `source` into the on-disk cache without touching the context's tables: safe on another host thread
+    void compileToCache(const std::string& source);
+    std::string cacheKey(const std::string& source);
     void* alloc(size_t bytes);
     void free(void* p);
     void setStream(hipStream_t s, bool callers);   // callers == false: back to the context's own stream

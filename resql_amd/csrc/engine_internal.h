@@ -2,7 +2,9 @@
 // generator (codegen.cpp) and the host tail (tail.cpp).
 #pragma once
 
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <map>
 #include <memory>
 #include <string>
@@ -84,6 +86,7 @@ struct Accum {
     std::string input;   // device expression of the input value
     Type type;
     int merge;           // rsq::Merge on the device: 0 sum, 2 min (i64), 3 max (i64)
+    Expr* inputExpr = nullptr;   // the input expression itself (null: the row index / a count), for the pre-compiled generic pipeline
 };
 
 struct DenseKey {
@@ -101,6 +104,23 @@ enum class SinkKind { AGGREGATE, BUILD, MATERIALIZE };
 
 struct ArgSlot { std::string name; std::string ctype; uint64_t value; };
 
+// ---- the pre-compiled generic pipeline (generic.cpp, aot_kernels.hip k_generic_aggregate) ------------------------------
+// One AOT kernel that interprets a register program per row: column loads, the reference's typed arithmetic / comparisons /
+// CASE / TYPECAST, the filter, dense group ranks and the accumulator updates.  It serves a plan shape whose specialised
+// kernel is not in the code-object cache yet, while hiprtc builds that kernel on a host thread (engine.cpp).
+struct GenericInstr { uint8_t op, dst, a, b; uint32_t c; int64_t imm; };      // 16 bytes
+enum GenericOp : uint8_t { G_COL = 1, G_CONST, G_ADD, G_SUB, G_MUL, G_DIV, G_LT, G_LE, G_GT, G_GE, G_EQ, G_NE, G_AND, G_OR, G_MULI, G_DIVI,
+                           G_SELECT, G_FILTER };
+enum { G_MAX_COLS = 16, G_MAX_KEYS = 4, G_MAX_ACCS = 16, G_MAX_SET = 16, G_REGS = 32, G_MAX_INSTR = 256 };
+struct GenericProgram {
+    std::vector<GenericInstr> code;
+    struct Col { const void* ptr; int kind; };          // kind: 1 u8, 2 i32 (INT, and DATE read as signed 32-bit like the reference), 3 i64
+    std::vector<Col> cols;
+    struct Key { int reg; int byteSet; int64_t min, card, stride; uint8_t values[G_MAX_SET]; int nValues; };
+    std::vector<Key> keys;
+    struct Acc { int reg; int merge; int64_t block; };   // reg -1: the row index, -2: the constant 1
+    std::vector<Acc> accs;
+};
 struct Pipeline {
     Table* src = nullptr;
     std::vector<int> cols;           // scanned columns (indices into src->cols)
@@ -252,12 +272,23 @@ struct Query {
     bool kernelTimePending = false;        // the fused step's events have not been read yet (resolveKernelTime)
     hipEvent_t gev0 = nullptr, gev1 = nullptr;   // start / stop of the fused step's kernel (hipExtModuleLaunchKernel)
     bool pendingFused = false;             // the enqueued asynchronous step was a fused one
+    // generic pipeline in front of the specialised kernel (see GenericProgram)
+    bool genericActive = false, genericForced = false;
+    GenericProgram generic;
+    GenericInstr* dGenericCode = nullptr;
+    std::thread bgCompiler;                // builds the specialised kernels into the code-object cache
+    std::atomic<int> bgState{0};           // 0 none, 1 running, 2 done, 3 failed
+    std::string bgError;
     bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
     std::string allSource, explainText;
 
     explicit Query(Context& c) : ctx(c) {}
     ~Query();
 };
+
+bool buildGenericProgram(Query& q, GenericProgram& out, std::string& why);
+void launchGenericAggregate(Context& ctx, const GenericProgram& prog, const GenericInstr* dCode, int64_t nRows, int64_t row0, uint64_t* dTable,
+                            int64_t denseGroups, int64_t tableWords);
 
 uint64_t opSize(OpNode* o);      // getSize() estimates of the reference's operators
 

@@ -158,7 +158,7 @@ static std::string compileWithHiprtc(Context& ctx, const std::string& source) {
     return code;
 }
 
-Kernel& Context::getKernel(const std::string& source, const std::string& entry) {
+std::string Context::cacheKey(const std::string& source) {
     // the key covers the generated source AND the hand-written header it includes
     if (headerText.empty() && !readFile(includeDir + "/rsq_device.h", headerText))
         throw Error(RSQ_ERR_DEVICE, "cannot read " + includeDir + "/rsq_device.h");
@@ -171,7 +171,33 @@ Kernel& Context::getKernel(const std::string& source, const std::string& entry) 
     }();
     char hex[32]; snprintf(hex, sizeof hex, "%016llx", (unsigned long long)(fnv1a(source) ^ (fnv1a(headerText) * 0x9E3779B97F4A7C15ull) ^
                                                                                (fnv1a(toolchain) * 0xBF58476D1CE4E5B9ull)));
-    std::string key(hex);
+    return std::string(hex);
+}
+
+bool Context::kernelCachedOnDisk(const std::string& source) {
+    const std::string key = cacheKey(source);
+    std::string code, stored;
+    return readFile(cacheDir + "/" + key + ".hsaco", code) && !code.empty() && (!readFile(cacheDir + "/" + key + ".hip", stored) || stored == source);
+}
+bool Context::kernelCached(const std::string& source) { return kernels.count(cacheKey(source)) || kernelCachedOnDisk(source); }
+
+static void writeCacheEntry(const std::string& cacheDir, const std::string& key, const std::string& code, const std::string& source) {
+    const std::string path = cacheDir + "/" + key + ".hsaco";
+    std::ofstream fs(cacheDir + "/" + key + ".hip");
+    if (fs.is_open()) { fs << source; fs.close(); }
+    std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    std::ofstream f(tmp, std::ios::binary);
+    if (f.is_open()) { f.write(code.data(), (std::streamsize)code.size()); f.close(); rename(tmp.c_str(), path.c_str()); }
+}
+
+void Context::compileToCache(const std::string& source) {
+    // (cacheKey reads headerText, which the calling thread has filled before it started this one)
+    const std::string key = cacheKey(source);
+    writeCacheEntry(cacheDir, key, compileWithHiprtc(*this, source), source);
+}
+
+Kernel& Context::getKernel(const std::string& source, const std::string& entry) {
+    const std::string key = cacheKey(source);
     auto it = kernels.find(key);
     if (it != kernels.end()) return it->second;
 
@@ -185,11 +211,7 @@ Kernel& Context::getKernel(const std::string& source, const std::string& entry) 
     } else {
         code = compileWithHiprtc(*this, source);
         jitCompiles++;
-        std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-        std::ofstream f(tmp, std::ios::binary);
-        if (f.is_open()) { f.write(code.data(), (std::streamsize)code.size()); f.close(); rename(tmp.c_str(), path.c_str()); }
-        std::ofstream fs(cacheDir + "/" + key + ".hip");
-        if (fs.is_open()) fs << source;
+        writeCacheEntry(cacheDir, key, code, source);
     }
     if (device >= 0) {
         RSQ_HIP(hipSetDevice(device));

@@ -1,0 +1,127 @@
+"""The pre-compiled generic pipeline (resql_amd/csrc/generic.cpp, aot_kernels.hip k_generic_aggregate): a plan shape whose
+specialised kernel is not in the code-object cache answers at once from an interpreter kernel while hiprtc builds the kernel
+on a host thread — the engine's answer to the reference's 0.6-3 ms compile times (JitContextFlounder.h:410-456).
+Same bytes as the specialised kernels and as the oracle."""
+import time
+
+import numpy as np
+import pytest
+
+from resql_amd import datagen, engine, plan as P, tpch
+from oracle import orc
+import fuzzplans
+
+pytestmark = pytest.mark.gpu
+
+
+def test_unseen_plan_shape_answers_cold_in_milliseconds(tmp_path):
+    """an empty code-object cache: compile + first execution of a Q6-shaped plan with constants no cache has seen"""
+    ctx = engine.Context(device=0, cache_dir=str(tmp_path))
+    try:
+        sf = 1.0
+        n = datagen.n_lineitem(sf)
+        dev = ctx.generate(engine.GEN_LINEITEM, n, sf)
+        host = tpch.lineitem_table(sf, tpch.Q6_COLUMNS)
+        args = ("1993-02-03", "1994-02-03", "0.05", "23")
+        want = orc.execute(tpch.q6_plan(host, *args)).text
+        schema_only = tpch.lineitem_table(0.001, tpch.Q6_COLUMNS, n_rows=0)
+        t0 = time.perf_counter()
+        q = ctx.compile(tpch.q6_plan(schema_only, *args), [dev])
+        t1 = time.perf_counter()
+        q.execute()
+        t2 = time.perf_counter()
+        assert q.result().text == want
+        assert "generic pre-compiled pipeline" in q.explain
+        cold_ms = (t2 - t0) * 1e3
+        print(f"cold: compile {1e3 * (t1 - t0):.2f} ms + first execution {1e3 * (t2 - t1):.2f} ms")
+        assert cold_ms < 20.0, f"compile + first execution took {cold_ms:.1f} ms"
+        # the specialised kernel arrives while the query keeps answering; the switch changes nothing in the result
+        deadline = time.time() + 60
+        switched = False
+        while time.time() < deadline:
+            q.execute()
+            assert q.result().text == want
+            if q.report().jit_compiles > 0:
+                switched = True
+                break
+            time.sleep(0.05)
+        assert switched, "the specialised kernel never arrived"
+        q.execute()
+        assert q.result().text == want and q.report().kernel_time_ms < 0.2        # the specialised scan (0.03-0.06 ms at SF1)
+        q.close()
+        # a second query of the same shape now finds the code object: no generic pipeline
+        q2 = ctx.compile(tpch.q6_plan(schema_only, *args), [dev])
+        assert "generic pre-compiled pipeline" not in q2.explain
+        q2.execute()
+        assert q2.result().text == want
+        q2.close(); dev.close()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("plan_of,cols", [(tpch.q1_plan, tpch.Q1_COLUMNS), (tpch.q6_plan, tpch.Q6_COLUMNS)])
+def test_forced_generic_equals_oracle_on_tpch(gpu_ctx, monkeypatch, plan_of, cols):
+    monkeypatch.setenv("RSQ_FORCE_GENERIC", "1")
+    li = tpch.lineitem_table(0.05, cols)
+    want = orc.execute(plan_of(li))
+    t = gpu_ctx.table(li)
+    q = gpu_ctx.compile(plan_of(li), [t])
+    try:
+        assert "generic pre-compiled pipeline" in q.explain and "forced" in q.explain
+        for _ in range(2):
+            q.execute()
+            got = q.result()
+            assert got.text == want.text and got.tuples == want.tuples
+    finally:
+        q.close(); t.close()
+
+
+@pytest.mark.parametrize("groups,sel", [(8, 0.5), (1024, 0.1), (1 << 16, 0.5)])
+def test_forced_generic_synthetic_groups(gpu_ctx, monkeypatch, groups, sel):
+    """register-sized, LDS-sized and HBM-sized aggregate tables through the interpreter's two table forms"""
+    monkeypatch.setenv("RSQ_FORCE_GENERIC", "1")
+    t = tpch.synthetic_table(200_001, groups)
+    plan = tpch.synthetic_plan(t, int(sel * (1 << 31)))
+    want = orc.execute(plan).text
+    dt = gpu_ctx.table(t)
+    q = gpu_ctx.compile(plan, [dt])
+    try:
+        assert "generic pre-compiled pipeline" in q.explain
+        q.execute()
+        assert q.result().text == want
+    finally:
+        q.close(); dt.close()
+
+
+def test_fuzz_plans_with_the_generic_pipeline_forced(gpu_ctx, monkeypatch):
+    """the differential fuzz plans (tests/fuzzplans.py) with every eligible plan on the interpreter: engine == oracle; plans
+    the generic pipeline does not take (joins, strings, hash aggregation, materialisation) run their specialised kernels"""
+    monkeypatch.setenv("RSQ_FORCE_GENERIC", "1")
+    taken = ran = 0
+    for seed in range(0, 160):
+        plan, kind = fuzzplans.make(seed)
+        try:
+            want = orc.execute(plan)
+        except orc.OracleError:
+            continue
+        tabs = [gpu_ctx.table(t) for t in plan.tables]
+        try:
+            q = gpu_ctx.compile(plan, tabs)
+        except engine.EngineError as e:
+            for t in tabs:
+                t.close()
+            if e.status == 3:
+                continue
+            raise
+        try:
+            q.execute()
+            got = q.result()
+            if "generic pre-compiled pipeline" in q.explain:
+                taken += 1
+            ran += 1
+            assert fuzzplans.same(kind, got.text, want.text), f"seed {seed}"
+        finally:
+            q.close()
+            for t in tabs:
+                t.close()
+    assert ran >= 100 and taken >= 10, (ran, taken)
