@@ -191,6 +191,11 @@ int rsq_query_execute(rsq_query* q) {
     return guarded(QH(q)->ctx, [&] { executeQuery(*QH(q)->q, false); });
 }
 
+int rsq_query_await_kernels(rsq_query* q) {
+    if (!q) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] { awaitKernels(*QH(q)->q); });
+}
+
 int rsq_query_execute_partial(rsq_query* q, void** dev_ptr, int64_t* n_min_words, int64_t* n_max_words, int64_t* n_sum_words) {
     if (!q || !dev_ptr || !n_min_words || !n_max_words || !n_sum_words) return RSQ_ERR_INVALID;
     return guarded(QH(q)->ctx, [&] {

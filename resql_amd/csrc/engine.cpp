@@ -585,6 +585,16 @@ static void tableFromPinned(Query& q) {
     else memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
 }
 
+// blocks until the query runs on its specialised kernels (joins the compiler thread of a query that started on the generic pipeline)
+void awaitKernels(Query& q) {
+    if (!q.genericActive || q.genericForced) return;
+    if (q.bgCompiler.joinable()) q.bgCompiler.join();
+    if (q.bgState.load() == 3) throw Error(RSQ_ERR_DEVICE, q.bgError);
+    resolveKernels(q);
+    q.genericActive = false;
+    q.report.jit_compiles = (int32_t)kernelSources(q).size();
+}
+
 // kernel time of a fused step: its events are read when somebody asks (the report) or before they are recorded again
 void resolveKernelTime(Query& q) {
     if (!q.kernelTimePending || q.pendingAsync) return;

@@ -152,6 +152,7 @@ void executeQuery(Query& q, bool partialOnly, bool async = false);
 void finalizeQuery(Query& q);
 void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords);
 void settleAsync(Query& q);
+void awaitKernels(Query& q);
 void resolveKernelTime(Query& q);
 void mergeShardResults(Query& into, const std::vector<Query*>& parts);
 bool queryIsDense(const Query& q);              // its aggregation ends in a dense partial table ([min | max | sum] words)

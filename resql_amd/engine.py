@@ -85,6 +85,7 @@ def lib():
         L.rsq_table_destroy.argtypes = [vp]
         L.rsq_query_compile.argtypes = [vp, C.POINTER(P.rsq_plan_desc), C.POINTER(vp), i32, C.POINTER(vp)]
         L.rsq_query_execute.argtypes = [vp]
+        L.rsq_query_await_kernels.argtypes = [vp]
         L.rsq_query_execute_partial.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.rsq_query_execute_partial_async.argtypes = [vp]
         L.rsq_ctx_set_stream.argtypes = [vp, vp, i32]
@@ -147,7 +148,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
     "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
-    "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_execute_partial",
+    "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_await_kernels", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
     "rsq_query_finalize", "rsq_query_merge_gathered", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
     "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
@@ -365,6 +366,10 @@ class Query:
 
     def execute(self):
         self.ctx._check(self.ctx._L.rsq_query_execute(self.h))
+
+    def await_kernels(self):
+        """block until the query runs on its specialised kernels (it may have started on the pre-compiled generic pipeline)"""
+        self.ctx._check(self.ctx._L.rsq_query_await_kernels(self.h))
 
     def execute_partial(self):
         """returns (device_pointer, n_min_words, n_max_words, n_sum_words)"""

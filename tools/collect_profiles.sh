@@ -1,41 +1,93 @@
 #!/bin/bash
 # Collect the per-round profile artefacts on the GPU box (run through gpurun from the repo root):
-#   bench line, rocprofv3 kernel statistics of the same command, and a separate --pmc FETCH_SIZE pass.
-# rocprofv3 is run from /tmp with TMPDIR=/tmp (it hangs when started inside the repo snapshot), every step under a hard timeout.
+#   bench line, rocprofv3 kernel statistics of the same command, separate --pmc passes (FETCH_SIZE; WRITE_SIZE), TPC-H Q3 per pipeline.
+# rocprofv3 is run from /tmp with TMPDIR=/tmp (it hangs when started inside the repo snapshot); the profiled program stands
+# directly behind `--`; every step runs under a hard timeout and a failed step is reported and skipped, not built upon.
 # usage: bash tools/collect_profiles.sh rNN
 set -u
-R=${1:-r01}
+R=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles
-mkdir -p $OUT
+mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 400 python3 $ROOT/bench.py > $OUT/${R}_bench_n1.log 2>&1
-grep '^{' $OUT/${R}_bench_n1.log | tail -1 > $OUT/${R}_bench_n1.json
-rm -rf /tmp/prof_ks /tmp/prof_pmc
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 $ROOT/bench.py --no-cpu-baseline > /tmp/ks.log 2>&1
-cp "$(find /tmp/prof_ks -name '*kernel_stats.csv' | head -1)" $OUT/${R}_q1_sf10_kernel_stats.csv
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_pmc -- python3 $ROOT/bench.py --no-cpu-baseline --steps 5 --warmup 1 > /tmp/pmc.log 2>&1
-python3 - "$(find /tmp/prof_pmc -name '*counter_collection.csv' | head -1)" $OUT/${R}_q1_sf10_pmc.json <<'PY'
+
+step() { echo "== $*"; }
+found() {   # found DIR PATTERN -> path of the first match, or empty (and a message)
+    local f; f=$(find "$1" -name "$2" 2>/dev/null | head -n 1)
+    if [ -z "$f" ]; then echo "   (no $2 under $1: step skipped)" >&2; fi
+    echo "$f"
+}
+
+step "bench line (N = 1)"
+if timeout -k 10 400 python3 "$ROOT/bench.py" > "$OUT/${R}_bench_n1.log" 2>&1; then
+    grep '^{' "$OUT/${R}_bench_n1.log" | tail -n 1 > "$OUT/${R}_bench_n1.json"
+else echo "   bench.py failed"; fi
+step "bench line, multi-rank step forced on one rank (RCCL world of one)"
+if timeout -k 10 300 python3 "$ROOT/bench.py" --dist-path --no-cpu-baseline > "$OUT/${R}_bench_distpath.log" 2>&1; then
+    grep '^{' "$OUT/${R}_bench_distpath.log" | tail -n 1 > "$OUT/${R}_bench_distpath.json"
+fi
+
+step "kernel trace + stats of the bench command"
+rm -rf /tmp/prof_ks
+if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 "$ROOT/bench.py" --no-cpu-baseline > /tmp/ks.log 2>&1; then
+    f=$(found /tmp/prof_ks '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_q1_sf10_kernel_stats.csv"
+else echo "   rocprofv3 --kernel-trace failed: $(tail -n 2 /tmp/ks.log)"; fi
+
+pmc_pass() {   # pmc_pass COUNTER OUTDIR -- program args
+    local c=$1 d=$2; shift 3
+    rm -rf "$d"
+    timeout -k 10 300 rocprofv3 --pmc "$c" --kernel-trace --output-format csv -d "$d" -- "$@" > "/tmp/pmc_$c.log" 2>&1 || echo "   rocprofv3 --pmc $c failed: $(tail -n 2 /tmp/pmc_$c.log)"
+}
+step "PMC FETCH_SIZE of the Q1 kernel (its own pass)"
+pmc_pass FETCH_SIZE /tmp/prof_pmc -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 5 --warmup 1
+f=$(found /tmp/prof_pmc '*counter_collection.csv')
+if [ -n "$f" ]; then python3 - "$f" "$OUT/${R}_q1_sf10_pmc.json" <<'PY'
 import csv, json, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kernel_Name"].startswith("rsq_pipeline") and r["Counter_Name"] == "FETCH_SIZE"]
-per_dispatch = {}
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Kernel_Name"].startswith("rsq_p0_lineitem_aggregate") and r["Counter_Name"] == "FETCH_SIZE"]
+per = {}
 for r in rows:
-    per_dispatch[r["Dispatch_Id"]] = per_dispatch.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
-n = len(per_dispatch)
-kb = sum(per_dispatch.values()) / max(n, 1)
-json.dump({"kernel": "rsq_pipeline (TPC-H Q1 SF10: scan 7 columns + filter + 6-group aggregation)", "launches": n,
+    per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+n = len(per); kb = sum(per.values()) / max(n, 1)
+json.dump({"kernel": "rsq_p0_lineitem_aggregate (TPC-H Q1 SF10: scan 7 columns + filter + 6-group aggregation + last-workgroup hand-over)", "launches": n,
            "FETCH_SIZE_KB_per_launch": kb,
            "note": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section) -> x2; collected in its own --pmc pass",
-           "hbm_read_bytes_per_launch_corrected": kb * 1024 * 2,
-           "algorithmic_bytes_per_launch": 38 * 59999996}, open(sys.argv[2], "w"), indent=1)
-print("pmc launches", n, "corrected bytes", kb * 1024 * 2)
+           "hbm_read_bytes_per_launch_corrected": kb * 1024 * 2, "algorithmic_bytes_per_launch": 38 * 59999996}, open(sys.argv[2], "w"), indent=1)
+print("   pmc launches", n, "corrected bytes", kb * 1024 * 2)
 PY
-# TPC-H Q3 at SF10 (BASELINE config 3): kernel statistics of a few executions, and the eight SQL statements at SF1
+fi
+
+step "TPC-H Q3 at SF10: executions (the first one is the cold one), kernel statistics per pipeline"
 rm -rf /tmp/prof_q3
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q3 -- python3 $ROOT/tools/profile_case.py q3 10 12 > $OUT/${R}_q3_sf10_runs.log 2>&1
-cp "$(find /tmp/prof_q3 -name '*kernel_stats.csv' | head -1)" $OUT/${R}_q3_sf10_kernel_stats.csv
-timeout -s KILL 300 python3 $ROOT/tools/sql_bench.py 1 --reference > $OUT/${R}_sql_sf1.log 2>&1
-grep '^{' $OUT/${R}_sql_sf1.log > $OUT/${R}_sql_sf1.jsonl
-head -3 $OUT/${R}_q1_sf10_kernel_stats.csv | cut -c1-150
-head -4 $OUT/${R}_q3_sf10_kernel_stats.csv | cut -c1-150
-cut -c1-400 $OUT/${R}_bench_n1.json
+if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q3 -- python3 "$ROOT/tools/profile_case.py" q3 10 12 > "$OUT/${R}_q3_sf10_runs.txt" 2>&1; then
+    f=$(found /tmp/prof_q3 '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_q3_sf10_kernel_stats.csv"
+fi
+step "TPC-H Q3 at SF10: FETCH_SIZE and WRITE_SIZE per pipeline (two passes)"
+for c in FETCH_SIZE WRITE_SIZE; do
+    pmc_pass $c /tmp/prof_q3_$c -- python3 "$ROOT/tools/profile_case.py" q3 10 5
+done
+python3 - "$OUT/${R}_q3_sf10_pmc.json" <<'PY'
+import csv, glob, json, sys
+out = {"note": "average per dispatch over the steady-state executions; KB as rocprofv3 reports them (gfx950: FETCH_SIZE counts 1/2 of wide streaming reads, "
+               "MI355X_MICROARCH.md) - random 8..32-byte accesses are counted in full 32-byte requests", "kernels": {}}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    fs = glob.glob(f"/tmp/prof_q3_{c}/*/*counter_collection.csv")
+    if not fs: continue
+    acc, n = {}, {}
+    for r in csv.DictReader(open(fs[0])):
+        k = r["Kernel_Name"].split("(")[0]
+        if r["Counter_Name"] != c or not (k.startswith("rsq_p") or "k_rank" in k or "k_compact" in k or "k_topk" in k or "k_prepare" in k or "k_fill" in k): continue
+        acc[k] = acc.get(k, 0.0) + float(r["Counter_Value"]); n.setdefault(k, set()).add(r["Dispatch_Id"])
+    for k in acc: out["kernels"].setdefault(k, {})[c + "_KB_per_dispatch"] = round(acc[k] / len(n[k]), 1)
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print("   q3 pmc kernels:", len(out["kernels"]))
+PY
+
+step "the reference's eight TPC-H statements from SQL text at SF1"
+timeout -k 10 300 python3 "$ROOT/tools/sql_bench.py" 1 --reference > "$OUT/${R}_sql_sf1.log" 2>&1 && grep '^{' "$OUT/${R}_sql_sf1.log" > "$OUT/${R}_sql_sf1.jsonl"
+step "compile latency, cold and warm"
+timeout -k 10 200 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_run.jsonl"
+
+[ -f "$OUT/${R}_q1_sf10_kernel_stats.csv" ] && head -n 3 "$OUT/${R}_q1_sf10_kernel_stats.csv" | cut -c1-150
+[ -f "$OUT/${R}_q3_sf10_kernel_stats.csv" ] && head -n 5 "$OUT/${R}_q3_sf10_kernel_stats.csv" | cut -c1-150
+[ -f "$OUT/${R}_bench_n1.json" ] && cut -c1-600 "$OUT/${R}_bench_n1.json"
+exit 0

@@ -22,6 +22,7 @@ for mode in ("1", "0"):
     node = p.projection([b, p.as_("s", s), p.as_("n", cnt)], node)
     node = p.orderby([p.desc(p.attr("s")), p.attr("b")], node)
     q = ctx.compile(p.set_root(node, limit=10), [t])
+    q.await_kernels()
     for _ in range(3):
         q.execute()
     r = q.report()

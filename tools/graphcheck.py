@@ -5,6 +5,7 @@ ctx = engine.Context(device=0)
 n = datagen.n_lineitem(1.0)
 t = ctx.generate(engine.GEN_LINEITEM, n, 1.0)
 q = ctx.compile(tpch.q1_plan(tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)), [t])
+q.await_kernels()
 for i in range(4):
     t0 = time.perf_counter(); q.execute(); dt = time.perf_counter() - t0
     r = q.report()

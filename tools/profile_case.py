@@ -26,6 +26,7 @@ else:
         cols = tpch.Q1_COLUMNS if kind == "q1" else tpch.Q6_COLUMNS
         plan = (tpch.q1_plan if kind == "q1" else tpch.q6_plan)(tpch.lineitem_table(0.001, cols, n_rows=0))
         q = ctx.compile(plan, [li])
+q.await_kernels()
 for _ in range(rep):
     q.execute()
     r = q.report()

@@ -35,6 +35,7 @@ for name, sql in tpch_full.QUERIES.items():
     if only and name not in only:
         continue
     q = ctx.sql_compile(sql, tabs)
+    q.await_kernels()
     best_k, best_e = 1e9, 1e9
     for _ in range(repeat):
         q.execute()

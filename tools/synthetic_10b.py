@@ -80,6 +80,7 @@ def main():
                 row0, n = shard_rows(args.rows, args.shards, s)
                 t = ctx.generate(engine.GEN_SYNTHETIC, n, 1.0, row0=row0, param=groups)     # untimed
                 q = ctx.compile(tpch.synthetic_plan(schema_only, thr), [t])
+                q.await_kernels()
                 n_min, n_max, n_sum = q.partial_layout()
                 if layout is None:
                     layout = (n_min, n_max, n_sum)
@@ -94,6 +95,7 @@ def main():
                     merge_into(total, part, n_min, n_max, n_sum)
                 # the checksum query: no group key, register accumulators
                 uq = ctx.compile(ungrouped_plan(schema_only, thr), [t])
+                uq.await_kernels()
                 a, b, c = uq.partial_layout()
                 upart = torch.zeros(a + b + c, dtype=torch.int64, device=dev)
                 uq.bind_partial(upart.data_ptr(), upart.numel() * 8)
