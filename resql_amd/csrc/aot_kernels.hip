@@ -3,7 +3,6 @@
 //   * the deterministic TPC-H-shaped generator (bit-identical to resql_amd/datagen.py)
 //   * the read-only streaming bandwidth probe (the measured roofline of SURVEY.md §8d)
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstring>
@@ -719,22 +718,72 @@ void partitionOffsets(Context& ctx, uint32_t* counts, int nWorkgroups, int nPart
 }
 
 // ------------------------------------------------------------------------------------------------
-// exclusive scan of per-slot tuple counts (u32) into output offsets (u64); `n` includes one trailing zero
-// slot so that offs[n - 1] is the total (rocPRIM device scan through hipCUB)
+// exclusive scan of per-slot tuple counts (u32) into output offsets (u64); `n` includes one trailing zero slot so that
+// offs[n - 1] is the total.  Hand-written (round 1 went through hipCUB): three launches — (1) every workgroup scans a chunk
+// of 4096 counts (16 per thread, wave shuffles + the four wave totals) and leaves chunk-relative offsets and its total,
+// (2) one workgroup scans the chunk totals (1024 at a time with a carry), (3) the chunk bases are added.  Reads the counts
+// once and writes the offsets twice: 4 + 16 bytes per slot, bandwidth-bound like the rocPRIM scan it replaces.
+// `temp` holds the chunk totals and bases: scanTempBytes(n).
 // ------------------------------------------------------------------------------------------------
-struct CastU64 { __host__ __device__ u64 operator()(const unsigned& v) const { return (u64)v; } };
-
-size_t scanTempBytes(int64_t n) {
-    size_t bytes = 0;
-    hipcub::TransformInputIterator<u64, CastU64, const unsigned*> in((const unsigned*)nullptr, CastU64());
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, (u64*)nullptr, (int)n, (hipStream_t)0);
-    return bytes;
+#define SCAN_CHUNK 4096
+__global__ void __launch_bounds__(256) k_scan_chunks(const unsigned* __restrict__ counts, u64* __restrict__ offs, i64 n, u64* __restrict__ chunkTotal) {
+    __shared__ u64 s_wave[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const i64 b0 = (i64)blockIdx.x * SCAN_CHUNK + (i64)t * 16;
+    unsigned c[16];
+    u64 mine = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { c[j] = b0 + j < n ? counts[b0 + j] : 0u; mine += c[j]; }
+    u64 incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u64 v = (u64)__shfl_up((long long)incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    u64 before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const u64 x = s_wave[w]; if (w < wave) before += x; total += x; }
+    u64 run = before + incl - mine;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { if (b0 + j < n) offs[b0 + j] = run; run += c[j]; }
+    if (t == 0) chunkTotal[blockIdx.x] = total;
 }
+__global__ void __launch_bounds__(1024) k_scan_chunk_totals(const u64* __restrict__ chunkTotal, i64 nChunks, u64* __restrict__ chunkBase) {
+    __shared__ u64 s[1024];
+    u64 carry = 0;
+    for (i64 base = 0; base < nChunks; base += 1024) {
+        const i64 i = base + threadIdx.x;
+        const u64 v = i < nChunks ? chunkTotal[i] : 0ull;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const u64 x = threadIdx.x >= (unsigned)off ? s[threadIdx.x - off] : 0ull;
+            __syncthreads();
+            s[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (i < nChunks) chunkBase[i] = carry + s[threadIdx.x] - v;
+        carry += s[1023];
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) k_scan_add_base(u64* __restrict__ offs, i64 n, const u64* __restrict__ chunkBase) {
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) offs[i] += chunkBase[i / SCAN_CHUNK];
+}
+
+size_t scanTempBytes(int64_t n) { return (size_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 16; }
 
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes) {
     if (n > 0x7fffffff) throw Error(RSQ_ERR_UNSUPPORTED, "materialisation of more than 2^31 lane slots");
-    hipcub::TransformInputIterator<u64, CastU64, const unsigned*> in((const unsigned*)counts, CastU64());
-    RSQ_HIP(hipcub::DeviceScan::ExclusiveSum(temp, tempBytes, in, (u64*)offs, (int)n, ctx.stream));
+    if (n <= 0) return;
+    const i64 nChunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (tempBytes < (size_t)(nChunks + 1) * 16) throw Error(RSQ_ERR_DEVICE, "exclusiveScanCounts: temporary buffer too small");
+    u64* chunkTotal = (u64*)temp;
+    u64* chunkBase = chunkTotal + nChunks;
+    hipLaunchKernelGGL(k_scan_chunks, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (const unsigned*)counts, (u64*)offs, (i64)n, chunkTotal);
+    hipLaunchKernelGGL(k_scan_chunk_totals, dim3(1), dim3(1024), 0, ctx.stream, (const u64*)chunkTotal, nChunks, chunkBase);
+    const unsigned grid = (unsigned)std::max<i64>(1, std::min<i64>(4096, (n + 255) / 256));
+    hipLaunchKernelGGL(k_scan_add_base, dim3(grid), dim3(256), 0, ctx.stream, (u64*)offs, (i64)n, (const u64*)chunkBase);
+    RSQ_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------------
