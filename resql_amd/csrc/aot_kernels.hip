@@ -925,7 +925,7 @@ void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uin
 // kernel behind the collective, instead of one reduction launch per segment.
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_merge_partials(const i64* __restrict__ parts, int nParts, i64 stride, i64 nMin, i64 nMax, i64 nSum,
-                                                        i64* __restrict__ out) {
+                                                        i64* __restrict__ out, i64* __restrict__ hostOut, u64* hostFlag, u64 seq) {
     const i64 words = nMin + nMax + nSum;
     for (i64 w = blockIdx.x * (i64)blockDim.x + threadIdx.x; w < words; w += (i64)gridDim.x * blockDim.x) {
         i64 v = parts[w];
@@ -933,15 +933,25 @@ __global__ void __launch_bounds__(256) k_merge_partials(const i64* __restrict__ 
         else if (w < nMin + nMax) { for (int r = 1; r < nParts; r++) { i64 x = parts[(i64)r * stride + w]; v = x > v ? x : v; } }
         else { u64 s = (u64)v; for (int r = 1; r < nParts; r++) s += (u64)parts[(i64)r * stride + w]; v = (i64)s; }
         out[w] = v;
+        if (hostOut) hostOut[w] = v;
+    }
+    // small tables (one workgroup): the merged table also goes straight into host-mapped memory, announced by a sequence
+    // number the finalising host polls for — no read-back copy, no stream synchronisation on the step's critical path
+    if (hostOut && gridDim.x == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(hostFlag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out) {
+void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out,
+                        int64_t* hostOut, uint64_t* hostFlag, uint64_t seq) {
     const int64_t words = nMin + nMax + nSum;
     if (words <= 0 || nParts <= 0) return;
     unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (words + 255) / 256));
+    if (hostOut && words <= 2048) grid = 1; else hostOut = nullptr;        // publication needs the single-workgroup form
     hipLaunchKernelGGL(k_merge_partials, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)parts, nParts, (i64)stride, (i64)nMin, (i64)nMax, (i64)nSum,
-                       (i64*)out);
+                       (i64*)out, (i64*)hostOut, (u64*)hostFlag, (u64)seq);
     RSQ_HIP(hipGetLastError());
 }
 

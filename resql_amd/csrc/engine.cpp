@@ -703,7 +703,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         q.finSeq = 0;
         q.kernelTimePending = true;
         q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
-        if (async && partialOnly) { q.pendingAsync = true; q.pendingFused = true; q.report.execution_time_ms = nowMs() - t0; return; }
+        if (async && partialOnly) {
+            // (the kernel leaves its working table reset, and whatever comes next on this stream is ordered behind it)
+            q.fusedReady = true;
+            q.pendingAsync = true; q.pendingFused = true; q.report.execution_time_ms = nowMs() - t0; return;
+        }
         if (poll) {
             // the finished table is in host memory as soon as the last workgroup's stores have landed: watch the sequence
             // number instead of waiting for the stream's completion signal (saves the interrupt path, ~8 us per step);
@@ -1039,8 +1043,27 @@ void finalizeQuery(Query& q) {
     if (!denseMode(q)) failUnsupported("partial execution / finalize is available for dense aggregations only");
     RSQ_HIP(hipSetDevice(ctx.device));
     double t1 = nowMs();
-    RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, ctx.stream));
-    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    if (q.mergePublishedSeq) {
+        // the merge kernel stored the merged table into host-mapped memory: watch for its sequence number (see the fused step)
+        const uint64_t seq = q.mergePublishedSeq;
+        q.mergePublishedSeq = 0;
+        volatile uint64_t* flag = q.hPinned + q.pinnedWords + 3;
+        const double deadline = nowMs() + 5.0;
+        unsigned spins = 0;
+        while (*flag != seq) {
+            if ((++spins & 1023u) == 0) {
+                hipError_t e = hipStreamQuery(ctx.stream);
+                if (e != hipSuccess && e != hipErrorNotReady) RSQ_HIP(e);
+                if (e == hipSuccess || nowMs() > deadline) { RSQ_HIP(hipStreamSynchronize(ctx.stream)); break; }
+            }
+            __builtin_ia32_pause();
+        }
+        if (*flag != seq) failRuntime("internal error: the merge kernel finished without publishing its table");
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, ctx.stream));
+        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    }
     if (q.pendingAsync) {         // the step was enqueued by rsq_query_execute_partial_async: account for it now
         q.pendingAsync = false;
         float ms = 0;
@@ -1141,7 +1164,12 @@ void mergeGathered(Query& q, const void* gathered, int nRanks) {
     if (q.ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(q.ctx.device));
     const int64_t G = q.denseGroups;
-    mergePartialsAsync(q.ctx, (const int64_t*)gathered, nRanks, (int64_t)q.tableWords, q.nMinBlocks * G, q.nMaxBlocks * G, q.nSumBlocks * G, (int64_t*)q.dAgg);
+    // small tables: the merge kernel also publishes the result to host-mapped memory (finalizeQuery polls for it)
+    static const bool pollOk = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
+    const bool publish = pollOk && q.dFinHost && q.tableWords <= 2048;
+    q.mergePublishedSeq = publish ? ++q.finSeqCounter : 0;
+    mergePartialsAsync(q.ctx, (const int64_t*)gathered, nRanks, (int64_t)q.tableWords, q.nMinBlocks * G, q.nMaxBlocks * G, q.nSumBlocks * G, (int64_t*)q.dAgg,
+                       publish ? (int64_t*)q.dFinHost : nullptr, publish ? q.dFinHost + q.pinnedWords + 3 : nullptr, q.mergePublishedSeq);
 }
 
 void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum) {

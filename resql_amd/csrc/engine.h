@@ -115,7 +115,10 @@ void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uin
                     const uint32_t* bitmap, int64_t bmMin, int64_t bmBits, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
                     int64_t capacity);
 // multi-GPU group-by merge: out[w] = min | max | sum over nParts partial tables (`stride` words apart) by segment
-void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out);
+// hostOut / hostFlag / seq (optional, tables of up to 2048 words): the merged table is also stored into host-mapped memory and
+// announced by `seq` in *hostFlag
+void mergePartialsAsync(Context& ctx, const int64_t* parts, int nParts, int64_t stride, int64_t nMin, int64_t nMax, int64_t nSum, int64_t* out,
+                        int64_t* hostOut = nullptr, uint64_t* hostFlag = nullptr, uint64_t seq = 0);
 // one launch: fill[0..nFill) = fillValue (u64), zeroA / zeroB cleared (u32 words), *count = 0 (any of them may be empty / null)
 void prepareTableAsync(Context& ctx, uint64_t* fill, size_t nFill, uint64_t fillValue, uint32_t* zeroA, size_t nZeroA, uint32_t* zeroB, size_t nZeroB,
                        uint32_t* count);

@@ -269,6 +269,7 @@ struct Query {
     bool fusedReady = false;               // working table, ticket and error word are at their identities
     uint64_t finSeq = 0;                   // > 0 around a launch the host polls for: the number the last workgroup writes behind the error word
     uint64_t finSeqCounter = 0;
+    uint64_t mergePublishedSeq = 0;        // > 0: rsq_query_merge_gathered also published the merged table to hPinned; finalize polls for this number
     bool kernelTimePending = false;        // the fused step's events have not been read yet (resolveKernelTime)
     hipEvent_t gev0 = nullptr, gev1 = nullptr;   // start / stop of the fused step's kernel (hipExtModuleLaunchKernel)
     bool pendingFused = false;             // the enqueued asynchronous step was a fused one
