@@ -198,40 +198,40 @@ int compareTyped(const Type& t, const uint8_t* l, const uint8_t* r) {
     }
 }
 
-// Restated with indices like the device version (kernels/rsq_device.h like()): the prefix and the suffix of the pattern are
-// matched independently (they may overlap in the string), infixes are searched greedily left to right; reading index ==
-// length yields the NUL the reference reads there.
-bool refLike(const char* S, const char* L) {
-    const int sn = (int)strlen(S), ln = (int)strlen(L);
-    auto at = [](const char* p, int n, int i) -> char { return i >= 0 && i < n ? p[i] : '\0'; };
-    auto likeChar = [](char c, char l) { return c == l || l == '_'; };
-    int sPos = 0, lPos = 0;
-    int lInStart = 0, lInEnd = ln, sInStart = 0, sInEnd = sn;
-    if (at(L, ln, 0) != '%') {                                   // prefix
-        for (; lPos < ln && sPos < sn && at(L, ln, lPos) != '%'; ++lPos, ++sPos)
-            if (!likeChar(at(S, sn, sPos), at(L, ln, lPos))) return false;
-        lInStart = lPos; sInStart = sPos;
+// LIKE with the reference's results (stringLikeCheck, src/qlib/scalar.h:49-118; pinned by tests/golden/like_reference.json).
+// Same three steps as the device version (kernels/rsq_device.h like()): the pattern's literal head, its literal tail
+// compared from the ends (it may reach into characters the head used), then the '%'-separated segments in between,
+// each at its leftmost place behind the one before.
+namespace {
+struct LikeText {
+    const char* p; int n;
+    char operator[](int i) const { return i >= 0 && i < n ? p[i] : '\0'; }
+};
+inline bool likeSame(char c, char pat) { return pat == '_' || c == pat; }
+}
+bool refLike(const char* str, const char* pattern) {
+    const LikeText S{str, (int)strlen(str)}, P{pattern, (int)strlen(pattern)};
+    int head = 0;
+    if (P[0] != '%') {
+        while (head < P.n && head < S.n && P[head] != '%') { if (!likeSame(S[head], P[head])) return false; head++; }
+        if (head == P.n) return head == S.n;
     }
-    if (lInStart == ln) return sInStart == sn;                   // no '%' left
-    if (at(L, ln, ln - 1) != '%') {                              // suffix
-        sPos = sn - 1; lPos = ln - 1;
-        for (; lPos >= 0 && sPos >= 0 && at(L, ln, lPos) != '%'; --lPos, --sPos)
-            if (!likeChar(at(S, sn, sPos), at(L, ln, lPos))) return false;
-        lInEnd = lPos; sInEnd = sPos + 1;
+    int patEnd = P.n, strEnd = S.n;
+    if (P[P.n - 1] != '%') {
+        int k = 0;
+        while (k < P.n && k < S.n && P[P.n - 1 - k] != '%') { if (!likeSame(S[S.n - 1 - k], P[P.n - 1 - k])) return false; k++; }
+        patEnd = P.n - 1 - k; strEnd = S.n - k;
+        if (head >= patEnd) return true;
     }
-    if (lInStart < lInEnd) {                                     // infixes
-        lPos = lInStart + 1; sPos = sInStart;
-        while (sPos < sInEnd && lPos < lInEnd) {
-            int lTrace = lPos, sTrace = sPos;
-            while (likeChar(at(S, sn, sTrace), at(L, ln, lTrace)) && sTrace < sInEnd) {
-                ++lTrace;
-                if (at(L, ln, lTrace) == '%') { lPos = ++lTrace; sPos = sTrace; break; }
-                ++sTrace;
-            }
-            ++sPos;
+    int seg = head + 1;
+    for (int at = head; at < strEnd && seg < patEnd; at++) {
+        int j = 0;
+        while (at + j < strEnd && likeSame(S[at + j], P[seg + j])) {
+            if (P[seg + j + 1] == '%') { at += j; seg += j + 2; break; }
+            j++;
         }
     }
-    return lPos >= lInEnd;
+    return seg >= patEnd;
 }
 
 void refQuicksort(uint8_t* data, int64_t n, size_t ts, const std::vector<OrderRequest>& order) {

@@ -225,41 +225,39 @@ RSQ_DEV bool ends_with_space(const Str& s) { const int n = str_len_exact(s); ret
 RSQ_DEV i64 str_addr(const Str& s) { return (i64)(u64)reinterpret_cast<unsigned long long>(s.p); }
 RSQ_DEV Str str_from_addr(i64 w, int cap) { return str(reinterpret_cast<const char*>((unsigned long long)(u64)w), cap); }
 
-// stringLikeCheck (reference src/qlib/scalar.h:49-118): '%' any run, '_' any one character.  Restated with indices;
-// the reference's behaviour is kept where it is peculiar (prefix and suffix of the pattern are matched independently
-// and may overlap in the string; infixes are searched greedily left to right).  str_at() yields the NUL the reference
-// reads at index == length.
+// LIKE ('%' any run, '_' any one character) with the reference's results (stringLikeCheck, src/qlib/scalar.h:49-118;
+// pinned by tests/golden/like_reference.json), peculiar ones included: the pattern's literal head and tail are matched
+// independently and may use the same characters ('ab' LIKE 'a%ab'); the '%'-separated segments between them are
+// placed leftmost-first; an empty segment ("%%") only matches a literal '%'.
+struct LikeText {
+    const Str& s; int n;
+    RSQ_DEV char operator[](int i) const { return i >= 0 && i < n ? s.p[i] : '\0'; }
+};
 RSQ_DEV int str_len(const Str& s) { int n = 0; while (n < s.cap && s.p[n] != '\0') n++; return n; }
-RSQ_DEV bool like_char(char c, char l) { return c == l || l == '_'; }
-RSQ_DEV u8 like(const Str& S, const Str& L) {
-    const int sn = str_len(S), ln = str_len(L);
-    int sPos = 0, lPos = 0;
-    int lInStart = 0, lInEnd = ln, sInStart = 0, sInEnd = sn;
-    if (str_at(L, 0) != '%') {                                   // prefix
-        for (; lPos < ln && sPos < sn && str_at(L, lPos) != '%'; ++lPos, ++sPos)
-            if (!like_char(str_at(S, sPos), str_at(L, lPos))) return 0;
-        lInStart = lPos; sInStart = sPos;
+RSQ_DEV bool like_same(char c, char pat) { return pat == '_' || c == pat; }
+RSQ_DEV u8 like(const Str& str, const Str& pattern) {
+    const LikeText S{str, str_len(str)}, P{pattern, str_len(pattern)};
+    int head = 0;                                               // literal head, as far as the string reaches
+    if (P[0] != '%') {
+        while (head < P.n && head < S.n && P[head] != '%') { if (!like_same(S[head], P[head])) return 0; head++; }
+        if (head == P.n) return (u8)(head == S.n);              // a pattern without '%': equal or nothing
     }
-    if (lInStart == ln) return (u8)(sInStart == sn);            // no '%' left
-    if (str_at(L, ln - 1) != '%') {                              // suffix
-        sPos = sn - 1; lPos = ln - 1;
-        for (; lPos >= 0 && sPos >= 0 && str_at(L, lPos) != '%'; --lPos, --sPos)
-            if (!like_char(str_at(S, sPos), str_at(L, lPos))) return 0;
-        lInEnd = lPos; sInEnd = sPos + 1;
+    int patEnd = P.n, strEnd = S.n;                             // literal tail, compared from the ends
+    if (P[P.n - 1] != '%') {
+        int k = 0;
+        while (k < P.n && k < S.n && P[P.n - 1 - k] != '%') { if (!like_same(S[S.n - 1 - k], P[P.n - 1 - k])) return 0; k++; }
+        patEnd = P.n - 1 - k; strEnd = S.n - k;
+        if (head >= patEnd) return 1;                           // nothing between head and tail
     }
-    if (lInStart < lInEnd) {                                     // infixes
-        lPos = lInStart + 1; sPos = sInStart;
-        while (sPos < sInEnd && lPos < lInEnd) {
-            int lTrace = lPos, sTrace = sPos;
-            while (like_char(sTrace < sn ? str_at(S, sTrace) : '\0', lTrace < ln ? str_at(L, lTrace) : '\0') && sTrace < sInEnd) {
-                ++lTrace;
-                if ((lTrace < ln ? str_at(L, lTrace) : '\0') == '%') { lPos = ++lTrace; sPos = sTrace; break; }
-                ++sTrace;
-            }
-            ++sPos;
+    int seg = head + 1;                                         // first pattern character behind the head's '%'
+    for (int at = head; at < strEnd && seg < patEnd; at++) {    // each segment at its leftmost place behind the last
+        int j = 0;
+        while (at + j < strEnd && like_same(S[at + j], P[seg + j])) {
+            if (P[seg + j + 1] == '%') { at += j; seg += j + 2; break; }
+            j++;
         }
     }
-    return (u8)(lPos >= lInEnd);
+    return (u8)(seg >= patEnd);
 }
 
 // ---- hash tables in HBM ----------------------------------------------------------------------
