@@ -1372,6 +1372,142 @@ struct Walker {
         s << "        else rsq::global_merge<0>(" << at << ", v);\n    }\n";
     }
 
+    // Form 3 of a large dense aggregation (rsq_device.h "staged partitioning"): the passing row becomes a PACKED record — the
+    // group's index inside its partition and the accumulator inputs, each in as many bits as its column's statistics need —
+    // handed to the workgroup's LDS rings; the first-row tracker is kept beside it (stage_track).  Available when the
+    // record fits 128 bits and the partitions fit the rings (<= 256); the wider cases stay with form 2.
+    void emitStagedScatter(int64_t D, int W, int gpp, int shift, int P) {
+        if (P > 256 || !envInt("RSQ_STAGED", 1, 0, 1) || q.accums[0].merge != 2) return;
+        struct Field { int w; int bits; int64_t min; bool check; int word, off; };
+        std::vector<Field> fields;
+        fields.push_back({-1, shift, 0, false, 0, 0});
+        for (int w : pipe.partRecordInputs) {
+            Field f{w, 64, 0, false, 0, 0};
+            const Expr* e = q.accums[(size_t)w].inputExpr;
+            if (e && e->tag == RSQ_E_ATTRIBUTE) {
+                const int ci = pipe.src->findCol(e->symbol);
+                if (ci >= 0 && pipe.src->cols[(size_t)ci].stats.valid) {
+                    const TableColumn& c = pipe.src->cols[(size_t)ci];
+                    const uint64_t range = (uint64_t)c.stats.max - (uint64_t)c.stats.min;
+                    int bits = 1; while (bits < 64 && (range >> bits) != 0) bits++;
+                    if (bits < 64) { f.bits = bits; f.min = c.stats.min; f.check = !c.owned || envInt("RSQ_CHECK_STATS", 0, 0, 1); }
+                }
+            }
+            fields.push_back(f);
+        }
+        int used[2] = {0, 0};
+        for (auto& f : fields) {
+            int wd = 0;
+            while (wd < 2 && used[wd] + f.bits > 64) wd++;
+            if (wd == 2) return;                                  // wider than two words: form 2
+            f.word = wd; f.off = used[wd]; used[wd] += f.bits;
+        }
+        const int RECW = used[1] ? 2 : 1;
+        const int ncolsNow = (int)colTypes.size();
+        const int RPT = envInt("RSQ_STAGED_ROWS", ncolsNow <= 6 ? 4 : 2, 2, 8) & ~1;
+        pipe.staged = true; pipe.stagedRecWords = RECW; pipe.stagedRows = RPT;
+        const std::string Ps = std::to_string(P), Rs = std::to_string(RECW), Ts = std::to_string(RPT);
+        const std::string LDS = "rsq::StageLds<" + Rs + ", " + Ps + ">";
+        line("#elif RSQ_AGG_VARIANT == 3");
+        openScope("{");
+        line("const u32 sp_p = (u32)(gid >> " + std::to_string(shift) + ");");
+        line("if (a.sp_mode) atomicAdd(&st.sp->tail[sp_p], 1u);          // counting only: exact region sizes after an overflow");
+        openScope("else {");
+        line("if ((u64)row < st.sp_wm) rsq::stage_track(*st.sp, a.out + " + std::to_string((long long)(q.accumSlot[0] * D)) + " + gid, row);");
+        for (int wd = 0; wd < RECW; wd++) {
+            std::string ex;
+            for (auto& f : fields) {
+                if (f.word != wd) continue;
+                std::string v;
+                if (f.w < 0) v = "(u64)(gid & " + std::to_string(gpp - 1) + ")";
+                else {
+                    const std::string in = "in" + std::to_string(f.w);
+                    if (f.bits == 64) v = "(u64)" + in;
+                    else {
+                        const std::string an = "sp_min" + std::to_string(f.w);
+                        addArg(an, "i64", (uint64_t)f.min);
+                        const std::string mask = std::to_string((unsigned long long)((1ull << f.bits) - 1ull)) + "ull";
+                        if (f.check) line("if ((u64)(" + in + " - a." + an + ") > " + mask + ") atomicOr(a.err, (u32)rsq::ERR_GROUP_OVERFLOW);");
+                        v = "((u64)(" + in + " - a." + an + ") & " + mask + ")";
+                    }
+                }
+                if (f.off) v = "(" + v + " << " + std::to_string(f.off) + ")";
+                ex += (ex.empty() ? "" : " | ") + v;
+            }
+            line("st.sp_rec[SP_SLOT * " + Rs + " + " + std::to_string(wd) + "] = " + (ex.empty() ? std::string("0ull") : ex) + ";");
+        }
+        line("st.sp_p[SP_SLOT] = sp_p;");
+        line("st.sp_k[SP_SLOT] = atomicAdd(&st.sp->tail[sp_p], 1u);");
+        line("st.sp_pending |= 1u << SP_SLOT;");
+        closeScope();
+        closeScope();
+        addArg("sp_base", "const u64*", 0); addArg("sp_cap", "const u32*", 0); addArg("sp_ctl", "rsq::StageCtl*", 0);
+        addArg("sp_counts", "u32*", 0); addArg("sp_rec", "u64*", 0); addArg("sp_mode", "u32", 0);
+        stateDecl += "#if RSQ_AGG_VARIANT == 3\n    " + LDS + "* sp;\n    u64 sp_wm;\n    u64 sp_rec[" + std::to_string(RPT * RECW) + "];\n    u32 sp_k[" + Ts +
+                     "];\n    u32 sp_p[" + Ts + "];\n    u32 sp_pending;\n#endif\n";
+        prologue += "#if RSQ_AGG_VARIANT == 3\n    __shared__ " + LDS + " s_stage;\n    rsq::stage_init(s_stage, a.sp_base, a.sp_cap, a.sp_ctl);\n";
+        prologue += "    st.sp = &s_stage; st.sp_pending = 0u; st.sp_wm = ~0ull;\n#endif\n";
+        // ---- aggregation of one partition's records (all workgroups' regions of it) in an LDS table ----
+        std::ostringstream k;
+        auto& A3 = pipe.argsStagedAgg;
+        A3.push_back({"sp_rec", "const u64*", 0});
+        A3.push_back({"sp_base", "const u64*", 0});
+        A3.push_back({"sp_cap", "const u32*", 0});
+        A3.push_back({"sp_counts", "const u32*", 0});
+        A3.push_back({"sp_nwg", "u32", 0});
+        A3.push_back({"out", "u64*", 0});
+        for (auto& f : fields) if (f.w >= 0 && f.bits < 64) A3.push_back({"sp_min" + std::to_string(f.w), "i64", (uint64_t)f.min});
+        k << "// generated by resql_amd/csrc/codegen.cpp: aggregation of one partition of packed records in an LDS table\n";
+        k << "#include \"rsq_device.h\"\nstruct Args {\n";
+        for (auto& a : A3) k << "    " << a.ctype << " " << a.name << ";\n";
+        k << "};\n";
+        // accumulator blocks 1 .. W-1 of the table (block 0, the first row, is the tracker's)
+        k << "static RSQ_DEV void merge_record(const Args& a, u64* tab";
+        for (int wd = 0; wd < RECW; wd++) k << ", const u64 w" << wd;
+        k << ") {\n";
+        for (auto& f : fields) {
+            std::string v = "w" + std::to_string(f.word);
+            if (f.off) v = "(" + v + " >> " + std::to_string(f.off) + ")";
+            if (f.bits < 64) v = "(" + v + " & " + std::to_string((unsigned long long)((1ull << f.bits) - 1ull)) + "ull)";
+            if (f.w < 0) k << "    const int g = (int)" << v << ";\n";
+            else if (f.bits < 64) k << "    const u64 in" << f.w << " = (u64)((i64)" << v << " + a.sp_min" << f.w << ");\n";
+            else k << "    const u64 in" << f.w << " = " << v << ";\n";
+        }
+        for (int w = 1; w < W; w++) {
+            std::string in = "(u64)" + q.accums[(size_t)w].input;             // a constant (COUNT's 1) unless it travels
+            for (auto& f : fields) if (f.w == w) in = "in" + std::to_string(w);
+            k << "    rsq::lds_merge<" << q.accums[(size_t)w].merge << ">(&tab[" << (int64_t)(w - 1) * gpp << " + g], " << in << ");\n";
+        }
+        k << "}\n";
+        k << "extern \"C\" __global__ void __launch_bounds__(1024) rsq_staged_agg(Args a) {\n";
+        k << "    __shared__ u64 s_tab[" << (int64_t)(W - 1) * gpp << "];\n";
+        k << "    for (int i = threadIdx.x; i < " << (int64_t)(W - 1) * gpp << "; i += blockDim.x) { const int w = 1 + (i >> " << shift << "); s_tab[i] = ";
+        for (int w = 1; w < W; w++) k << (w > 1 ? " : " : "") << (w < W - 1 ? "w == " + std::to_string(w) + " ? " : "") << identityOf(q.accums[(size_t)w].merge);
+        k << "; }\n    __syncthreads();\n";
+        k << "    const int p = blockIdx.x, lane = threadIdx.x & 63;\n";
+        k << "    const u64 base = a.sp_base[p]; const u32 cap = a.sp_cap[p];\n";
+        k << "    for (u32 wg = threadIdx.x >> 6; wg < a.sp_nwg; wg += blockDim.x >> 6) {\n";
+        k << "        const u64 st = base + (u64)wg * cap;\n        const u32 cnt = min(a.sp_counts[(u64)wg * " << P << " + p], cap);\n";
+        if (RECW == 1) {
+            k << "        for (u32 i = lane * 2; i < cnt; i += 128) {\n";
+            k << "            const rsq::u64x2 v = *reinterpret_cast<const rsq::u64x2*>(a.sp_rec + st + i);\n";
+            k << "            merge_record(a, s_tab, v.x);\n            if (i + 1 < cnt) merge_record(a, s_tab, v.y);\n        }\n";
+        } else {
+            k << "        for (u32 i = lane; i < cnt; i += 64) {\n";
+            k << "            const rsq::u64x2 v = *reinterpret_cast<const rsq::u64x2*>(a.sp_rec + (st + i) * 2);\n";
+            k << "            merge_record(a, s_tab, v.x, v.y);\n        }\n";
+        }
+        k << "    }\n    __syncthreads();\n";
+        k << "    for (int i = threadIdx.x; i < " << (int64_t)(W - 1) * gpp << "; i += blockDim.x) {\n";
+        k << "        const int w = 1 + (i >> " << shift << ");\n";
+        k << "        const i64 g = (i64)p * " << gpp << " + (i & " << (gpp - 1) << ");\n";
+        // accumulator w lives in block accumSlot[w] of the [block][group] table
+        k << "        const i64 blk = ";
+        for (int w = 1; w < W; w++) k << (w > 1 ? " : " : "") << (w < W - 1 ? "w == " + std::to_string(w) + " ? " : "") << "(i64)" << q.accumSlot[(size_t)w];
+        k << ";\n        if (g < " << D << ") a.out[blk * " << D << " + g] = s_tab[i];\n    }\n}\n";
+        pipe.sourceStagedAgg = k.str();
+    }
+
     void emitDenseAggregation(OpNode* o) {
         const int64_t D = q.denseGroups;
         const int W = (int)q.accums.size();
@@ -1540,6 +1676,7 @@ struct Walker {
                 for (size_t j = 0; j < pipe.partRecordInputs.size(); j++)
                     line("rec[" + std::to_string(j + 1) + "] = (u64)in" + std::to_string(pipe.partRecordInputs[j]) + ";");
                 closeScope();
+                emitStagedScatter(D, W, gpp, shift, (int)P);
                 line("#else");
             }
             pipe.partAtomicsPerRow = 0;
@@ -1553,7 +1690,7 @@ struct Walker {
                 addArg("part_counts", "u32*", 0); addArg("part_start", "const u32*", 0); addArg("tile_step", "i64", 1);
                 stateDecl += "    u32* part;\n";
                 const std::string Ps = std::to_string((long long)P);
-                prologue += "#if RSQ_AGG_VARIANT != 0\n    __shared__ u32 s_part[" + Ps + "];\n";
+                prologue += "#if RSQ_AGG_VARIANT == 1 || RSQ_AGG_VARIANT == 2\n    __shared__ u32 s_part[" + Ps + "];\n";
                 prologue += "    for (int i = threadIdx.x; i < " + Ps + "; i += blockDim.x)\n";
                 prologue += "        s_part[i] = RSQ_AGG_VARIANT == 2 ? a.part_start[i] + a.part_counts[(u64)blockIdx.x * " + Ps + " + i] : 0u;\n";
                 prologue += "    __syncthreads();\n    st.part = s_part;\n#endif\n";
@@ -1696,6 +1833,9 @@ struct Walker {
         s << "#include \"rsq_device.h\"\n";
         s << fileScope;
         const bool cq = pipe.compact;
+        // (the staged form's round loop knows neither the compaction queues nor prefetched bitmap words nor string columns)
+        if (pipe.staged && (cq || mat || !bitmapPrefetch.empty() || !pipe.lazyCols.empty() ||
+                            std::find(colIsString.begin(), colIsString.end(), true) != colIsString.end())) pipe.staged = false;
         // 63 left over + 128 pushed by one tile, rounded up.  (RSQ_QCAP=128 drains after every row_fn call instead: smaller
         // queues, 7 instead of 4 workgroups of a five-word pipeline per CU — measured slower: Q3's orders pipeline 0.24 ->
         // 0.31 ms, its inserts do not want more waves.)
@@ -1743,6 +1883,7 @@ struct Walker {
             }
             s << ");\n        st.cq_rows++;\n    }\n    st.cq_n -= count;\n}\n";
         }
+        if (pipe.staged) s << "#if RSQ_AGG_VARIANT == 3\ntemplate <int SP_SLOT>       // the row's place among the rows a thread handles per round\n#endif\n";
         s << "static RSQ_DEV void row_fn(const Args& a, State& st, const i64 lr" << (cq ? ", const bool valid" : "") << rowParams << ") {\n";
         s << "    const i64 row = a.row0 + lr;\n";
         if (cq) {
@@ -1776,9 +1917,47 @@ struct Walker {
         s << "    const i64 ntiles = a.n_rows >> 7;\n";
         if (pipe.partitioned) s << "#if RSQ_AGG_VARIANT == 1\n    const i64 tstep = a.tile_step;      // > 1: sample every n-th tile\n#else\n    const i64 tstep = 1;\n#endif\n";
         else s << "    const i64 tstep = 1;\n";
+        const int ncols = (int)colTypes.size();
+        if (pipe.staged) {
+            // Form 3 walks the table in ROUNDS of blockDim.x * RPT rows with the workgroup in step (every thread reaches the
+            // barriers of stage_commit): wave w of the workgroup takes RPT/2 consecutive 128-row tiles of the round.
+            const int H = pipe.stagedRows / 2;
+            s << "#if RSQ_AGG_VARIANT == 3\n";
+            s << "    const i64 tpr = (i64)(blockDim.x >> 6) * " << H << ";        // tiles per round\n";
+            s << "    const i64 nrounds = (ntiles + tpr - 1) / tpr;\n";
+            s << "    for (i64 round = blockIdx.x; round < nrounds; round += gridDim.x) {\n";
+            s << "        st.sp_pending = 0u; st.sp_wm = s_stage.wm;\n";
+            s << "        const i64 t0 = round * tpr + (i64)(threadIdx.x >> 6) * " << H << ";\n";
+            for (int u = 0; u < H; u++) {
+                for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2];\n";
+                s << "        if (t0 + " << u << " < ntiles) {\n            const i64 b = ((t0 + " << u << ") << 7) + lane * 2;\n";
+                for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "            rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
+                s << "        }\n";
+            }
+            for (int u = 0; u < H; u++) {
+                s << "        if (t0 + " << u << " < ntiles) {\n";
+                for (int j = 0; j < 2; j++) {
+                    s << "            row_fn<" << (2 * u + j) << ">(a, st, ((t0 + " << u << ") << 7) + lane * 2 + " << j;
+                    for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
+                    s << ");\n";
+                }
+                s << "        }\n";
+            }
+            s << "        if (!a.sp_mode) rsq::stage_commit<" << pipe.stagedRecWords << ", " << pipe.partCount << ", " << pipe.stagedRows
+              << ">(s_stage, st.sp_rec, st.sp_k, st.sp_p, st.sp_pending, a.sp_rec, a.sp_ctl, " << q.denseGroups << "u);\n";
+            s << "    }\n";
+            s << "    if (blockIdx.x == 0 && (a.n_rows & 127)) {        // the rows behind the last whole tile: one more round of workgroup 0\n";
+            s << "        st.sp_pending = 0u; st.sp_wm = s_stage.wm;\n";
+            s << "        const i64 r = (ntiles << 7) + threadIdx.x;\n";
+            s << "        if (r < a.n_rows) row_fn<0>(a, st, r" << rowArgsTail << ");\n";
+            s << "        if (!a.sp_mode) rsq::stage_commit<" << pipe.stagedRecWords << ", " << pipe.partCount << ", " << pipe.stagedRows
+              << ">(s_stage, st.sp_rec, st.sp_k, st.sp_p, st.sp_pending, a.sp_rec, a.sp_ctl, " << q.denseGroups << "u);\n";
+            s << "    }\n";
+            s << "    rsq::stage_finish(s_stage, a.sp_rec, a.sp_counts, a.sp_ctl, a.sp_mode != 0u);\n";
+            s << "#else\n";
+        }
         // main loop, textually unrolled: the loads of U tiles are issued before the first row is processed
         s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
-        const int ncols = (int)colTypes.size();
         for (int u = 0; u < U; u++) {
             s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2];\n";
@@ -1828,6 +2007,7 @@ struct Walker {
             if (mat) s << "#if RSQ_PASS == 1\n        a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
             s << "    }\n";
         }
+        if (pipe.staged) s << "#endif\n";
         s << epilogue << "}\n";
         pipe.source = s.str();
         if (!pipe.lazyCols.empty()) pipe.source = "#define RSQ_LAZY 0\n" + pipe.source;
@@ -1845,6 +2025,7 @@ struct Walker {
             // count and scatter run as ONE 1024-thread workgroup per CU (see the note at the record stores)
             pipe.sourcePartCount = "#define RSQ_AGG_VARIANT 1\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
             pipe.sourcePartScatter = "#define RSQ_AGG_VARIANT 2\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
+            if (pipe.staged) pipe.sourceStagedScatter = "#define RSQ_AGG_VARIANT 3\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
             pipe.source = "#define RSQ_AGG_VARIANT 0\n" + pipe.source;
         }
         if (!pipe.lazyCols.empty()) {          // the late-load form of the full-execution kernel: same text, RSQ_LAZY 1
@@ -1856,6 +2037,7 @@ struct Walker {
         }
         std::string ex = "pipeline " + std::to_string(q.pipelines.size()) + ": ";
         for (size_t i = 0; i < explainSteps.size(); i++) ex += (i ? " -> " : "") + explainSteps[i];
+        if (pipe.staged) ex += " [partitioned as packed " + std::to_string(8 * pipe.stagedRecWords) + "-byte records staged through LDS rings]";
         pipe.explain = ex;
         q.pipelines.push_back(pipe);
     }

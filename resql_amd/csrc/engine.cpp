@@ -134,6 +134,10 @@ Query::~Query() {
     if (dCandRows) ctx.free(dCandRows);
     if (dPartCounts) ctx.free(dPartCounts);
     if (dPartStart) ctx.free(dPartStart);
+    if (dStageBase) ctx.free(dStageBase);
+    if (dStageCap) ctx.free(dStageCap);
+    if (dStageCtl) ctx.free(dStageCtl);
+    if (dStageCounts) ctx.free(dStageCounts);
     if (dPartTotals) ctx.free(dPartTotals);
     for (void* r : dPartRecords) if (r) ctx.scratchFree(r);
     for (auto& h : hashTables) {
@@ -193,6 +197,7 @@ static std::vector<std::string> kernelSources(const Query& q) {
         if (!p.sourcePass1.empty()) v.push_back(p.sourcePass1);
         if (!p.sourceFlat.empty()) v.push_back(p.sourceFlat);
         if (p.partitioned) { v.push_back(p.sourcePartCount); v.push_back(p.sourcePartScatter); v.push_back(p.sourcePartAgg); }
+        if (p.staged) { v.push_back(p.sourceStagedScatter); v.push_back(p.sourceStagedAgg); }
         v.push_back(p.source);
     }
     return v;
@@ -208,6 +213,10 @@ static void resolveKernels(Query& q) {
             p.kernelPartCount = &ctx.getKernel(p.sourcePartCount, p.entry);
             p.kernelPartScatter = &ctx.getKernel(p.sourcePartScatter, p.entry);
             p.kernelPartAgg = &ctx.getKernel(p.sourcePartAgg, "rsq_part_agg");
+        }
+        if (p.staged) {
+            p.kernelStagedScatter = &ctx.getKernel(p.sourceStagedScatter, p.entry);
+            p.kernelStagedAgg = &ctx.getKernel(p.sourceStagedAgg, "rsq_staged_agg");
         }
         p.kernel = &ctx.getKernel(p.source, p.entry);
         if (!p.sourceLazy.empty() && ctx.device < 0) (void)ctx.getKernel(p.sourceLazy, p.entry);      // build(): warm the cache with both forms
@@ -318,7 +327,13 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     if (a.name == "part_counts") return (uint64_t)(uintptr_t)q.dPartCounts;
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
-    if (a.name == "rec") return q.dPartRecords.empty() ? 0 : (uint64_t)(uintptr_t)q.dPartRecords[0];
+    if (a.name == "rec" || a.name == "sp_rec") return q.dPartRecords.empty() ? 0 : (uint64_t)(uintptr_t)q.dPartRecords[0];
+    if (a.name == "sp_base") return (uint64_t)(uintptr_t)q.dStageBase;
+    if (a.name == "sp_cap") return (uint64_t)(uintptr_t)q.dStageCap;
+    if (a.name == "sp_ctl") return (uint64_t)(uintptr_t)q.dStageCtl;
+    if (a.name == "sp_counts") return (uint64_t)(uintptr_t)q.dStageCounts;
+    if (a.name == "sp_mode") return (uint64_t)q.stageMode;
+    if (a.name == "sp_nwg") return (uint64_t)q.stageWorkgroups;
     (void)p;
     if (a.name == "cq_total") return (uint64_t)(uintptr_t)(q.dPipeStats + (&p - q.pipelines.data()));
     if (a.name == "cnt") return (uint64_t)(uintptr_t)q.dMatCnt;
@@ -385,6 +400,112 @@ static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1
     if (getenv("RSQ_TRACE") && p.compact) fprintf(stderr, "[rsq trace]     %s: %u workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(), p.lastGrid, (long long)p.stage2Rows);
 }
 
+// Form 3 of a large dense aggregation (rsq_device.h "staged partitioning"): one pass turns the passing rows into packed
+// records, region by region, and one workgroup per partition aggregates them in LDS.  `estimate[p]` is the number of records
+// expected in partition p (from the sampled counting pass); every workgroup gets the same share of it plus slack.  A region
+// that runs full is reported by the pass; the regions are then sized by counting (the same kernel, tickets only) and the
+// pipeline remembers to do so.  Returns false when the exact regions would not be worth their memory (form 2 runs instead).
+static bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64_t>& estimate) {
+    Context& ctx = q.ctx;
+    const int P = p.partCount;
+    const unsigned block = 1024;
+    const int64_t tiles = p.src->nRows >> 7;
+    const int64_t tilesPerRound = (int64_t)(block / 64) * (p.stagedRows / 2);
+    const int64_t rounds = std::max<int64_t>(1, (tiles + tilesPerRound - 1) / tilesPerRound);
+    const unsigned nwg = (unsigned)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx.numCUs, rounds));
+    const uint64_t lineRecords = (uint64_t)(16 / p.stagedRecWords);
+    const size_t recBytes = 8 * (size_t)p.stagedRecWords;
+    const bool trace = getenv("RSQ_TRACE") != nullptr;
+    if (!q.dStageBase) {
+        q.dStageBase = (uint64_t*)ctx.alloc((size_t)P * 8);
+        q.dStageCap = (uint32_t*)ctx.alloc((size_t)P * 4);
+        q.dStageCtl = ctx.alloc(32);
+    }
+    if (q.stageCountsWords < (size_t)nwg * (size_t)P) {
+        if (q.dStageCounts) ctx.free(q.dStageCounts);
+        q.stageCountsWords = (size_t)nwg * (size_t)P;
+        q.dStageCounts = (uint32_t*)ctx.alloc(q.stageCountsWords * 4);
+    }
+    q.stageWorkgroups = nwg;
+    std::vector<uint64_t> base((size_t)P);
+    std::vector<uint32_t> cap((size_t)P);
+    auto layout = [&]() -> uint64_t {          // region(workgroup, p) = base[p] + workgroup * cap[p]; uploads both, returns the records provided for
+        uint64_t pos = 0;
+        for (int i = 0; i < P; i++) { base[(size_t)i] = pos; pos += (uint64_t)cap[(size_t)i] * nwg; }
+        RSQ_HIP(hipMemcpyAsync(q.dStageBase, base.data(), (size_t)P * 8, hipMemcpyHostToDevice, ctx.stream));
+        RSQ_HIP(hipMemcpyAsync(q.dStageCap, cap.data(), (size_t)P * 4, hipMemcpyHostToDevice, ctx.stream));
+        RSQ_HIP(hipStreamSynchronize(ctx.stream));          // (the vectors are reused)
+        const size_t need = (size_t)std::max<uint64_t>(pos, 1) * recBytes;
+        if (q.dPartRecords.empty() || q.stageRecBytes < need) {
+            for (void* r : q.dPartRecords) ctx.scratchFree(r);
+            q.dPartRecords.clear();
+            q.partRecordCapacity = 0;                          // (form 2 allocates anew should it run later)
+            q.dPartRecords.push_back(ctx.scratchAlloc(need));
+            q.stageRecBytes = need;
+        }
+        return pos;
+    };
+    auto pass = [&](uint32_t mode) {
+        q.stageMode = mode;
+        launchPipelineKernel(q, p, *p.kernelStagedScatter, -1, nwg, block);
+        q.stageMode = 0;
+    };
+    auto overflowed = [&]() -> bool {
+        uint32_t ctl[8] = {0};
+        RSQ_HIP(hipMemcpyAsync(ctl, q.dStageCtl, 32, hipMemcpyDeviceToHost, ctx.stream));
+        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        if (trace) fprintf(stderr, "[rsq trace]     staged pass: %u of %lld groups seen, watermark row %llu%s\n", ctl[4], (long long)q.denseGroups,
+                           (unsigned long long)(((uint64_t)ctl[3] << 32) | ctl[2]), ctl[5] ? ", a region ran full" : "");
+        return ctl[5] != 0;
+    };
+    auto aggregate = [&]() {
+        std::vector<uint64_t> args;
+        for (auto& a : p.argsStagedAgg) args.push_back(argValue(q, p, a, -1));
+        launch(ctx, *p.kernelStagedAgg, (unsigned)P, 1024u, args);
+        q.report.num_kernels++;
+    };
+    RSQ_HIP(hipMemsetAsync(q.dStageCtl, 0, 32, ctx.stream));
+    if (!p.stagedExact) {
+        const bool reuse = estimate.empty();
+        if (reuse) cap = p.stagedCaps;
+        else for (int i = 0; i < P; i++) {
+            const uint64_t per = (uint64_t)((double)estimate[(size_t)i] / (double)nwg * 1.15) + 256;
+            cap[(size_t)i] = (uint32_t)std::min<uint64_t>((per + lineRecords - 1) / lineRecords * lineRecords, 0xfffffff0ull);
+        }
+        const uint64_t provided = layout();
+        if (trace) fprintf(stderr, "[rsq trace]     staged partitioning: %u workgroups x %d partitions, %zu-byte records, regions for %llu records (%s)\n",
+                           nwg, P, recBytes, (unsigned long long)provided, reuse ? "as in the last execution" : "sampled");
+        pass(0);
+        aggregate();                       // (enqueued before the pass's verdict is read: it never reads beyond a region, and is repeated if one ran full)
+        if (!overflowed()) { p.stagedCaps = cap; p.stagedCapsRows = p.src->nRows; return true; }
+        p.stagedCaps.clear();
+        if (reuse) return false;           // the data changed under the remembered regions: the caller samples again
+        p.stagedExact = true;
+        RSQ_HIP(hipMemsetAsync((char*)q.dStageCtl + 20, 0, 4, ctx.stream));      // the overflow flag; the tracker's state stays (its table is final)
+    }
+    // regions sized by counting: the tickets of the same kernel
+    for (int i = 0; i < P; i++) cap[(size_t)i] = 0;
+    (void)layout();
+    pass(1);
+    std::vector<uint32_t> counts((size_t)nwg * (size_t)P);
+    RSQ_HIP(hipMemcpyAsync(counts.data(), q.dStageCounts, counts.size() * 4, hipMemcpyDeviceToHost, ctx.stream));
+    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    uint64_t records = 0, provided = 0;
+    for (int i = 0; i < P; i++) {
+        uint64_t mx = 0;
+        for (unsigned w = 0; w < nwg; w++) { const uint64_t c = counts[(size_t)w * (size_t)P + (size_t)i]; records += c; mx = std::max(mx, c); }
+        cap[(size_t)i] = (uint32_t)std::min<uint64_t>((mx + lineRecords - 1) / lineRecords * lineRecords, 0xfffffff0ull);
+        provided += (uint64_t)cap[(size_t)i] * nwg;
+    }
+    if (trace) fprintf(stderr, "[rsq trace]     staged partitioning, counted: %llu records, regions for %llu\n", (unsigned long long)records, (unsigned long long)provided);
+    if (provided > 2 * records + (64ull << 20)) return false;          // one workgroup's rows differ wildly from the others': exact positions (form 2)
+    (void)layout();
+    pass(0);
+    if (overflowed()) failRuntime("internal error: a counted staging region ran full");
+    aggregate();
+    return true;
+}
+
 // Aggregation into a large dense table (see emitDenseAggregation, DENSE_GLOBAL): pick, per execution, between HBM
 // atomics (few rows pass the filter) and count -> scatter -> per-partition LDS aggregation (many rows pass).
 // RSQ_PARTITION=0 never partitions (decided at compile time), 2 always does (tests), 1 / unset decides from a sample.
@@ -423,15 +544,28 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
         q.partTileStep = 1;
         return total;
     };
-    const size_t recBytes = 8 * (1 + p.partRecordInputs.size());
-    if (!force) {
-        const int64_t step = 32;
+    const size_t recBytes = p.staged ? 8 * (size_t)p.stagedRecWords : 8 * (1 + p.partRecordInputs.size());
+    const int64_t step = rows >= (64 << 20) ? 32 : rows >= (8 << 20) ? 8 : 1;
+    // the regions that held the last execution's records hold this one's, unless the table changed (then the pass says so)
+    if (p.staged && !p.stagedExact && !p.stagedCaps.empty() && p.stagedCapsRows == rows && q.stageWorkgroups != 0) {
+        if (runStagedAggregation(q, p, {})) return;
+        RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+        fillU64Async(ctx, q.dAgg + (size_t)q.accumSlot[0] * (size_t)q.denseGroups, (size_t)q.denseGroups, 0x7fffffffffffffffull);
+    }
+    if (!force || p.staged) {
         const double passing = (double)countPass(step) * (double)step;
         const double direct = passing * (double)std::max(1, p.partAtomicsPerRow) / 25e9;
-        const double parted = ((double)rows * 16.0 + (double)rows * (double)p.bytesPerRow) / 6e12 + passing * (double)recBytes * 2.0 / 4e12 + 60e-6;
+        const double parted = p.staged ? (double)rows * (double)p.bytesPerRow / 6e12 + passing * (double)recBytes * 2.0 / 4e12 + 80e-6
+                                       : ((double)rows * 16.0 + (double)rows * (double)p.bytesPerRow) / 6e12 + passing * (double)recBytes * 2.0 / 4e12 + 60e-6;
         if (trace) fprintf(stderr, "[rsq trace]     large dense aggregation: ~%.0f of %lld rows pass; atomics %.3f ms vs partitioned %.3f ms\n",
                            passing, (long long)rows, direct * 1e3, parted * 1e3);
-        if (direct <= parted) { launchPipeline(q, p, -1); return; }
+        if (!force && direct <= parted) { launchPipeline(q, p, -1); return; }
+    }
+    if (p.staged) {
+        std::vector<uint64_t> estimate((size_t)P + 1);
+        RSQ_HIP(hipMemcpy(estimate.data(), q.dPartTotals, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost));
+        for (auto& e : estimate) e *= (uint64_t)step;
+        if (runStagedAggregation(q, p, estimate)) return;
     }
     const uint64_t total = countPass(1);
     if (total >= 0xffffffffull) { launchPipeline(q, p, -1); return; }          // record positions are 32-bit

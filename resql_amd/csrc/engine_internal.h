@@ -141,6 +141,15 @@ struct Pipeline {
     int partCount = 0;                   // P: number of partitions
     int partGroups = 0;                  // groups per partition (power of two)
     int partAtomicsPerRow = 0;           // HBM atomics the direct form issues per passing row (sum accumulators)
+    // form 3, staged partitioning (rsq_device.h): packed records through LDS rings, regions sized from a sample
+    bool staged = false;
+    int stagedRecWords = 1, stagedRows = 4;
+    std::string sourceStagedScatter, sourceStagedAgg;
+    Kernel* kernelStagedScatter = nullptr; Kernel* kernelStagedAgg = nullptr;
+    std::vector<ArgSlot> argsStagedAgg;
+    bool stagedExact = false;            // the last execution overflowed a sampled region: size the regions by counting
+    std::vector<uint32_t> stagedCaps;    // region capacities that held the last execution's records (reused while the row count stays)
+    int64_t stagedCapsRows = -1;
     std::string entry = "rsq_pipeline";
     std::vector<ArgSlot> args;
     Kernel* kernel = nullptr;
@@ -207,6 +216,11 @@ struct Query {
     std::vector<void*> dPartRecords;       // [0] keys (group-in-partition << 40 | row - row0), then one array per record input
     uint64_t partRecordCapacity = 0;
     int64_t partTileStep = 1;              // > 1: the counting pass samples every n-th tile (selectivity estimate)
+    // staged partitioning (form 3): region layout [P] base / capacity per workgroup, tracker control block, per-(workgroup, partition) counts
+    uint64_t* dStageBase = nullptr; uint32_t* dStageCap = nullptr; void* dStageCtl = nullptr;
+    uint32_t* dStageCounts = nullptr; size_t stageCountsWords = 0;
+    size_t stageRecBytes = 0;              // bytes of dPartRecords[0] when it was allocated for form 3
+    uint32_t stageMode = 0, stageWorkgroups = 0;
 
     uint64_t* dPipeStats = nullptr;        // per pipeline: rows that reached stage 2 (behind the wave compaction)
 

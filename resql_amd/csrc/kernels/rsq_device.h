@@ -48,6 +48,7 @@ RSQ_DEV i64 div(i64 a, i64 b, u32* err) {
 
 // ---- tile loads -----------------------------------------------------------------------------
 struct __attribute__((aligned(16))) i64x2 { i64 x, y; };
+struct __attribute__((aligned(16))) u64x2 { u64 x, y; };
 struct __attribute__((aligned(8))) i32x2 { i32 x, y; };
 struct __attribute__((aligned(2))) u8x2 { u8 x, y; };
 
@@ -360,5 +361,146 @@ RSQ_DEV u64 hash64(u64 x) {     // splitmix64 finaliser; the engine's own table 
 
 // blocked hash of a join key with a known range: d = key - min, m = (capacity << 32) / range (see codegen.cpp slotOf)
 RSQ_DEV u64 blocked_slot(u64 d, u64 m, u64 mask) { return (hash64(d >> 7) + (((d & 127ull) * m) >> 32)) & mask; }
+
+// ---- staged partitioning (large dense aggregations: codegen.cpp emitDenseAggregation, form 3) ------------------------------
+// One pass over the rows turns every passing row into a packed record in the region of its partition (partition = a
+// contiguous range of groups small enough for an LDS table); a second kernel aggregates each partition in LDS.  The pass is
+// HBM-bound, so records must reach HBM as whole 128-byte lines and must not be counted first:
+//  * a workgroup numbers the records of each partition with an LDS ticket counter; record k of partition p belongs at
+//    region(workgroup, p) + k.  It first goes to slot k % 32 of the partition's LDS ring; once per round (one tile of rows per
+//    thread) the workgroup meets at a barrier and writes every complete line of 16 / RECW records with one 128-byte store.
+//    A record whose slot still holds an unflushed record waits for the next flush (skewed keys; uniform keys never wait).
+//  * regions are sized from a sample of the table (engine.cpp), not from a counting pass; a region that runs full raises
+//    StageCtl::overflow and the engine repeats the pass with exact sizes.
+//  * the row index is not part of the record.  The first-row tracker (block 0 of the table: the reference emits groups in
+//    the order of their first rows) is kept with HBM atomics, filtered by a load — and only for rows below the WATERMARK:
+//    once every one of the D groups has been seen, no row at or behind 1 + (largest first sighting) can be a group's
+//    first row.  Workgroups report their first sightings every few rounds (largest row, then count, in this order), the
+//    report that completes the count publishes the watermark, and from then on rows behind it skip the tracker.
+struct StageCtl { u64 maxFirst; u64 watermark; u32 seen; u32 overflow; };        // zeroed before a launch; watermark 0: not known yet
+
+template <int RECW, int P>
+struct StageLds {
+    static constexpr int S = 32;                     // ring slots per partition (two lines of 8-byte records)
+    alignas(16) u64 ring[P * S * RECW];
+    u64 start[P];
+    u32 cap[P], tail[P], head[P];
+    u64 maxFirst, wm;
+    u32 newSeen, rounds;
+    u32 waiting[2];
+};
+
+template <int RECW, int P>
+RSQ_DEV void stage_init(StageLds<RECW, P>& L, const u64* partBase, const u32* partCap, const StageCtl* ctl) {
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        L.cap[i] = partCap[i]; L.start[i] = partBase[i] + (u64)blockIdx.x * partCap[i];
+        L.tail[i] = 0u; L.head[i] = 0u;
+    }
+    if (threadIdx.x == 0) {
+        L.newSeen = 0u; L.rounds = 0u; L.maxFirst = 0ull; L.waiting[0] = L.waiting[1] = 0u;
+        const u64 w = __hip_atomic_load(&ctl->watermark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.wm = w ? w : ~0ull;
+    }
+    __syncthreads();
+}
+
+// first-row tracker of one passing row in front of the watermark
+template <int RECW, int P>
+RSQ_DEV void stage_track(StageLds<RECW, P>& L, u64* cell, i64 row) {
+    if (row < peek_i64(cell)) {
+        const i64 old = atomicMin(reinterpret_cast<i64*>(cell), row);
+        if (old == (i64)0x7fffffffffffffffll) { atomicAdd(&L.newSeen, 1u); atomicMax(&L.maxFirst, (u64)row); }
+    }
+}
+
+template <int RECW, int P>
+RSQ_DEV void stage_flush_lines(StageLds<RECW, P>& L, u64* recOut, StageCtl* ctl) {
+    constexpr int S = StageLds<RECW, P>::S, LPR = 16 / RECW;
+    const int j = threadIdx.x & 7;                   // 8 lanes per partition, 16 bytes each: one 128-byte line per step
+    for (int p = threadIdx.x >> 3; p < P; p += blockDim.x >> 3) {
+        u32 h = L.head[p];
+        const u32 tl = min(L.tail[p], h + (u32)S);
+        const u32 full = tl / LPR * LPR;
+        if (h < full) {
+            const u32 cap = L.cap[p];
+            for (; h < full; h += LPR) {
+                const u64x2 v = *reinterpret_cast<const u64x2*>(&L.ring[((u32)p * S + (h & (S - 1))) * RECW + j * 2]);
+                if (h + LPR <= cap) *reinterpret_cast<u64x2*>(&recOut[(L.start[p] + h) * RECW + j * 2]) = v;
+                else if (j == 0) atomicOr(&ctl->overflow, 1u);
+            }
+            if (j == 0) L.head[p] = h;
+        }
+    }
+}
+
+// Workgroup barrier that orders LDS only.  __syncthreads() also waits for every outstanding global load and store
+// (s_waitcnt vmcnt(0)); the staging rounds keep their column loads and line stores in flight across the barrier.
+RSQ_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// end of a round: the round's records into the rings, complete lines out, first sightings reported
+template <int RECW, int P, int RPT>
+RSQ_DEV void stage_commit(StageLds<RECW, P>& L, const u64 (&rec)[RPT * RECW], const u32 (&k)[RPT], const u32 (&pp)[RPT], u32 pending,
+                          u64* recOut, StageCtl* ctl, u32 D) {
+    constexpr int S = StageLds<RECW, P>::S;
+    for (int it = 0;; it++) {
+#pragma unroll
+        for (int i = 0; i < RPT; i++) {
+            if ((pending >> i) & 1u) {
+                if (k[i] - L.head[pp[i]] < (u32)S) {
+                    u64* slot = &L.ring[(pp[i] * S + (k[i] & (S - 1))) * RECW];
+#pragma unroll
+                    for (int w = 0; w < RECW; w++) slot[w] = rec[i * RECW + w];
+                    pending &= ~(1u << i);
+                }
+            }
+        }
+        // "does anyone still hold a record?" is voted through two LDS words used in turn: this iteration's word is set before
+        // the first barrier and read behind it; the other word is cleared between the barriers, when nobody writes it
+        if (pending) L.waiting[it & 1] = 1u;
+        lds_barrier();
+        stage_flush_lines<RECW, P>(L, recOut, ctl);
+        const u32 any = L.waiting[it & 1];
+        if (threadIdx.x == blockDim.x - 1) {
+            L.waiting[(it + 1) & 1] = 0u;
+            // first sightings are reported every 8th round: the two dependent atomics keep the whole workgroup at the barrier
+            if (L.newSeen && (++L.rounds & 7u) == 0u) {
+                // the largest first sighting must have been performed before the count that may complete D is added
+                const u64 m = atomicMax(&ctl->maxFirst, L.maxFirst);
+                asm volatile("" :: "v"(m));
+                const u32 seen = atomicAdd(&ctl->seen, L.newSeen + (u32)(m & 0ull)) + L.newSeen;
+                if (seen == D)
+                    __hip_atomic_store(&ctl->watermark, __hip_atomic_load(&ctl->maxFirst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                L.newSeen = 0u; L.maxFirst = 0ull;
+            }
+            if (L.wm == ~0ull) {
+                const u64 w = __hip_atomic_load(&ctl->watermark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (w) L.wm = w;
+            }
+        }
+        lds_barrier();
+        if (!any) break;
+    }
+}
+
+// end of the pass: the incomplete last line of every partition, and the number of records per (workgroup, partition)
+template <int RECW, int P>
+RSQ_DEV void stage_finish(StageLds<RECW, P>& L, u64* recOut, u32* counts, StageCtl* ctl, bool countOnly) {
+    constexpr int S = StageLds<RECW, P>::S;
+    __syncthreads();
+    if (!countOnly) {
+        const int j = threadIdx.x & 7;
+        for (int p = threadIdx.x >> 3; p < P; p += blockDim.x >> 3) {
+            const u32 h = L.head[p], tl = L.tail[p];
+            if (h < tl) {
+                if (tl <= L.cap[p]) {
+                    if ((u32)(j * 2 / RECW) < tl - h)
+                        *reinterpret_cast<u64x2*>(&recOut[(L.start[p] + h) * RECW + j * 2]) = *reinterpret_cast<const u64x2*>(&L.ring[((u32)p * S + (h & (S - 1))) * RECW + j * 2]);
+                } else if (j == 0) atomicOr(&ctl->overflow, 1u);
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < P; i += blockDim.x) counts[(u64)blockIdx.x * P + i] = L.tail[i];
+}
 
 }  // namespace rsq

@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The GPU tests are about the specialised kernels: a plan shape the code-object cache has not seen compiles them before the first
+# execution instead of starting on the pre-compiled generic pipeline (tests/test_gpu_generic_pipeline.py turns that back on).
+os.environ.setdefault("RSQ_GENERIC", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

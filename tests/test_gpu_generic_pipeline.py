@@ -14,6 +14,11 @@ import fuzzplans
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def generic_pipeline_allowed(monkeypatch):
+    monkeypatch.setenv("RSQ_GENERIC", "1")         # (tests/conftest.py switches it off for every other test)
+
+
 def test_unseen_plan_shape_answers_cold_in_milliseconds(tmp_path):
     """an empty code-object cache: compile + first execution of a Q6-shaped plan with constants no cache has seen"""
     ctx = engine.Context(device=0, cache_dir=str(tmp_path))

@@ -102,3 +102,108 @@ def test_generic_hash_aggregation_with_many_groups(gpu_ctx):
     want = orc.execute(plan)
     assert got.n_rows == want.n_rows > 400_000
     assert got.text == want.text
+
+
+# ---- form 3: packed records staged through LDS rings (rsq_device.h "staged partitioning") ---------------------------------
+
+def _synthetic_like(n, b, seed=3, c_max=1 << 20):
+    rng = np.random.default_rng(seed)
+    cols = [P.Column("a", T.BIGINT(), rng.integers(0, 1 << 31, n).astype(np.int64)), P.Column("b", T.BIGINT(), b.astype(np.int64)),
+            P.Column("c", T.BIGINT(), rng.integers(0, c_max, n).astype(np.int64)), P.Column("d", T.BIGINT(), rng.integers(0, 1 << 20, n).astype(np.int64))]
+    return P.Table("t", cols, n)
+
+
+@pytest.mark.parametrize("staged", ["1", "0"])
+def test_both_partitioned_forms_stay_under_test(gpu_ctx, monkeypatch, staged):
+    monkeypatch.setenv("RSQ_STAGED", staged)
+    t = tpch.synthetic_table(700_003, 1 << 20)
+    plan = tpch.synthetic_plan(t, int(0.4 * (1 << 31)))
+    got, explain = run_forced(gpu_ctx, monkeypatch, plan, 2)
+    assert ("staged through LDS rings" in explain) == (staged == "1")
+    assert "8-byte records" in explain or staged == "0"
+    assert got == orc.execute(plan).text
+
+
+@pytest.mark.parametrize("n", [77, 4096 * 3 + 77, 1024 * 4 * 2, 128 * 16 * 2 * 5 + 1])
+def test_staged_rounds_with_ragged_ends(gpu_ctx, monkeypatch, n):
+    """fewer rows than one round, a partial last round, rows behind the last whole tile"""
+    rng = np.random.default_rng(n)
+    t = _synthetic_like(n, rng.integers(0, 1 << 17, n))
+    plan = tpch.synthetic_plan(t, 1 << 31)
+    got, explain = run_forced(gpu_ctx, monkeypatch, plan, 2)
+    assert "staged through LDS rings" in explain
+    assert got == orc.execute(plan).text
+
+
+def test_staged_regions_run_full_on_clustered_keys_and_are_counted(gpu_ctx, monkeypatch, capfd):
+    """rows sorted by the group key: a round's records all go to one or two partitions (they wait for ring slots), and a
+    workgroup's share of a partition is nothing like the average the sampled regions assume"""
+    n = 3_000_000
+    rng = np.random.default_rng(9)
+    t = _synthetic_like(n, np.sort(rng.integers(0, 1 << 18, n)))
+    plan = tpch.synthetic_plan(t, int(0.9 * (1 << 31)))
+    monkeypatch.setenv("RSQ_TRACE", "1")
+    got, explain = run_forced(gpu_ctx, monkeypatch, plan, 2)
+    err = capfd.readouterr().err
+    assert "staged through LDS rings" in explain
+    assert "a region ran full" in err and "counted" in err
+    assert got == orc.execute(plan).text
+
+
+def test_staged_with_one_hot_group(gpu_ctx, monkeypatch):
+    n = 1_500_000
+    rng = np.random.default_rng(10)
+    b = rng.integers(0, 1 << 17, n)
+    b[rng.random(n) < 0.97] = 4242
+    t = _synthetic_like(n, b)
+    plan = tpch.synthetic_plan(t, 1 << 31)
+    got, explain = run_forced(gpu_ctx, monkeypatch, plan, 2)
+    assert "staged through LDS rings" in explain
+    assert got == orc.execute(plan).text
+
+
+def test_staged_with_absent_groups_and_wide_inputs(gpu_ctx, monkeypatch):
+    """not every group of the domain occurs (no watermark: the tracker works to the end); inputs too wide for one word"""
+    n = 400_000
+    rng = np.random.default_rng(12)
+    b = rng.integers(0, 1 << 16, n) * 4            # three quarters of the domain never occur
+    t = _synthetic_like(n, b, c_max=1 << 40)
+    plan = tpch.synthetic_plan(t, int(0.7 * (1 << 31)))
+    got, explain = run_forced(gpu_ctx, monkeypatch, plan, 2)
+    assert "16-byte records" in explain
+    assert got == orc.execute(plan).text
+
+
+def test_staged_reuses_regions_and_notices_changed_data(gpu_ctx, monkeypatch, capfd):
+    import torch
+    from resql_amd import engine
+    monkeypatch.setenv("RSQ_PARTITION", "2")
+    monkeypatch.setenv("RSQ_TRACE", "1")
+    n = 2_000_000
+    rng = np.random.default_rng(14)
+    host = _synthetic_like(n, rng.integers(0, 1 << 17, n))
+    dev = {c.name: torch.from_numpy(c.data).cuda() for c in host.columns}
+    t = gpu_ctx.table_from_device("t", n, [(c.name, T.BIGINT(), dev[c.name].data_ptr()) for c in host.columns])
+    plan = tpch.synthetic_plan(host, int(0.1 * (1 << 31)))
+    q = gpu_ctx.compile(plan, [t])
+    try:
+        q.execute(); first = q.result().text
+        assert first == orc.execute(plan).text
+        q.execute()
+        assert q.result().text == first
+        assert "as in the last execution" in capfd.readouterr().err
+        # the same rows, but now nearly all of them pass the filter: the remembered regions are far too small
+        dev["a"].fill_(1)
+        torch.cuda.synchronize()
+        host.columns[0].data[:] = 1
+        q.execute()
+        assert q.result().text == orc.execute(plan).text
+        assert "a region ran full" in capfd.readouterr().err
+        # an accumulator input outside the range its column had when the table was adopted: refused, no silent truncation
+        dev["c"][17] = 1 << 40
+        torch.cuda.synchronize()
+        with pytest.raises(engine.EngineError) as e:
+            q.execute()
+        assert "column statistics" in str(e.value)
+    finally:
+        q.close(); t.close()
