@@ -137,6 +137,7 @@ Query::~Query() {
     if (dStageBase) ctx.free(dStageBase);
     if (dStageCap) ctx.free(dStageCap);
     if (dStageCtl) ctx.free(dStageCtl);
+    if (hStageLayout) (void)hipHostFree(hStageLayout);
     if (dStageCounts) ctx.free(dStageCounts);
     if (dPartTotals) ctx.free(dPartTotals);
     for (void* r : dPartRecords) if (r) ctx.scratchFree(r);
@@ -223,6 +224,8 @@ static void resolveKernels(Query& q) {
     }
 }
 
+static void prepareStageBuffers(Query& q, const Pipeline& p);
+
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables) {
     double t0 = nowMs();
     std::unique_ptr<Query> q(new Query(ctx));
@@ -290,6 +293,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     }
     if (ctx.device >= 0) {
         if (denseMode(*q)) prepareDenseBuffers(*q);
+        for (auto& p : q->pipelines) if (p.partitioned) prepareStageBuffers(*q, p);
         for (auto& h : q->hashTables) {
             h->dCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
         }
@@ -400,6 +404,35 @@ static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1
     if (getenv("RSQ_TRACE") && p.compact) fprintf(stderr, "[rsq trace]     %s: %u workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(), p.lastGrid, (long long)p.stage2Rows);
 }
 
+// the small buffers of a partitioned aggregation (allocated when the query is compiled: an allocation inside an execution
+// is a pause of the device the execution's events measure)
+static void prepareStageBuffers(Query& q, const Pipeline& p) {
+    Context& ctx = q.ctx;
+    const int P = p.partCount;
+    const size_t words = (size_t)ctx.numCUs * (size_t)P;
+    if (q.partCountsWords < words) {
+        if (q.dPartCounts) ctx.free(q.dPartCounts);
+        q.dPartCounts = (uint32_t*)ctx.alloc(words * 4);
+        q.partCountsWords = words;
+    }
+    if (!q.dPartStart) {
+        q.dPartStart = (uint32_t*)ctx.alloc(((size_t)P + 1) * 4);
+        q.dPartTotals = (uint64_t*)ctx.alloc(((size_t)P + 1) * 8);       // [P] column totals, [P] = grand total
+    }
+    if (!p.staged) return;
+    if (!q.dStageBase) {
+        q.dStageBase = (uint64_t*)ctx.alloc((size_t)P * 8);
+        q.dStageCap = (uint32_t*)ctx.alloc((size_t)P * 4);
+        q.dStageCtl = ctx.alloc(32);
+        RSQ_HIP(hipHostMalloc((void**)&q.hStageLayout, (size_t)P * 12, hipHostMallocDefault));     // the layout travels from pinned memory: no wait for the copy
+    }
+    if (q.stageCountsWords < words) {
+        if (q.dStageCounts) ctx.free(q.dStageCounts);
+        q.stageCountsWords = words;
+        q.dStageCounts = (uint32_t*)ctx.alloc(q.stageCountsWords * 4);
+    }
+}
+
 // Form 3 of a large dense aggregation (rsq_device.h "staged partitioning"): one pass turns the passing rows into packed
 // records, region by region, and one workgroup per partition aggregates them in LDS.  `estimate[p]` is the number of records
 // expected in partition p (from the sampled counting pass); every workgroup gets the same share of it plus slack.  A region
@@ -416,25 +449,16 @@ static bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64
     const uint64_t lineRecords = (uint64_t)(16 / p.stagedRecWords);
     const size_t recBytes = 8 * (size_t)p.stagedRecWords;
     const bool trace = getenv("RSQ_TRACE") != nullptr;
-    if (!q.dStageBase) {
-        q.dStageBase = (uint64_t*)ctx.alloc((size_t)P * 8);
-        q.dStageCap = (uint32_t*)ctx.alloc((size_t)P * 4);
-        q.dStageCtl = ctx.alloc(32);
-    }
-    if (q.stageCountsWords < (size_t)nwg * (size_t)P) {
-        if (q.dStageCounts) ctx.free(q.dStageCounts);
-        q.stageCountsWords = (size_t)nwg * (size_t)P;
-        q.dStageCounts = (uint32_t*)ctx.alloc(q.stageCountsWords * 4);
-    }
+    prepareStageBuffers(q, p);
     q.stageWorkgroups = nwg;
-    std::vector<uint64_t> base((size_t)P);
     std::vector<uint32_t> cap((size_t)P);
     auto layout = [&]() -> uint64_t {          // region(workgroup, p) = base[p] + workgroup * cap[p]; uploads both, returns the records provided for
+        // (every earlier copy out of the pinned buffer has been executed: each pass ends in a synchronisation)
+        uint64_t* hb = (uint64_t*)q.hStageLayout; uint32_t* hc = (uint32_t*)(hb + P);
         uint64_t pos = 0;
-        for (int i = 0; i < P; i++) { base[(size_t)i] = pos; pos += (uint64_t)cap[(size_t)i] * nwg; }
-        RSQ_HIP(hipMemcpyAsync(q.dStageBase, base.data(), (size_t)P * 8, hipMemcpyHostToDevice, ctx.stream));
-        RSQ_HIP(hipMemcpyAsync(q.dStageCap, cap.data(), (size_t)P * 4, hipMemcpyHostToDevice, ctx.stream));
-        RSQ_HIP(hipStreamSynchronize(ctx.stream));          // (the vectors are reused)
+        for (int i = 0; i < P; i++) { hb[i] = pos; hc[i] = cap[(size_t)i]; pos += (uint64_t)cap[(size_t)i] * nwg; }
+        RSQ_HIP(hipMemcpyAsync(q.dStageBase, hb, (size_t)P * 8, hipMemcpyHostToDevice, ctx.stream));
+        RSQ_HIP(hipMemcpyAsync(q.dStageCap, hc, (size_t)P * 4, hipMemcpyHostToDevice, ctx.stream));
         const size_t need = (size_t)std::max<uint64_t>(pos, 1) * recBytes;
         if (q.dPartRecords.empty() || q.stageRecBytes < need) {
             for (void* r : q.dPartRecords) ctx.scratchFree(r);
@@ -523,29 +547,21 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
     const bool trace = getenv("RSQ_TRACE") != nullptr;
     if (!force && rows < (4 << 20)) { launchPipeline(q, p, -1); return; }       // small inputs: the extra passes cost more than they save
     const size_t words = (size_t)grid * (size_t)P;
-    if (q.partCountsWords < words) {
-        if (q.dPartCounts) ctx.free(q.dPartCounts);
-        q.dPartCounts = (uint32_t*)ctx.alloc(words * 4);
-        q.partCountsWords = words;
-    }
-    if (!q.dPartStart) {
-        q.dPartStart = (uint32_t*)ctx.alloc(((size_t)P + 1) * 4);
-        q.dPartTotals = (uint64_t*)ctx.alloc(((size_t)P + 1) * 8);       // [P] column totals, [P] = grand total
-    }
+    prepareStageBuffers(q, p);
+    std::vector<uint64_t> hostTotals((size_t)P + 1);        // records per partition, [P] = all of them
     auto countPass = [&](int64_t step) -> uint64_t {
         q.partTileStep = step;
         RSQ_HIP(hipMemsetAsync(q.dPartCounts, 0, words * 4, ctx.stream));
         launchPipelineKernel(q, p, *p.kernelPartCount, -1, grid, block);
         partitionOffsets(ctx, q.dPartCounts, (int)grid, P, q.dPartTotals, q.dPartStart, q.dPartTotals + P);
         q.report.num_kernels += 2;
-        uint64_t total = 0;
-        RSQ_HIP(hipMemcpyAsync(&total, q.dPartTotals + P, 8, hipMemcpyDeviceToHost, ctx.stream));
+        RSQ_HIP(hipMemcpyAsync(hostTotals.data(), q.dPartTotals, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx.stream));
         RSQ_HIP(hipStreamSynchronize(ctx.stream));
         q.partTileStep = 1;
-        return total;
+        return hostTotals[(size_t)P];
     };
     const size_t recBytes = p.staged ? 8 * (size_t)p.stagedRecWords : 8 * (1 + p.partRecordInputs.size());
-    const int64_t step = rows >= (64 << 20) ? 32 : rows >= (8 << 20) ? 8 : 1;
+    const int64_t step = rows >= (512 << 20) ? 128 : rows >= (64 << 20) ? 32 : rows >= (8 << 20) ? 8 : 1;       // the sampled pass reads every step-th tile
     // the regions that held the last execution's records hold this one's, unless the table changed (then the pass says so)
     if (p.staged && !p.stagedExact && !p.stagedCaps.empty() && p.stagedCapsRows == rows && q.stageWorkgroups != 0) {
         if (runStagedAggregation(q, p, {})) return;
@@ -562,8 +578,7 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
         if (!force && direct <= parted) { launchPipeline(q, p, -1); return; }
     }
     if (p.staged) {
-        std::vector<uint64_t> estimate((size_t)P + 1);
-        RSQ_HIP(hipMemcpy(estimate.data(), q.dPartTotals, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> estimate = hostTotals;
         for (auto& e : estimate) e *= (uint64_t)step;
         if (runStagedAggregation(q, p, estimate)) return;
     }

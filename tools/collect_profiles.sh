@@ -82,6 +82,44 @@ json.dump(out, open(sys.argv[1], "w"), indent=1)
 print("   q3 pmc kernels:", len(out["kernels"]))
 PY
 
+step "large-group aggregation (1.25 B rows, 2^20 groups, 10 % and 50 % pass): kernel statistics, FETCH_SIZE and WRITE_SIZE in separate passes"
+for s in 0.1 0.5; do
+    rm -rf /tmp/prof_lg_$s
+    if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lg_$s -- python3 "$ROOT/tools/profile_case.py" synthetic 1250000000 1048576 $s 6 > "$OUT/${R}_synth_g20_sel${s}_runs.txt" 2>&1; then
+        f=$(found /tmp/prof_lg_$s '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_synth_g20_sel${s}_kernel_stats.csv"
+    fi
+    for c in FETCH_SIZE WRITE_SIZE; do
+        pmc_pass $c /tmp/prof_lg_${s}_$c -- python3 "$ROOT/tools/profile_case.py" synthetic 1250000000 1048576 $s 3
+    done
+done
+python3 - "$OUT/${R}_synth_g20_pmc.json" <<'PY'
+import csv, glob, json, sys
+rows = 1250000000
+out = {"workload": "synthetic 4 x int64, a < tau, group by b (2^20 groups), sum(c), sum(d), count(*): one 1.25 B-row shard (40 GB)",
+       "note": "per dispatch, the LARGEST dispatch of each kernel name (the sampled counting pass shares the scan kernel's name and is small); KB as "
+               "rocprofv3 reports them; gfx950: FETCH_SIZE counts 1/2 of the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section) "
+               "-> x2 in *_corrected; WRITE_SIZE as is; FETCH_SIZE and WRITE_SIZE were collected in separate passes",
+       "algorithmic_bytes": 32 * rows, "selectivity": {}}
+for s in ("0.1", "0.5"):
+    e = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        fs = glob.glob(f"/tmp/prof_lg_{s}_{c}/*/*counter_collection.csv")
+        if not fs: continue
+        per = {}
+        for r in csv.DictReader(open(fs[0])):
+            k = r["Kernel_Name"].split("(")[0]
+            if r["Counter_Name"] != c or not (k.startswith("rsq_p") or k.startswith("rsq_staged")): continue
+            per.setdefault(k, {}); per[k][r["Dispatch_Id"]] = per[k].get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+        for k, d in per.items():
+            kb = max(d.values())
+            e.setdefault(k, {})[c + "_KB"] = round(kb, 1)
+            e[k]["hbm_read_bytes_corrected" if c == "FETCH_SIZE" else "hbm_write_bytes"] = round(kb * 1024 * (2 if c == "FETCH_SIZE" else 1))
+    moved = sum(v.get("hbm_read_bytes_corrected", 0) + v.get("hbm_write_bytes", 0) for v in e.values())
+    out["selectivity"][s] = {"kernels": e, "bytes_moved": moved, "bytes_moved_per_row": round(moved / rows, 2), "over_algorithmic": round(moved / (32 * rows), 3)}
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print("   large-group pmc:", {s: v["bytes_moved_per_row"] for s, v in out["selectivity"].items()}, "bytes per row")
+PY
+
 step "the reference's eight TPC-H statements from SQL text at SF1"
 timeout -k 10 300 python3 "$ROOT/tools/sql_bench.py" 1 --reference > "$OUT/${R}_sql_sf1.log" 2>&1 && grep '^{' "$OUT/${R}_sql_sf1.log" > "$OUT/${R}_sql_sf1.jsonl"
 step "compile latency, cold and warm"
