@@ -7,6 +7,7 @@
 // (aggregation.h:240-295).  The hand-written skeleton around the row function (tile loads,
 // reductions, hash-table access) comes from kernels/rsq_device.h.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <sstream>
@@ -271,6 +272,9 @@ struct Walker {
     bool multiMatchAbove = false;
     // wave-level compaction (see compactThen)
     bool selective = false, compacted = false;
+    // the selection directly above the scan: its text over the row's column variables, the columns it reads and the fraction of
+    // rows it is expected to pass (column statistics, values taken as uniform) - the late-load form of the tile loop (below)
+    std::string leadCond; std::vector<int> leadCols; double leadPass = 1.0;
     std::string stage2Body;
     std::vector<std::pair<std::string, Sym>> cqLive;     // carried symbols: name -> stage-1 variable and type
 
@@ -357,6 +361,7 @@ struct Walker {
         explainSteps.clear(); indent = 1; matchSlotTable = -1; slotVar.clear(); symbolOrigin.clear(); symbolWord.clear();
         multiMatchAbove = false;
         selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
+        leadCond.clear(); leadCols.clear(); leadPass = 1.0;
         eg.symbols.clear();
         o->schema.clear();
         for (size_t ci = 0; ci < t->cols.size(); ci++) {
@@ -394,6 +399,91 @@ struct Walker {
         finishPipeline();
     }
 
+    // ---- the selection directly above the scan ---------------------------------------------------------------------------------
+    // value range of one side of a comparison: a column of the scanned table (its statistics), a constant, or either under a cast
+    bool sideRange(const Expr* e, double& lo, double& hi, int& col) {
+        if (e->tag == RSQ_E_TYPECAST && e->child) {
+            if (!sideRange(e->child, lo, hi, col)) return false;
+            const int ds = (e->type.tag == RSQ_DECIMAL ? e->type.scale : 0) - (e->child->type.tag == RSQ_DECIMAL ? e->child->type.scale : 0);
+            const double f = std::pow(10.0, (double)ds);
+            lo *= f; hi *= f;
+            return true;
+        }
+        // DATE values are yyyymmdd integers: spread them evenly (12 x 31 days a year) before they are taken as uniform
+        auto linear = [&](double v) -> double {
+            if (e->type.tag != RSQ_DATE) return v;
+            const int64_t d = (int64_t)v;
+            return (double)((d / 10000) * 372 + ((d / 100) % 100 - 1) * 31 + (d % 100 - 1));
+        };
+        if (e->tag == RSQ_E_CONSTANT && !e->type.isString()) { lo = hi = linear((double)e->ival); col = -1; return true; }
+        if ((e->tag == RSQ_E_ADD || e->tag == RSQ_E_SUB) && e->child && e->child->next && e->type.tag != RSQ_DATE) {      // constant arithmetic (0.06 - 0.01)
+            double alo, ahi, blo, bhi; int ac = -1, bc = -1;
+            if (!sideRange(e->child, alo, ahi, ac) || !sideRange(e->child->next, blo, bhi, bc) || ac >= 0 || bc >= 0) return false;
+            const int s0 = e->type.tag == RSQ_DECIMAL ? e->type.scale : 0;
+            const double fa = std::pow(10.0, (double)(s0 - (e->child->type.tag == RSQ_DECIMAL ? e->child->type.scale : 0)));
+            const double fb = std::pow(10.0, (double)(s0 - (e->child->next->type.tag == RSQ_DECIMAL ? e->child->next->type.scale : 0)));
+            lo = hi = e->tag == RSQ_E_ADD ? alo * fa + blo * fb : alo * fa - blo * fb; col = -1;
+            return true;
+        }
+        if (e->tag == RSQ_E_ATTRIBUTE) {
+            auto so = symbolOrigin.find(e->symbol);
+            if (so == symbolOrigin.end() || so->second != -1) return false;
+            const int ci = pipe.src->findCol(e->symbol);
+            if (ci < 0 || !pipe.src->cols[(size_t)ci].stats.valid || pipe.src->cols[(size_t)ci].type.isString()) return false;
+            lo = linear((double)pipe.src->cols[(size_t)ci].stats.min); hi = linear((double)pipe.src->cols[(size_t)ci].stats.max); col = ci;
+            return true;
+        }
+        return false;
+    }
+    // expected fraction of rows a predicate passes; 1 (no claim) for whatever it does not understand
+    double passFraction(const Expr* e) {
+        if (e->tag == RSQ_E_AND || e->tag == RSQ_E_OR) {
+            double all = 1.0, none = 1.0;
+            for (Expr* c : e->children()) { const double f = passFraction(c); all *= f; none *= 1.0 - f; }
+            return e->tag == RSQ_E_AND ? all : 1.0 - none;
+        }
+        if (e->tag < RSQ_E_LT || e->tag > RSQ_E_NEQ || !e->child || !e->child->next) return 1.0;
+        double alo, ahi, blo, bhi; int ac = -1, bc = -1;
+        if (!sideRange(e->child, alo, ahi, ac) || !sideRange(e->child->next, blo, bhi, bc)) return 1.0;
+        if ((ac >= 0) == (bc >= 0)) return 1.0;                      // column against constant only
+        int tag = e->tag;
+        if (ac < 0) {                                                // constant OP column -> column OP' constant
+            std::swap(alo, blo); std::swap(ahi, bhi);
+            tag = tag == RSQ_E_LT ? RSQ_E_GT : tag == RSQ_E_LE ? RSQ_E_GE : tag == RSQ_E_GT ? RSQ_E_LT : tag == RSQ_E_GE ? RSQ_E_LE : tag;
+        }
+        const double width = ahi - alo + 1.0, c = blo;
+        double below = (c - alo) / width;                            // fraction of values < c
+        below = std::min(1.0, std::max(0.0, below));
+        const double at = (c >= alo && c <= ahi) ? 1.0 / width : 0.0;
+        switch (tag) {
+            case RSQ_E_LT: return below;
+            case RSQ_E_LE: return std::min(1.0, below + at);
+            case RSQ_E_GT: return std::max(0.0, 1.0 - below - at);
+            case RSQ_E_GE: return 1.0 - below;
+            case RSQ_E_EQ: return at;
+            default: return 1.0 - at;
+        }
+    }
+    void leadColumnsOf(const Expr* e, std::vector<int>& out, bool& ok) {
+        if (e->tag == RSQ_E_ATTRIBUTE) {
+            auto sy = eg.symbols.find(e->symbol);
+            auto so = symbolOrigin.find(e->symbol);
+            if (sy == eg.symbols.end() || so == symbolOrigin.end() || so->second != -1 || sy->second.var.compare(0, 2, "v_") != 0) { ok = false; return; }
+            const int k = atoi(sy->second.var.c_str() + 2);
+            if (k < 0 || k >= (int)colIsString.size() || colIsString[(size_t)k]) { ok = false; return; }
+            if (std::find(out.begin(), out.end(), k) == out.end()) out.push_back(k);
+            return;
+        }
+        for (Expr* c : e->children()) leadColumnsOf(c, out, ok);
+    }
+    void noteLeadingSelection(const Expr* e, const std::string& cond) {
+        bool ok = true;
+        std::vector<int> cols;
+        leadColumnsOf(e, cols, ok);
+        if (!ok || cols.empty()) return;
+        leadCond = cond; leadCols = cols; leadPass = passFraction(e);
+    }
+
     // -------------------------------------------------------------------------------------------
     void consume(OpNode* o, OpNode* from) {
         if (!o) failInvalid("plan root must be a materializing operator");
@@ -403,7 +493,11 @@ struct Walker {
                 if (!q.requestAll) o->schema = prune(o->schema, requestOf[o]);
                 q.pool.addId(o->exprs[0]);
                 selective = true;
-                openScope("if (" + eg.emit(o->exprs[0]) + ") {");
+                {
+                    const std::string cond = eg.emit(o->exprs[0]);
+                    if (from->tag == RSQ_OP_SCAN && leadCond.empty()) noteLeadingSelection(o->exprs[0], cond);
+                    openScope("if (" + cond + ") {");
+                }
                 explainSteps.push_back("selection " + serializeExpr(o->exprs[0]));
                 consume(o->parent, o);
                 closeScope();
@@ -1809,6 +1903,19 @@ struct Walker {
     }
 
     // -------------------------------------------------------------------------------------------
+    // second round of loads of tile `tile` (unrolled copy u): the late columns, by the lanes that hold a row the leading selection passes
+    void emitLateLoads(std::ostringstream& s, const std::string& tile, int u, const std::vector<char>& lateCol) {
+        s << "        if (" << tile << " < ntiles) {\n";
+        for (int j = 0; j < 2; j++) {
+            s << "            const bool lp" << j << " = lead_pred(a";
+            for (int k : leadCols) s << ", t" << k << "_" << u << "[" << j << "]";
+            s << ");\n";
+        }
+        s << "            if (lp0 | lp1) {\n                const i64 b = ((" << tile << ") << 7) + lane * 2;\n";
+        for (size_t k = 0; k < lateCol.size(); k++) if (lateCol[k]) s << "                rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
+        s << "            }\n        }\n";
+    }
+
     void finishPipeline() {
         while (indent > 1) closeScope();
         addArg("n_rows", "i64", (uint64_t)pipe.src->nRows);
@@ -1839,6 +1946,22 @@ struct Walker {
         // (the staged form's round loop knows neither the compaction queues nor prefetched bitmap words nor string columns)
         if (pipe.staged && (cq || mat || !bitmapPrefetch.empty() || !pipe.lazyCols.empty() ||
                             std::find(colIsString.begin(), colIsString.end(), true) != colIsString.end())) pipe.staged = false;
+        // Late loads: the columns the leading selection does not read are loaded only by lanes that hold a passing row.  Memory
+        // is fetched in 128-byte lines (16 rows of an 8-byte column): at 1 % selectivity 85 % of those columns' lines are never
+        // fetched (measured: 1.25 B rows x 4 int64 at 1 %: 6.0 -> 3.5 ms, TPC-H Q6 SF10 0.259 -> 0.207 ms), at 10 % 19 % (-1..4 %);
+        // above that the second, dependent round of loads costs more than it saves.  Decided here from the column statistics,
+        // values taken as uniform (RSQ_LATE_LOADS: 0 never, 2 whenever there is a leading selection; RSQ_LATE_LOADS_BELOW percent).
+        std::vector<char> lateCol(colTypes.size(), 0);
+        bool late = false;
+        {
+            const int mode = envInt("RSQ_LATE_LOADS", 1, 0, 2);
+            const double below = (double)envInt("RSQ_LATE_LOADS_BELOW", 12, 0, 100) / 100.0;
+            if (mode && !cq && !mat && !leadCond.empty() && bitmapPrefetch.empty() && pipe.lazyCols.empty() && (mode == 2 || leadPass <= below)) {
+                for (size_t k = 0; k < colTypes.size(); k++)
+                    if (!colIsString[k] && std::find(leadCols.begin(), leadCols.end(), (int)k) == leadCols.end()) { lateCol[k] = 1; late = true; }
+            }
+        }
+        pipe.lateLoads = late;
         // 63 left over + 128 pushed by one tile, rounded up.  (RSQ_QCAP=128 drains after every row_fn call instead: smaller
         // queues, 7 instead of 4 workgroups of a five-word pipeline per CU — measured slower: Q3's orders pipeline 0.24 ->
         // 0.31 ms, its inserts do not want more waves.)
@@ -1886,6 +2009,11 @@ struct Walker {
             }
             s << ");\n        st.cq_rows++;\n    }\n    st.cq_n -= count;\n}\n";
         }
+        if (late) {
+            s << "static RSQ_DEV bool lead_pred(const Args& a";
+            for (int k : leadCols) s << ", " << colTypes[(size_t)k] << " v_" << k;
+            s << ") { return " << leadCond << "; }\n";
+        }
         if (pipe.staged) s << "#if RSQ_AGG_VARIANT == 3\ntemplate <int SP_SLOT>       // the row's place among the rows a thread handles per round\n#endif\n";
         s << "static RSQ_DEV void row_fn(const Args& a, State& st, const i64 lr" << (cq ? ", const bool valid" : "") << rowParams << ") {\n";
         s << "    const i64 row = a.row0 + lr;\n";
@@ -1932,11 +2060,12 @@ struct Walker {
             s << "        st.sp_pending = 0u; st.sp_wm = s_stage.wm;\n";
             s << "        const i64 t0 = round * tpr + (i64)(threadIdx.x >> 6) * " << H << ";\n";
             for (int u = 0; u < H; u++) {
-                for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2];\n";
+                for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2]" << (lateCol[(size_t)k] ? " = {0, 0}" : "") << ";\n";
                 s << "        if (t0 + " << u << " < ntiles) {\n            const i64 b = ((t0 + " << u << ") << 7) + lane * 2;\n";
-                for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "            rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
+                for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k] && !lateCol[(size_t)k]) s << "            rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
                 s << "        }\n";
             }
+            if (late) for (int u = 0; u < H; u++) emitLateLoads(s, "t0 + " + std::to_string(u), u, lateCol);
             for (int u = 0; u < H; u++) {
                 s << "        if (t0 + " << u << " < ntiles) {\n";
                 for (int j = 0; j < 2; j++) {
@@ -1963,9 +2092,9 @@ struct Walker {
         s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
         for (int u = 0; u < U; u++) {
             s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
-            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2];\n";
+            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2]" << (lateCol[(size_t)k] ? " = {0, 0}" : "") << ";\n";
             s << "        if (tt" << u << " < ntiles) {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
-            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) {
+            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k] && !lateCol[(size_t)k]) {
                 const bool lazy = std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) != pipe.lazyCols.end();
                 if (lazy) s << "#if !RSQ_LAZY\n";
                 s << "            rsq::ld2(a.c" << k << " + b, t" << k << "_" << u << ");\n";
@@ -1973,6 +2102,7 @@ struct Walker {
             }
             s << "        }\n";
         }
+        if (late) for (int u = 0; u < U; u++) emitLateLoads(s, "tt" + std::to_string(u), u, lateCol);
         for (int u = 0; u < U; u++)
             for (auto& pf : bitmapPrefetch) {
                 s << "        u32 pf_" << pf.first << "_" << u << "[2] = {0u, 0u};\n";
@@ -2040,6 +2170,11 @@ struct Walker {
         }
         std::string ex = "pipeline " + std::to_string(q.pipelines.size()) + ": ";
         for (size_t i = 0; i < explainSteps.size(); i++) ex += (i ? " -> " : "") + explainSteps[i];
+        if (pipe.lateLoads) {
+            char buf[96];
+            snprintf(buf, sizeof buf, " [late loads: ~%.1f %% of the rows expected to pass the leading selection]", leadPass * 100.0);
+            ex += buf;
+        }
         if (pipe.staged) ex += " [partitioned as packed " + std::to_string(8 * pipe.stagedRecWords) + "-byte records staged through LDS rings]";
         pipe.explain = ex;
         q.pipelines.push_back(pipe);

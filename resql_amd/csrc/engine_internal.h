@@ -143,6 +143,7 @@ struct Pipeline {
     int partAtomicsPerRow = 0;           // HBM atomics the direct form issues per passing row (sum accumulators)
     // form 3, staged partitioning (rsq_device.h): packed records through LDS rings, regions sized from a sample
     bool staged = false;
+    bool lateLoads = false;              // the tile loop loads the columns behind the leading selection only for lanes with a passing row
     int stagedRecWords = 1, stagedRows = 4;
     std::string sourceStagedScatter, sourceStagedAgg;
     Kernel* kernelStagedScatter = nullptr; Kernel* kernelStagedAgg = nullptr;
