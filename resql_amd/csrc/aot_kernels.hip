@@ -292,6 +292,63 @@ __global__ void __launch_bounds__(256) k_fill_u64(u64* __restrict__ p, i64 n, u6
     if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) p[n - 1] = v;
 }
 
+// Several fills in ONE launch (blockIdx.y picks the item).  An execution clears a handful of small things — the error word,
+// counters, the candidate selection's scratch, accumulator blocks — and a stream operation each costs ~5 us of device time
+// whatever its size (TPC-H Q3 at SF10: 7 of them = 30 of 445 us).  Units are 4-byte words; the value is a 64-bit pattern.
+struct FillBatchArgs { unsigned* p[8]; u64 n32[8]; u64 v[8]; };
+__global__ void __launch_bounds__(256) k_fill_batch(FillBatchArgs a) {
+    const int it = blockIdx.y;
+    unsigned* p = a.p[it];
+    const u64 n = a.n32[it], v = a.v[it];
+    const u64 gtid = (u64)blockIdx.x * blockDim.x + threadIdx.x, gsz = (u64)gridDim.x * blockDim.x;
+    if ((reinterpret_cast<unsigned long long>(p) & 15ull) != 0 || n < 256) {
+        for (u64 i = gtid; i < n; i += gsz) p[i] = (unsigned)((i & 1) ? (v >> 32) : v);
+        return;
+    }
+    u64x2 vv; vv.x = v; vv.y = v;
+    u64x2* p4 = reinterpret_cast<u64x2*>(p);
+    const u64 n4 = n >> 2;
+    for (u64 i = gtid; i < n4; i += gsz) p4[i] = vv;
+    if (gtid == 0) for (u64 i = n4 << 2; i < n; i++) p[i] = (unsigned)((i & 1) ? (v >> 32) : v);
+}
+
+void fillBatchAsync(Context& ctx, const FillItem* items, int count) {
+    for (int base = 0; base < count; base += 8) {
+        FillBatchArgs a;
+        memset(&a, 0, sizeof a);
+        const int n = std::min(8, count - base);
+        u64 most = 1;
+        int k = 0;
+        for (int i = 0; i < n; i++) {
+            const FillItem& f = items[base + i];
+            if (!f.p || f.bytes == 0) continue;
+            if ((f.bytes & 3) || ((uintptr_t)f.p & 3)) throw Error(RSQ_ERR_DEVICE, "fillBatchAsync: a fill must cover whole 4-byte words");
+            a.p[k] = (unsigned*)f.p; a.n32[k] = f.bytes / 4; a.v[k] = f.value; most = std::max<u64>(most, f.bytes / 16);
+            k++;
+        }
+        if (k == 0) continue;
+        const unsigned gx = (unsigned)std::min<u64>(2048, (most + 255) / 256);
+        hipLaunchKernelGGL(k_fill_batch, dim3(gx, (unsigned)k), dim3(256), 0, ctx.stream, a);
+        RSQ_HIP(hipGetLastError());
+    }
+}
+
+__global__ void k_publish_status(u64* __restrict__ host, const unsigned* __restrict__ err, const unsigned* __restrict__ groupCount,
+                                 const unsigned* __restrict__ candCount, const u64* __restrict__ pipeStats, int nPipelines) {
+    const int t = threadIdx.x;
+    if (t == 0) host[0] = (u64)*err;
+    if (t == 1 && groupCount) host[1] = (u64)*groupCount;
+    if (t == 2 && candCount) host[2] = (u64)*candCount;
+    if (pipeStats && t >= 8 && t < 8 + nPipelines) host[t] = pipeStats[t - 8];
+}
+void publishStatusAsync(Context& ctx, uint64_t* hostWords, const uint32_t* err, const uint32_t* groupCount, const uint32_t* candCount,
+                        const uint64_t* pipeStats, int nPipelines) {
+    if (nPipelines > 56) throw Error(RSQ_ERR_UNSUPPORTED, "more than 56 pipelines in one query");
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(64), 0, ctx.stream, (u64*)hostWords, (const unsigned*)err, (const unsigned*)groupCount,
+                       (const unsigned*)candCount, (const u64*)pipeStats, nPipelines);
+    RSQ_HIP(hipGetLastError());
+}
+
 // One launch that readies a join table for its build: the fill of the key / state words, the clear of the key bitmap and of
 // the entry counter.  (Three stream operations before every build add up: TPC-H Q5 runs five builds over tiny tables and
 // spent a third of its 0.3 ms on clears and launches.)
@@ -633,7 +690,8 @@ __global__ void __launch_bounds__(256) k_topk_range_gather(const i64* __restrict
 size_t topkHistBytes() { return 24 + (size_t)TOPK_PASSES * TOPK_BINS * sizeof(unsigned); }
 
 // to be enqueued BEFORE the compaction that collects the image range: clears range, candidate count and the histogram
-void prepareTopCandidatesRange(Context& ctx, void* scratch) { RSQ_HIP(hipMemsetAsync(scratch, 0, 24 + TOPK_BINS * sizeof(unsigned), ctx.stream)); }
+size_t topkRangeScratchBytes() { return 24 + TOPK_BINS * sizeof(unsigned); }
+void prepareTopCandidatesRange(Context& ctx, void* scratch) { RSQ_HIP(hipMemsetAsync(scratch, 0, topkRangeScratchBytes(), ctx.stream)); }
 
 void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                               uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* cand, uint32_t capacity) {
@@ -823,63 +881,32 @@ __global__ void __launch_bounds__(256) k_rank_blocks(unsigned* __restrict__ bm, 
     if (threadIdx.x == 255) chunkTotal[blockIdx.x] = s_tot[255];
 }
 
-__global__ void __launch_bounds__(1024) k_rank_chunks(const unsigned* __restrict__ chunkTotal, int nChunks, unsigned* __restrict__ chunkBase /* [nChunks + 1] */) {
-    __shared__ unsigned s[1024];
-    unsigned carry = 0;
-    for (int base = 0; base < nChunks; base += 1024) {
-        const int i = base + (int)threadIdx.x;
-        const unsigned v = i < nChunks ? chunkTotal[i] : 0u;
-        s[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            unsigned t = threadIdx.x >= (unsigned)off ? s[threadIdx.x - off] : 0u;
-            __syncthreads();
-            s[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < nChunks) chunkBase[i] = carry + s[threadIdx.x] - v;
-        carry += s[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) chunkBase[nChunks] = carry;          // number of distinct keys
-}
-
-__global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp, const unsigned* __restrict__ used, unsigned nWaves, unsigned region,
-                                                    const unsigned* __restrict__ nRecords, int nWords,
-                                                    const unsigned* __restrict__ bm, i64 bmMin, const unsigned* __restrict__ blockRank,
-                                                    const unsigned* __restrict__ chunkBase, int nChunks, i64* __restrict__ words, i64 capacity,
-                                                    unsigned* __restrict__ err) {
-    // as many records as distinct keys, and no more than the table was sized for — anything else means the build side changed
-    // since the sizing pass (two rows with one key, more rows): the host then falls back to the hash table
-    if (blockIdx.x == 0 && threadIdx.x == 0 && (*nRecords != chunkBase[nChunks] || (i64)*nRecords > capacity)) atomicOr(err, 64u);
-    const i64 slots = (i64)nWaves * region;          // the build pipeline's waves own `region` slots each, used[wave] of them filled
-    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < slots; i += (i64)gridDim.x * blockDim.x) {
-        const unsigned w = (unsigned)(i / region), o = (unsigned)(i % region);
-        if (o >= used[w]) continue;
-        const i64* rec = temp + i * nWords;
-        const u64 d = (u64)(rec[0] - bmMin);
-        const unsigned* blk = bm + ((d >> 8) << 3);
-        const unsigned wi = (unsigned)(d >> 5) & 7u, bit = (unsigned)d & 31u;
-        unsigned r = blockRank[d >> 8];
-        for (unsigned j = 0; j < 8; j++) {
-            const unsigned x = blk[j];
-            r += j < wi ? __popc(x) : (j == wi ? __popc(x & ((1u << bit) - 1u)) : 0u);
-        }
-        if ((i64)r < capacity) for (int k = 0; k < nWords; k++) words[(i64)r * nWords + k] = rec[k];
-    }
-}
-
 // the rank words become absolute (chunk base added): a probe then needs nothing but the block it tested
-__global__ void __launch_bounds__(256) k_rank_absolute(unsigned* __restrict__ bm, i64 nBlocks, const unsigned* __restrict__ chunkBase) {
-    for (i64 b = blockIdx.x * (i64)blockDim.x + threadIdx.x; b < nBlocks; b += (i64)gridDim.x * blockDim.x) bm[b * 8] += chunkBase[b / RANK_CHUNK_BLOCKS];
+// one workgroup per chunk: it sums the totals of the chunks before it (a few hundred words; a separate single-workgroup scan of
+// them was one more launch, ~5 us of a 0.45 ms query), adds that base to its blocks' rank words and leaves it in chunkBase
+__global__ void __launch_bounds__(256) k_rank_absolute(unsigned* __restrict__ bm, i64 nBlocks, const unsigned* __restrict__ chunkTotal, int nChunks,
+                                                       unsigned* __restrict__ chunkBase /* [nChunks + 1] */) {
+    __shared__ unsigned s_part[4];
+    unsigned v = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += blockDim.x) v += chunkTotal[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const unsigned base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (threadIdx.x == 0) {
+        chunkBase[blockIdx.x] = base;
+        if ((int)blockIdx.x == nChunks - 1) chunkBase[nChunks] = base + chunkTotal[blockIdx.x];          // number of distinct keys
+    }
+    const i64 b0 = (i64)blockIdx.x * RANK_CHUNK_BLOCKS;
+    for (i64 b = b0 + threadIdx.x; b < b0 + RANK_CHUNK_BLOCKS && b < nBlocks; b += blockDim.x) bm[b * 8] += base;
 }
 
 void rankTableIndex(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chunkTotal, uint32_t* chunkBase) {
     const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
     hipLaunchKernelGGL(k_rank_blocks, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (unsigned*)bitmap, (i64)nBlocks, (unsigned*)chunkTotal);
-    hipLaunchKernelGGL(k_rank_chunks, dim3(1), dim3(1024), 0, ctx.stream, (const unsigned*)chunkTotal, nChunks, (unsigned*)chunkBase);
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(1024, (nBlocks + 255) / 256));
-    hipLaunchKernelGGL(k_rank_absolute, dim3(grid), dim3(256), 0, ctx.stream, (unsigned*)bitmap, (i64)nBlocks, (const unsigned*)chunkBase);
+    hipLaunchKernelGGL(k_rank_absolute, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (unsigned*)bitmap, (i64)nBlocks, (const unsigned*)chunkTotal, nChunks,
+                       (unsigned*)chunkBase);
     RSQ_HIP(hipGetLastError());
 }
 

@@ -302,13 +302,17 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         size_t pw = q->pinnedWords + 8 + q->pipelines.size();
         RSQ_HIP(hipHostMalloc((void**)&q->hPinned, pw * 8, hipHostMallocDefault));
         memset(q->hPinned, 0, pw * 8);
-        if (q->aggMode == AggMode::DENSE_REG && q->aggPad > 1) {
+        {   // the device's view of the pinned words: status words are published by one kernel instead of one copy each
             void* dv = nullptr;
-            if (hipHostGetDevicePointer(&dv, q->hPinned, 0) == hipSuccess && dv) {
+            if (hipHostGetDevicePointer(&dv, q->hPinned, 0) == hipSuccess && dv) q->dPinnedDev = (uint64_t*)dv; else (void)hipGetLastError();
+        }
+        if (q->aggMode == AggMode::DENSE_REG && q->aggPad > 1) {
+            void* dv = q->dPinnedDev;
+            if (dv) {
                 q->dFinHost = (uint64_t*)dv;
                 q->dFinTicket = (uint32_t*)ctx.alloc(sizeof(uint32_t));
                 RSQ_HIP(hipMemset(q->dFinTicket, 0, sizeof(uint32_t)));
-            } else (void)hipGetLastError();
+            }
         }
     }
     q->report.compilation_time_ms = nowMs() - t0;
@@ -888,10 +892,19 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     }
     if (denseMode(q)) enqueueTableInit(q);
     ctx.errWordClean = false;      // until this execution has read the word back as 0
-    RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
     bool anyCompaction = false;
     for (auto& p : q.pipelines) anyCompaction |= p.compact;
-    if (anyCompaction) RSQ_HIP(hipMemsetAsync(q.dPipeStats, 0, q.pipelines.size() * 8, ctx.stream));
+    // everything small this execution wants cleared, in one launch (aot_kernels.hip k_fill_batch): the error word, the pipelines'
+    // row counters, the group counter and the candidate selection's scratch of a compaction behind the last pipeline
+    bool groupCountCleared = false, topkScratchCleared = false;
+    {
+        FillItem f[4]; int n = 0;
+        f[n++] = FillItem{ctx.dErr, 4, 0};
+        if (anyCompaction) f[n++] = FillItem{q.dPipeStats, q.pipelines.size() * 8, 0};
+        if (q.dGroupCount) { f[n++] = FillItem{q.dGroupCount, 4, 0}; groupCountCleared = true; }
+        if (q.dTopkHists) { f[n++] = FillItem{q.dTopkHists, topkRangeScratchBytes(), 0}; topkScratchCleared = true; }
+        fillBatchAsync(ctx, f, n);
+    }
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
     const bool trace = getenv("RSQ_TRACE") != nullptr;      // per-pipeline wall time (synchronises after each one)
     double tPipe = nowMs();
@@ -913,10 +926,12 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         if (p.sink == SinkKind::MATERIALIZE) { materializePipeline(q, p); tracePoint(p); continue; }
         auto resetAccumulators = [&](HashTable& h) {
             // aggregate words beside the entries: first-row / min blocks to +inf, max blocks to -inf, sums to 0
+            std::vector<FillItem> f;
             for (int b = 0; b < h.nAccBlocks; b++) {
                 uint64_t idv = b < q.nMinBlocks ? 0x7fffffffffffffffull : b < q.nMinBlocks + q.nMaxBlocks ? 0x8000000000000000ull : 0ull;
-                fillU64Async(ctx, (uint64_t*)h.dAcc + (size_t)b * (size_t)h.capacity, (size_t)h.capacity, idv);
+                f.push_back(FillItem{(uint64_t*)h.dAcc + (size_t)b * (size_t)h.capacity, (size_t)h.capacity * 8, idv});
             }
+            fillBatchAsync(ctx, f.data(), (int)f.size());
         };
         if (q.aggMode == AggMode::AT_JOIN_ENTRY) resetAccumulators(*q.hashTables[(size_t)q.aggTable]);
         if (q.aggMode == AggMode::HASH) {
@@ -997,9 +1012,9 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 q.dCandRows = (int64_t*)ctx.alloc((size_t)topkCapacity * (size_t)q.groupRowWords * 8);
                 q.candCapacity = topkCapacity; q.candRowWords = q.groupRowWords;
             }
-            prepareTopCandidatesRange(ctx, q.dTopkHists);
+            if (!topkScratchCleared) prepareTopCandidatesRange(ctx, q.dTopkHists);
         }
-        RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
+        if (!groupCountCleared) RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
                        q.dGroupRows, groupRowsAllocated, q.dGroupCount,
                        h.rank && !(getenv("RSQ_RANK_SCRAMBLE") && atoi(getenv("RSQ_RANK_SCRAMBLE")) == 0),
@@ -1044,8 +1059,8 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 q.dCandRows = (int64_t*)ctx.alloc((size_t)topkCapacity * (size_t)q.groupRowWords * 8);
                 q.candCapacity = topkCapacity; q.candRowWords = q.groupRowWords;
             }
-            prepareTopCandidatesRange(ctx, q.dTopkHists);
-            RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
+            if (!topkScratchCleared) prepareTopCandidatesRange(ctx, q.dTopkHists);
+            if (!groupCountCleared) RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
             compactEntries(ctx, (const int64_t*)q.dAgg /* block 0 = first row */, (int64_t)D, nullptr, 1, false, (const int64_t*)q.dAgg, W,
                            q.dGroupRows, D, q.dGroupCount, false, q.topkWord, q.topkIs32, q.topkDesc, (uint64_t*)q.dTopkHists);
             selectTopCandidatesRange(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, D, q.topkWant,
@@ -1057,14 +1072,20 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
     }
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
-    RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
-    if (!partialOnly && denseMode(q) && !denseTopk) enqueueTableReadback(q);
-    if (!partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH || denseTopk))
-        RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
-    if (anyCompaction) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 8, q.dPipeStats, q.pipelines.size() * 8, hipMemcpyDeviceToHost, ctx.stream));
-    if (topkCapacity) {
-        RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 2, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
-        RSQ_HIP(hipMemcpyAsync(q.hGroupRows, q.dCandRows, (size_t)topkSpec * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost, ctx.stream));
+    {
+        const bool wantGroups = !partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH || denseTopk);
+        if (q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0)) {
+            // error word, group count, candidate count and the pipelines' row counters: one kernel writes them into the pinned words
+            publishStatusAsync(ctx, q.dPinnedDev + words, ctx.dErr, wantGroups ? q.dGroupCount : nullptr, topkCapacity ? q.dCandCount : nullptr,
+                               anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size());
+        } else {
+            RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+            if (wantGroups) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+            if (anyCompaction) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 8, q.dPipeStats, q.pipelines.size() * 8, hipMemcpyDeviceToHost, ctx.stream));
+            if (topkCapacity) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 2, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
+        }
+        if (!partialOnly && denseMode(q) && !denseTopk) enqueueTableReadback(q);
+        if (topkCapacity) RSQ_HIP(hipMemcpyAsync(q.hGroupRows, q.dCandRows, (size_t)topkSpec * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost, ctx.stream));
     }
     if (async && partialOnly) {
         // everything is enqueued; the caller orders its own work (the group-by merge collective) behind it on the same

@@ -107,6 +107,13 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
 size_t scanTempBytes(int64_t n);
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
+// several fills in one launch: whole 4-byte words, `value` a 64-bit pattern (aot_kernels.hip k_fill_batch)
+struct FillItem { void* p; size_t bytes; uint64_t value; };
+// the words an execution's host side reads first, written into host-mapped pinned memory by one kernel: [0] error word, [1] group count,
+// [2] candidate count, [8 + i] row counter of pipeline i (null sources are skipped)
+void publishStatusAsync(Context& ctx, uint64_t* hostWords, const uint32_t* err, const uint32_t* groupCount, const uint32_t* candCount,
+                        const uint64_t* pipeStats, int nPipelines);
+void fillBatchAsync(Context& ctx, const FillItem* items, int count);
 // bitmap-rank dictionary (aot_kernels.hip): the rank words of a bitmap laid out in nBlocks 32-byte blocks [rank | 224 bits]
 // (chunkTotal / chunkBase[ceil(nBlocks / 4096) (+ 1)] are scratch), and the placement of appended build records at the rank of
 // their key
@@ -141,6 +148,7 @@ size_t topkHistBytes();
 void selectTopCandidates(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                          uint32_t rowsUpperBound, uint32_t want, uint64_t* images, void* scratch, int64_t* cand, uint32_t capacity);
 void prepareTopCandidatesRange(Context& ctx, void* scratch);
+size_t topkRangeScratchBytes();      // the part of the scratch prepareTopCandidatesRange zeroes (an execution may fold it into its batched fill)
 void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                               uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* cand, uint32_t capacity);
 

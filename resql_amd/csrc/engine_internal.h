@@ -218,6 +218,7 @@ struct Query {
     uint64_t partRecordCapacity = 0;
     int64_t partTileStep = 1;              // > 1: the counting pass samples every n-th tile (selectivity estimate)
     // staged partitioning (form 3): region layout [P] base / capacity per workgroup, tracker control block, per-(workgroup, partition) counts
+    uint64_t* dPinnedDev = nullptr;        // hPinned as the device addresses it (status words are published by a kernel)
     uint64_t* dStageBase = nullptr; uint32_t* dStageCap = nullptr; void* dStageCtl = nullptr; void* hStageLayout = nullptr;
     uint32_t* dStageCounts = nullptr; size_t stageCountsWords = 0;
     size_t stageRecBytes = 0;              // bytes of dPartRecords[0] when it was allocated for form 3
