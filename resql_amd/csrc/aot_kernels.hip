@@ -850,15 +850,17 @@ void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, i
 // 256-bit blocks.  Input that is clustered by the key (TPC-H orders by o_orderkey) arrives nearly in rank order, so the
 // placement writes walk the entry array almost sequentially; input in random order is still placed correctly.
 // ------------------------------------------------------------------------------------------------
-#define RANK_CHUNK_BLOCKS 4096          /* = RSQ_RANK_CHUNK_BLOCKS: 32-byte blocks per workgroup */
-// blocks are [rank word | 7 bitmap words]; this pass writes every block's rank relative to its chunk of 4096 blocks
+#define RANK_CHUNK_BLOCKS RSQ_RANK_CHUNK_BLOCKS          /* 32-byte blocks per workgroup (engine.h): 1024 — with 4096 a 60 M-bit bitmap
+                                                           gave 66 workgroups to 256 CUs: 10.6 us instead of ~4 */
+#define RANK_PT (RANK_CHUNK_BLOCKS / 256)          /* blocks per thread */
+// blocks are [rank word | 7 bitmap words]; this pass writes every block's rank relative to its chunk
 __global__ void __launch_bounds__(256) k_rank_blocks(unsigned* __restrict__ bm, i64 nBlocks, unsigned* __restrict__ chunkTotal) {
     __shared__ unsigned s_tot[256];
-    const i64 b0 = (i64)blockIdx.x * RANK_CHUNK_BLOCKS + (i64)threadIdx.x * 16;
-    unsigned c[16];
+    const i64 b0 = (i64)blockIdx.x * RANK_CHUNK_BLOCKS + (i64)threadIdx.x * RANK_PT;
+    unsigned c[RANK_PT];
     unsigned mine = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
+    for (int j = 0; j < RANK_PT; j++) {
         unsigned n = 0;
         if (b0 + j < nBlocks) {
             const uint4* w = reinterpret_cast<const uint4*>(bm + (b0 + j) * 8);
@@ -877,7 +879,7 @@ __global__ void __launch_bounds__(256) k_rank_blocks(unsigned* __restrict__ bm, 
     }
     unsigned run = s_tot[threadIdx.x] - mine;
 #pragma unroll
-    for (int j = 0; j < 16; j++) { if (b0 + j < nBlocks) bm[(b0 + j) * 8] = run; run += c[j]; }
+    for (int j = 0; j < RANK_PT; j++) { if (b0 + j < nBlocks) bm[(b0 + j) * 8] = run; run += c[j]; }
     if (threadIdx.x == 255) chunkTotal[blockIdx.x] = s_tot[255];
 }
 

@@ -1926,6 +1926,10 @@ struct Walker {
         // 0.293 -> 0.254 ms with two tiles, the 32 B synthetic rows gained ~1.5 %; Q1 itself is slower with two (0.363 vs 0.348).
         if (!getenv("RSQ_UNROLL") && pipe.gridPerCU == 2 && pipe.bytesPerRow > 0)
             pipe.unroll = (int)std::max<int64_t>(1, std::min<int64_t>(4, (4608 + pipe.bytesPerRow * 128 - 1) / (pipe.bytesPerRow * 128)));
+        // A pipeline behind a wave compaction waits twice per tile — for the key columns, then (join probes) for the bitmap words their
+        // values address — and few of its rows go further: it wants several tiles in flight per wave.  TPC-H Q3 at SF10, all kernels:
+        // 0.415 ms with one tile, 0.381 with two, 0.367 with three, 0.363 with four (RSQ_COMPACT_UNROLL).
+        if (!getenv("RSQ_UNROLL") && pipe.compact) pipe.unroll = envInt("RSQ_COMPACT_UNROLL", 4, 1, 8);
         const int U = pipe.unroll;
         const bool mat = pipe.sink == SinkKind::MATERIALIZE;
         std::ostringstream s;

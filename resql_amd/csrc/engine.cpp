@@ -669,7 +669,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
             // a dictionary that carries aggregates scatters them with a multiplicative bijection: power-of-two capacity
             const int64_t capMul = getenv("RSQ_DEBUG_RANK_CAP") ? std::max(1, atoi(getenv("RSQ_DEBUG_RANK_CAP"))) : 1;      // (measurement only)
             h.capacity = q.aggTable == h.id ? nextPow2(std::max<int64_t>(64, (int64_t)n * capMul)) : std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);
-            const int64_t nChunks = (h.bmBlocks + 4095) / 4096;
+            const int64_t nChunks = (h.bmBlocks + RSQ_RANK_CHUNK_BLOCKS - 1) / RSQ_RANK_CHUNK_BLOCKS;
             // arrival-order buffer: one region per wave of the largest grid this pipeline launches, four times the mean
             // number of records per wave of the smallest one
             const int64_t wpb = p.blockThreads / 64;

@@ -12,6 +12,8 @@
 #include "expr.h"
 #include "resql_hip.h"
 
+#define RSQ_RANK_CHUNK_BLOCKS 1024       /* 32-byte bitmap blocks one workgroup of the rank index handles (aot_kernels.hip) */
+
 namespace rsq {
 
 #define RSQ_HIP(call)                                                                              \
@@ -115,7 +117,7 @@ void publishStatusAsync(Context& ctx, uint64_t* hostWords, const uint32_t* err, 
                         const uint64_t* pipeStats, int nPipelines);
 void fillBatchAsync(Context& ctx, const FillItem* items, int count);
 // bitmap-rank dictionary (aot_kernels.hip): the rank words of a bitmap laid out in nBlocks 32-byte blocks [rank | 224 bits]
-// (chunkTotal / chunkBase[ceil(nBlocks / 4096) (+ 1)] are scratch), and the placement of appended build records at the rank of
+// (chunkTotal / chunkBase[ceil(nBlocks / RSQ_RANK_CHUNK_BLOCKS) (+ 1)] are scratch), and the placement of appended build records at the rank of
 // their key
 void rankTableIndex(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chunkTotal, uint32_t* chunkBase);
 void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uint32_t nWaves, uint32_t region, const uint32_t* nRecords, int nWords,
