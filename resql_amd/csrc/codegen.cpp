@@ -800,7 +800,11 @@ struct Walker {
         // Bitmap-rank dictionary (HashTable::rankCapable, kernels/rsq_device.h rank_of): a table that is probed single-match over
         // one integer key with a key bitmap needs no hashing when its build keys prove unique.  The same kernel carries both
         // forms behind a uniform branch on a.<T>_rank; the host decides once, from the sizing pass.
-        ht->rankCapable = ht->unique && ht->hasBitmap && ht->keyCas && ht->aos && keyVars.size() == 1 && envInt("RSQ_JOIN_RANK", 1, 0, 1) != 0;
+        // (A join probed for ALL matches qualifies too: with unique build keys every probe has at most one.  If such a table carries
+        // nothing but its key - TPC-H Q3's customer side - the bitmap IS the table in the rank form: a KEY SET, no entries at all.)
+        ht->rankCapable = (ht->unique || envInt("RSQ_JOIN_RANK_MULTI", 1, 0, 1)) && ht->hasBitmap && ht->keyCas && ht->aos && keyVars.size() == 1 &&
+                          envInt("RSQ_JOIN_RANK", 1, 0, 1) != 0;
+        ht->setOnly = ht->rankCapable && !ht->unique && ht->payload.empty();
         // (a table that may become a rank dictionary keeps its bitmap in the interleaved layout, rsq_device.h bmi_word)
         ht->bmInterleaved = ht->rankCapable;
         const std::string bmw = ht->bmInterleaved ? "rsq::bmi_word(d)" : "d >> 5";
@@ -825,6 +829,14 @@ struct Walker {
             line("st.n_" + T + "++;");
             line("{ " + bitSet + "const u32 b = 1u << (d & 31); if (atomicOr(&a." + T + "_bm[" + bmw + "], b) & b) atomicOr(a.err, (u32)rsq::NOTE_BUILD_KEYS_NOT_UNIQUE); }");
             closeScope();
+            if (ht->setOnly) {
+                // key set: the bit is everything; a bit that is already set means the build side changed since the sizing pass
+                openScope("else if (a." + T + "_rank) {");
+                line("{ " + bitSet + "const u32 b = 1u << (d & 31); if (atomicOr(&a." + T + "_bm[" + bmw + "], b) & b) atomicOr(a.err, (u32)rsq::NOTE_BUILD_KEYS_NOT_UNIQUE); }");
+                line("st.n_" + T + "++;");
+                closeScope();
+                openScope("else {");
+            } else {
             openScope("else if (a." + T + "_rank) {");
             // The record goes to the arrival-order buffer, into the region of the wave that produced it: a.<T>_treg records
             // per wave (the host sizes the regions at four times the mean from the sizing pass; tiles are dealt to the waves
@@ -863,6 +875,7 @@ struct Walker {
             line("st.n_" + T + "++;");
             closeScope();
             openScope("else {");
+            }
         } else
         openScope("if (a." + T + "_countonly) { st.n_" + T + "++; } else {");
         line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
@@ -906,7 +919,8 @@ struct Walker {
                                std::to_string(ht->payload.size()) + " payload word(s), sized by a counting pass" +
                                (ht->hasBitmap ? ", key bitmap of " + std::to_string((long long)ht->bmBits) + " bits" : "") +
                                (ht->keyCas ? ", key word is the slot state" : "") +
-                               (ht->rankCapable ? "; a bitmap-rank dictionary instead when the build keys prove unique" : "") + ")");
+                               (ht->setOnly ? "; nothing but the bitmap when the build keys prove unique" :
+                                ht->rankCapable ? "; a bitmap-rank dictionary instead when the build keys prove unique" : "") + ")");
         q.hashTables.push_back(std::move(ht));
     }
 
@@ -1047,6 +1061,27 @@ struct Walker {
             closeScope();
             openScope("if (" + T + "_hit) {");
             consumeMatch(o, ht, T, keyVars, probeKeyNames);
+            closeScope();
+            return;
+        }
+        if (ht.rankCapable) {
+            // all matches of a table that may be a rank dictionary (unique build keys): the walk below in the hash form; in the rank
+            // form the one entry of a key whose bit is set (tested above) - one pass through the same loop body
+            addArg(T + "_rank", "u64", 0);
+            line("const u64 " + T + "_mask = a." + T + "_cap - 1;");
+            if (ht.setOnly) line("u64 " + T + "_s = a." + T + "_rank ? 0ull : " + slotOf(ht, T, keyVars) + ";");
+            else line("u64 " + T + "_s = a." + T + "_rank ? rsq::rank_of(a." + T + "_bm, (u64)(" + keyVars[0] + " - a." + T + "_bmmin)) : " + slotOf(ht, T, keyVars) + ";");
+            openScope("for (u64 " + T + "_n = 0; " + T + "_n <= " + T + "_mask; " + T + "_n++, " + T + "_s = (" + T + "_s + 1) & " + T + "_mask) {");
+            line("bool " + T + "_eq = true;");
+            openScope("if (!a." + T + "_rank) {");
+            line("const i64 " + T + "_kk = " + wordAt(ht, T, 0) + ";");
+            line("if (" + T + "_kk == (i64)0x8000000000000000ull) break;");
+            line(T + "_eq = " + T + "_kk == " + keyVars[0] + ";");
+            closeScope();
+            openScope("if (" + T + "_eq) {");
+            consumeMatch(o, ht, T, keyVars, probeKeyNames);
+            closeScope();
+            line("if (a." + T + "_rank) break;");
             closeScope();
             return;
         }

@@ -665,7 +665,9 @@ static void buildHashTable(Query& q, Pipeline& p) {
         RSQ_HIP(hipStreamSynchronize(ctx.stream));
         h.rank = h.rankCapable && !(err & 64u);
         if (err & 64u) { err &= ~64u; RSQ_HIP(hipMemcpy(ctx.dErr, &err, 4, hipMemcpyHostToDevice)); }
-        if (h.rank) {
+        if (h.rank && h.setOnly) {
+            h.capacity = std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);          // (nothing is allocated: the bitmap is the table)
+        } else if (h.rank) {
             // a dictionary that carries aggregates scatters them with a multiplicative bijection: power-of-two capacity
             const int64_t capMul = getenv("RSQ_DEBUG_RANK_CAP") ? std::max(1, atoi(getenv("RSQ_DEBUG_RANK_CAP"))) : 1;      // (measurement only)
             h.capacity = q.aggTable == h.id ? nextPow2(std::max<int64_t>(64, (int64_t)n * capMul)) : std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);
@@ -689,6 +691,13 @@ static void buildHashTable(Query& q, Pipeline& p) {
         }
         if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
         if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.rank ? "bitmap-rank dictionary" : "hash table", n);
+    }
+    if (h.rank && h.setOnly) {
+        prepareTableAsync(ctx, nullptr, 0, 0, nullptr, 0, h.dBitmap, bmWords, h.dCount);
+        q.report.num_kernels++;
+        launchPipeline(q, p, -1);
+        q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
+        return;
     }
     if (h.rank) {
         // ONE launch clears the bitmap and both counters' words; the records then arrive in the append buffer, the bitmap

@@ -69,6 +69,7 @@ struct HashTable {
     // entry number rank(key): no CAS, no scattered read-modify-writes, nearly sequential stores for input clustered by the key.
     // `capacity` is then the number of entries; words[entry][k] and acc[block][entry] as for the hash form.
     bool rankCapable = false;
+    bool setOnly = false;            // ... probed for all matches and carrying nothing but its key: in the rank form the bitmap alone (no entries)
     bool bmInterleaved = false;      // the bitmap's layout: 32-byte blocks of [rank word | 7 words = 224 bits] (rank-capable tables)
     bool rank = false;
     int64_t* dTemp = nullptr;        // arrival-order buffer: [wave of the build grid][tempRegion] records
