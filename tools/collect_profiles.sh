@@ -58,7 +58,8 @@ fi
 
 step "TPC-H Q3 at SF10: executions (the first one is the cold one), kernel statistics per pipeline"
 rm -rf /tmp/prof_q3
-if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q3 -- python3 "$ROOT/tools/profile_case.py" q3 10 12 > "$OUT/${R}_q3_sf10_runs.txt" 2>&1; then
+if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_q3 -- python3 "$ROOT/tools/profile_case.py" q3 10 12 > /tmp/q3_runs.log 2>&1; then
+    grep '^q3 ' /tmp/q3_runs.log > "$OUT/${R}_q3_sf10_runs.txt"
     f=$(found /tmp/prof_q3 '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_q3_sf10_kernel_stats.csv"
 fi
 step "TPC-H Q3 at SF10: FETCH_SIZE and WRITE_SIZE per pipeline (two passes)"
@@ -85,7 +86,8 @@ PY
 step "large-group aggregation (1.25 B rows, 2^20 groups, 10 % and 50 % pass): kernel statistics, FETCH_SIZE and WRITE_SIZE in separate passes"
 for s in 0.1 0.5; do
     rm -rf /tmp/prof_lg_$s
-    if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lg_$s -- python3 "$ROOT/tools/profile_case.py" synthetic 1250000000 1048576 $s 6 > "$OUT/${R}_synth_g20_sel${s}_runs.txt" 2>&1; then
+    if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lg_$s -- python3 "$ROOT/tools/profile_case.py" synthetic 1250000000 1048576 $s 6 > /tmp/lg_runs.log 2>&1; then
+        grep '^synthetic ' /tmp/lg_runs.log > "$OUT/${R}_synth_g20_sel${s}_runs.txt"
         f=$(found /tmp/prof_lg_$s '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_synth_g20_sel${s}_kernel_stats.csv"
     fi
     for c in FETCH_SIZE WRITE_SIZE; do
