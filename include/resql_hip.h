@@ -163,6 +163,10 @@ int  rsq_query_bind_partial(rsq_query* q, void* dev_ptr, size_t bytes);
 int  rsq_query_merge_gathered(rsq_query* q, const void* gathered_dev, int32_t n_ranks);
 int  rsq_query_result(rsq_query* q, rsq_result_view* out);
 int  rsq_query_report(const rsq_query* q, rsq_report* out);
+/* Device time (HIP events around the launches) summed over the executions since the last reset, and their number: what a
+ * benchmark loop reads ONCE after its timed region instead of a report per step (the reference prints executionTime per
+ * query, JitContextFlounder.h:132-150; a loop of 50 steps would otherwise time its own bookkeeping). */
+int  rsq_query_kernel_time_stats(rsq_query* q, double* sum_ms, uint64_t* executions, int32_t reset);
 /* Generated HIP source and pipeline description of the compiled query (debugging). */
 const char* rsq_query_source(const rsq_query* q);
 const char* rsq_query_explain(const rsq_query* q);

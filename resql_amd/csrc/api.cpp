@@ -252,6 +252,11 @@ int rsq_query_report(const rsq_query* q, rsq_report* out) {
     return guarded(h->ctx, [&] { queryReport(*h->q, out); });
 }
 
+int rsq_query_kernel_time_stats(rsq_query* q, double* sum_ms, uint64_t* executions, int32_t reset) {
+    if (!q) return RSQ_ERR_INVALID;
+    return guarded(QH(q)->ctx, [&] { queryKernelTimeStats(*QH(q)->q, sum_ms, executions, reset != 0); });
+}
+
 const char* rsq_query_source(const rsq_query* q) { return q ? querySource(*reinterpret_cast<const QueryHandle*>(q)->q) : ""; }
 const char* rsq_query_explain(const rsq_query* q) { return q ? queryExplain(*reinterpret_cast<const QueryHandle*>(q)->q) : ""; }
 

@@ -122,6 +122,7 @@ Query::~Query() {
     if (dFinTicket) ctx.free(dFinTicket);
     if (gev0) (void)hipEventDestroy(gev0);
     if (gev1) (void)hipEventDestroy(gev1);
+    for (auto& e : evRing) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (dMatCnt) ctx.free(dMatCnt);
     if (dMatOffs) ctx.free(dMatOffs);
     if (dScanTemp) ctx.free(dScanTemp);
@@ -759,13 +760,24 @@ void awaitKernels(Query& q) {
 
 // kernel time of a fused step: its events are read when somebody asks (the report) or before they are recorded again
 void resolveKernelTime(Query& q) {
+    // the one-launch steps that ran to their end record into a ring of event pairs, read here in one go: reading a pair costs the
+    // host 2.4 us, which a benchmark loop would otherwise pay between every two steps
+    if (q.evHead < q.evTail) RSQ_HIP(hipSetDevice(q.ctx.device));
+    for (; q.evHead < q.evTail; q.evHead++) {
+        auto& e = q.evRing[q.evHead % q.evRing.size()];
+        RSQ_HIP(hipEventSynchronize(e.second));
+        float ems = 0;
+        RSQ_HIP(hipEventElapsedTime(&ems, e.first, e.second));
+        q.report.kernel_time_ms = ems; q.kernelTimeSumMs += ems; q.kernelTimeLaunches++;
+        q.report.hbm_gbps = ems > 0 ? (double)q.report.bytes_read / (ems * 1e-3) / 1e9 : 0;
+    }
     if (!q.kernelTimePending || q.pendingAsync) return;
     q.kernelTimePending = false;
     RSQ_HIP(hipSetDevice(q.ctx.device));
     RSQ_HIP(hipEventSynchronize(q.gev1));
     float ms = 0;
     RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1));
-    q.report.kernel_time_ms = ms;
+    q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
 }
 
@@ -813,7 +825,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (async && partialOnly) { q.pendingAsync = true; q.pendingFused = false; q.report.execution_time_ms = nowMs() - t0; return; }
             RSQ_HIP(hipStreamSynchronize(ctx.stream));
             float gms = 0; RSQ_HIP(hipEventElapsedTime(&gms, ctx.ev0, ctx.ev1));
-            q.report.kernel_time_ms = gms;
+            q.report.kernel_time_ms = gms; q.kernelTimeSumMs += gms; q.kernelTimeLaunches++;
             q.report.hbm_gbps = gms > 0 ? (double)q.report.bytes_read / (gms * 1e-3) / 1e9 : 0;
             ctx.errWordClean = (uint32_t)q.hPinned[words] == 0;
             checkDeviceError((uint32_t)q.hPinned[words]);
@@ -844,7 +856,17 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
             ctx.errWordClean = true;
         }
-        resolveKernelTime(q);                                  // the previous step's events, before they are recorded again
+        static const bool stepTrace0 = getenv("RSQ_STEP_TRACE") != nullptr;
+        // a step that runs to its end here takes the next pair of the event ring (read when somebody asks, or when the ring is
+        // full); an asynchronous partial step keeps the single pair finalize / settle read
+        const bool ringEvents = !(async && partialOnly);
+        if (ringEvents) {
+            if (q.evRing.empty()) {
+                q.evRing.resize(256);
+                for (auto& e : q.evRing) { RSQ_HIP(hipEventCreate(&e.first)); RSQ_HIP(hipEventCreate(&e.second)); }
+            }
+            if (q.kernelTimePending || q.evTail - q.evHead == q.evRing.size()) resolveKernelTime(q);
+        } else resolveKernelTime(q);                           // the previous step's events, before they are recorded again
         q.fusedReady = false;
         q.flatRun = false;                                     // always the padded kernel: the last workgroup unpads
         static const bool pollOk = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
@@ -854,16 +876,30 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         q.finOut = partialOnly ? q.dAgg : q.dFinHost;          // device partial table | host-mapped pinned read-back buffer
         q.finErr = q.dFinHost + q.pinnedWords;
         if (!q.gev0) { RSQ_HIP(hipEventCreate(&q.gev0)); RSQ_HIP(hipEventCreate(&q.gev1)); }
-        static const bool extEvents = !(getenv("RSQ_EXT_EVENTS") && atoi(getenv("RSQ_EXT_EVENTS")) == 0);
-        if (extEvents) launchPipelineKernel(q, p, *p.kernel, -1, 0, 0, q.gev0, q.gev1);
+        hipEvent_t evA = q.gev0, evB = q.gev1;
+        if (ringEvents) { auto& e = q.evRing[q.evTail % q.evRing.size()]; evA = e.first; evB = e.second; }
+        // two event records around the launch.  (The extended launch that takes the events itself - RSQ_EXT_EVENTS=1 - costs the
+        // host 3 us more per step and the tail another 1.5: measured 16 us of step overhead against 11.5.)
+        static const bool extEvents = getenv("RSQ_EXT_EVENTS") && atoi(getenv("RSQ_EXT_EVENTS")) == 1;
+        if (extEvents) launchPipelineKernel(q, p, *p.kernel, -1, 0, 0, evA, evB);
         else {
-            RSQ_HIP(hipEventRecord(q.gev0, ctx.stream));
+            const double tB = stepTrace0 ? nowMs() : 0;
+            RSQ_HIP(hipEventRecord(evA, ctx.stream));
+            const double tC = stepTrace0 ? nowMs() : 0;
             launchPipelineKernel(q, p, *p.kernel, -1);
-            RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
+            const double tD = stepTrace0 ? nowMs() : 0;
+            RSQ_HIP(hipEventRecord(evB, ctx.stream));
+            if (stepTrace0) {
+                static double a[3] = {0, 0, 0}; static int n = 0;
+                a[0] += tC - tB; a[1] += tD - tC; a[2] += nowMs() - tD;
+                if (++n == 64) { fprintf(stderr, "[rsq step]   event record %.1f us, launch %.1f us, event record %.1f us\n", a[0] / 64 * 1e3, a[1] / 64 * 1e3, a[2] / 64 * 1e3); a[0] = a[1] = a[2] = 0; n = 0; }
+            }
         }
         q.finOut = nullptr;
         q.finSeq = 0;
-        q.kernelTimePending = true;
+        if (ringEvents) q.evTail++; else q.kernelTimePending = true;
+        static const bool stepTrace = getenv("RSQ_STEP_TRACE") != nullptr;        // host-side phases of the one-launch step, averaged over 64 steps
+        const double tLaunched = stepTrace ? nowMs() : 0;
         q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
         if (async && partialOnly) {
             // (the kernel leaves its working table reset, and whatever comes next on this stream is ordered behind it)
@@ -889,6 +925,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             std::atomic_thread_fence(std::memory_order_acquire);
         } else RSQ_HIP(hipStreamSynchronize(ctx.stream));
         q.fusedReady = true;
+        const double tSeen = stepTrace ? nowMs() : 0;
         checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
         if (!partialOnly) {
             double t1 = nowMs();
@@ -897,6 +934,17 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             q.report.finalize_time_ms = nowMs() - t1;
         }
         q.report.execution_time_ms = nowMs() - t0;
+        if (stepTrace) {
+            static double acc[4] = {0, 0, 0, 0}; static int n = 0; static double lastEnd = 0;
+            const double tEnd = nowMs();
+            acc[0] += tLaunched - t0; acc[1] += tSeen - tLaunched; acc[2] += tEnd - tSeen; if (lastEnd > 0) acc[3] += t0 - lastEnd;
+            lastEnd = tEnd;
+            if (++n == 64) {
+                fprintf(stderr, "[rsq step] enqueue %.1f us, launch -> result seen %.1f us, tail %.1f us, between executions %.1f us\n",
+                        acc[0] / 64 * 1e3, acc[1] / 64 * 1e3, acc[2] / 64 * 1e3, acc[3] / 63 * 1e3);
+                acc[0] = acc[1] = acc[2] = acc[3] = 0; n = 0; lastEnd = 0;
+            }
+        }
         return;
     }
     if (denseMode(q)) enqueueTableInit(q);
@@ -1110,7 +1158,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (p.compact) p.stage2Rows = (int64_t)((double)q.hPinned[words + 8 + i] * (double)std::max(1u, p.lastGrid) / (double)std::min(64u, std::max(1u, p.lastGrid)));
         }
     float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
-    q.report.kernel_time_ms = ms;
+    q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
     ctx.errWordClean = (uint32_t)q.hPinned[words] == 0;
     if (((uint32_t)q.hPinned[words] & 64u) && !async) {
@@ -1248,7 +1296,7 @@ void finalizeQuery(Query& q) {
         float ms = 0;
         if (q.pendingFused) { RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.fusedReady = true; q.kernelTimePending = false; }
         else RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
-        q.report.kernel_time_ms = ms;
+        q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
         q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
         if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;
         checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
@@ -1269,7 +1317,7 @@ void settleAsync(Query& q) {
     float ms = 0;
     if (q.pendingFused) { RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.fusedReady = true; q.kernelTimePending = false; }
     else RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
-    q.report.kernel_time_ms = ms;
+    q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
     if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;
     checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
@@ -1382,6 +1430,12 @@ void queryResult(Query& q, rsq_result_view* out) {
 void queryReport(const Query& q, rsq_report* out) {
     resolveKernelTime(const_cast<Query&>(q));
     *out = q.report;
+}
+void queryKernelTimeStats(Query& q, double* sumMs, uint64_t* executions, bool reset) {
+    resolveKernelTime(q);
+    if (sumMs) *sumMs = q.kernelTimeSumMs;
+    if (executions) *executions = q.kernelTimeLaunches;
+    if (reset) { q.kernelTimeSumMs = 0; q.kernelTimeLaunches = 0; }
 }
 bool queryIsDense(const Query& q) { return denseMode(q); }
 void queryDenseLayout(const Query& q, int64_t* nMin, int64_t* nMax, int64_t* nSum, void** dptr) {

@@ -176,6 +176,7 @@ void mergeGathered(Query& q, const void* gathered, int nRanks);
 void partialBuffer(Query& q, void** dptr, int64_t* nMin, int64_t* nMax, int64_t* nSum);
 void queryResult(Query& q, rsq_result_view* out);
 void queryReport(const Query& q, rsq_report* out);
+void queryKernelTimeStats(Query& q, double* sumMs, uint64_t* executions, bool reset);
 const char* querySource(const Query& q);
 const char* queryExplain(const Query& q);
 void destroyQuery(Query* q);

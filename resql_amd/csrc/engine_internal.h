@@ -219,6 +219,7 @@ struct Query {
     uint64_t partRecordCapacity = 0;
     int64_t partTileStep = 1;              // > 1: the counting pass samples every n-th tile (selectivity estimate)
     // staged partitioning (form 3): region layout [P] base / capacity per workgroup, tracker control block, per-(workgroup, partition) counts
+    double kernelTimeSumMs = 0; uint64_t kernelTimeLaunches = 0;      // device time of the executions since the last reset (rsq_query_kernel_time_stats)
     uint64_t* dPinnedDev = nullptr;        // hPinned as the device addresses it (status words are published by a kernel)
     uint64_t* dStageBase = nullptr; uint32_t* dStageCap = nullptr; void* dStageCtl = nullptr; void* hStageLayout = nullptr;
     uint32_t* dStageCounts = nullptr; size_t stageCountsWords = 0;
@@ -288,6 +289,7 @@ struct Query {
     uint64_t finSeqCounter = 0;
     uint64_t mergePublishedSeq = 0;        // > 0: rsq_query_merge_gathered also published the merged table to hPinned; finalize polls for this number
     bool kernelTimePending = false;        // the fused step's events have not been read yet (resolveKernelTime)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evRing; size_t evHead = 0, evTail = 0;      // event pairs of the one-launch steps not read yet
     hipEvent_t gev0 = nullptr, gev1 = nullptr;   // start / stop of the fused step's kernel (hipExtModuleLaunchKernel)
     bool pendingFused = false;             // the enqueued asynchronous step was a fused one
     // generic pipeline in front of the specialised kernel (see GenericProgram)

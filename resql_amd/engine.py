@@ -96,6 +96,7 @@ def lib():
         L.rsq_query_partial_layout.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.rsq_query_result.argtypes = [vp, C.POINTER(P.rsq_result_view)]
         L.rsq_query_report.argtypes = [vp, C.POINTER(rsq_report)]
+        L.rsq_query_kernel_time_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int32]
         L.rsq_query_source.restype = C.c_char_p
         L.rsq_query_source.argtypes = [vp]
         L.rsq_query_explain.restype = C.c_char_p
@@ -150,7 +151,7 @@ EXPORTED_SYMBOLS = [
     "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_await_kernels", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
-    "rsq_query_finalize", "rsq_query_merge_gathered", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_source", "rsq_query_explain",
+    "rsq_query_finalize", "rsq_query_merge_gathered", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_kernel_time_stats", "rsq_query_source", "rsq_query_explain",
     "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
     "rsq_measure_read_bandwidth",
     "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
@@ -414,6 +415,12 @@ class Query:
         r = rsq_report()
         self.ctx._check(self.ctx._L.rsq_query_report(self.h, C.byref(r)))
         return r
+
+    def kernel_time_stats(self, reset: bool = False):
+        """(device ms summed over the executions since the last reset, number of executions)"""
+        s, n = C.c_double(0), C.c_uint64(0)
+        self.ctx._check(self.ctx._L.rsq_query_kernel_time_stats(self.h, C.byref(s), C.byref(n), 1 if reset else 0))
+        return s.value, n.value
 
     @property
     def source(self) -> str:
