@@ -548,6 +548,9 @@ struct Walker {
     }
     bool compactThen(OpNode* o, const std::function<void()>& downstream) {
         if (compacted || !selective || !envInt("RSQ_COMPACT", 1, 0, 1) || downstreamMaterializes(o)) return false;
+        // not inside the match loop of a join probed for all matches: the queue takes ONE entry per row function call, and a row
+        // with several matches would keep only its last (found with a constant build key: every build row the same key)
+        if (multiMatchAbove) return false;
         compacted = true;
         pipe.compact = true;
         cqLive.assign(eg.symbols.begin(), eg.symbols.end());
@@ -649,7 +652,8 @@ struct Walker {
     // Key value(s) of one expression as table words: one word for numbers, ceil(len / 8) words of bytes for strings
     // (see rsq_device.h: str_word).  stripChar: CHAR(n) equality ignores trailing spaces (joins); group keys keep the
     // exact bytes and the host merges space-equivalent groups, because the group shows the FIRST row's spelling.
-    std::vector<std::string> keyWords(Expr* e, const std::string& prefix, bool stripChar, std::vector<std::string>* endsWithSpace = nullptr) {
+    // stripMode: -1 by the expression's own type (CHAR keys ignore trailing spaces when stripChar), 0 exact bytes, 1 ignore trailing spaces
+    std::vector<std::string> keyWords(Expr* e, const std::string& prefix, bool stripChar, std::vector<std::string>* endsWithSpace = nullptr, int stripMode = -1) {
         std::vector<std::string> out;
         const std::string v = eg.emit(e);
         if (!e->type.isString()) {
@@ -657,8 +661,24 @@ struct Walker {
             out.push_back(prefix);
             return out;
         }
-        if (e->tag == RSQ_E_CONSTANT) failUnsupported("a string constant as a join or group key");
-        const bool strip = stripChar && e->type.tag == RSQ_CHAR;
+        const bool strip = stripMode >= 0 ? stripMode == 1 : (stripChar && e->type.tag == RSQ_CHAR);
+        if (e->tag == RSQ_E_CONSTANT) {
+            // a string constant as a key: its words are literals (the text, NUL padded to the constant's declared length;
+            // without its trailing spaces where the comparison ignores them)
+            std::string text = e->symbol.substr(0, (size_t)std::max(0, e->type.len));
+            const size_t nul = text.find('\0');
+            if (nul != std::string::npos) text.resize(nul);
+            if (endsWithSpace && e->type.tag == RSQ_CHAR && !strip) endsWithSpace->push_back(!text.empty() && text.back() == ' ' ? "true" : "false");
+            if (strip) while (!text.empty() && text.back() == ' ') text.pop_back();
+            for (int w = 0; w < (e->type.len + 7) / 8; w++) {
+                uint64_t word = 0;
+                for (int b = 0; b < 8; b++) { const size_t i = (size_t)w * 8 + (size_t)b; if (i < text.size()) word |= (uint64_t)(unsigned char)text[i] << (8 * b); }
+                std::string kv = prefix + "_" + std::to_string(w);
+                line("const i64 " + kv + " = (i64)" + std::to_string((unsigned long long)word) + "ull;");
+                out.push_back(kv);
+            }
+            return out;
+        }
         if (!strip) {
             // exact bytes: the column is NUL padded to its width (resql_plan.h), so the key words ARE the stored bytes —
             // one unaligned load per word instead of a byte loop per word (32 key words for TPC-H Q10's group-by)
@@ -684,10 +704,25 @@ struct Walker {
     // at the NUL, so VARCHAR(a) = VARCHAR(b) matches equal strings — both sides take the word count of the wider one, the
     // narrower side's missing words are zero.  hashChar pads with spaces to the DECLARED length (qlib/hash.h:131-147), so
     // CHAR(a) = CHAR(b), a != b, never has equal hashes and never matches: the two sides get pad words that differ.
-    // (CHAR against VARCHAR of another length stays refused.)
+    // CHAR against VARCHAR (any lengths): equal hashes need the VARCHAR value to be exactly as long as the CHAR column is wide
+    // (hashChar counts the pad spaces, hashVarchar only the characters), and the key comparison is the PROBE side's
+    // (checkEquality(probeKeys, entryKeys), hashjoin.h:142/191: compareChar ignores trailing spaces, compareVarchar does not).
+    // So both sides form their words the probe side's way (joinKeyStripMode), padded to the wider side's word count, plus one
+    // word that holds the hashed length: the declared width of a CHAR key, the actual length of a VARCHAR key.
+    static bool mixedStringKinds(const Expr* a, const Expr* b) { return a->type.isString() && b->type.isString() && a->type.tag != b->type.tag; }
+    static int joinKeyStripMode(const Expr* side, const Expr* probeSide, const Expr* buildSide) {
+        (void)side;
+        return mixedStringKinds(probeSide, buildSide) ? (probeSide->type.tag == RSQ_CHAR ? 1 : 0) : -1;
+    }
     void padKeyWords(Expr* mine, Expr* other, size_t w0, std::vector<std::string>& keyVars, bool buildSide) {
-        if (!mine->type.isString() || !other->type.isString() || mine->type.len == other->type.len) return;
-        if (mine->type.tag != other->type.tag) failUnsupported("CHAR and VARCHAR join keys of different declared lengths");
+        if (!mine->type.isString() || !other->type.isString()) return;
+        if (mine->type.tag != other->type.tag) {
+            const size_t want = (size_t)(std::max(mine->type.len, other->type.len) + 7) / 8;
+            while (keyVars.size() - w0 < want) keyVars.push_back("((i64)0)");
+            keyVars.push_back(mine->type.tag == RSQ_CHAR ? "((i64)" + std::to_string(mine->type.len) + ")" : "((i64)rsq::str_len_exact(" + eg.emit(mine) + "))");
+            return;
+        }
+        if (mine->type.len == other->type.len) return;
         const size_t want = (size_t)(std::max(mine->type.len, other->type.len) + 7) / 8 + (mine->type.tag == RSQ_CHAR ? 1 : 0);
         const std::string pad = mine->type.tag == RSQ_CHAR && !buildSide ? "((i64)-1)" : "((i64)0)";
         while (keyVars.size() - w0 < want) keyVars.push_back(pad);
@@ -746,7 +781,7 @@ struct Walker {
             q.pool.addId(l);
             size_t w0 = keyVars.size();
             keyFirstWord.push_back(l->type.isString() ? -1 : (int)w0);
-            for (auto& kv : keyWords(l, T + "_k" + std::to_string(k++), true)) keyVars.push_back(kv);
+            for (auto& kv : keyWords(l, T + "_k" + std::to_string(k++), true, nullptr, joinKeyStripMode(l, eq->child->next, l))) keyVars.push_back(kv);
             padKeyWords(l, eq->child->next, w0, keyVars, true);
             for (size_t w = w0; w < keyVars.size(); w++)
                 ht->keys.push_back({w == w0 ? expressionName(l) : expressionName(l) + "#" + std::to_string(w - w0), w == w0 && !l->type.isString() ? l->type : Type(RSQ_BIGINT)});
@@ -932,7 +967,7 @@ struct Walker {
             Expr* r = eq->child->next;
             q.pool.addId(r);
             const size_t w0 = keyVars.size();
-            for (auto& kv : keyWords(r, T + "_p" + std::to_string(k++), true)) keyVars.push_back(kv);
+            for (auto& kv : keyWords(r, T + "_p" + std::to_string(k++), true, nullptr, joinKeyStripMode(r, r, eq->child))) keyVars.push_back(kv);
             padKeyWords(r, eq->child, w0, keyVars, false);
             // (only a one-word key can stand in for the build key of the matched entry, see tryJoinEntry)
             probeKeyNames.push_back(keyVars.size() - w0 == 1 ? expressionName(r) : std::string());
