@@ -1720,17 +1720,45 @@ struct Walker {
                 }
                 closeScope();
             }
+            const bool dbgTail = envInt("RSQ_DEBUG_TAIL", 0, 0, 1) != 0;      // (measurement only: device timestamps of the epilogue's stages)
+            auto stamp = [&](int k) { if (dbgTail) ep << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + " << k << "] = (u64)wall_clock64();\n"; };
+            if (dbgTail) { addArg("dbg", "u64*", 0); prologue += "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 0] = (u64)wall_clock64();\n"; }
+            stamp(1);
             ep << "    __shared__ u64 s_acc[" << W * D << "];\n";
+            if (envInt("RSQ_FLUSH_LANES", 1, 0, 1)) {
+                // The workgroup's accumulators meet LANE BY LANE first: every wave merges its cells into s_lane[cell][lane] (LDS
+                // atomics, no two lanes on one word), then each wave folds a share of the cells across the 64 lanes (DPP, rsq_device.h
+                // wave_reduce_to_lane63).  One cross-lane reduction per cell and workgroup instead of one per cell and WAVE: the
+                // reductions of TPC-H Q1's 42 cells in all 8 waves took 14-20 us of every launch as ds_bpermute butterflies and
+                // still 9-11 us as DPP (device timestamps, RSQ_DEBUG_TAIL).
+                const int64_t cells = W * D;
+                ep << "    __shared__ u64 s_lane[" << cells * 64 << "];\n";
+                ep << "    for (int i = threadIdx.x; i < " << cells * 64 << "; i += blockDim.x) { const int blk = (i >> 6) / " << D << "; s_lane[i] = " << blockIdentityExpr("blk") << "; }\n";
+                ep << "    __syncthreads();\n";
+                for (int w = 0; w < W; w++)
+                    for (int64_t g = 0; g < D; g++)
+                        ep << "    rsq::lds_merge<" << q.accums[(size_t)w].merge << ">(&s_lane[" << (q.accumSlot[(size_t)w] * D + g) * 64 << " + (threadIdx.x & 63)], (u64)st.acc_" << w << "_" << g << ");\n";
+                ep << "    __syncthreads();\n";
+                ep << "    for (int c = threadIdx.x >> 6; c < " << cells << "; c += blockDim.x >> 6) {\n";
+                ep << "        const int blk = c / " << D << ";\n        const u64 v = s_lane[c * 64 + (threadIdx.x & 63)];\n";
+                ep << "        const u64 r = blk < " << q.nMinBlocks << " ? rsq::wave_reduce_to_lane63<2>(v) : blk < " << (q.nMinBlocks + q.nMaxBlocks)
+                   << " ? rsq::wave_reduce_to_lane63<3>(v) : rsq::wave_reduce_to_lane63<0>(v);\n";
+                ep << "        if ((threadIdx.x & 63) == 63) s_acc[c] = r;\n    }\n";
+                ep << "    __syncthreads();\n";
+            } else {
             ep << "    for (int i = threadIdx.x; i < " << W * D << "; i += blockDim.x) { const int blk = i / " << D << "; s_acc[i] = " << blockIdentityExpr("blk") << "; }\n";
             ep << "    __syncthreads();\n";
             for (int w = 0; w < W; w++)
                 for (int64_t g = 0; g < D; g++)
                     ep << "    rsq::wave_to_lds<" << q.accums[(size_t)w].merge << ">(&s_acc[" << (q.accumSlot[(size_t)w] * D + g) << "], (u64)st.acc_" << w << "_" << g << ");\n";
             ep << "    __syncthreads();\n";
+            }
             // The workgroups flush into a PADDED copy of the table, one cell per 64-byte line (engine.cpp unpads it):
             // memory-side atomics serialise per line, and the 42 cells of TPC-H Q1 otherwise share six lines.
             q.aggPad = envInt("RSQ_AGG_PAD", 8, 1, 16);
+            stamp(2);
             emitGlobalFlush(ep, std::to_string((long long)(W * D)), "s_acc[i]", D, q.aggPad);
+            stamp(3);
             // The step in ONE launch (engine.cpp runFusedStep): the workgroup that flushes last hands the finished table to
             // the host — plain stores into host-mapped pinned memory (a full execution) or into the partial table the
             // group-by merge reads (a multi-GPU step) — together with the device error word, and puts the working table,
@@ -1747,6 +1775,7 @@ struct Walker {
             addArg("fin_seq", "u64", 0);
             ep << "    if (a.fin_out) {\n        __shared__ u32 s_last;\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        __syncthreads();\n";
             ep << "        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;\n        __syncthreads();\n";
+            if (dbgTail) ep << "        if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 4] = (u64)wall_clock64();\n";
             ep << "        if (s_last) {\n";
             ep << "            for (int i = threadIdx.x; i < " << W * D << "; i += blockDim.x) {\n                const int blk = i / " << D << ";\n";
             ep << "                const u64 idv = " << blockIdentityExpr("blk") << ";\n";
@@ -1755,8 +1784,12 @@ struct Walker {
             ep << "                __hip_atomic_store(a.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n            }\n";
             // a full execution is announced to the polling host by a sequence number behind the table: written after every
             // thread's table stores have been acknowledged, with a system-scope release (one wave, once per launch)
+            if (dbgTail) ep << "            if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 5] = (u64)wall_clock64();\n";
             ep << "            if (a.fin_seq) {\n                asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n                __syncthreads();\n";
-            ep << "                if (threadIdx.x == 0) __hip_atomic_store(a.fin_err + 1, a.fin_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n            }\n";
+            if (dbgTail) ep << "                if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 6] = (u64)wall_clock64();\n";
+            ep << "                if (threadIdx.x == 0) __hip_atomic_store(a.fin_err + 1, a.fin_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n";
+            if (dbgTail) ep << "                if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 7] = (u64)wall_clock64();\n";
+            ep << "            }\n";
             ep << "        }\n    }\n";
             // One 512-thread workgroup per CU: the same 8 waves per CU as 2 x 256, but half as many workgroups flush.
             // The flush is 42 atomics per workgroup (TPC-H Q1) onto six 64-byte lines, where they serialise: going from

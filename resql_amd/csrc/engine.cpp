@@ -135,6 +135,7 @@ Query::~Query() {
     if (dCandRows) ctx.free(dCandRows);
     if (dPartCounts) ctx.free(dPartCounts);
     if (dPartStart) ctx.free(dPartStart);
+    if (dDebugStamps) ctx.free(dDebugStamps);
     if (dStageBase) ctx.free(dStageBase);
     if (dStageCap) ctx.free(dStageCap);
     if (dStageCtl) ctx.free(dStageCtl);
@@ -337,6 +338,10 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
     if (a.name == "rec" || a.name == "sp_rec") return q.dPartRecords.empty() ? 0 : (uint64_t)(uintptr_t)q.dPartRecords[0];
+    if (a.name == "dbg") {          // RSQ_DEBUG_TAIL: [workgroup][8] device timestamps (100 MHz), printed by the one-launch step
+        if (!q.dDebugStamps) { q.dDebugStamps = (uint64_t*)q.ctx.alloc(4096 * 8 * 8); RSQ_HIP(hipMemset(q.dDebugStamps, 0, 4096 * 8 * 8)); }
+        return (uint64_t)(uintptr_t)q.dDebugStamps;
+    }
     if (a.name == "sp_base") return (uint64_t)(uintptr_t)q.dStageBase;
     if (a.name == "sp_cap") return (uint64_t)(uintptr_t)q.dStageCap;
     if (a.name == "sp_ctl") return (uint64_t)(uintptr_t)q.dStageCtl;
@@ -926,6 +931,24 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         } else RSQ_HIP(hipStreamSynchronize(ctx.stream));
         q.fusedReady = true;
         const double tSeen = stepTrace ? nowMs() : 0;
+        if (q.dDebugStamps) {
+            static int nPrinted = 0;
+            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            std::vector<uint64_t> st((size_t)p.lastGrid * 8);
+            RSQ_HIP(hipMemcpy(st.data(), q.dDebugStamps, st.size() * 8, hipMemcpyDeviceToHost));
+            uint64_t t0s = ~0ull, endLoop = 0, endRed = 0, endFlush = 0, endTicket = 0, last5 = 0, last6 = 0, last7 = 0;
+            for (unsigned w = 0; w < p.lastGrid; w++) {
+                t0s = std::min(t0s, st[w * 8 + 0]); endLoop = std::max(endLoop, st[w * 8 + 1]); endRed = std::max(endRed, st[w * 8 + 2]);
+                endFlush = std::max(endFlush, st[w * 8 + 3]); endTicket = std::max(endTicket, st[w * 8 + 4]);
+                last5 = std::max(last5, st[w * 8 + 5]); last6 = std::max(last6, st[w * 8 + 6]); last7 = std::max(last7, st[w * 8 + 7]);
+            }
+            if (++nPrinted % 50 == 0)
+                fprintf(stderr, "[rsq tail] %u workgroups; us since the first workgroup started: last loop end %.2f, wave reductions %.2f, flush issued %.2f, "
+                                "ticket taken %.2f, cells exchanged + stored to host %.2f, stores acknowledged %.2f, flag stored %.2f\n", p.lastGrid,
+                        (endLoop - t0s) / 100.0, (endRed - t0s) / 100.0, (endFlush - t0s) / 100.0, (endTicket - t0s) / 100.0, (last5 - t0s) / 100.0,
+                        (last6 - t0s) / 100.0, (last7 - t0s) / 100.0);
+            RSQ_HIP(hipMemset(q.dDebugStamps, 0, st.size() * 8));
+        }
         checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
         if (!partialOnly) {
             double t1 = nowMs();

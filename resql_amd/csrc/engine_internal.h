@@ -220,6 +220,7 @@ struct Query {
     int64_t partTileStep = 1;              // > 1: the counting pass samples every n-th tile (selectivity estimate)
     // staged partitioning (form 3): region layout [P] base / capacity per workgroup, tracker control block, per-(workgroup, partition) counts
     double kernelTimeSumMs = 0; uint64_t kernelTimeLaunches = 0;      // device time of the executions since the last reset (rsq_query_kernel_time_stats)
+    uint64_t* dDebugStamps = nullptr;      // RSQ_DEBUG_TAIL (measurement only)
     uint64_t* dPinnedDev = nullptr;        // hPinned as the device addresses it (status words are published by a kernel)
     uint64_t* dStageBase = nullptr; uint32_t* dStageCap = nullptr; void* dStageCtl = nullptr; void* hStageLayout = nullptr;
     uint32_t* dStageCounts = nullptr; size_t stageCountsWords = 0;

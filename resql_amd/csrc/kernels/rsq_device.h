@@ -106,14 +106,45 @@ RSQ_DEV void lds_merge(u64* slot, u64 v) {
     else if (OP == M_MIN_I64) atomicMin(reinterpret_cast<i64*>(slot), (i64)v);
     else atomicMax(reinterpret_cast<i64*>(slot), (i64)v);
 }
+// Reduction of one 64-bit value per lane to LANE 63, in the VALU: DPP row shifts (an inclusive scan inside each row of 16 lanes),
+// then the two row broadcasts of the GCN / CDNA lineage (lane 15 of rows 0 and 2 into rows 1 and 3, lane 31 into rows 2 and 3).
+// Lanes whose source lane does not exist take the identity.  The butterfly above goes through __shfl_xor = ds_bpermute_b32, two
+// per step and value: the 42 accumulators of TPC-H Q1 cost every launch 14-20 us of LDS crossbar (device timestamps,
+// RSQ_DEBUG_TAIL) - a third of the kernel at SF1, 5 % at SF10.
+template <int OP, int CTRL, int ROW_MASK>
+RSQ_DEV u64 dpp_step(u64 v) {
+    constexpr u64 idv = OP == M_SUM ? 0ull : OP == M_MIN_U64 ? ~0ull : OP == M_MIN_I64 ? 0x7fffffffffffffffull : 0x8000000000000000ull;
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)idv, (int)(u32)v, CTRL, ROW_MASK, 0xf, false);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(idv >> 32), (int)(u32)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    const u64 o = ((u64)hi << 32) | lo;
+    if (OP == M_SUM) return v + o;
+    if (OP == M_MIN_U64) return o < v ? o : v;
+    if (OP == M_MIN_I64) return (i64)o < (i64)v ? o : v;
+    return (i64)o > (i64)v ? o : v;
+}
+template <int OP>
+RSQ_DEV u64 wave_reduce_to_lane63(u64 v) {
+    v = dpp_step<OP, 0x111, 0xf>(v);          // row_shr:1
+    v = dpp_step<OP, 0x112, 0xf>(v);          // row_shr:2
+    v = dpp_step<OP, 0x114, 0xf>(v);          // row_shr:4
+    v = dpp_step<OP, 0x118, 0xf>(v);          // row_shr:8   -> lane 15 of every row holds the row
+    v = dpp_step<OP, 0x142, 0xa>(v);          // row_bcast:15 into rows 1 and 3
+    v = dpp_step<OP, 0x143, 0xc>(v);          // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave
+    return v;
+}
 template <int OP>
 RSQ_DEV void wave_to_lds(u64* slot, u64 v) {
+#ifdef RSQ_BUTTERFLY_FLUSH
     u64 r;
     if (OP == M_SUM) r = wave_sum(v);
     else if (OP == M_MIN_U64) r = wave_min_u64(v);
     else if (OP == M_MIN_I64) r = (u64)wave_min_i64((i64)v);
     else r = (u64)wave_max_i64((i64)v);
     if ((threadIdx.x & 63) == 0) lds_merge<OP>(slot, r);
+#else
+    const u64 r = wave_reduce_to_lane63<OP>(v);
+    if ((threadIdx.x & 63) == 63) lds_merge<OP>(slot, r);
+#endif
 }
 // HBM atomics execute at the memory side, one 64-byte request each (MI355X_MICROARCH.md "Global float atomics"; the
 // int64 forms measure the same ≈25 G requests/s chip-wide on scattered addresses), so a min / max that cannot change
