@@ -942,6 +942,14 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 endFlush = std::max(endFlush, st[w * 8 + 3]); endTicket = std::max(endTicket, st[w * 8 + 4]);
                 last5 = std::max(last5, st[w * 8 + 5]); last6 = std::max(last6, st[w * 8 + 6]); last7 = std::max(last7, st[w * 8 + 7]);
             }
+            if ((nPrinted + 1) % 50 == 0) {
+                std::vector<uint64_t> ends;
+                for (unsigned w = 0; w < p.lastGrid; w++) ends.push_back(st[w * 8 + 2]);
+                std::sort(ends.begin(), ends.end());
+                fprintf(stderr, "[rsq tail] workgroups done with their rows and reductions at: first %.2f, 10 %% %.2f, median %.2f, 90 %% %.2f, last %.2f us\n",
+                        (ends.front() - t0s) / 100.0, (ends[ends.size() / 10] - t0s) / 100.0, (ends[ends.size() / 2] - t0s) / 100.0,
+                        (ends[ends.size() * 9 / 10] - t0s) / 100.0, (ends.back() - t0s) / 100.0);
+            }
             if (++nPrinted % 50 == 0)
                 fprintf(stderr, "[rsq tail] %u workgroups; us since the first workgroup started: last loop end %.2f, wave reductions %.2f, flush issued %.2f, "
                                 "ticket taken %.2f, cells exchanged + stored to host %.2f, stores acknowledged %.2f, flag stored %.2f\n", p.lastGrid,
