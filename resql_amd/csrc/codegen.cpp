@@ -2050,6 +2050,9 @@ struct Walker {
         s << "#include \"rsq_device.h\"\n";
         s << fileScope;
         const bool cq = pipe.compact;
+        // (measurement only, RSQ_DEBUG_TAIL=1: device timestamps per workgroup - [0] start, [1] rows done, [2] drains done, [3] end)
+        const bool dbgStamps = envInt("RSQ_DEBUG_TAIL", 0, 0, 1) != 0 && !(pipe.sink == SinkKind::AGGREGATE && q.aggMode == AggMode::DENSE_REG);
+        if (dbgStamps) addArg("dbg", "u64*", 0);
         // (the staged form's round loop knows neither the compaction queues nor prefetched bitmap words nor string columns)
         if (pipe.staged && (cq || mat || !bitmapPrefetch.empty() || !pipe.lazyCols.empty() ||
                             std::find(colIsString.begin(), colIsString.end(), true) != colIsString.end())) pipe.staged = false;
@@ -2080,8 +2083,12 @@ struct Walker {
             // the queues take LDS: as many workgroups per CU as fit next to each other, at most the 8 of a random-access pipeline
             const int ldsPerWG = (pipe.blockThreads / 64) * NV * QCAP * 8 + pipe.extraLdsBytes;
             const int ldsPerWGLazy = (pipe.blockThreads / 64) * NVL * QCAP * 8 + pipe.extraLdsBytes;
-            pipe.gridPerCU = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(8, (144 * 1024) / std::max(1, ldsPerWG))), 1, 16);
-            pipe.gridPerCULazy = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(8, (144 * 1024) / std::max(1, ldsPerWGLazy))), 1, 16);
+            // (at most 6: with four tiles in flight these kernels hold 70-80 VGPRs, and a seventh workgroup per CU is not resident
+            // whatever the occupancy query says - TPC-H Q3's lineitem pipeline started 256 of 1792 workgroups 67 us late; the
+            // engine also clamps every grid to the query's answer, engine.cpp residentWorkgroupsPerCU)
+            const int wgCap = pipe.unroll >= 3 ? 6 : 8;
+            pipe.gridPerCU = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(wgCap, (144 * 1024) / std::max(1, ldsPerWG))), 1, 16);
+            pipe.gridPerCULazy = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(wgCap, (144 * 1024) / std::max(1, ldsPerWGLazy))), 1, 16);
             stateDecl += "    int cq_n = 0;\n    u32 cq_rows = 0;\n    i64* cq;\n";
             // rows that reached stage 2, for the host's choice between the two forms of the kernel (see compactThen).  Only
             // the first 64 workgroups report (tiles are dealt round-robin, so they are a fair sample; the host scales): every
@@ -2149,6 +2156,7 @@ struct Walker {
         }
         s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n";
         s << "    State st;\n" << prologue;
+        if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 0] = (u64)wall_clock64();\n";
         s << "    const int lane = threadIdx.x & 63;\n";
         s << "    const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n";
         s << "    const i64 nwaves = (i64)gridDim.x * (blockDim.x >> 6);\n";
@@ -2233,6 +2241,7 @@ struct Walker {
             s << "        }\n";
         }
         s << "    }\n";
+        if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 1] = (u64)wall_clock64();\n";
         if (cq) {
             // tail rows with a wave-uniform trip count (the push votes across the wave)
             s << "    for (i64 rb = (ntiles << 7) + (i64)blockIdx.x * blockDim.x; rb < a.n_rows; rb += (i64)gridDim.x * blockDim.x) {\n";
@@ -2248,7 +2257,10 @@ struct Walker {
             s << "    }\n";
         }
         if (pipe.staged) s << "#endif\n";
-        s << epilogue << "}\n";
+        if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 2] = (u64)wall_clock64();\n";
+        s << epilogue;
+        if (dbgStamps) s << "    __syncthreads();\n    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 3] = (u64)wall_clock64();\n";
+        s << "}\n";
         pipe.source = s.str();
         if (!pipe.lazyCols.empty()) pipe.source = "#define RSQ_LAZY 0\n" + pipe.source;
         if (mat) {   // two code objects from one source

@@ -383,12 +383,32 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     return a.value;
 }
 
+// Workgroups of `k` a CU holds at a time.  A grid larger than what is resident runs in ROUNDS: the tiles are dealt to the grid's
+// waves up front, so the workgroups of the second round start when the first ones end and the launch takes twice as long as its
+// work (TPC-H Q3's lineitem pipeline with four tiles in flight: 8 workgroups per CU asked for, fewer resident - device timestamps
+// showed a quarter of the workgroups starting 61 us late and the kernel ending at 107 us with the median workgroup done at 66).
+static int residentWorkgroupsPerCU(Kernel* k, int blockThreads) {
+    if (!k || !k->fn) return 1 << 20;
+    auto it = k->residentPerCU.find(blockThreads);
+    if (it != k->residentPerCU.end()) return it->second;
+    int n = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, k->fn, blockThreads, 0) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 1 << 20; }
+    k->residentPerCU[blockThreads] = n;
+    return n;
+}
+
 static unsigned pipelineGrid(const Query& q, const Pipeline& p, bool lazyForm = false) {
     const int64_t tiles = p.src->nRows >> 7;
     const int wavesPerBlock = p.blockThreads / 64;
     int64_t want = (tiles + (int64_t)wavesPerBlock * p.unroll - 1) / ((int64_t)wavesPerBlock * p.unroll);
     const int64_t maxGrid = p.maxGrid ? (int64_t)p.maxGrid : (int64_t)(lazyForm ? p.gridPerCULazy : p.gridPerCU) * (int64_t)q.ctx.numCUs;
-    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(maxGrid * 256 / p.blockThreads, want));
+    int64_t grid = std::min<int64_t>(maxGrid * 256 / p.blockThreads, want);
+    static const bool clamp = !(getenv("RSQ_RESIDENT_GRID") && atoi(getenv("RSQ_RESIDENT_GRID")) == 0);
+    if (clamp && !p.maxGrid) {
+        Kernel* k = lazyForm && p.kernelLazy ? p.kernelLazy : p.kernel;
+        grid = std::min<int64_t>(grid, (int64_t)residentWorkgroupsPerCU(k, p.blockThreads) * (int64_t)q.ctx.numCUs);
+    }
+    return (unsigned)std::max<int64_t>(1, grid);
 }
 
 static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnlyTable, unsigned grid = 0, unsigned block = 0,
@@ -400,6 +420,33 @@ static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnly
     q.report.num_kernels++;
 }
 
+// RSQ_DEBUG_TAIL=1 (measurement only): the device timestamps a pipeline's workgroups left (codegen.cpp finishPipeline)
+static void debugStamps(Query& q, Pipeline& p) {
+    if (!q.dDebugStamps || p.lastGrid == 0 || p.lastGrid > 4096) return;
+    bool has = false;
+    for (auto& a : p.args) has = has || a.name == "dbg";
+    if (!has) return;
+    RSQ_HIP(hipStreamSynchronize(q.ctx.stream));
+    std::vector<uint64_t> st((size_t)p.lastGrid * 8);
+    RSQ_HIP(hipMemcpy(st.data(), q.dDebugStamps, st.size() * 8, hipMemcpyDeviceToHost));
+    RSQ_HIP(hipMemset(q.dDebugStamps, 0, st.size() * 8));
+    uint64_t t0 = ~0ull;
+    for (unsigned w = 0; w < p.lastGrid; w++) if (st[w * 8]) t0 = std::min(t0, st[w * 8]);
+    auto dist = [&](int k) {
+        std::vector<double> v;
+        for (unsigned w = 0; w < p.lastGrid; w++) if (st[w * 8 + k]) v.push_back((double)(st[w * 8 + k] - t0) / 100.0);
+        std::sort(v.begin(), v.end());
+        char buf[96];
+        if (v.empty()) return std::string("-");
+        snprintf(buf, sizeof buf, "%.1f / %.1f / %.1f", v.front(), v[v.size() / 2], v.back());
+        return std::string(buf);
+    };
+    unsigned early = 0;
+    for (unsigned w = 0; w < p.lastGrid; w++) if (st[w * 8] && st[w * 8] - t0 < 500) early++;
+    fprintf(stderr, "[rsq tail] %s, %u workgroups (%u started within 5 us), us since the first one started (first / median / last workgroup): started %s, rows done %s, drains done %s, end %s\n",
+            p.entry.c_str(), p.lastGrid, early, dist(0).c_str(), dist(1).c_str(), dist(2).c_str(), dist(3).c_str());
+}
+
 static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
     Kernel* k = pass1 ? p.kernelPass1 : (q.flatRun && p.kernelFlat ? p.kernelFlat : p.kernel);
     // late column loads (codegen.cpp compactThen): worth it when the previous execution sent few rows to stage 2
@@ -407,11 +454,13 @@ static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1
     if (!pass1 && k == p.kernel && !p.sourceLazy.empty() && p.stage2Rows >= 0 && p.stage2Rows * lazyDen < p.src->nRows) {
         if (!p.kernelLazy) p.kernelLazy = &q.ctx.getKernel(p.sourceLazy, p.entry);
         launchPipelineKernel(q, p, *p.kernelLazy, countOnlyTable, pipelineGrid(q, p, true));
+        debugStamps(q, p);
         if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     %s: late-load form, %u workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(), p.lastGrid, (long long)p.stage2Rows);
         return;
     }
     launchPipelineKernel(q, p, *k, countOnlyTable);
     if (getenv("RSQ_TRACE") && p.compact) fprintf(stderr, "[rsq trace]     %s: %u workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(), p.lastGrid, (long long)p.stage2Rows);
+    debugStamps(q, p);
 }
 
 // the small buffers of a partitioned aggregation (allocated when the query is compiled: an allocation inside an execution
@@ -681,6 +730,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
             // arrival-order buffer: one region per wave of the largest grid this pipeline launches, four times the mean
             // number of records per wave of the smallest one
             const int64_t wpb = p.blockThreads / 64;
+            if (!p.sourceLazy.empty() && !p.kernelLazy) p.kernelLazy = &ctx.getKernel(p.sourceLazy, p.entry);      // (both forms' grids are final below)
             const int64_t wavesMax = (int64_t)std::max(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
             const int64_t wavesMin = (int64_t)std::min(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
             h.tempWaves = wavesMax;

@@ -60,6 +60,7 @@ struct Kernel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     bool fromCache = false;
+    std::map<int, int> residentPerCU;          // workgroup size -> workgroups of this kernel one CU holds at a time (registers, LDS)
 };
 
 struct Context {
