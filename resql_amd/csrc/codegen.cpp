@@ -1780,6 +1780,7 @@ struct Walker {
             ep << "            for (int i = threadIdx.x; i < " << W * D << "; i += blockDim.x) {\n                const int blk = i / " << D << ";\n";
             ep << "                const u64 idv = " << blockIdentityExpr("blk") << ";\n";
             ep << "                a.fin_out[i] = __hip_atomic_exchange(a.out + i" << (q.aggPad > 1 ? " * RSQ_OUT_STRIDE" : "") << ", idv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n            }\n";
+            ep << "#if RSQ_DYN_TILES\n            for (int i = threadIdx.x; i < 256; i += blockDim.x) a.tile_ctr[i * 32] = 0u;      // every workgroup is done drawing tiles\n#endif\n";
             ep << "            if (threadIdx.x == 0) {\n                a.fin_err[0] = (u64)atomicExch(a.err, 0u);\n";
             ep << "                __hip_atomic_store(a.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n            }\n";
             // a full execution is announced to the polling host by a sequence number behind the table: written after every
@@ -2007,8 +2008,8 @@ struct Walker {
 
     // -------------------------------------------------------------------------------------------
     // second round of loads of tile `tile` (unrolled copy u): the late columns, by the lanes that hold a row the leading selection passes
-    void emitLateLoads(std::ostringstream& s, const std::string& tile, int u, const std::vector<char>& lateCol) {
-        s << "        if (" << tile << " < ntiles) {\n";
+    void emitLateLoads(std::ostringstream& s, const std::string& tile, int u, const std::vector<char>& lateCol, const std::string& tileEnd = "ntiles") {
+        s << "        if (" << tile << " < " << tileEnd << ") {\n";
         for (int j = 0; j < 2; j++) {
             s << "            const bool lp" << j << " = lead_pred(a";
             for (int k : leadCols) s << ", t" << k << "_" << u << "[" << j << "]";
@@ -2047,12 +2048,15 @@ struct Walker {
         }
         s << "\n";
         if (envInt("RSQ_NT", 1, 0, 1)) s << "#define RSQ_NT_LOADS 1\n";
+        s << "#define RSQ_DYN_TILES " << ((envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) != 0 && !pipe.partitioned) ? 1 : 0) << "\n";
         s << "#include \"rsq_device.h\"\n";
         s << fileScope;
         const bool cq = pipe.compact;
         // (measurement only, RSQ_DEBUG_TAIL=1: device timestamps per workgroup - [0] start, [1] rows done, [2] drains done, [3] end)
         const bool dbgStamps = envInt("RSQ_DEBUG_TAIL", 0, 0, 1) != 0 && !(pipe.sink == SinkKind::AGGREGATE && q.aggMode == AggMode::DENSE_REG);
         if (dbgStamps) addArg("dbg", "u64*", 0);
+        const bool dynamicTiles = envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) != 0 && !pipe.partitioned;       // (see the main loop below)
+        if (dynamicTiles) { addArg("tile_ctr", "u32*", 0); addArg("tile_pools", "u32", 1); pipe.dynamicTiles = true; }
         // (the staged form's round loop knows neither the compaction queues nor prefetched bitmap words nor string columns)
         if (pipe.staged && (cq || mat || !bitmapPrefetch.empty() || !pipe.lazyCols.empty() ||
                             std::find(colIsString.begin(), colIsString.end(), true) != colIsString.end())) pipe.staged = false;
@@ -2204,11 +2208,38 @@ struct Walker {
             s << "#else\n";
         }
         // main loop, textually unrolled: the loads of U tiles are issued before the first row is processed
-        s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
+        // (RSQ_DYNAMIC_TILES=1, OFF by default: measured slower - TPC-H Q1 SF10 370 instead of 338 us, Q3 0.341 instead of 0.302 ms,
+        // Q6 0.24 instead of 0.207 ms - although the counters sit one per cache line, the tickets are taken two chunks ahead and
+        // behind the loads, and the pools interleave their chunks; the returning atomics still cost more than the tail they remove.)
+        // Tiles are handed out DYNAMICALLY (RSQ_DYNAMIC_TILES): the table is cut into one range per pool (up to 256 pools;
+        // workgroup b draws from pool b % pools), and a wave takes the next U consecutive tiles of its pool with one atomic, issued
+        // an iteration ahead so that its latency hides behind the loads.  With tiles dealt to the waves up front, the waves that
+        // were dispatched first run ahead (the SIMDs favour older waves: device timestamps show TPC-H Q3's lineitem workgroups
+        // finishing between 61 and 97 us in the order of their index) and the launch ends on the few that are left alone with a
+        // CU; sharing a pool between workgroups of different age lets the fast ones take the rest.
+        if (dynamicTiles) {
+            // chunks of U consecutive tiles, dealt to the pools round-robin (chunk c belongs to pool c % pools): at any moment the
+            // pools work on neighbouring chunks, i.e. the chip reads one contiguous window of the table, spread over all HBM
+            // channels.  (One contiguous RANGE per pool - 256 sequential streams 1.8 MB apart - halved the bandwidth.)
+            s << "    const u32 tpool = blockIdx.x % a.tile_pools;\n";
+            s << "    const i64 tend = ntiles, tchunks = (ntiles + " << (U - 1) << ") / " << U << ";\n";
+            // (one counter per 128-byte line: atomics on one LINE serialise at the memory side like atomics on one word - with the
+            // 256 counters in eight lines TPC-H Q1 took 608 us instead of 338)
+            // (two tickets in flight, the new one issued BEHIND the chunk's loads: memory operations return in order, and loads
+            // issued behind a returning atomic wait for it)
+            s << "    u32 tgrab = rsq::wave_grab_issue(a.tile_ctr + tpool * 32u, 1u), tgrab2 = rsq::wave_grab_issue(a.tile_ctr + tpool * 32u, 1u);\n";
+            s << "    for (;;) {\n        const i64 tchunk = (i64)tpool + (i64)a.tile_pools * (i64)rsq::wave_grab_value(tgrab);\n        if (tchunk >= tchunks) break;\n";
+            s << "        const i64 t = tchunk * " << U << ";\n";
+        } else {
+            s << "    const i64 tend = ntiles;\n";
+            s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
+        }
         for (int u = 0; u < U; u++) {
+            if (dynamicTiles) s << "        const i64 tt" << u << " = t + " << u << ";\n";
+            else
             s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2]" << (lateCol[(size_t)k] ? " = {0, 0}" : "") << ";\n";
-            s << "        if (tt" << u << " < ntiles) {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
+            s << "        if (tt" << u << " < tend) {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k] && !lateCol[(size_t)k]) {
                 const bool lazy = std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) != pipe.lazyCols.end();
                 if (lazy) s << "#if !RSQ_LAZY\n";
@@ -2217,18 +2248,19 @@ struct Walker {
             }
             s << "        }\n";
         }
-        if (late) for (int u = 0; u < U; u++) emitLateLoads(s, "tt" + std::to_string(u), u, lateCol);
+        if (dynamicTiles) s << "        tgrab = tgrab2; tgrab2 = rsq::wave_grab_issue(a.tile_ctr + tpool * 32u, 1u);\n";
+        if (late) for (int u = 0; u < U; u++) emitLateLoads(s, "tt" + std::to_string(u), u, lateCol, "tend");
         for (int u = 0; u < U; u++)
             for (auto& pf : bitmapPrefetch) {
                 s << "        u32 pf_" << pf.first << "_" << u << "[2] = {0u, 0u};\n";
-                s << "        if (tt" << u << " < ntiles) {\n";
+                s << "        if (tt" << u << " < tend) {\n";
                 for (int j = 0; j < 2; j++)
                     s << "            pf_" << pf.first << "_" << u << "[" << j << "] = " << (pf.interleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") << pf.first << "_bm, a." << pf.first << "_bmmin, a." << pf.first
                       << "_bmbits, (i64)t" << pf.second << "_" << u << "[" << j << "]);\n";
                 s << "        }\n";
             }
         for (int u = 0; u < U; u++) {
-            s << "        if (tt" << u << " < ntiles) {\n";
+            s << "        if (tt" << u << " < tend) {\n";
             if (mat) s << "            const i64 slot = tt" << u << " * 64 + lane;\n#if RSQ_PASS == 2\n            st.pos = a.offs[slot];\n#endif\n";
             for (int j = 0; j < 2; j++) {
                 s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");

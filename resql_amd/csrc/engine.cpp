@@ -135,6 +135,7 @@ Query::~Query() {
     if (dCandRows) ctx.free(dCandRows);
     if (dPartCounts) ctx.free(dPartCounts);
     if (dPartStart) ctx.free(dPartStart);
+    if (dTileCtr) ctx.free(dTileCtr);
     if (dDebugStamps) ctx.free(dDebugStamps);
     if (dStageBase) ctx.free(dStageBase);
     if (dStageCap) ctx.free(dStageCap);
@@ -301,6 +302,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         }
         if (q->aggMode == AggMode::AT_JOIN_ENTRY || q->aggMode == AggMode::HASH) q->dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
         q->dPipeStats = (uint64_t*)ctx.alloc(std::max<size_t>(1, q->pipelines.size()) * 8);
+        q->dTileCtr = (uint32_t*)ctx.alloc(std::max<size_t>(1, q->pipelines.size()) * 256 * 32 * 4);       // [pipeline][256 pools], one counter per 128-byte line
         size_t pw = q->pinnedWords + 8 + q->pipelines.size();
         RSQ_HIP(hipHostMalloc((void**)&q->hPinned, pw * 8, hipHostMallocDefault));
         memset(q->hPinned, 0, pw * 8);
@@ -338,6 +340,8 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
     if (a.name == "rec" || a.name == "sp_rec") return q.dPartRecords.empty() ? 0 : (uint64_t)(uintptr_t)q.dPartRecords[0];
+    if (a.name == "tile_ctr") return (uint64_t)(uintptr_t)(q.dTileCtr + (size_t)(&p - q.pipelines.data()) * 256 * 32);
+    if (a.name == "tile_pools") return (uint64_t)std::max(1u, std::min(256u, p.lastGrid));
     if (a.name == "dbg") {          // RSQ_DEBUG_TAIL: [workgroup][8] device timestamps (100 MHz), printed by the one-launch step
         if (!q.dDebugStamps) { q.dDebugStamps = (uint64_t*)q.ctx.alloc(4096 * 8 * 8); RSQ_HIP(hipMemset(q.dDebugStamps, 0, 4096 * 8 * 8)); }
         return (uint64_t)(uintptr_t)q.dDebugStamps;
@@ -413,9 +417,15 @@ static unsigned pipelineGrid(const Query& q, const Pipeline& p, bool lazyForm = 
 
 static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnlyTable, unsigned grid = 0, unsigned block = 0,
                                  hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
+    p.lastGrid = grid ? grid : pipelineGrid(q, p);
+    if (p.dynamicTiles) {
+        // (the execution's first fill batch zeroed every pipeline's counters; a pipeline launched again within the execution - sizing
+        // pass, second pass of a materialisation, a grown hash table - zeroes its own)
+        if (!p.tileCtrClean) RSQ_HIP(hipMemsetAsync(q.dTileCtr + (size_t)(&p - q.pipelines.data()) * 256 * 32, 0, 256 * 32 * 4, q.ctx.stream));
+        p.tileCtrClean = false;
+    }
     std::vector<uint64_t> args;
     for (auto& a : p.args) args.push_back(argValue(q, p, a, countOnlyTable));
-    p.lastGrid = grid ? grid : pipelineGrid(q, p);
     launch(q.ctx, k, p.lastGrid, block ? block : (unsigned)p.blockThreads, args, start, stop);
     q.report.num_kernels++;
 }
@@ -443,6 +453,19 @@ static void debugStamps(Query& q, Pipeline& p) {
     };
     unsigned early = 0;
     for (unsigned w = 0; w < p.lastGrid; w++) if (st[w * 8] && st[w * 8] - t0 < 500) early++;
+    if (getenv("RSQ_DEBUG_TAIL") && atoi(getenv("RSQ_DEBUG_TAIL")) >= 2) {
+        double byMod[8] = {0}, n8[8] = {0}, byQuarter[4] = {0}, n4[4] = {0};
+        for (unsigned w = 0; w < p.lastGrid; w++) {
+            if (!st[w * 8 + 1]) continue;
+            const double t = (double)(st[w * 8 + 1] - t0) / 100.0;
+            byMod[w % 8] += t; n8[w % 8]++; byQuarter[(size_t)w * 4 / p.lastGrid] += t; n4[(size_t)w * 4 / p.lastGrid]++;
+        }
+        fprintf(stderr, "[rsq tail]   mean 'rows done' by workgroup index mod 8:");
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %.1f", byMod[i] / std::max(1.0, n8[i]));
+        fprintf(stderr, "; by quarter of the grid:");
+        for (int i = 0; i < 4; i++) fprintf(stderr, " %.1f", byQuarter[i] / std::max(1.0, n4[i]));
+        fprintf(stderr, "\n");
+    }
     fprintf(stderr, "[rsq tail] %s, %u workgroups (%u started within 5 us), us since the first one started (first / median / last workgroup): started %s, rows done %s, drains done %s, end %s\n",
             p.entry.c_str(), p.lastGrid, early, dist(0).c_str(), dist(1).c_str(), dist(2).c_str(), dist(3).c_str());
 }
@@ -909,8 +932,10 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, ctx.stream));
             RSQ_HIP(hipMemsetAsync(q.dFinTicket, 0, 4, ctx.stream));
             RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+            if (p.dynamicTiles) RSQ_HIP(hipMemsetAsync(q.dTileCtr, 0, q.pipelines.size() * 256 * 32 * 4, ctx.stream));
             ctx.errWordClean = true;
         }
+        p.tileCtrClean = true;                                 // (the kernel's last workgroup puts the tile counters back, like the ticket)
         static const bool stepTrace0 = getenv("RSQ_STEP_TRACE") != nullptr;
         // a step that runs to its end here takes the next pair of the event ring (read when somebody asks, or when the ring is
         // full); an asynchronous partial step keeps the single pair finalize / settle read
@@ -1036,8 +1061,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     // row counters, the group counter and the candidate selection's scratch of a compaction behind the last pipeline
     bool groupCountCleared = false, topkScratchCleared = false;
     {
-        FillItem f[4]; int n = 0;
+        FillItem f[5]; int n = 0;
         f[n++] = FillItem{ctx.dErr, 4, 0};
+        bool anyDynamic = false;
+        for (auto& p : q.pipelines) { anyDynamic |= p.dynamicTiles; p.tileCtrClean = p.dynamicTiles; }
+        if (anyDynamic) f[n++] = FillItem{q.dTileCtr, q.pipelines.size() * 256 * 32 * 4, 0};
         if (anyCompaction) f[n++] = FillItem{q.dPipeStats, q.pipelines.size() * 8, 0};
         if (q.dGroupCount) { f[n++] = FillItem{q.dGroupCount, 4, 0}; groupCountCleared = true; }
         if (q.dTopkHists) { f[n++] = FillItem{q.dTopkHists, topkRangeScratchBytes(), 0}; topkScratchCleared = true; }

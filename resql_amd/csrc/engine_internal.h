@@ -143,6 +143,8 @@ struct Pipeline {
     int partGroups = 0;                  // groups per partition (power of two)
     int partAtomicsPerRow = 0;           // HBM atomics the direct form issues per passing row (sum accumulators)
     // form 3, staged partitioning (rsq_device.h): packed records through LDS rings, regions sized from a sample
+    bool dynamicTiles = false;           // the kernel draws its tiles from per-pool counters (Query::dTileCtr), zeroed before every launch
+    bool tileCtrClean = false;
     bool staged = false;
     bool lateLoads = false;              // the tile loop loads the columns behind the leading selection only for lanes with a passing row
     int stagedRecWords = 1, stagedRows = 4;
@@ -220,6 +222,7 @@ struct Query {
     int64_t partTileStep = 1;              // > 1: the counting pass samples every n-th tile (selectivity estimate)
     // staged partitioning (form 3): region layout [P] base / capacity per workgroup, tracker control block, per-(workgroup, partition) counts
     double kernelTimeSumMs = 0; uint64_t kernelTimeLaunches = 0;      // device time of the executions since the last reset (rsq_query_kernel_time_stats)
+    uint32_t* dTileCtr = nullptr;          // [pipeline][256] tile counters of the dynamically scheduled pipelines
     uint64_t* dDebugStamps = nullptr;      // RSQ_DEBUG_TAIL (measurement only)
     uint64_t* dPinnedDev = nullptr;        // hPinned as the device addresses it (status words are published by a kernel)
     uint64_t* dStageBase = nullptr; uint32_t* dStageCap = nullptr; void* dStageCtl = nullptr; void* hStageLayout = nullptr;

@@ -326,6 +326,20 @@ RSQ_DEV u32 wave_reserve(u32* ctr) {
     return base + (u32)__popcll(active & ((1ull << lane) - 1ull));
 }
 
+// the next `n` units of a shared counter for the whole wave: one atomic by lane 0, the value broadcast (the caller is wave-uniform)
+RSQ_DEV u32 wave_grab(u32* ctr, u32 n) {
+    u32 v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, n);
+    return (u32)__builtin_amdgcn_readfirstlane((int)v);
+}
+// ... in two halves, so that the atomic's latency can pass behind other work: issue (the answer lands in lane 0's register), value
+RSQ_DEV u32 wave_grab_issue(u32* ctr, u32 n) {
+    u32 v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, n);
+    return v;
+}
+RSQ_DEV u32 wave_grab_value(u32 issued) { return (u32)__builtin_amdgcn_readfirstlane((int)issued); }
+
 // the 32-bit word of a key-domain bitmap that holds `key`'s bit (0 for keys outside the domain)
 RSQ_DEV u32 bm_word(const u32* bm, i64 bmmin, u64 bmbits, i64 key) {
     const u64 d = (u64)(key - bmmin);
