@@ -11,6 +11,12 @@
  *                    only (expression typing, expression ids/names, symbol table decisions,
  *                    operator schemas, hash table sizes);
  *   execute phase  = what the generated code does per tuple, single thread.
+ *
+ * One behaviour of the reference is deliberately NOT restated: ht_get (qlib/hash.h:427-477) continues a probe from a
+ * hash-equal entry in the table's LAST slot by reading one entry past the allocation (it wraps around only behind a
+ * non-matching entry) and so loses the rest of a chain of hash-equal entries that crosses the table's end.  The oracle
+ * walks such a chain to its end; tests/golden/make_string_join_golden.py records reference answers only on data where the
+ * two agree.
  */
 #define _GNU_SOURCE
 #include "resql_oracle.h"
