@@ -2078,6 +2078,7 @@ struct Walker {
             }
         }
         pipe.lateLoads = late;
+        pipe.leadPass = leadCond.empty() ? -1.0 : leadPass;
         // 63 left over + 128 pushed by one tile, rounded up.  (RSQ_QCAP=128 drains after every row_fn call instead: smaller
         // queues, 7 instead of 4 workgroups of a five-word pipeline per CU — measured slower: Q3's orders pipeline 0.24 ->
         // 0.31 ms, its inserts do not want more waves.)

@@ -520,7 +520,7 @@ static void prepareStageBuffers(Query& q, const Pipeline& p) {
 // expected in partition p (from the sampled counting pass); every workgroup gets the same share of it plus slack.  A region
 // that runs full is reported by the pass; the regions are then sized by counting (the same kernel, tickets only) and the
 // pipeline remembers to do so.  Returns false when the exact regions would not be worth their memory (form 2 runs instead).
-static bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64_t>& estimate) {
+static bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64_t>& estimate, bool tentative = false) {
     Context& ctx = q.ctx;
     const int P = p.partCount;
     const unsigned block = 1024;
@@ -580,12 +580,12 @@ static bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64
         }
         const uint64_t provided = layout();
         if (trace) fprintf(stderr, "[rsq trace]     staged partitioning: %u workgroups x %d partitions, %zu-byte records, regions for %llu records (%s)\n",
-                           nwg, P, recBytes, (unsigned long long)provided, reuse ? "as in the last execution" : "sampled");
+                           nwg, P, recBytes, (unsigned long long)provided, reuse ? "as in the last execution" : tentative ? "from the column statistics" : "sampled");
         pass(0);
         aggregate();                       // (enqueued before the pass's verdict is read: it never reads beyond a region, and is repeated if one ran full)
         if (!overflowed()) { p.stagedCaps = cap; p.stagedCapsRows = p.src->nRows; return true; }
         p.stagedCaps.clear();
-        if (reuse) return false;           // the data changed under the remembered regions: the caller samples again
+        if (reuse || tentative) return false;           // the data changed under the remembered regions / the statistics misled: the caller samples
         p.stagedExact = true;
         RSQ_HIP(hipMemsetAsync((char*)q.dStageCtl + 20, 0, 4, ctx.stream));      // the overflow flag; the tracker's state stays (its table is final)
     }
@@ -647,6 +647,22 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
     // the regions that held the last execution's records hold this one's, unless the table changed (then the pass says so)
     if (p.staged && !p.stagedExact && !p.stagedCaps.empty() && p.stagedCapsRows == rows && q.stageWorkgroups != 0) {
         if (runStagedAggregation(q, p, {})) return;
+        RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+        fillU64Async(ctx, q.dAgg + (size_t)q.accumSlot[0] * (size_t)q.denseGroups, (size_t)q.denseGroups, 0x7fffffffffffffffull);
+    }
+    // A first execution knows the expected selectivity from the column statistics (the estimate behind the late loads): the
+    // regions are laid out from it - every partition its even share - without the sampled pass and its two synchronisations
+    // (0.3-0.4 ms of a 10 ms shard).  Skewed keys or a wrong estimate overflow a region and take the counted path below.
+    static const bool sampleAlways = getenv("RSQ_STAGED_SAMPLE") && atoi(getenv("RSQ_STAGED_SAMPLE")) != 0;
+    if (p.staged && !force && !sampleAlways && !p.stagedExact && p.leadPass >= 0.0) {
+        const double passing = (double)rows * p.leadPass;
+        const double direct = passing * (double)std::max(1, p.partAtomicsPerRow) / 25e9;
+        const double parted = (double)rows * (double)p.bytesPerRow / 6e12 + passing * (double)recBytes * 2.0 / 4e12 + 80e-6;
+        if (trace) fprintf(stderr, "[rsq trace]     large dense aggregation: ~%.0f of %lld rows expected to pass (column statistics); atomics %.3f ms vs partitioned %.3f ms\n",
+                           passing, (long long)rows, direct * 1e3, parted * 1e3);
+        if (direct <= parted) { launchPipeline(q, p, -1); return; }
+        std::vector<uint64_t> estimate((size_t)P + 1, (uint64_t)(passing / (double)P) + 1);
+        if (runStagedAggregation(q, p, estimate, true)) return;
         RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
         fillU64Async(ctx, q.dAgg + (size_t)q.accumSlot[0] * (size_t)q.denseGroups, (size_t)q.denseGroups, 0x7fffffffffffffffull);
     }

@@ -146,6 +146,7 @@ struct Pipeline {
     bool dynamicTiles = false;           // the kernel draws its tiles from per-pool counters (Query::dTileCtr), zeroed before every launch
     bool tileCtrClean = false;
     bool staged = false;
+    double leadPass = -1.0;              // fraction of the rows the selection directly above the scan is expected to pass (column statistics), < 0: none
     bool lateLoads = false;              // the tile loop loads the columns behind the leading selection only for lanes with a passing row
     int stagedRecWords = 1, stagedRows = 4;
     std::string sourceStagedScatter, sourceStagedAgg;
