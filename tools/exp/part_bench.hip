@@ -11,6 +11,11 @@ typedef long long i64; typedef unsigned long long u64; typedef unsigned int u32;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 
 constexpr int P = 256, GPP = 4096, G = P * GPP;
+#ifdef NOCOUNT
+#define AGG_COUNT(g)
+#else
+#define AGG_COUNT(g) atomicAdd(&tab[3 * GPP + g], 1ull);
+#endif
 #ifdef LIGHT
 __device__ inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #else
@@ -185,8 +190,8 @@ __global__ void __launch_bounds__(1024) part_agg(const u64* __restrict__ rec, co
         if (RECW == 1) {
             for (u32 i = lane * 2; i < cnt; i += 128) {
                 const ulonglong2 v = *(const ulonglong2*)&rec[st + i];
-                { const int g = (int)(v.x >> 40); atomicAdd(&tab[GPP + g], (v.x >> 20) & 0xfffff); atomicAdd(&tab[2 * GPP + g], v.x & 0xfffff); atomicAdd(&tab[3 * GPP + g], 1ull); }
-                if (i + 1 < cnt) { const int g = (int)(v.y >> 40); atomicAdd(&tab[GPP + g], (v.y >> 20) & 0xfffff); atomicAdd(&tab[2 * GPP + g], v.y & 0xfffff); atomicAdd(&tab[3 * GPP + g], 1ull); }
+                { const int g = (int)(v.x >> 40); atomicAdd(&tab[GPP + g], (v.x >> 20) & 0xfffff); atomicAdd(&tab[2 * GPP + g], v.x & 0xfffff); AGG_COUNT(g) }
+                if (i + 1 < cnt) { const int g = (int)(v.y >> 40); atomicAdd(&tab[GPP + g], (v.y >> 20) & 0xfffff); atomicAdd(&tab[2 * GPP + g], v.y & 0xfffff); AGG_COUNT(g) }
             }
         } else {
             for (u32 i = lane; i < cnt; i += 64) {
