@@ -430,6 +430,23 @@ static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnly
     q.report.num_kernels++;
 }
 
+// The synchronisation at the end of an execution: the stream is queried in a loop for up to 2 ms before the thread blocks
+// (hipStreamSynchronize sleeps on the completion signal's interrupt: 10-20 us of wake-up on a sub-millisecond execution).
+static void waitForStream(Context& ctx) {
+    static const bool spin = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
+    if (spin) {
+        const double deadline = nowMs() + 2.0;
+        for (;;) {
+            const hipError_t e = hipStreamQuery(ctx.stream);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) RSQ_HIP(e);
+            if (nowMs() > deadline) break;
+            __builtin_ia32_pause();
+        }
+    }
+    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+}
+
 // RSQ_DEBUG_TAIL=1 (measurement only): the device timestamps a pipeline's workgroups left (codegen.cpp finishPipeline)
 static void debugStamps(Query& q, Pipeline& p) {
     if (!q.dDebugStamps || p.lastGrid == 0 || p.lastGrid > 4096) return;
@@ -559,7 +576,7 @@ static bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64
     auto overflowed = [&]() -> bool {
         uint32_t ctl[8] = {0};
         RSQ_HIP(hipMemcpyAsync(ctl, q.dStageCtl, 32, hipMemcpyDeviceToHost, ctx.stream));
-        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        waitForStream(ctx);
         if (trace) fprintf(stderr, "[rsq trace]     staged pass: %u of %lld groups seen, watermark row %llu%s\n", ctl[4], (long long)q.denseGroups,
                            (unsigned long long)(((uint64_t)ctl[3] << 32) | ctl[2]), ctl[5] ? ", a region ran full" : "");
         return ctl[5] != 0;
@@ -595,7 +612,7 @@ static bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64
     pass(1);
     std::vector<uint32_t> counts((size_t)nwg * (size_t)P);
     RSQ_HIP(hipMemcpyAsync(counts.data(), q.dStageCounts, counts.size() * 4, hipMemcpyDeviceToHost, ctx.stream));
-    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    waitForStream(ctx);
     uint64_t records = 0, provided = 0;
     for (int i = 0; i < P; i++) {
         uint64_t mx = 0;
@@ -638,7 +655,7 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
         partitionOffsets(ctx, q.dPartCounts, (int)grid, P, q.dPartTotals, q.dPartStart, q.dPartTotals + P);
         q.report.num_kernels += 2;
         RSQ_HIP(hipMemcpyAsync(hostTotals.data(), q.dPartTotals, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost, ctx.stream));
-        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        waitForStream(ctx);
         q.partTileStep = 1;
         return hostTotals[(size_t)P];
     };
@@ -719,7 +736,7 @@ static void materializePipeline(Query& q, Pipeline& p) {
     q.report.num_kernels++;
     uint64_t total = 0;
     RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + (slots - 1), 8, hipMemcpyDeviceToHost, ctx.stream));
-    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    waitForStream(ctx);
     // MaterializeOp with a LIMIT leaves the pipeline once count >= limit, i.e. after max(limit, 1) tuples (materialize.h:197-206)
     uint64_t keep = total;
     if (q.matOp->hasLimit) keep = std::min<uint64_t>(total, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));
@@ -756,7 +773,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
         uint32_t n = 0, err = 0;
         RSQ_HIP(hipMemcpyAsync(&n, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
-        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        waitForStream(ctx);
         h.rank = h.rankCapable && !(err & 64u);
         if (err & 64u) { err &= ~64u; RSQ_HIP(hipMemcpy(ctx.dErr, &err, 4, hipMemcpyHostToDevice)); }
         if (h.rank && h.setOnly) {
@@ -917,7 +934,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
             if (!partialOnly) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, ctx.stream));
             if (async && partialOnly) { q.pendingAsync = true; q.pendingFused = false; q.report.execution_time_ms = nowMs() - t0; return; }
-            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            waitForStream(ctx);
             float gms = 0; RSQ_HIP(hipEventElapsedTime(&gms, ctx.ev0, ctx.ev1));
             q.report.kernel_time_ms = gms; q.kernelTimeSumMs += gms; q.kernelTimeLaunches++;
             q.report.hbm_gbps = gms > 0 ? (double)q.report.bytes_read / (gms * 1e-3) / 1e9 : 0;
@@ -1013,18 +1030,18 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 if ((++spins & 1023u) == 0) {
                     hipError_t e = hipStreamQuery(ctx.stream);
                     if (e != hipSuccess && e != hipErrorNotReady) RSQ_HIP(e);
-                    if (e == hipSuccess || nowMs() > deadline) { RSQ_HIP(hipStreamSynchronize(ctx.stream)); break; }
+                    if (e == hipSuccess || nowMs() > deadline) { waitForStream(ctx); break; }
                 }
                 __builtin_ia32_pause();
             }
             if (*flag != seq) failRuntime("internal error: the fused step finished without publishing its table");
             std::atomic_thread_fence(std::memory_order_acquire);
-        } else RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        } else waitForStream(ctx);
         q.fusedReady = true;
         const double tSeen = stepTrace ? nowMs() : 0;
         if (q.dDebugStamps) {
             static int nPrinted = 0;
-            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            waitForStream(ctx);
             std::vector<uint64_t> st((size_t)p.lastGrid * 8);
             RSQ_HIP(hipMemcpy(st.data(), q.dDebugStamps, st.size() * 8, hipMemcpyDeviceToHost));
             uint64_t t0s = ~0ull, endLoop = 0, endRed = 0, endFlush = 0, endTicket = 0, last5 = 0, last6 = 0, last7 = 0;
@@ -1139,7 +1156,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 launchPipeline(q, p, -1);
                 uint32_t err = 0;
                 RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
-                RSQ_HIP(hipStreamSynchronize(ctx.stream));
+                waitForStream(ctx);
                 q.charGroupsNeedMerge = (err & 32u) != 0;
                 if (!(err & 2)) break;
                 if (h.capacity >= ((int64_t)1 << 31)) failRuntime("Hash table full");
@@ -1168,7 +1185,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         uint32_t nEntries = h.lastCount;
         if (q.aggMode != AggMode::AT_JOIN_ENTRY || nEntries == 0 || getenv("RSQ_TRACE")) {
             RSQ_HIP(hipMemcpyAsync(&nEntries, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
-            RSQ_HIP(hipStreamSynchronize(ctx.stream));
+            waitForStream(ctx);
             h.lastCount = nEntries;
         }
         groupRowsAllocated = std::max<uint32_t>(1, nEntries);
@@ -1276,7 +1293,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         q.report.execution_time_ms = nowMs() - t0;
         return;
     }
-    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    waitForStream(ctx);
     if (anyCompaction)      // a build pipeline that also ran its counting pass reports both passes: only ever an over-estimate
         for (size_t i = 0; i < q.pipelines.size(); i++) {
             Pipeline& p = q.pipelines[i];           // the first 64 workgroups report: scale to the grid
@@ -1313,7 +1330,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                             q.dTopkHists, q.dCandRows, topkCapacity);
         uint32_t n = 0;
         RSQ_HIP(hipMemcpyAsync(&n, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
-        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        waitForStream(ctx);
         if (n <= topkCapacity) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dCandRows, (size_t)n * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost));
         return (int64_t)n;
     };
@@ -1337,7 +1354,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             }
             if (!done) {            // the candidates do not decide it: the whole table after all
                 enqueueTableReadback(q);
-                RSQ_HIP(hipStreamSynchronize(ctx.stream));
+                waitForStream(ctx);
                 tableFromPinned(q);
                 runTail(q);
             }
@@ -1406,7 +1423,7 @@ void finalizeQuery(Query& q) {
             if ((++spins & 1023u) == 0) {
                 hipError_t e = hipStreamQuery(ctx.stream);
                 if (e != hipSuccess && e != hipErrorNotReady) RSQ_HIP(e);
-                if (e == hipSuccess || nowMs() > deadline) { RSQ_HIP(hipStreamSynchronize(ctx.stream)); break; }
+                if (e == hipSuccess || nowMs() > deadline) { waitForStream(ctx); break; }
             }
             __builtin_ia32_pause();
         }
@@ -1414,7 +1431,7 @@ void finalizeQuery(Query& q) {
         std::atomic_thread_fence(std::memory_order_acquire);
     } else {
         RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, ctx.stream));
-        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        waitForStream(ctx);
     }
     if (q.pendingAsync) {         // the step was enqueued by rsq_query_execute_partial_async: account for it now
         q.pendingAsync = false;
@@ -1437,7 +1454,7 @@ void settleAsync(Query& q) {
     Context& ctx = q.ctx;
     if (!q.pendingAsync) return;
     RSQ_HIP(hipSetDevice(ctx.device));
-    RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    waitForStream(ctx);
     q.pendingAsync = false;
     float ms = 0;
     if (q.pendingFused) { RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.fusedReady = true; q.kernelTimePending = false; }
