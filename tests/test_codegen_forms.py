@@ -4,7 +4,18 @@ import numpy as np
 
 from resql_amd import plan as P, tpch
 
+import pytest
+
 T = P.TypeInit
+
+
+@pytest.fixture(scope="module")
+def compile_ctx(tmp_path_factory):
+    """a compile-only context of this module's own (the session's shared one counts cache hits that other tests assert on)"""
+    from resql_amd import engine
+    ctx = engine.Context(device=-1, cache_dir=str(tmp_path_factory.mktemp("kcache_forms")))
+    yield ctx
+    ctx.close()
 
 
 def _explain_and_source(ctx, plan):
