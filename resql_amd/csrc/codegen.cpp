@@ -275,6 +275,7 @@ struct Walker {
     // the selection directly above the scan: its text over the row's column variables, the columns it reads and the fraction of
     // rows it is expected to pass (column statistics, values taken as uniform) - the late-load form of the tile loop (below)
     std::string leadCond; std::vector<int> leadCols; double leadPass = 1.0;
+    bool leadPassComplete = true;       // every part of the predicate was understood (else the estimate is an upper bound only)
     std::string stage2Body;
     std::vector<std::pair<std::string, Sym>> cqLive;     // carried symbols: name -> stage-1 variable and type
 
@@ -361,7 +362,7 @@ struct Walker {
         explainSteps.clear(); indent = 1; matchSlotTable = -1; slotVar.clear(); symbolOrigin.clear(); symbolWord.clear();
         multiMatchAbove = false;
         selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
-        leadCond.clear(); leadCols.clear(); leadPass = 1.0;
+        leadCond.clear(); leadCols.clear(); leadPass = 1.0; leadPassComplete = true;
         eg.symbols.clear();
         o->schema.clear();
         for (size_t ci = 0; ci < t->cols.size(); ci++) {
@@ -442,10 +443,10 @@ struct Walker {
             for (Expr* c : e->children()) { const double f = passFraction(c); all *= f; none *= 1.0 - f; }
             return e->tag == RSQ_E_AND ? all : 1.0 - none;
         }
-        if (e->tag < RSQ_E_LT || e->tag > RSQ_E_NEQ || !e->child || !e->child->next) return 1.0;
+        if (e->tag < RSQ_E_LT || e->tag > RSQ_E_NEQ || !e->child || !e->child->next) { leadPassComplete = false; return 1.0; }
         double alo, ahi, blo, bhi; int ac = -1, bc = -1;
-        if (!sideRange(e->child, alo, ahi, ac) || !sideRange(e->child->next, blo, bhi, bc)) return 1.0;
-        if ((ac >= 0) == (bc >= 0)) return 1.0;                      // column against constant only
+        if (!sideRange(e->child, alo, ahi, ac) || !sideRange(e->child->next, blo, bhi, bc)) { leadPassComplete = false; return 1.0; }
+        if ((ac >= 0) == (bc >= 0)) { leadPassComplete = false; return 1.0; }                      // column against constant only
         int tag = e->tag;
         if (ac < 0) {                                                // constant OP column -> column OP' constant
             std::swap(alo, blo); std::swap(ahi, bhi);
@@ -481,7 +482,7 @@ struct Walker {
         std::vector<int> cols;
         leadColumnsOf(e, cols, ok);
         if (!ok || cols.empty()) return;
-        leadCond = cond; leadCols = cols; leadPass = passFraction(e);
+        leadCond = cond; leadCols = cols; leadPassComplete = true; leadPass = passFraction(e);
     }
 
     // -------------------------------------------------------------------------------------------
@@ -2078,7 +2079,7 @@ struct Walker {
             }
         }
         pipe.lateLoads = late;
-        pipe.leadPass = leadCond.empty() ? -1.0 : leadPass;
+        pipe.leadPass = leadCond.empty() || !leadPassComplete ? -1.0 : leadPass;      // (for the engine's first layout of staged regions: only a complete estimate)
         // 63 left over + 128 pushed by one tile, rounded up.  (RSQ_QCAP=128 drains after every row_fn call instead: smaller
         // queues, 7 instead of 4 workgroups of a five-word pipeline per CU — measured slower: Q3's orders pipeline 0.24 ->
         // 0.31 ms, its inserts do not want more waves.)
