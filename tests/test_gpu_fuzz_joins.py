@@ -22,8 +22,11 @@ def _strs(vals, width):
     return a
 
 
-def make(seed):
+def make(seed, with_spec=False):
+    """-> (plan, description); with_spec=True: (plan, description, spec) where `spec` holds every decision taken, for an
+    independent evaluation of the same query (tests/test_join_shapes_pandas.py)"""
     r = random.Random(seed)
+    spec = {}
     rng = np.random.default_rng(seed)
     n, m = r.choice([300, 5000, 40000]), r.choice([7, 200, 3000])
     key_kind = r.choice(["narrow", "wide", "computed", "varchar", "char", "mixed"])
@@ -55,17 +58,22 @@ def make(seed):
         eq = p.eq(p.attr("ds"), p.attr("fs"))
     left = p.scan("d")
     if r.random() < 0.3:
-        left = p.selection(p.lt(p.attr("dx"), p.constant(str(r.choice([100, 500, 900])), P.BIGINT)), left)
+        spec["dx_below"] = r.choice([100, 500, 900])
+        left = p.selection(p.lt(p.attr("dx"), p.constant(str(spec["dx_below"]), P.BIGINT)), left)
     right = p.scan("f")
     if r.random() < 0.4:
-        right = p.selection(p.ge(p.attr("fx"), p.constant(str(r.choice([50, 500, 950])), P.BIGINT)), right)
+        spec["fx_from"] = r.choice([50, 500, 950])
+        right = p.selection(p.ge(p.attr("fx"), p.constant(str(spec["fx_from"]), P.BIGINT)), right)
     node = p.hashjoin([eq], left, right, single_match=unique and r.random() < 0.5)
     if r.random() < 0.3:
-        node = p.selection(p.lt(p.add(p.attr("dx"), p.attr("fx")), p.constant(str(r.choice([400, 1000, 1600])), P.BIGINT)), node)
+        spec["sum_below"] = r.choice([400, 1000, 1600])
+        node = p.selection(p.lt(p.add(p.attr("dx"), p.attr("fx")), p.constant(str(spec["sum_below"]), P.BIGINT)), node)
     top = r.choice(["dense", "hash", "rows", "global"])
+    spec["key_kind"], spec["top"] = key_kind, top
     s, c, mx = p.sum(p.attr("fx")), p.count(p.star()), p.max(p.attr("dx"))
     if top == "dense":
         keys = [p.attr("dg"), p.attr("fg")] if r.random() < 0.5 else [p.attr("fg")]
+        spec["dense_keys"] = len(keys)
         node = p.projection(keys + [p.as_("s", s), p.as_("c", c), p.as_("mx", mx)], p.aggregation([s, c, mx], keys, node))
     elif top == "hash":
         key = p.add(p.attr("dx"), p.attr("fg"))
@@ -74,7 +82,8 @@ def make(seed):
         node = p.projection([p.as_("s", s), p.as_("c", c), p.as_("mx", mx)], p.aggregation([s, c, mx], [], node))
     else:
         node = p.projection([p.attr("dx"), p.attr("fx"), p.attr("fg")], node)
-    return p.set_root(p.materialize(node)), f"{key_kind}/{'unique' if unique else 'dups'}/{top}"
+    plan, what = p.set_root(p.materialize(node)), f"{key_kind}/{'unique' if unique else 'dups'}/{top}"
+    return (plan, what, spec) if with_spec else (plan, what)
 
 
 @pytest.mark.parametrize("block", range(0, 120, 20))
