@@ -1655,14 +1655,15 @@ struct Walker {
         k << "    const u64 base = a.sp_base[p]; const u32 cap = a.sp_cap[p];\n";
         k << "    for (u32 wg = threadIdx.x >> 6; wg < a.sp_nwg; wg += blockDim.x >> 6) {\n";
         k << "        const u64 st = base + (u64)wg * cap;\n        const u32 cnt = min(a.sp_counts[(u64)wg * " << P << " + p], cap);\n";
-        // four 16-byte loads per lane in flight (one per lane leaves a CU with 16 KB outstanding: 4.8 TB/s; four: see DESIGN §4)
+        const int AU = envInt("RSQ_STAGED_AGG_UNROLL", 4, 1, 16);
+        // AU 16-byte loads per lane in flight (one per lane leaves a CU with 16 KB outstanding: 4.8 TB/s; four: see DESIGN §4)
         const int step = RECW == 1 ? 128 : 64;              // records one wave-load covers
-        k << "        for (u32 i0 = 0; i0 < cnt; i0 += " << 4 * step << ") {\n";
-        k << "            rsq::u64x2 v[4];\n";
-        k << "#pragma unroll\n            for (int u = 0; u < 4; u++) {\n";
+        k << "        for (u32 i0 = 0; i0 < cnt; i0 += " << AU * step << ") {\n";
+        k << "            rsq::u64x2 v[" << AU << "];\n";
+        k << "#pragma unroll\n            for (int u = 0; u < " << AU << "; u++) {\n";
         k << "                const u32 i = i0 + u * " << step << " + lane * " << (RECW == 1 ? 2 : 1) << ";\n";
         k << "                if (i < cnt) v[u] = *reinterpret_cast<const rsq::u64x2*>(a.sp_rec + (st + i) * " << RECW << ");\n            }\n";
-        k << "#pragma unroll\n            for (int u = 0; u < 4; u++) {\n";
+        k << "#pragma unroll\n            for (int u = 0; u < " << AU << "; u++) {\n";
         k << "                const u32 i = i0 + u * " << step << " + lane * " << (RECW == 1 ? 2 : 1) << ";\n";
         if (RECW == 1) k << "                if (i < cnt) merge_record(a, s_tab, v[u].x);\n                if (i + 1 < cnt) merge_record(a, s_tab, v[u].y);\n";
         else k << "                if (i < cnt) merge_record(a, s_tab, v[u].x, v[u].y);\n";
