@@ -112,6 +112,10 @@ int  rsq_table_load_tbl(rsq_ctx* ctx, const rsq_table_desc* schema, const char* 
 int  rsq_table_generate(rsq_ctx* ctx, int32_t kind, int64_t row0, int64_t n_rows, double scale_factor,
                         int64_t param, uint64_t seed, rsq_table** out);
 int64_t rsq_table_rows(const rsq_table* t);
+/* A table that is a row range [row0, row0 + n_rows) of a larger one (a shard): rows are numbered from row0 wherever a row number
+ * is observable — the order in which groups first occur decides the emission order of an aggregation (operators/aggregation.h:
+ * 298-343 scans the hash table the groups entered in input order).  Set before queries are compiled over the table. */
+int  rsq_table_set_first_row(rsq_table* t, int64_t row0);
 /* Copy one device column back (tests). */
 int  rsq_table_read_column(rsq_ctx* ctx, const rsq_table* t, const char* name, void* host_dst, size_t bytes);
 void rsq_table_destroy(rsq_table* t);
@@ -244,9 +248,16 @@ void rsq_db_destroy(rsq_db* db);
  * ncclCommInitAll; librccl is dlopen'ed by rsq_multi_create) — then finalises on the root.  Integer min / max / sum:
  * the result is bit-identical to the single-GPU one.
  *
- * Plans that do not end in a dense partial table (joins with many groups, hash aggregation, materialisation) run whole on
- * every shard concurrently; the caller shards the probe-side table on a boundary of the group key and gives every shard the
- * full build-side tables, and the merge is the host-side ordered merge of the shards' (LIMIT-ed) rows.
+ * Plans that do not end in a dense partial table (joins with many groups, hash aggregation, materialisation) run their
+ * pipelines on every shard concurrently (every shard holds the full build-side tables) and merge on the host:
+ * the GENERAL merge reads all shards' group rows (or materialised rows, in shard = scan order) back, re-aggregates groups that
+ * occur in several shards by key (sum / min / max per accumulator, the smallest first row — the reference has ONE hash table
+ * all its workers reach, src/operators/aggregation.h:240-295) and runs ONE tail (AVG, projection, emission order, ORDER BY,
+ * LIMIT) over them: the result is the single-GPU result whatever the sharding.  Rows are numbered over the whole table for
+ * that: shard tables carry their first row's number (rsq_table_generate's row0, rsq_table_set_first_row).  When the column
+ * statistics prove that a group-by attribute has disjoint value ranges on the shards (the caller sharded on a boundary of
+ * that key, rsq_multi_table_generate_on_key) and the plan ends in ORDER BY ... LIMIT k, every shard runs its own tail and only
+ * its k leading rows are merged by the sort keys.
  *
  * devices may list a GPU more than once (shards that share a GPU: how a one-GPU box runs N shards); RCCL cannot hold a device
  * twice, so such handles — and any handle created with RSQ_MERGE_PEER_COPY — move the partial tables with peer copies to
@@ -271,12 +282,19 @@ void rsq_multi_shard_rows(int64_t n_total, int32_t n_shards, int32_t shard, int6
 /* rsq_table_generate over all shards: out_tables[i] = rows of shard i of an n_rows_total table, on GPU i */
 int  rsq_multi_table_generate(rsq_multi* m, int32_t kind, int64_t n_rows_total, double scale_factor, int64_t param, uint64_t seed,
                               rsq_table** out_tables /* [n_devices] */);
+/* The same with every shard boundary moved forward to the next change of `key_column` (an integer column the table is clustered
+ * by, e.g. lineitem's l_orderkey): no key value spans two shards, which lets plans grouped by that key take the short merge
+ * below.  Correctness never depends on it. */
+int  rsq_multi_table_generate_on_key(rsq_multi* m, int32_t kind, int64_t n_rows_total, double scale_factor, int64_t param, uint64_t seed,
+                                     const char* key_column, rsq_table** out_tables /* [n_devices] */);
 /* tables[shard * n_tables + t] is table t of the plan on that shard's context */
 int  rsq_multi_query_compile(rsq_multi* m, const rsq_plan_desc* plan, rsq_table* const* tables, int32_t n_tables, rsq_multi_query** out);
 int  rsq_multi_query_execute(rsq_multi_query* q);                /* blocking, like JitContextFlounder::execute() */
 int  rsq_multi_query_result(rsq_multi_query* q, rsq_result_view* out);
 /* kernel_time_ms = the slowest shard's; shard_kernel_ms (may be NULL) receives every shard's */
 int  rsq_multi_query_report(const rsq_multi_query* q, rsq_report* out, double* shard_kernel_ms /* [n_devices] */);
+/* which merge the query takes and why (dense partial tables / ordered merge of LIMIT-ed rows / general merge), for logs and tests */
+const char* rsq_multi_query_merge_name(const rsq_multi_query* q);
 void rsq_multi_query_destroy(rsq_multi_query* q);
 
 /* Sustained read-only streaming bandwidth of this GPU (grid-stride int64 sum over `bytes` of

@@ -158,6 +158,11 @@ int rsq_table_generate(rsq_ctx* ctx, int32_t kind, int64_t row0, int64_t n_rows,
 }
 
 int64_t rsq_table_rows(const rsq_table* t) { return t ? reinterpret_cast<const Table*>(t)->nRows : -1; }
+int rsq_table_set_first_row(rsq_table* t, int64_t row0) {
+    if (!t || row0 < 0) return RSQ_ERR_INVALID;
+    reinterpret_cast<Table*>(t)->row0 = row0;
+    return RSQ_OK;
+}
 
 int rsq_table_read_column(rsq_ctx* ctx, const rsq_table* t, const char* name, void* host_dst, size_t bytes) {
     if (!ctx || !t || !name || !host_dst) return RSQ_ERR_INVALID;

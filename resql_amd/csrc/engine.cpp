@@ -660,12 +660,18 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
         return hostTotals[(size_t)P];
     };
     const size_t recBytes = p.staged ? 8 * (size_t)p.stagedRecWords : 8 * (1 + p.partRecordInputs.size());
+    // A staged attempt whose region ran full has already aggregated what it did stage: rsq_staged_agg stored partial sums into
+    // every accumulator block and the tracker holds first rows.  Whatever form runs next — the atomics form ADDS onto the
+    // table — must start from the identity image again, the whole table, not just the tracker block.
+    auto afterFailedAttempt = [&] {
+        RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+        RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, q.tableWords * 8, hipMemcpyDeviceToDevice, ctx.stream));
+    };
     const int64_t step = rows >= (512 << 20) ? 128 : rows >= (64 << 20) ? 32 : rows >= (8 << 20) ? 8 : 1;       // the sampled pass reads every step-th tile
     // the regions that held the last execution's records hold this one's, unless the table changed (then the pass says so)
     if (p.staged && !p.stagedExact && !p.stagedCaps.empty() && p.stagedCapsRows == rows && q.stageWorkgroups != 0) {
         if (runStagedAggregation(q, p, {})) return;
-        RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
-        fillU64Async(ctx, q.dAgg + (size_t)q.accumSlot[0] * (size_t)q.denseGroups, (size_t)q.denseGroups, 0x7fffffffffffffffull);
+        afterFailedAttempt();
     }
     // A first execution knows the expected selectivity from the column statistics (the estimate behind the late loads): the
     // regions are laid out from it - every partition its even share - without the sampled pass and its two synchronisations
@@ -680,8 +686,7 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
         if (direct <= parted) { launchPipeline(q, p, -1); return; }
         std::vector<uint64_t> estimate((size_t)P + 1, (uint64_t)(passing / (double)P) + 1);
         if (runStagedAggregation(q, p, estimate, true)) return;
-        RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
-        fillU64Async(ctx, q.dAgg + (size_t)q.accumSlot[0] * (size_t)q.denseGroups, (size_t)q.denseGroups, 0x7fffffffffffffffull);
+        afterFailedAttempt();
     }
     if (!force || p.staged) {
         const double passing = (double)countPass(step) * (double)step;
@@ -696,6 +701,7 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
         std::vector<uint64_t> estimate = hostTotals;
         for (auto& e : estimate) e *= (uint64_t)step;
         if (runStagedAggregation(q, p, estimate)) return;
+        afterFailedAttempt();       // (form 2 overwrites every block; the atomics form below does not)
     }
     const uint64_t total = countPass(1);
     if (total >= 0xffffffffull) { launchPipeline(q, p, -1); return; }          // record positions are 32-bit
@@ -899,6 +905,10 @@ static bool fusedEligible(const Query& q) {
            !q.pipelines[0].partitioned && q.dFinTicket != nullptr;
 }
 
+// a shard of a multi-GPU plan that does not end in a dense partial table runs its pipelines and reads the group rows (or the
+// materialised columns) back, but leaves the tail to the root, which merges all shards' groups first (tail.cpp runTailMerged)
+static void tailUnlessHeld(Query& q) { if (!q.holdTail) runTail(q); }
+
 void executeQuery(Query& q, bool partialOnly, bool async) {
     Context& ctx = q.ctx;
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
@@ -943,7 +953,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (!partialOnly) {
                 double t1 = nowMs();
                 memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
-                runTail(q);
+                tailUnlessHeld(q);
                 q.report.finalize_time_ms = nowMs() - t1;
             }
             q.report.execution_time_ms = nowMs() - t0;
@@ -1069,7 +1079,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         if (!partialOnly) {
             double t1 = nowMs();
             memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
-            runTail(q);
+            tailUnlessHeld(q);
             q.report.finalize_time_ms = nowMs() - t1;
         }
         q.report.execution_time_ms = nowMs() - t0;
@@ -1202,7 +1212,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
         if (q.topkWord == -2) planDeviceTopK(q);
-        const bool preselect = q.topkWord >= 0 && nEntries >= 2048 && (uint64_t)nEntries > 4ull * q.topkWant && !(q.topkNeedsNoMerge && q.charGroupsNeedMerge);
+        const bool preselect = !q.holdTail && q.topkWord >= 0 && nEntries >= 2048 && (uint64_t)nEntries > 4ull * q.topkWant && !(q.topkNeedsNoMerge && q.charGroupsNeedMerge);
         if (preselect) {
             topkCapacity = std::min<uint32_t>(nEntries, std::max<uint32_t>(1024, 4 * q.topkWant));
             if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = q.dTopkHists + 4; }
@@ -1234,7 +1244,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     // accumulator blocks] and go through the same candidate pre-selection; the table itself (tens of MB) is only read back
     // when the candidates do not decide the answer
     bool denseTopk = false;
-    if (!partialOnly && q.aggMode == AggMode::DENSE_GLOBAL && q.aggPad == 1 && q.denseGroups >= 65536 && q.denseGroups <= (1 << 21)) {
+    if (!partialOnly && !q.holdTail && q.aggMode == AggMode::DENSE_GLOBAL && q.aggPad == 1 && q.denseGroups >= 65536 && q.denseGroups <= (1 << 21)) {
         if (q.topkWord == -2) planDeviceTopK(q);
         if (q.topkWord >= 0) {
             const uint32_t D = (uint32_t)q.denseGroups;
@@ -1348,7 +1358,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                                       (size_t)(nCand - topkSpec) * rowBytes, hipMemcpyDeviceToHost));
                 q.candidateRun = true;
                 q.nGroupRows = nCand; q.totalGroups = nGroups;
-                runTail(q);
+                tailUnlessHeld(q);
                 q.candidateRun = false;
                 done = !q.tailNeedsAllGroups;
             }
@@ -1356,7 +1366,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 enqueueTableReadback(q);
                 waitForStream(ctx);
                 tableFromPinned(q);
-                runTail(q);
+                tailUnlessHeld(q);
             }
             q.report.finalize_time_ms = nowMs() - t1;
             q.report.execution_time_ms = nowMs() - t0;
@@ -1389,19 +1399,19 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                                       (size_t)(nCand - topkSpec) * rowBytes, hipMemcpyDeviceToHost));
                 q.candidateRun = true;
                 q.nGroupRows = nCand; q.totalGroups = nGroups;
-                runTail(q);
+                tailUnlessHeld(q);
                 q.candidateRun = false;
             }
             if (!topkCapacity || q.tailNeedsAllGroups || !(nCand <= (int64_t)topkCapacity && nCand < nGroups)) {
                 q.nGroupRows = nGroups;
                 if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * rowBytes, hipMemcpyDeviceToHost));
-                runTail(q);
+                tailUnlessHeld(q);
             }
             q.report.finalize_time_ms = nowMs() - t1;
             q.report.execution_time_ms = nowMs() - t0;
             return;
         }
-        runTail(q);
+        tailUnlessHeld(q);
         q.report.finalize_time_ms = nowMs() - t1;
     }
     q.report.execution_time_ms = nowMs() - t0;
@@ -1506,6 +1516,44 @@ void mergeShardResults(Query& into, const std::vector<Query*>& parts) {
         into.resultTuples.swap(all);
     }
     into.resultRows = rows;
+}
+
+void setHoldTail(Query& q, bool hold) { q.holdTail = hold; }
+bool queryOrderedWithLimit(const Query& q) { return q.root && q.root->tag == RSQ_OP_ORDERBY && q.root->hasLimit; }
+bool queryAsyncCapable(const Query& q) {
+    if (!denseMode(q)) return false;
+    for (auto& p : q.pipelines) if (p.sink != SinkKind::AGGREGATE) return false;
+    return true;
+}
+
+// Can a group of this plan occur in two shards?  Not if one of the group-by values is a plain attribute of a scanned table whose
+// [min, max] ranges (column statistics of every shard's instance of that table) do not overlap between the shards: the caller
+// sharded on a boundary of that key.  `why` names the attribute, or says what was missing.
+bool shardGroupsDisjoint(const std::vector<Query*>& parts, std::string& why) {
+    if (parts.empty() || !parts[0]->agg) { why = "no aggregation"; return false; }
+    const Query& q0 = *parts[0];
+    for (Expr* g : q0.agg->exprs2) {
+        if (g->tag != RSQ_E_ATTRIBUTE) continue;
+        std::vector<std::pair<int64_t, int64_t>> ranges;
+        bool usable = true;
+        for (size_t i = 0; i < parts.size() && usable; i++) {
+            const Table* tab = nullptr; int col = -1;
+            for (Table* t : parts[i]->tables) { int c = t->findCol(g->symbol); if (c >= 0) { tab = t; col = c; break; } }
+            if (!tab) { usable = false; break; }
+            if (tab->nRows == 0) continue;
+            const ColumnStats& st = tab->cols[(size_t)col].stats;
+            if (!st.valid || !st.distinctBytes.empty() || tab->cols[(size_t)col].type.isString()) { usable = false; break; }
+            ranges.emplace_back(st.min, st.max);
+        }
+        if (!usable) continue;
+        std::sort(ranges.begin(), ranges.end());
+        bool disjoint = true;
+        for (size_t i = 1; i < ranges.size(); i++) if (ranges[i].first <= ranges[i - 1].second) disjoint = false;
+        if (disjoint) { why = "group key " + g->symbol + " has disjoint value ranges on the shards"; return true; }
+        why = "the value ranges of group key " + g->symbol + " overlap between shards";
+    }
+    if (why.empty()) why = "no group key is a plain integer attribute with column statistics";
+    return false;
 }
 
 void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords) {

@@ -169,6 +169,12 @@ void settleAsync(Query& q);
 void awaitKernels(Query& q);
 void resolveKernelTime(Query& q);
 void mergeShardResults(Query& into, const std::vector<Query*>& parts);
+// shards of one plan that does not end in a dense partial table (engine.cpp / tail.cpp; multi.cpp explains when each is used)
+void setHoldTail(Query& q, bool hold);                  // execute stops in front of the host tail
+void runTailMerged(Query& root, const std::vector<Query*>& parts);   // all parts' groups (or materialised rows) merged by key, then root's tail
+bool shardGroupsDisjoint(const std::vector<Query*>& parts, std::string& why);   // provably no group in two shards (column statistics)
+bool queryOrderedWithLimit(const Query& q);             // ORDER BY ... LIMIT k at the root
+bool queryAsyncCapable(const Query& q);                 // every pipeline can be enqueued without the host in between
 bool queryIsDense(const Query& q);              // its aggregation ends in a dense partial table ([min | max | sum] words)
 void queryDenseLayout(const Query& q, int64_t* nMin, int64_t* nMax, int64_t* nSum, void** dptr);
 std::string queryPartialLayoutText(const Query& q);   // the "partial table: ..." line of explain (same on every mergeable shard)

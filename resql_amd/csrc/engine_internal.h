@@ -305,6 +305,7 @@ struct Query {
     std::atomic<int> bgState{0};           // 0 none, 1 running, 2 done, 3 failed
     std::string bgError;
     bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
+    bool holdTail = false;                 // a shard of a multi-GPU plan: execute reads the group rows / materialised columns back and stops (tail.cpp runTailMerged)
     std::string allSource, explainText;
 
     explicit Query(Context& c) : ctx(c) {}

@@ -86,6 +86,9 @@ struct rsq_multi_query {
     rsq_multi* m = nullptr;
     std::vector<Query*> qs;             // one compiled query per device, same plan
     bool dense = false;
+    bool async = false;                 // dense and every pipeline can be enqueued without the host in between (no join builds)
+    bool orderedFast = false;           // not dense: shards provably disjoint in a group key + ORDER BY ... LIMIT: merge of the shards' ordered rows
+    std::string mergeText;              // which merge this query takes, and why
     int64_t nMin = 0, nMax = 0, nSum = 0;
     int64_t* gathered = nullptr;        // peer-copy mode: [n][words] on the root device
     std::vector<hipEvent_t> ready;      // peer-copy mode: shard i's partial table is complete
@@ -234,6 +237,57 @@ int rsq_multi_table_generate(rsq_multi* m, int32_t kind, int64_t n_rows_total, d
     });
 }
 
+// Row-range shards whose boundaries fall where `key_column` changes: no value of the clustering key spans two shards, so a
+// plan grouped by it (TPC-H Q3: l_orderkey) keeps every group on one GPU.  Every tile boundary of
+// rsq_multi_shard_rows is moved forward to the first row whose key differs from the row before it; the rows around a boundary
+// are generated (the generator is a function of seed and row number) on the root GPU and read back, a window at a time.
+int rsq_multi_table_generate_on_key(rsq_multi* m, int32_t kind, int64_t n_rows_total, double scale_factor, int64_t param, uint64_t seed,
+                                    const char* key_column, rsq_table** out_tables) {
+    if (!m || !out_tables || n_rows_total < 0 || !key_column) return RSQ_ERR_INVALID;
+    const int n = (int)m->ctxs.size();
+    for (int i = 0; i < n; i++) out_tables[i] = nullptr;
+    return guardedM(m, [&] {
+        Context& root = *m->ctxs[0];
+        auto snap = [&](int64_t b) -> int64_t {
+            if (b <= 0 || b >= n_rows_total) return std::max<int64_t>(0, std::min(b, n_rows_total));
+            const int64_t window = 4096;
+            int64_t prevKey = 0; bool havePrev = false;
+            for (int64_t at = b - 1; at < n_rows_total; at += window) {
+                const int64_t cnt = std::min(window, n_rows_total - at);
+                Table t;
+                generateTable(root, t, kind, at, cnt, scale_factor, param, seed);
+                const int c = t.findCol(key_column);
+                if (c < 0 || !t.cols[(size_t)c].dptr) failInvalid(std::string("table has no generated column ") + key_column);
+                const Type& ty = t.cols[(size_t)c].type;
+                if (ty.isString() || (columnWidth(ty) != 4 && columnWidth(ty) != 8)) failUnsupported("the shard key must be an INT / DATE / BIGINT / DECIMAL column");
+                std::vector<int64_t> keys((size_t)cnt);
+                if (columnWidth(ty) == 4) {
+                    std::vector<int32_t> k4((size_t)cnt);
+                    RSQ_HIP(hipMemcpy(k4.data(), t.cols[(size_t)c].dptr, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+                    for (int64_t j = 0; j < cnt; j++) keys[(size_t)j] = k4[(size_t)j];
+                } else RSQ_HIP(hipMemcpy(keys.data(), t.cols[(size_t)c].dptr, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+                for (int64_t j = 0; j < cnt; j++) {
+                    if (havePrev && keys[(size_t)j] != prevKey) return at + j;
+                    prevKey = keys[(size_t)j]; havePrev = true;
+                }
+            }
+            return n_rows_total;
+        };
+        std::vector<int64_t> bound((size_t)n + 1, n_rows_total);
+        bound[0] = 0;
+        for (int i = 1; i < n; i++) {
+            int64_t r0, nr;
+            rsq_multi_shard_rows(n_rows_total, n, i, &r0, &nr);
+            bound[(size_t)i] = std::max(bound[(size_t)i - 1], snap(r0));
+        }
+        for (int i = 0; i < n; i++) {
+            std::unique_ptr<Table> t(new Table());
+            generateTable(*m->ctxs[(size_t)i], *t, kind, bound[(size_t)i], bound[(size_t)i + 1] - bound[(size_t)i], scale_factor, param, seed);
+            out_tables[i] = reinterpret_cast<rsq_table*>(t.release());
+        }
+    });
+}
+
 int rsq_multi_query_compile(rsq_multi* m, const rsq_plan_desc* plan, rsq_table* const* tables, int32_t n_tables, rsq_multi_query** out) {
     if (!m || !plan || !out || n_tables < 0 || (n_tables > 0 && !tables)) return RSQ_ERR_INVALID;
     *out = nullptr;
@@ -265,8 +319,25 @@ int rsq_multi_query_compile(rsq_multi* m, const rsq_plan_desc* plan, rsq_table* 
                 mq->ready.assign((size_t)n, nullptr);
                 for (int i = 1; i < n; i++) { RSQ_HIP(hipSetDevice(m->ctxs[(size_t)i]->device)); RSQ_HIP(hipEventCreateWithFlags(&mq->ready[(size_t)i], hipEventDisableTiming)); }
             }
+            mq->async = true;
+            for (Query* q : mq->qs) mq->async = mq->async && queryAsyncCapable(*q);
+            mq->mergeText = std::string("dense partial tables: ") + rsq_multi_merge_name(m) + (mq->async ? "" : " (join builds: the shards run on host threads)");
         } else {
             for (int i = 1; i < n; i++) if (queryIsDense(*mq->qs[(size_t)i])) failUnsupported("shards disagree on the aggregation strategy");
+            // Groups may straddle shard boundaries (the reference has ONE hash table all workers reach, aggregation.h:240-295):
+            // the general merge reads every shard's group rows back and re-aggregates them by key before the root's tail runs.
+            // Only when the column statistics PROVE that no group lives in two shards (the caller sharded on a boundary of a
+            // group key) and the plan ends in ORDER BY ... LIMIT k is the short way taken: every shard's own top k, merged by the
+            // sort keys.  RSQ_MULTI_GENERAL_MERGE=1 forces the general merge (tests).
+            std::string why;
+            const bool disjoint = n > 1 && shardGroupsDisjoint(mq->qs, why);
+            const bool forceGeneral = getenv("RSQ_MULTI_GENERAL_MERGE") && atoi(getenv("RSQ_MULTI_GENERAL_MERGE")) != 0;
+            mq->orderedFast = disjoint && queryOrderedWithLimit(*mq->qs[0]) && !forceGeneral;
+            if (n == 1) mq->mergeText = "single shard";
+            else if (mq->orderedFast) mq->mergeText = "ordered merge of the shards' LIMIT-ed rows (" + why + ")";
+            else mq->mergeText = "general merge: all shards' group rows re-aggregated by key on the host, then one tail (" +
+                                 (forceGeneral ? std::string("forced") : disjoint ? std::string("no ORDER BY ... LIMIT to shorten") : why) + ")";
+            if (n > 1 && !mq->orderedFast) for (Query* q : mq->qs) setHoldTail(*q, true);
         }
         mq->shardKernelMs.assign((size_t)n, 0.0);
         *out = mq.release();
@@ -280,27 +351,38 @@ int rsq_multi_query_execute(rsq_multi_query* mq) {
         const int n = (int)m->ctxs.size();
         const double t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        if (mq->dense) {
+        // every shard's execution on its own host thread (plans whose pipelines need the host between kernels: join builds size
+        // their tables, hash aggregations grow theirs)
+        auto onThreads = [&](bool partialOnly) {
+            std::vector<std::string> errs((size_t)n);
+            std::vector<int> status((size_t)n, RSQ_OK);
+            std::vector<std::thread> th;
+            for (int i = 0; i < n; i++)
+                th.emplace_back([&, i, partialOnly] {
+                    try { executeQuery(*mq->qs[(size_t)i], partialOnly); }
+                    catch (const Error& e) { status[(size_t)i] = e.status; errs[(size_t)i] = e.what(); }
+                    catch (const std::exception& e) { status[(size_t)i] = RSQ_ERR_RUNTIME; errs[(size_t)i] = e.what(); }
+                });
+            for (auto& t : th) t.join();
+            for (int i = 0; i < n; i++) if (status[(size_t)i] != RSQ_OK) throw Error(status[(size_t)i], "shard " + std::to_string(i) + ": " + errs[(size_t)i]);
+        };
+        if (mq->dense && mq->async) {
             // fan out: enqueue every shard's pipelines (no host synchronisation), then the merge behind them, then ONE
             // synchronising read-back on the root
             for (int i = 0; i < n; i++) executeQuery(*mq->qs[(size_t)i], true, true);
             enqueueMerge(*mq);
             finalizeQuery(*mq->qs[0]);
             for (int i = 1; i < n; i++) settleAsync(*mq->qs[(size_t)i]);
+        } else if (mq->dense) {
+            // join builds in front of the dense aggregation (TPC-H Q14-like): the shards run to their partial tables with the
+            // host's help, the merge and the root's finalisation follow
+            onThreads(true);
+            enqueueMerge(*mq);
+            finalizeQuery(*mq->qs[0]);
         } else {
-            std::vector<std::string> errs((size_t)n);
-            std::vector<int> status((size_t)n, RSQ_OK);
-            std::vector<std::thread> th;
-            for (int i = 0; i < n; i++)
-                th.emplace_back([&, i] {
-                    try { executeQuery(*mq->qs[(size_t)i], false); }
-                    catch (const Error& e) { status[(size_t)i] = e.status; errs[(size_t)i] = e.what(); }
-                    catch (const std::exception& e) { status[(size_t)i] = RSQ_ERR_RUNTIME; errs[(size_t)i] = e.what(); }
-                });
-            for (auto& t : th) t.join();
-            for (int i = 0; i < n; i++) if (status[(size_t)i] != RSQ_OK) throw Error(status[(size_t)i], "shard " + std::to_string(i) + ": " + errs[(size_t)i]);
+            onThreads(false);
             double t1 = now();
-            if (n > 1) mergeShardResults(*mq->qs[0], mq->qs);
+            if (n > 1) { if (mq->orderedFast) mergeShardResults(*mq->qs[0], mq->qs); else runTailMerged(*mq->qs[0], mq->qs); }
             mq->report.finalize_time_ms = now() - t1;
         }
         // report: the slowest shard's kernel time (the shards run concurrently), bytes of all shards
@@ -332,6 +414,8 @@ int rsq_multi_query_report(const rsq_multi_query* mq, rsq_report* out, double* s
     if (shard_kernel_ms) for (size_t i = 0; i < mq->shardKernelMs.size(); i++) shard_kernel_ms[i] = mq->shardKernelMs[i];
     return RSQ_OK;
 }
+
+const char* rsq_multi_query_merge_name(const rsq_multi_query* mq) { return mq ? mq->mergeText.c_str() : ""; }
 
 void rsq_multi_query_destroy(rsq_multi_query* mq) { delete mq; }
 

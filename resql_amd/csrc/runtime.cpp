@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <fstream>
 #include <sstream>
 
@@ -182,12 +183,20 @@ bool Context::kernelCachedOnDisk(const std::string& source) {
 bool Context::kernelCached(const std::string& source) { return kernels.count(cacheKey(source)) || kernelCachedOnDisk(source); }
 
 static void writeCacheEntry(const std::string& cacheDir, const std::string& key, const std::string& code, const std::string& source) {
-    const std::string path = cacheDir + "/" + key + ".hsaco";
-    std::ofstream fs(cacheDir + "/" + key + ".hip");
-    if (fs.is_open()) { fs << source; fs.close(); }
-    std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-    std::ofstream f(tmp, std::ios::binary);
-    if (f.is_open()) { f.write(code.data(), (std::streamsize)code.size()); f.close(); rename(tmp.c_str(), path.c_str()); }
+    // every writer gets its own temporary names (process id + a counter): two compiler threads of one process may build the same
+    // key at once (two queries with one plan on a cold cache), and a rename must never publish a file another writer still fills
+    static std::atomic<unsigned> writer{0};
+    const std::string tag = ".tmp" + std::to_string((long)getpid()) + "_" + std::to_string(writer.fetch_add(1));
+    auto publish = [&](const std::string& path, const std::string& bytes) {
+        const std::string tmp = path + tag;
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f.is_open()) return;
+        f.write(bytes.data(), (std::streamsize)bytes.size());
+        f.close();
+        if (!f || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
+    };
+    publish(cacheDir + "/" + key + ".hip", source);          // (the source first: a code object is only trusted beside its own source)
+    publish(cacheDir + "/" + key + ".hsaco", code);
 }
 
 void Context::compileToCache(const std::string& source) {

@@ -309,37 +309,61 @@ Groups groupsFromJoinEntries(Query& q) {
 
 // The device groups CHAR(n) keys by their exact bytes; the reference's group equality for CHAR ignores trailing spaces
 // (Values::checkEqualityBool -> compareChar, qlib/scalar.h:27-46) and shows the spelling of the group's FIRST row.
-// Merge the device groups that are equal in that sense: accumulators by their merge kind, keys from the member with the
-// smallest first row.
-void mergeSpaceEquivalentGroups(Query& q, Groups& G) {
-    bool any = false;
-    for (Expr* g : q.agg->exprs2) if (g->type.tag == RSQ_CHAR && g->type.len > 1) any = true;
-    if (!any || G.n < 2 || !q.charGroupsNeedMerge) return;
-    auto normalised = [&](size_t i) {
-        std::string key;
-        for (size_t k = 0; k < G.nKeys; k++) {
-            const Type& t = q.agg->exprs2[k]->type;
-            const Val& v = G.keys(i)[k];
-            if (t.isString()) {
-                std::string sv(v.s);
-                if (t.tag == RSQ_CHAR) while (!sv.empty() && sv.back() == ' ') sv.pop_back();
-                key += sv; key.push_back('\0');
-            } else key.append((const char*)&v.i, 8);
+// Merge the groups that are equal in that sense: accumulators by their merge kind, keys from the member with the
+// smallest first row.  The same merge joins the shards of a multi-GPU plan (runTailMerged): a group that occurs in several
+// shards comes in several rows (reference: ONE hash table all workers reach, aggregation.h:240-295).
+// Keys are normalised into fixed-width blobs (8 bytes per value, strings NUL padded to their width, CHAR without its trailing
+// spaces) and matched through an open-addressing table of group indices.
+void mergeEqualGroups(Query& q, Groups& G) {
+    if (G.n < 2) return;
+    const size_t K = G.nKeys, W = G.nAcc;
+    std::vector<size_t> off(K + 1, 0);
+    for (size_t k = 0; k < K; k++) {
+        const Type& t = q.agg->exprs2[k]->type;
+        off[k + 1] = off[k] + (t.isString() ? (((size_t)t.len + 8) & ~(size_t)7) : 8);
+    }
+    const size_t kb = std::max<size_t>(off[K], 8);
+    std::vector<uint8_t> blob(G.n * kb, 0);
+    std::vector<uint64_t> hash(G.n);
+    parallelFor(G.n, tailThreads(G.n), [&](size_t lo, size_t hi, int) {
+        for (size_t i = lo; i < hi; i++) {
+            uint8_t* b = &blob[i * kb];
+            for (size_t k = 0; k < K; k++) {
+                const Type& t = q.agg->exprs2[k]->type;
+                const Val& v = G.keys(i)[k];
+                if (t.isString()) {
+                    size_t n = strnlen(v.s, (size_t)t.len);
+                    if (t.tag == RSQ_CHAR) while (n > 0 && v.s[n - 1] == ' ') n--;
+                    memcpy(b + off[k], v.s, n);
+                } else {
+                    int64_t x = v.i;
+                    if (t.tag == RSQ_INT || t.tag == RSQ_DATE) x = (int64_t)(uint32_t)x;
+                    else if (t.tag == RSQ_BOOL || t.tag == RSQ_CHAR) x = (int64_t)(uint8_t)x;
+                    memcpy(b + off[k], &x, 8);
+                }
+            }
+            uint64_t h = 0x9E3779B97F4A7C15ull;
+            for (size_t w = 0; w < kb; w += 8) { uint64_t x; memcpy(&x, b + w, 8); h = (h ^ x) * 0xBF58476D1CE4E5B9ull; h ^= h >> 29; }
+            hash[i] = h;
         }
-        return key;
-    };
-    std::map<std::string, size_t> rep;
-    std::vector<size_t> target(G.n);
+    });
+    size_t cap = 16; while (cap < G.n * 2) cap <<= 1;
+    std::vector<uint32_t> slots(cap, 0xffffffffu);
+    if (G.n >= 0xffffffffull) failUnsupported("more than 4 G group rows in a merge");
+    std::vector<uint32_t> target(G.n);
     bool merged = false;
     for (size_t i = 0; i < G.n; i++) {
-        auto it = rep.emplace(normalised(i), i);
-        target[i] = it.first->second;
-        if (!it.second) merged = true;
+        size_t s0 = (size_t)hash[i] & (cap - 1);
+        for (;;) {
+            const uint32_t j = slots[s0];
+            if (j == 0xffffffffu) { slots[s0] = (uint32_t)i; target[i] = (uint32_t)i; break; }
+            if (hash[j] == hash[i] && memcmp(&blob[(size_t)j * kb], &blob[i * kb], kb) == 0) { target[i] = j; merged = true; break; }
+            s0 = (s0 + 1) & (cap - 1);
+        }
     }
     if (!merged) return;
-    const size_t W = G.nAcc;
-    std::vector<size_t> bestMember(G.n);
-    for (size_t i = 0; i < G.n; i++) bestMember[i] = i;
+    std::vector<uint32_t> bestMember(G.n);
+    for (size_t i = 0; i < G.n; i++) bestMember[i] = (uint32_t)i;
     for (size_t i = 0; i < G.n; i++) {
         const size_t t = target[i];
         if (t == i) continue;
@@ -351,21 +375,28 @@ void mergeSpaceEquivalentGroups(Query& q, Groups& G) {
             else if (m == 2) dst[w] = std::min(dst[w], src[w]);
             else dst[w] = std::max(dst[w], src[w]);
         }
-        if (G.firstRow[i] < G.firstRow[bestMember[t]]) bestMember[t] = i;
+        if (G.firstRow[i] < G.firstRow[bestMember[t]]) bestMember[t] = (uint32_t)i;
     }
     Groups R;
-    R.nKeys = G.nKeys; R.nAcc = W;
+    R.nKeys = K; R.nAcc = W;
     R.strings.swap(G.strings);                     // Val::s pointers stay valid
     for (size_t i = 0; i < G.n; i++) {
         if (target[i] != i) continue;
         const size_t b = bestMember[i];
         R.firstRow.push_back(G.firstRow[b]);
-        for (size_t k = 0; k < G.nKeys; k++) R.keyData.push_back(G.keys(b)[k]);
+        for (size_t k = 0; k < K; k++) R.keyData.push_back(G.keys(b)[k]);
         for (size_t w = 0; w < W; w++) R.accData.push_back(G.accData[i * W + w]);
         R.accData[R.firstRow.size() * W - W] = G.firstRow[b];
     }
     R.n = R.firstRow.size();
     G = std::move(R);
+}
+
+void mergeSpaceEquivalentGroups(Query& q, Groups& G) {
+    bool any = false;
+    for (Expr* g : q.agg->exprs2) if (g->type.tag == RSQ_CHAR && g->type.len > 1) any = true;
+    if (!any || G.n < 2 || !q.charGroupsNeedMerge) return;
+    mergeEqualGroups(q, G);
 }
 
 }  // namespace
@@ -491,9 +522,82 @@ void planDeviceTopK(Query& q) {
     q.topkWord = it->second.first;
 }
 
+static void runTailOn(Query& q, Groups& G);
+
 void runTail(Query& q) {
     q.tailNeedsAllGroups = false;
     if (!q.agg) { runMaterializeTail(q); return; }
+    const double t0 = nowMs();
+    Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) ? groupsFromJoinEntries(q)
+             : q.candidateRun ? groupsFromDenseRows(q) : groupsFromDense(q);
+    if (q.aggMode == AggMode::HASH) mergeSpaceEquivalentGroups(q, G);
+    if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     tail: %.3f ms  groups from the device tables\n", nowMs() - t0);
+    runTailOn(q, G);
+}
+
+// The shards of a multi-GPU plan that does not end in a dense partial table (multi.cpp): every part has run its pipelines with
+// the tail held back (engine.cpp setHoldTail) and holds its group rows — or, without an aggregation, its materialised columns in
+// scan order — in host memory.  Groups that occur in several parts are merged by key (sum / min / max by accumulator kind, the
+// first row = the smallest one: rows are numbered over the whole table, Table::row0), then `root`'s tail runs over all of them:
+// AVG, projections, the replay of the reference's hash table for the emission order, ORDER BY, LIMIT.  The result is the one the
+// unsharded plan gives on one GPU, whatever the sharding (reference: one hash table all workers reach, aggregation.h:240-343).
+void runTailMerged(Query& root, const std::vector<Query*>& parts) {
+    root.tailNeedsAllGroups = false;
+    root.candidateRun = false;
+    if (!root.agg) {
+        // materialize.h:78-220 appends in scan order: the parts' columns back to back, parts in shard order
+        const size_t nCols = root.matSchema.size();
+        std::vector<std::vector<uint8_t>> cols(nCols);
+        int64_t rows = 0;
+        for (Query* p : parts) {
+            if (p->matSchema.size() != nCols) failInvalid("shard results have different schemas");
+            for (size_t c = 0; c < nCols; c++) {
+                const size_t bytes = (size_t)p->matRows * (size_t)columnWidth(root.matSchema[c].type);
+                if (p->hMatCols.size() != nCols || p->hMatCols[c].size() < bytes) failRuntime("internal error: a shard holds no materialised rows");
+                cols[c].insert(cols[c].end(), p->hMatCols[c].begin(), p->hMatCols[c].begin() + (long)bytes);
+            }
+            rows += p->matRows;
+        }
+        if (root.matOp->hasLimit) rows = std::min<int64_t>(rows, std::max<int64_t>(root.matOp->limit, 1));      // materialize.h:197-206
+        root.hMatCols.swap(cols);
+        root.matRows = rows;
+        runMaterializeTail(root);
+        return;
+    }
+    if (root.aggMode != AggMode::AT_JOIN_ENTRY && root.aggMode != AggMode::HASH) failUnsupported("group-level merge of a dense aggregation (its partial tables merge on the device)");
+    Groups G;
+    G.nKeys = root.agg->exprs2.size(); G.nAcc = root.accums.size();
+    std::vector<Groups> each;
+    size_t total = 0, strBytes = 0;
+    for (Query* p : parts) {
+        if (p->aggMode != root.aggMode || p->accums.size() != root.accums.size()) failInvalid("shards disagree on the aggregation strategy");
+        each.push_back(groupsFromJoinEntries(*p));
+        total += each.back().n; strBytes += each.back().strings.size();
+    }
+    G.firstRow.reserve(total); G.keyData.reserve(total * G.nKeys); G.accData.reserve(total * G.nAcc);
+    G.strings.reserve(strBytes + 1);               // (reserved once: Val::s pointers into it stay valid while the parts are appended)
+    for (Groups& e : each) {
+        const char* oldBase = e.strings.data();
+        const size_t at = G.strings.size();
+        G.strings.insert(G.strings.end(), e.strings.begin(), e.strings.end());
+        const char* newBase = G.strings.data() + at;
+        G.firstRow.insert(G.firstRow.end(), e.firstRow.begin(), e.firstRow.end());
+        G.accData.insert(G.accData.end(), e.accData.begin(), e.accData.end());
+        for (size_t i = 0; i < e.n; i++)
+            for (size_t k = 0; k < G.nKeys; k++) {
+                Val v = e.keys(i)[k];
+                if (root.agg->exprs2[k]->type.isString()) v.s = newBase + (v.s - oldBase);
+                G.keyData.push_back(v);
+            }
+    }
+    G.n = total;
+    const double t0 = nowMs();
+    mergeEqualGroups(root, G);
+    if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     tail: %.3f ms  %zu group rows of %zu shards merged into %zu groups\n", nowMs() - t0, total, parts.size(), G.n);
+    runTailOn(root, G);
+}
+
+static void runTailOn(Query& q, Groups& G) {
     OpNode* agg = q.agg;
     const bool trace = getenv("RSQ_TRACE") != nullptr;
     double tPhase = nowMs();
@@ -503,10 +607,6 @@ void runTail(Query& q) {
         fprintf(stderr, "[rsq trace]     tail: %.3f ms  %s\n", t - tPhase, what);
         tPhase = t;
     };
-    Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) ? groupsFromJoinEntries(q)
-             : q.candidateRun ? groupsFromDenseRows(q) : groupsFromDense(q);
-    if (q.aggMode == AggMode::HASH) mergeSpaceEquivalentGroups(q, G);
-    phase("groups from the device tables");
 
     // ---- operators above the aggregation (bottom-up) and their schemas ----
     OpNode* mat = nullptr; OpNode* orderBy = nullptr;

@@ -82,6 +82,7 @@ def lib():
         L.rsq_table_rows.restype = i64
         L.rsq_table_rows.argtypes = [vp]
         L.rsq_table_read_column.argtypes = [vp, vp, C.c_char_p, vp, C.c_size_t]
+        L.rsq_table_set_first_row.argtypes = [vp, i64]
         L.rsq_table_destroy.argtypes = [vp]
         L.rsq_query_compile.argtypes = [vp, C.POINTER(P.rsq_plan_desc), C.POINTER(vp), i32, C.POINTER(vp)]
         L.rsq_query_execute.argtypes = [vp]
@@ -137,6 +138,9 @@ def lib():
         L.rsq_multi_shard_rows.restype = None
         L.rsq_multi_shard_rows.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
         L.rsq_multi_table_generate.argtypes = [vp, i32, i64, C.c_double, i64, C.c_uint64, C.POINTER(vp)]
+        L.rsq_multi_table_generate_on_key.argtypes = [vp, i32, i64, C.c_double, i64, C.c_uint64, C.c_char_p, C.POINTER(vp)]
+        L.rsq_multi_query_merge_name.restype = C.c_char_p
+        L.rsq_multi_query_merge_name.argtypes = [vp]
         L.rsq_multi_query_compile.argtypes = [vp, C.POINTER(P.rsq_plan_desc), C.POINTER(vp), i32, C.POINTER(vp)]
         L.rsq_multi_query_execute.argtypes = [vp]
         L.rsq_multi_query_result.argtypes = [vp, C.POINTER(P.rsq_result_view)]
@@ -148,7 +152,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
-    "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_read_column",
+    "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_set_first_row", "rsq_table_read_column",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_await_kernels", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
     "rsq_query_finalize", "rsq_query_merge_gathered", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_kernel_time_stats", "rsq_query_source", "rsq_query_explain",
@@ -157,7 +161,7 @@ EXPORTED_SYMBOLS = [
     "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
     "rsq_db_create", "rsq_db_execute", "rsq_db_message", "rsq_db_adopt_table", "rsq_db_report", "rsq_db_destroy",
     "rsq_multi_create", "rsq_multi_destroy", "rsq_multi_last_error", "rsq_multi_devices", "rsq_multi_ctx", "rsq_multi_merge_name",
-    "rsq_multi_shard_rows", "rsq_multi_table_generate", "rsq_multi_query_compile", "rsq_multi_query_execute",
+    "rsq_multi_shard_rows", "rsq_multi_table_generate", "rsq_multi_table_generate_on_key", "rsq_multi_query_merge_name", "rsq_multi_query_compile", "rsq_multi_query_execute",
     "rsq_multi_query_result", "rsq_multi_query_report", "rsq_multi_query_destroy",
 ]
 
@@ -348,6 +352,10 @@ class DeviceTable:
     def n_rows(self) -> int:
         return self.ctx._L.rsq_table_rows(self.h)
 
+    def set_row0(self, row0: int):
+        """this table is rows [row0, row0 + n_rows) of a larger one (a shard); before queries are compiled over it"""
+        self.ctx._check(self.ctx._L.rsq_table_set_first_row(self.h, row0))
+
     def read_column(self, name: str, dtype, count: Optional[int] = None) -> np.ndarray:
         n = self.n_rows if count is None else count
         out = np.empty(n, dtype=dtype)
@@ -525,6 +533,14 @@ class MultiContext:
         name = ["lineitem", "orders", "customer", "t"][kind]
         return [DeviceTable(self.shards[i], C.c_void_p(arr[i]), name) for i in range(self.n)]
 
+    def generate_on_key(self, kind: int, n_rows_total: int, sf: float, key_column: str, param: int = 0,
+                        seed: int = 20240613) -> List["DeviceTable"]:
+        """like generate, with every shard boundary moved to the next change of `key_column`"""
+        arr = (C.c_void_p * self.n)()
+        self._check(self._L.rsq_multi_table_generate_on_key(self.h, kind, n_rows_total, sf, param, seed, key_column.encode(), arr))
+        name = ["lineitem", "orders", "customer", "t"][kind]
+        return [DeviceTable(self.shards[i], C.c_void_p(arr[i]), name) for i in range(self.n)]
+
     def compile(self, plan: P.Plan, tables_per_shard: Sequence[Sequence["DeviceTable"]]) -> "MultiQuery":
         keep: list = []
         d = plan.to_c(keep)
@@ -535,17 +551,34 @@ class MultiContext:
         self._check(self._L.rsq_multi_query_compile(self.h, C.byref(d), arr, nt, C.byref(h)))
         return MultiQuery(self, h)
 
+    def _adopt(self, query):
+        import weakref
+        if not hasattr(self, "_queries"):
+            self._queries = weakref.WeakSet()
+        self._queries.add(query)
+
     def close(self):
+        """queries first (rsq_multi_query_destroy frees device memory of the shard contexts and reads their tables), then the
+        shards' tables, then the handle (which deletes the contexts)"""
         if getattr(self, "h", None):
+            for q in list(getattr(self, "_queries", ())):
+                q.close()
             for s in self.shards:
                 s.close()
             self._L.rsq_multi_destroy(self.h)
             self.h = None
 
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 class MultiQuery:
     def __init__(self, m: MultiContext, h):
         self.m, self.h = m, h
+        m._adopt(self)
 
     def execute(self):
         self.m._check(self.m._L.rsq_multi_query_execute(self.h))
@@ -556,6 +589,10 @@ class MultiQuery:
         res = P.Result.from_view(v)
         res.text = res.serialize()
         return res
+
+    @property
+    def merge_name(self) -> str:
+        return self.m._L.rsq_multi_query_merge_name(self.h).decode()
 
     def report(self):
         """(rsq_report, [kernel ms of every shard])"""

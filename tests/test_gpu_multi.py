@@ -133,3 +133,180 @@ def test_q3_over_key_aligned_shards():
                 t.close()
     finally:
         m.close()
+
+
+# ---- the general merge: any sharding gives the single-GPU answer (round-2 verdict: tile-aligned shards + Q3 used to concatenate
+# the partial groups of an order that straddles a cut) -------------------------------------------------------------------------
+
+def _q3_inputs(sf):
+    cu, od, li = tpch.customer_table(sf), tpch.orders_table(sf), tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+    schema = tpch.q3_plan(tpch.customer_table(0.001), tpch.orders_table(0.001), tpch.lineitem_table(0.001, tpch.Q3_LINEITEM_COLUMNS, n_rows=0))
+    return cu, od, li, schema
+
+
+def _close_all(per_shard):
+    for ts in per_shard:
+        for t in ts:
+            t.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 5])
+def test_q3_over_tile_aligned_shards_takes_the_general_merge(n_shards):
+    """rsq_multi_table_generate cuts on 128-row tiles: orders straddle the cuts, so their groups come from two shards and must be
+    re-aggregated before ORDER BY ... LIMIT sees them.  Byte-identical to the oracle — tie order included, the tail being the
+    single-GPU tail over the merged groups."""
+    sf = 0.05
+    cu, od, li, schema = _q3_inputs(sf)
+    want = orc.execute(tpch.q3_plan(cu, od, li))
+    m = engine.MultiContext([0] * n_shards)
+    try:
+        shards = m.generate(engine.GEN_LINEITEM, li.n_rows, sf, param=1)
+        per_shard = [[m.shards[i].table(cu), m.shards[i].table(od), shards[i]] for i in range(n_shards)]
+        q = m.compile(schema, per_shard)
+        assert "general merge" in q.merge_name and "overlap" in q.merge_name
+        for _ in range(2):
+            q.execute()
+            got = q.result()
+            assert got.text == want.text and got.tuples == want.tuples
+        q.close()
+        _close_all(per_shard)
+    finally:
+        m.close()
+
+
+def test_q3_key_aligned_shards_from_the_c_abi(monkeypatch):
+    """rsq_multi_table_generate_on_key: no l_orderkey spans two shards -> the statistics prove the groups disjoint -> every shard's
+    own top 10 + ordered merge; the general merge, forced, gives the same rows"""
+    sf = 0.05
+    cu, od, li, schema = _q3_inputs(sf)
+    want = orc.execute(tpch.q3_plan(cu, od, li))
+    keys = {c.name: c.data for c in li.columns}["l_orderkey"]
+    for force in ("0", "1"):
+        monkeypatch.setenv("RSQ_MULTI_GENERAL_MERGE", force)
+        m = engine.MultiContext([0, 0, 0])
+        try:
+            shards = m.generate_on_key(engine.GEN_LINEITEM, li.n_rows, sf, "l_orderkey", param=1)
+            assert sum(t.n_rows for t in shards) == li.n_rows
+            at = 0
+            for t in shards[:-1]:                              # every cut sits on a key change, at or behind the tile-aligned cut
+                at += t.n_rows
+                assert keys[at] != keys[at - 1]
+            assert [m.shard_rows(li.n_rows, i)[0] <= sum(t.n_rows for t in shards[:i]) for i in range(3)] == [True] * 3
+            per_shard = [[m.shards[i].table(cu), m.shards[i].table(od), shards[i]] for i in range(3)]
+            q = m.compile(schema, per_shard)
+            assert ("ordered merge" in q.merge_name) == (force == "0"), q.merge_name
+            q.execute()
+            got = q.result()
+            if force == "1":
+                assert got.text == want.text
+            key = lambda res: [(res.value(r, 1), res.value(r, 2)) for r in range(res.n_rows)]
+            assert key(got) == key(want) and sorted(got.text.splitlines()) == sorted(want.text.splitlines())
+            q.close()
+            _close_all(per_shard)
+        finally:
+            m.close()
+
+
+def test_hash_aggregation_without_limit_over_shards_keeps_the_emission_order():
+    """a computed group key (generic hash aggregation), every group in every shard: the merged groups leave in the reference's
+    hash-table order, which depends on each group's FIRST row over the whole table (shard tables carry row0)"""
+    n, groups = 400_000, 5000
+    host = tpch.synthetic_table(n, groups)
+
+    def plan_of(t):
+        p = P.Plan([t])
+        key = p.add(p.mul(p.attr("b"), p.constant("3", P.BIGINT)), p.constant("1", P.BIGINT))
+        sc, cnt, lo, hi, av = p.sum(p.attr("c")), p.count(p.star()), p.min(p.attr("d")), p.max(p.attr("c")), p.avg(p.attr("d"))
+        node = p.selection(p.lt(p.attr("a"), p.constant(str(1 << 30), P.BIGINT)), p.scan("t"))
+        node = p.aggregation([sc, cnt, lo, hi, av], [key], node)
+        node = p.projection([p.as_("k", key), p.as_("s", sc), p.as_("n", cnt), p.as_("lo", lo), p.as_("hi", hi), p.as_("av", av)], node)
+        return p.set_root(p.materialize(node))
+
+    want = orc.execute(plan_of(host))
+    m = engine.MultiContext([0, 0, 0, 0])
+    try:
+        shards = m.generate(engine.GEN_SYNTHETIC, n, 1.0, param=groups)
+        q = m.compile(plan_of(tpch.synthetic_table(0, groups)), [[t] for t in shards])
+        assert "general merge" in q.merge_name
+        q.execute()
+        got = q.result()
+        assert got.n_rows == want.n_rows == groups
+        assert got.text == want.text
+        q.close()
+        for t in shards:
+            t.close()
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("order", [False, True])
+def test_materialised_rows_over_shards_keep_scan_order(order):
+    """no aggregation: the shards' materialised rows back to back are the single-GPU scan order; ORDER BY runs the reference's
+    (unstable) quicksort over exactly that order, LIMIT as MaterializeOp / OrderByOp apply it"""
+    n = 300_000
+    host = tpch.synthetic_table(n, 64)
+
+    def plan_of(t):
+        p = P.Plan([t])
+        node = p.selection(p.lt(p.attr("a"), p.constant(str(1 << 24), P.BIGINT)), p.scan("t"))
+        node = p.projection([p.attr("b"), p.attr("c"), p.as_("e", p.add(p.attr("c"), p.attr("d")))], node)
+        if order:
+            return p.set_root(p.orderby([p.asc(p.attr("b")), p.desc(p.attr("c"))], node), limit=500)
+        return p.set_root(p.materialize(node), limit=700)
+
+    want = orc.execute(plan_of(host))
+    m = engine.MultiContext([0, 0, 0])
+    try:
+        shards = m.generate(engine.GEN_SYNTHETIC, n, 1.0, param=64)
+        q = m.compile(plan_of(tpch.synthetic_table(0, 64)), [[t] for t in shards])
+        q.execute()
+        got = q.result()
+        assert got.n_rows == want.n_rows > 100
+        assert got.text == want.text
+        q.close()
+        for t in shards:
+            t.close()
+    finally:
+        m.close()
+
+
+def test_join_in_front_of_a_dense_aggregation_over_shards():
+    """TPC-H Q14's shape: a build pipeline, then probe + ungrouped sums (register accumulators).  The shards cannot be enqueued
+    without the host (the build sizes its table), so they run on host threads up to their partial tables; merge and finalize as
+    for Q1.  (Round 2 refused this shape: the asynchronous path takes no join pipelines.)"""
+    sf = 0.02
+    od, li = tpch.orders_table(sf), tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+
+    def plan_of(o, l):
+        p = P.Plan([o, l])
+        rev, cnt = p.sum(p.mul(p.attr("l_extendedprice"), p.sub(p.constant("1", P.BIGINT), p.attr("l_discount")))), p.count(p.star())
+        build = p.selection(p.lt(p.attr("o_orderdate"), p.constant("1995-03-15", P.DATE)), p.scan("orders"))
+        node = p.hashjoin([p.eq(p.attr("o_orderkey"), p.attr("l_orderkey"))], build, p.scan("lineitem"), single_match=True)
+        node = p.aggregation([rev, cnt], [], node)
+        return p.set_root(p.materialize(p.projection([p.as_("revenue", rev), p.as_("n", cnt)], node)))
+
+    want = orc.execute(plan_of(od, li))
+    m = engine.MultiContext([0, 0, 0])
+    try:
+        shards = m.generate(engine.GEN_LINEITEM, li.n_rows, sf, param=1)
+        per_shard = [[m.shards[i].table(od), shards[i]] for i in range(3)]
+        q = m.compile(plan_of(tpch.orders_table(0.001), tpch.lineitem_table(0.001, tpch.Q3_LINEITEM_COLUMNS, n_rows=0)), per_shard)
+        assert "dense partial tables" in q.merge_name and "host threads" in q.merge_name
+        for _ in range(2):
+            q.execute()
+            assert q.result().text == want.text
+        q.close()
+        _close_all(per_shard)
+    finally:
+        m.close()
+
+
+def test_closing_the_multi_context_first_closes_its_queries():
+    """MultiContext.close() destroys the shard contexts: queries compiled on them go first (a later MultiQuery.close() is a no-op)"""
+    m = engine.MultiContext([0, 0])
+    shards = m.generate(engine.GEN_LINEITEM, 20_000, 0.01)
+    q = m.compile(tpch.q1_plan(_schema(tpch.Q1_COLUMNS)), [[t] for t in shards])
+    q.execute()
+    m.close()
+    assert q.h is None
+    q.close()

@@ -228,3 +228,36 @@ def test_statistics_mislead_and_the_sampled_pass_takes_over(gpu_ctx, monkeypatch
         assert q.result().text == orc.execute(plan).text
     finally:
         q.close(); tabs[0].close()
+
+
+def test_overflowed_staged_attempt_followed_by_the_atomics_form(gpu_ctx, monkeypatch, capfd):
+    """The column statistics overstate the pass rate (values of `a` sit at the ends of its range: 'uniform' says 50 %, 2 % pass)
+    and the passing rows' keys crowd into ONE partition: the first, tentative staged attempt overflows its even-share regions
+    after rsq_staged_agg has already stored partial sums, the sampled pass then picks the HBM-atomics form — which adds onto the
+    table.  The table must be back at its identities in between (round-2 advisor finding)."""
+    monkeypatch.delenv("RSQ_PARTITION", raising=False)
+    monkeypatch.setenv("RSQ_TRACE", "1")
+    n = 6_000_000
+    rng = np.random.default_rng(21)
+    passing = rng.random(n) < 0.02
+    a = np.where(passing, 0, (1 << 31) - 1).astype(np.int64)
+    b = np.where(passing, rng.integers(0, 1500, n), rng.integers(0, 1 << 20, n)).astype(np.int64)
+    b[0] = (1 << 20) - 1                           # (keeps the key range at 2^20 whatever the draw)
+    cols = [P.Column("a", T.BIGINT(), a), P.Column("b", T.BIGINT(), b),
+            P.Column("c", T.BIGINT(), rng.integers(0, 1 << 20, n).astype(np.int64)), P.Column("d", T.BIGINT(), rng.integers(0, 1 << 20, n).astype(np.int64))]
+    t = P.Table("t", cols, n)
+    plan = tpch.synthetic_plan(t, 1 << 30)
+    want = orc.execute(plan).text
+    tabs = [gpu_ctx.table(t)]
+    q = gpu_ctx.compile(plan, tabs)
+    try:
+        q.await_kernels()
+        q.execute()
+        err = capfd.readouterr().err
+        assert "from the column statistics" in err and "a region ran full" in err      # the tentative attempt ran and overflowed
+        assert "rows pass; atomics" in err                                               # ... and the sample decided afterwards
+        assert q.result().text == want
+        q.execute()
+        assert q.result().text == want
+    finally:
+        q.close(); tabs[0].close()
