@@ -8,17 +8,21 @@ N > 1 needs one process per GPU.  Two ways in, same code path afterwards:
     WORLD_SIZE / MASTER_* come from the environment;
   * plain `python bench.py --gpus N`: this process — BEFORE it imports torch or touches a GPU — starts N fresh rank
     processes of itself with those variables set (rendezvous on 127.0.0.1, a free port), relays rank 0's JSON line and
-    exits non-zero if any rank does.  (Mirrors the reference's execute(): one call fans out to all workers and joins
-    them, reference src/JitContextFlounder.h:459-487.)
+    exits non-zero if any rank does; it watches ALL of them and ends the others as soon as one has failed.  (Mirrors the
+    reference's execute(): one call fans out to all workers and joins them, reference src/JitContextFlounder.h:459-487.)
 
 One *step* = one execution of the compiled Q1 plan over the whole lineitem table that is already resident in HBM
 (device-generated, deterministic; H2D is not part of any timed region): scan 7 columns -> filter -> 6-group aggregation
 kernel -> group-by merge (one RCCL all-gather of the 42-word partial tables + one fused merge kernel when N > 1) -> host
 finalisation (AVG, projection, ORDER BY) to ReSQL's result relation.  `value` = lineitem rows of the whole job / wall
-time of the K steps (max over ranks).
+time of the K steps (max over ranks).  After the timed region the answer is compared with the UNMODIFIED reference's answer
+on the same rows (tests/golden/ref_full_q1_sf{1,10}.tbl): "parity_checked", and a non-zero exit code on a mismatch.
 
 N > 1 shards the SF10 table by row range across the ranks ("morsel-sharded", BASELINE.json config 4): total work is
 fixed, so scaling is "strong".
+
+`--path capi` runs the same step through rsq_multi_* (include/resql_hip.h): ONE host process over the N GPUs, RCCL reduce
+issued by the library — the way a C++ ReSQL host would call it.  Under a launcher only rank 0 works in that mode.
 
 Extra objects on the JSON line:
   roofline     — the scan+aggregate kernel: ALGORITHMIC bytes (38 B/row x rows per launch) / its average
@@ -29,6 +33,14 @@ Extra objects on the JSON line:
   cpu_baseline — the UNMODIFIED reference (oracle/_ref/ref_harness: ReSQL's asmjit path, threads=1; ReSQL's aggregation
                  pipelines are single-threaded by construction) timed on this box's host cores on the SAME
                  rows the value is quoted on (SF10 lineitem read back from the device table), rank 0, N = 1 only.
+  config.phases (N > 1, or --dist-path) — where a step's time goes, measured in a second, UNTIMED loop of the same steps:
+                 kernel_ms per rank (the engine's HIP events), collective_ms (an event pair around the merge on the step's
+                 stream), finalize_ms (rank 0's host tail): at 8 GPUs the SF10 kernel is ~45 us per GPU, so the step is
+                 launch- and collective-latency shaped, and the line says so.
+  extras.weak_scaling — BASELINE config 5, the scaling showcase: every rank holds ONE 1.25 B-row shard
+                 (40 GB) of the 10 B-row synthetic table, `a < tau` at 10 % selectivity, group by b into G = 8 (register
+                 accumulators, 3 merged words) and G = 2^20 (HBM table, 32 MB all-reduced) — rows/s of the whole job and
+                 the fraction of N x 8 TB/s in algorithmic bytes (32 B/row).  Untimed for `value`; skipped with --no-extras.
 
 `--backend gloo --no-gpu` is a dry mode for machines without a GPU (the CPU test of the launch path): every rank takes a
 compile-only engine context, a deterministic stand-in partial table goes through the same sharding, layout check, merge
@@ -41,13 +53,21 @@ import json
 import os
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
-PMC_PROFILE = "profiles/r02_q1_sf10_pmc.json"
+PMC_PROFILES = ("profiles/r03_q1_sf10_pmc.json", "profiles/r02_q1_sf10_pmc.json", "profiles/r01_q1_sf10_pmc.json")
+INIT_TIMEOUT_S = 120        # rendezvous of the ranks (a rank that never arrives must not hold the others for minutes)
+
+
+def _mark(what: str):
+    """progress on stderr with RSQ_BENCH_TRACE=1 (which phase a run that printed no line reached)"""
+    if os.environ.get("RSQ_BENCH_TRACE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {what}", file=sys.stderr, flush=True)
 
 
 def parse_args(argv=None):
@@ -62,6 +82,12 @@ def parse_args(argv=None):
     ap.add_argument("--dist-path", action="store_true",
                     help="take the multi-rank step (async partial + merge + finalize) even with one rank: lets a 1-GPU box "
                          "exercise the exact code the N > 1 runs use")
+    ap.add_argument("--path", choices=["dist", "capi"], default="dist",
+                    help="dist: one process per GPU, torch.distributed (RCCL) merge; capi: ONE process over all GPUs through rsq_multi_*")
+    ap.add_argument("--capi-devices", type=str, default=None,
+                    help="--path capi: comma-separated device ordinals (default 0..gpus-1; a device may repeat: shards sharing a GPU)")
+    ap.add_argument("--no-extras", action="store_true", help="skip extras.weak_scaling (BASELINE config 5 shards)")
+    ap.add_argument("--weak-rows", type=int, default=1_250_000_000, help="rows per GPU of the weak-scaling extra")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the group-by merge (nccl = RCCL over xGMI; gloo only with --no-gpu)")
     ap.add_argument("--no-gpu", action="store_true", help="dry mode, see the module docstring")
@@ -78,8 +104,10 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(n: int, argv) -> int:
-    """start n rank processes of this script, wait for all, relay rank 0's stdout; returns the exit code"""
+def launch_ranks(n: int, argv, poll_s: float = 0.05, grace_s: float = 5.0) -> int:
+    """start n rank processes of this script, watch ALL of them, relay rank 0's stdout; returns the exit code.
+    The first rank that exits non-zero ends the job: the others (which would sit in the rendezvous or in a collective
+    until its timeout) are terminated, then killed — fresh children only, nothing here has touched a GPU."""
     port = _free_port()
     procs = []
     for rank in range(n):
@@ -89,15 +117,39 @@ def launch_ranks(n: int, argv) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if rank == 0 else sys.stderr, text=(rank == 0) or None))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    if out0:
-        sys.stdout.write(out0)
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)     # rank 0's pipe must be drained while we poll
+    reader.start()
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        print(f"bench.py: rank {failed} exited with code {codes[failed]}; ending the other ranks", file=sys.stderr)
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                p.terminate()
+        deadline = time.time() + grace_s
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                try:
+                    codes[r] = p.wait(timeout=max(0.1, deadline - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    codes[r] = p.wait()
+    reader.join(timeout=10)
+    if failed is None and out0 and out0[0]:
+        sys.stdout.write(out0[0])
         sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
-        return next(c for _, c in bad) or 1
+    if failed is not None:
+        return codes[failed] if codes[failed] and codes[failed] > 0 else 1
     return 0
 
 
@@ -107,7 +159,6 @@ def cpu_baseline(sample_sf: float, device_table=None, repeat: int = 3):
     device_table: the resident lineitem table of the run — its columns are read back so that the reference scans exactly
     the rows the GPU number is quoted on (the numpy generator makes the same bits, but takes minutes at SF10)."""
     from resql_amd import tpch, datagen
-    from resql_amd import plan as P
     from oracle import orc
     import numpy as np
     n = datagen.n_lineitem(sample_sf)
@@ -147,7 +198,7 @@ def committed_traffic(bytes_per_launch: int):
     """HBM bytes per launch of the Q1 kernel from the rocprofv3 --pmc pass committed under profiles/ (FETCH_SIZE,
     collected in its own run and corrected as MI355X_MICROARCH.md prescribes for gfx950) — only for the configuration
     it was measured on.  Returns (traffic, source)."""
-    for rel in (PMC_PROFILE, "profiles/r01_q1_sf10_pmc.json"):
+    for rel in PMC_PROFILES:
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 pmc = json.load(f)
@@ -156,6 +207,32 @@ def committed_traffic(bytes_per_launch: int):
         except Exception:
             continue
     return None, None
+
+
+def golden_answer(sf: float):
+    """the UNMODIFIED reference's Q1 answer on the rows of this scale factor (tests/golden/make_fullsize_golden.py), or None"""
+    path = os.path.join(ROOT, "tests", "golden", f"ref_full_q1_sf{sf:g}.tbl")
+    try:
+        with open(path) as f:
+            return f.read(), os.path.relpath(path, ROOT)
+    except OSError:
+        return None, None
+
+
+def check_parity(result_text: str, sf: float, out: dict) -> int:
+    """compare the timed plan's answer with the reference's; fills out['parity_checked' / 'parity_source'], returns the exit code"""
+    want, src = golden_answer(sf)
+    if want is None:
+        out["parity_checked"] = None
+        out["parity_source"] = f"no committed reference answer for SF{sf:g} (tests/golden/ref_full_q1_sf{{1,10}}.tbl)"
+        return 0
+    ok = result_text == want
+    out["parity_checked"] = bool(ok)
+    out["parity_source"] = f"{src}: the unmodified reference's answer on the same rows, compared byte for byte after the timed region"
+    if not ok:
+        print(f"bench.py: the answer of the timed plan differs from {src}:\n{result_text}\nvs\n{want}", file=sys.stderr)
+        return 4
+    return 0
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -172,7 +249,7 @@ def dry_run(args, world: int, rank: int) -> int:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         import datetime
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
         grouped = True
     else:
         grouped = False
@@ -200,6 +277,8 @@ def dry_run(args, world: int, rank: int) -> int:
         mine = partial.clone()
         merger.partial = mine
         merger.merge()
+    # the per-rank phase figures travel the way the measured path sends them (one all-gather of a small tensor)
+    per_rank = gather_per_rank(dist if grouped else None, world, float(rank + 1), device=None)
     if grouped:
         dist.barrier()
     if rank == 0:
@@ -208,6 +287,7 @@ def dry_run(args, world: int, rank: int) -> int:
         tri = world * (world + 1) // 2
         expect_sum = [tri * (i + 1) for i in range(n_sum)]
         ok = mine[:n_min].tolist() == list(range(n_min)) and mine[n_min + n_max:].tolist() == expect_sum
+        ok = ok and per_rank == [float(r + 1) for r in range(world)]
         print(json.dumps({"metric": "TPC-H Q1 rows/s at SF10", "dry_run": True, "value": None, "unit": "rows/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "config": {"workload": "launch / merge / finalize plumbing only (no GPU)", "rows": n_total,
@@ -215,7 +295,8 @@ def dry_run(args, world: int, rank: int) -> int:
                                      "backend": dist.get_backend() if grouped else "none",
                                      "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
                                      "shards": [list(shard_rows(n_total, world, r)) for r in range(world)],
-                                     "merge": merger.strategy, "merged_ok": bool(ok), "result_groups": res.n_rows}}),
+                                     "merge": merger.strategy, "merged_ok": bool(ok), "result_groups": res.n_rows,
+                                     "phases": {"kernel_ms_per_rank": per_rank}}}),
               flush=True)
         if not ok:
             return 1
@@ -227,12 +308,155 @@ def dry_run(args, world: int, rank: int) -> int:
     return 0
 
 
+def gather_per_rank(dist, world: int, value: float, device):
+    """[value of rank 0, ..., value of rank world-1] on every rank (one all-gather of one double per rank)"""
+    import torch
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist is None or world == 1:
+        return [float(t.item())]
+    every = torch.empty(world, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(every, t)
+    return [float(v) for v in every.cpu().tolist()]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# --path capi: ONE host process over N GPUs through rsq_multi_* (the C ABI a C++ ReSQL host binds)
+# ------------------------------------------------------------------------------------------------------------------
+def run_capi(args) -> int:
+    from resql_amd import datagen, engine, tpch
+    devices = [int(d) for d in args.capi_devices.split(",")] if args.capi_devices else list(range(args.gpus))
+    n_dev = len(devices)
+    n_total = datagen.n_lineitem(args.sf)
+    m = engine.MultiContext(devices)
+    try:
+        shards = m.generate(engine.GEN_LINEITEM, n_total, args.sf)
+        schema_only = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
+        q = m.compile(tpch.q1_plan(schema_only), [[t] for t in shards])
+        for _ in range(max(1, args.warmup)):
+            q.execute()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            q.execute()
+        elapsed = time.perf_counter() - t0
+        # per-shard kernel times: a second, untimed loop (a report per step inside the timed loop would time its own bookkeeping)
+        probe = max(1, min(args.steps, 20))
+        per = [0.0] * n_dev
+        fin = 0.0
+        for _ in range(probe):
+            q.execute()
+            rep, k = q.report()
+            per = [a + b for a, b in zip(per, k)]
+            fin += rep.finalize_time_ms
+        per = [v / probe for v in per]
+        result = q.result()
+        rows_per = [t.n_rows for t in shards]
+        bytes_per_launch = tpch.Q1_BYTES_PER_ROW * max(rows_per)
+        slowest = max(per)
+        achieved = bytes_per_launch / (slowest * 1e-3) / 1e9
+        out = {
+            "metric": "TPC-H Q1 rows/s at SF10", "value": n_total * args.steps / elapsed, "unit": "rows/s",
+            "n_gpus": len(set(devices)), "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"TPC-H Q1 over lineitem SF{args.sf:g} ({n_total} rows, 7 columns, 38 B/row) resident in HBM, "
+                                   f"row-range sharded over {n_dev} shard(s) on devices {devices}",
+                       "rows": n_total, "rows_per_shard": rows_per, "result_groups": result.n_rows, "path": "capi",
+                       "parallelism": f"one host process, rsq_multi_* over {n_dev} shard(s): {m.merge_name}; {q.merge_name}",
+                       "phases": {"kernel_ms_per_rank": per, "finalize_ms": fin / probe,
+                                  "step_minus_slowest_kernel_ms": elapsed / args.steps * 1e3 - slowest}},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "traffic_source": None,
+                         "kernel": "scan+filter+dense aggregation pipeline (the slowest shard's launches)", "kernel_ms": slowest,
+                         "bytes_per_launch": bytes_per_launch},
+        }
+        rc = check_parity(result.text, args.sf, out)
+        print(json.dumps(out), flush=True)
+        q.close()
+        for t in shards:
+            t.close()
+        return rc
+    finally:
+        m.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# extras.weak_scaling: BASELINE config 5, one 1.25 B-row shard per GPU
+# ------------------------------------------------------------------------------------------------------------------
+def weak_scaling_extra(args, ctx, dist, world: int, rank: int, device, steps: int = 3):
+    """every rank: one shard of `--weak-rows` rows of the synthetic 4 x int64 table (rows [rank * rows, (rank + 1) * rows) of the
+    whole), `a < tau` at 10 %, group by b, 2 sums + count: partial aggregation -> merge (PartialMerger: all-gather for the
+    3-word G = 8 table, one all-reduce per segment for the 2^20-group table) -> rank 0 finalises.  Returns a list of dicts
+    (rank 0) or None."""
+    import torch
+    from resql_amd import engine, tpch
+    from resql_amd.dist import PartialMerger
+    rows = int(args.weak_rows)
+    out = []
+    threshold = int(0.10 * (1 << 31))
+    for groups in (8, 1 << 20):
+        shard = ctx.generate(engine.GEN_SYNTHETIC, rows, 1.0, row0=rank * rows, param=groups)
+        q = ctx.compile(tpch.synthetic_plan(tpch.synthetic_table(16, groups), threshold), [shard])
+        q.await_kernels()
+        n_min, n_max, n_sum = q.partial_layout()
+        partial = torch.zeros(n_min + n_max + n_sum, dtype=torch.int64, device=device)
+        q.bind_partial(partial.data_ptr(), partial.numel() * 8)
+        merger = PartialMerger(dist, partial, n_min, n_max, n_sum, world, query=q) if dist is not None else None
+
+        def step():
+            if merger is None:
+                q.execute()
+                return
+            q.execute_partial_async()
+            merger.merge()
+            if rank == 0:
+                q.finalize()
+
+        def fence():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        step()                                           # first execution: sizes regions / picks the form
+        fence()
+        q.kernel_time_stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if merger is not None and rank != 0:
+            q.finalize()
+        ksum, kn = q.kernel_time_stats()
+        kms = gather_per_rank(dist, world, ksum / max(1, kn), device)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            res = q.result(text=False)
+            total_rows = rows * world
+            ms = dt / steps * 1e3
+            out.append({"groups": groups, "selectivity": 0.10, "rows_per_gpu": rows, "rows": total_rows, "ms_per_step": ms,
+                        "rows_per_s": total_rows / (ms * 1e-3), "result_groups": res.n_rows,
+                        "algorithmic_gbps": total_rows * 32 / (ms * 1e-3) / 1e9,
+                        "frac_of_peak_end_to_end": total_rows * 32 / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world),
+                        "kernel_ms_per_rank": kms, "merge": merger.strategy if merger is not None else "single GPU",
+                        "partial_table_words": n_min + n_max + n_sum})
+        q.close()
+        shard.close()
+        del partial
+    return out if rank == 0 else None
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
     if args.backend == "gloo" and not args.no_gpu:
         raise SystemExit("--backend gloo exists for the --no-gpu dry mode only: the measured path merges over RCCL")
+    if args.path == "capi":
+        if int(os.environ.get("RANK", "0")) != 0:
+            return 0                                      # under a launcher: ONE process drives all GPUs, the other ranks have nothing to do
+        return run_capi(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, argv)              # nothing GPU-related has been imported yet
 
@@ -249,13 +473,15 @@ def main(argv=None) -> int:
 
     dist = None
     if world > 1 or args.dist_path:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
@@ -305,9 +531,11 @@ def main(argv=None) -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
+    _mark("compiled; warm-up")
     for _ in range(args.warmup):
         step()
     fence()
+    _mark("timed region")
     q.kernel_time_stats(reset=True)                   # the engine sums the device time of every launch (HIP events); read once below
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -317,18 +545,58 @@ def main(argv=None) -> int:
     if multi and rank != 0:
         q.finalize()                                  # the other ranks check their device error word once, untimed
     ksum, kn = q.kernel_time_stats()
-    kernel_ms = [ksum / max(1, kn)]
+    avg_kernel_ms = ksum / max(1, kn)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    _mark(f"timed region done: {elapsed / args.steps * 1e3:.4f} ms per step")
+    # ---- where a multi-rank step's time goes: a second, UNTIMED loop of the same steps with an event pair around the merge ----
+    phases = None
+    if multi:
+        probe = max(1, min(args.steps, 20))
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(probe)]
+        fin_ms = 0.0
+        step_ms = 0.0
+        for i in range(probe):
+            fence()
+            ts = time.perf_counter()
+            q.execute_partial_async()
+            ev[i][0].record()
+            merger.merge()
+            ev[i][1].record()
+            if rank == 0:
+                q.finalize()
+                fin_ms += q.report().finalize_time_ms
+            torch.cuda.synchronize()
+            step_ms += (time.perf_counter() - ts) * 1e3
+        if rank != 0:
+            q.finalize()
+        coll = sum(a.elapsed_time(b) for a, b in ev) / probe
+        per_kernel = gather_per_rank(dist, world, avg_kernel_ms, device)
+        per_coll = gather_per_rank(dist, world, coll, device)
+        phases = {"kernel_ms_per_rank": per_kernel, "collective_ms_per_rank": per_coll, "collective_ms": max(per_coll),
+                  "finalize_ms": fin_ms / probe, "isolated_step_ms_rank0": step_ms / probe,
+                  "note": "untimed second loop of the same steps, every step fenced (barrier + synchronize): collective_ms is the "
+                          "event pair around the merge on the step's stream and includes waiting for the slowest rank's kernel"}
+
+    _mark("phases done")
+    # ---- the weak-scaling extra runs on every rank (its collectives need all of them), after the headline measurement ----
+    weak = None
+    weak_error = None
+    if not args.no_extras:
+        try:
+            weak = weak_scaling_extra(args, ctx, dist if (dist is not None and world > 1) else None, world, rank, device)
+        except Exception as e:  # an extra never costs the bench line
+            weak_error = f"{type(e).__name__}: {e}"
+
+    _mark(f"extras done ({weak_error})")
     rc = 0
     if rank == 0:
         result = q.result()
         bytes_per_launch = tpch.Q1_BYTES_PER_ROW * n_rows
         traffic, traffic_source = committed_traffic(bytes_per_launch) if world == 1 else (None, None)
-        avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = bytes_per_launch / (avg_kernel_ms * 1e-3) / 1e9
         # the read-only streaming roofline of THIS box, measured after the timed region with the access form the scan
         # uses (16 B per lane, non-temporal, 2 workgroups per CU): SURVEY.md §8d asks for the fraction against it too
@@ -336,6 +604,16 @@ def main(argv=None) -> int:
             measured = ctx.read_bandwidth(4 << 30, 5)
         except Exception:
             measured = None
+        config = {"workload": f"TPC-H Q1 over lineitem SF{args.sf:g} ({n_total} rows, 7 columns, 38 B/row) "
+                              f"resident in HBM, row-range sharded over {world} GPU(s)",
+                  "rows": n_total, "rows_per_gpu": n_rows, "result_groups": result.n_rows, "path": "dist",
+                  "world_size": dist.get_world_size() if dist is not None else 1,
+                  "backend": (dist.get_backend() + " (RCCL)") if dist is not None else "none (single process, single GPU)",
+                  "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
+                  "parallelism": f"row-range shards x{world}, group-by merge over RCCL: {merger.strategy}"
+                  if multi else "single GPU"}
+        if phases is not None:
+            config["phases"] = phases
         out = {
             "metric": "TPC-H Q1 rows/s at SF10",
             "value": n_total * args.steps / elapsed,
@@ -349,14 +627,7 @@ def main(argv=None) -> int:
             "vs_baseline": None,
             "dtype": "int64",
             "data": "synthetic",
-            "config": {"workload": f"TPC-H Q1 over lineitem SF{args.sf:g} ({n_total} rows, 7 columns, 38 B/row) "
-                                   f"resident in HBM, row-range sharded over {world} GPU(s)",
-                       "rows": n_total, "rows_per_gpu": n_rows, "result_groups": result.n_rows,
-                       "world_size": dist.get_world_size() if dist is not None else 1,
-                       "backend": (dist.get_backend() + " (RCCL)") if dist is not None else "none (single process, single GPU)",
-                       "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
-                       "parallelism": f"row-range shards x{world}, group-by merge over RCCL: {merger.strategy}"
-                       if multi else "single GPU"},
+            "config": config,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "scan+filter+dense aggregation pipeline (rank 0's launches)", "kernel_ms": avg_kernel_ms,
@@ -364,6 +635,11 @@ def main(argv=None) -> int:
                          "measured_read_roofline": measured,
                          "frac_of_measured_read_roofline": (achieved / measured) if measured else None},
         }
+        rc = check_parity(result.text, args.sf, out)
+        if weak is not None or weak_error is not None:
+            out["extras"] = {"weak_scaling": weak if weak is not None else {"error": weak_error},
+                             "weak_scaling_note": "BASELINE config 5: one synthetic 4 x int64 shard per GPU (rows_per_gpu), a < tau at 10 %, "
+                                                  "group by b, 2 sums + count; whole step incl. merge and rank 0's host tail; untimed for `value`"}
         if world == 1 and not args.no_cpu_baseline:
             want_sf = args.cpu_baseline_sf if args.cpu_baseline_sf is not None else args.sf
             try:
@@ -376,6 +652,7 @@ def main(argv=None) -> int:
                     out["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 0, "kind": "reference",
                                            "sample": f"failed: {e2}"}
         print(json.dumps(out), flush=True)
+        _mark("line printed")
 
     q.close()
     table.close()

@@ -850,6 +850,15 @@ static void checkDeviceError(uint32_t err) {
     if (err) failRuntime("device error word " + std::to_string(err));
 }
 
+// An asynchronous step cannot start over (its caller has already enqueued the merge behind it), so it only ever runs plans
+// without join tables (executeQuery refuses the others) and NOTE_BUILD_KEYS_NOT_UNIQUE — "a rank dictionary dropped build rows,
+// go back to the hash form and repeat" — cannot be raised; should it be set all the same, the step fails instead of returning
+// an answer with missing matches.
+static void checkAsyncDeviceError(uint32_t err) {
+    if (err & 64u) failRuntime("internal error: an asynchronous step reported build keys that are not unique (no join tables can run asynchronously)");
+    checkDeviceError(err);
+}
+
 // the dense aggregate table at the start / end of an execution: register-mode kernels work on the padded copy
 static void enqueueTableInit(Query& q) {
     q.fusedReady = false;          // the plain path leaves the working table as the kernels left it
@@ -1451,7 +1460,7 @@ void finalizeQuery(Query& q) {
         q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
         q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
         if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;
-        checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
+        checkAsyncDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
     }
     memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
     runTail(q);
@@ -1472,7 +1481,7 @@ void settleAsync(Query& q) {
     q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
     if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;
-    checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
+    checkAsyncDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
 }
 
 // Results of the same plan over disjoint shards (every group lives in exactly one shard: the caller shards on the group key)

@@ -30,6 +30,7 @@ def _check(rec: dict, world: int, self_launched: bool):
     cfg = rec["config"]
     assert cfg["world_size"] == world and cfg["backend"] == "gloo" and cfg["self_launched"] is self_launched
     assert cfg["merged_ok"] is True and cfg["result_groups"] == 6
+    assert cfg["phases"]["kernel_ms_per_rank"] == [float(r + 1) for r in range(world)]      # per-rank figures arrive in rank order
     shards = cfg["shards"]
     assert shards[0][0] == 0 and sum(n for _, n in shards) == cfg["rows"] == 59_999_996
     for (a0, an), (b0, _) in zip(shards, shards[1:]):
@@ -55,12 +56,30 @@ def test_bench_under_torch_distributed_run():
     _check(_line(pr.stdout), 2, False)
 
 
-def test_a_failing_rank_fails_the_call():
+def test_a_failing_rank_fails_the_call_quickly():
+    """rank 1 dies before the rendezvous; rank 0 would sit in init_process_group until its timeout (120 s) — the launcher watches
+    all ranks, ends rank 0 and returns rank 1's exit code"""
+    import time
     env = _env()
     env["RSQ_BENCH_DRY_FAIL_RANK"] = "1"
+    t0 = time.time()
     pr = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--no-gpu", "--steps", "1", "--warmup", "0"],
                         env=env, capture_output=True, text=True, timeout=240)
-    assert pr.returncode != 0
+    took = time.time() - t0
+    assert pr.returncode == 3, (pr.returncode, pr.stderr[-1000:])
+    assert took < 30, f"the launcher took {took:.0f} s to notice the dead rank"
+    assert "rank 1 exited with code 3" in pr.stderr
+    assert not [l for l in pr.stdout.splitlines() if l.startswith("{")]
+
+
+def test_a_failing_rank_zero_ends_the_others():
+    import time
+    env = _env()
+    env["RSQ_BENCH_DRY_FAIL_RANK"] = "0"
+    t0 = time.time()
+    pr = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--backend", "gloo", "--no-gpu", "--steps", "1", "--warmup", "0"],
+                        env=env, capture_output=True, text=True, timeout=240)
+    assert pr.returncode == 3 and time.time() - t0 < 30
     assert not [l for l in pr.stdout.splitlines() if l.startswith("{")]
 
 

@@ -193,3 +193,26 @@ def test_q3_sf10_sharded_equals_unsharded(gpu_ctx, big):
     merged = merge_ordered_results(None, both, [("revenue", False), ("o_orderdate", True)], 20, 1)
     assert merged.text.splitlines()[:11] == first.text.splitlines()
     cu.close(); od.close()
+
+
+def test_q1_sf10_over_eight_shards_through_the_multi_gpu_c_abi():
+    """BASELINE config 4's split — SF10 lineitem in 8 row-range shards — through rsq_multi_* (one host process; the box has one
+    GPU, so the eight shards share device 0 and merge with peer copies + the merge kernel): the answer is the reference's,
+    byte for byte, and the per-shard kernels are the 1/8-size launches an 8-GPU node runs (~45 us each)."""
+    n = datagen.n_lineitem(SF)
+    m = engine.MultiContext([0] * 8)
+    try:
+        shards = m.generate(engine.GEN_LINEITEM, n, SF)
+        assert [t.n_rows for t in shards] == [shard_rows(n, 8, r)[1] for r in range(8)] and sum(t.n_rows for t in shards) == n
+        q = m.compile(tpch.q1_plan(tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)), [[t] for t in shards])
+        for _ in range(3):
+            q.execute()
+            assert q.result().text == _golden("q1_sf10")
+        rep, per = q.report()
+        assert len(per) == 8 and all(0 < k < 0.45 for k in per), per      # (the eight shards share ONE GPU here: their kernels overlap and wait for each other)
+        assert rep.bytes_read == n * tpch.Q1_BYTES_PER_ROW
+        q.close()
+        for t in shards:
+            t.close()
+    finally:
+        m.close()
