@@ -60,7 +60,16 @@ typedef struct rsq_config {
     int32_t optimize;            /* JitConfig::optimizeFlounder: ignored */
     int32_t device;              /* HIP device ordinal this context drives (one context per GPU / process) */
     const char* kernel_cache_dir;/* directory with pre-built code objects (NULL: <library dir>/../_kcache) */
+    int32_t emission_order;      /* rsq_emission_order: order of an aggregation's rows when the plan does not sort them */
 } rsq_config;
+
+/* Without ORDER BY the reference emits an aggregation's groups in the slot order of its hash table (operators/aggregation.h:
+ * 298-343), which depends on the order the groups first occur in the input, its hash function, prime table sizes and growth rule.
+ * RSQ_EMIT_REFERENCE (0, the default) reproduces that order exactly — the result relation is byte-identical to ReSQL's — at the
+ * price of replaying that table on the host (a few ms per million groups).  RSQ_EMIT_ANY returns the same rows in whatever
+ * order the device tables hold them (the reference's own tests compare such results as multisets, test/test_common.h:152-190);
+ * ORDER BY still sorts them with the reference's quicksort, but rows that tie on all sort keys may then come in another order. */
+enum rsq_emission_order { RSQ_EMIT_REFERENCE = 0, RSQ_EMIT_ANY = 1 };
 
 /* Mirrors JitExecutionReport (reference src/JitContextFlounder.h:114-129), times in ms, plus the
  * GPU-side figures SURVEY.md §8(b) asks for. */
@@ -185,6 +194,11 @@ char* rsq_serialize_expr(rsq_ctx* ctx, const rsq_plan_desc* plan, int32_t expr, 
 /* serializeRelation (reference src/dbdata.h:688-701) of a result view. */
 char* rsq_result_serialize(const rsq_result_view* view);
 void  rsq_free(void* p);
+/* The slot order of the reference's aggregation hash table (allocateHashTable / ht_put / growHashTable, src/qlib/hash.h:225-287,
+ * 330-419) after inserting n groups with the given Values::hash values in this order into a table allocated for min_size
+ * entries: out[k] = index of the group in the k-th occupied slot.  parallel != 0 takes the cluster-parallel replay the engine's
+ * tail uses for many groups, 0 the sequential one; both give the same permutation (tests compare them). */
+int   rsq_ref_emission_order(const uint64_t* hashes, int64_t n, uint64_t min_size, int32_t parallel, uint32_t* out);
 
 /* ---- SQL text in front of the path --------------------------------------
  * The reference turns SQL text into an operator tree with parseSql (src/parser/parseSql.h:130-166:

@@ -294,6 +294,22 @@ char* rsq_result_serialize(const rsq_result_view* view) {
 
 void rsq_free(void* p) { free(p); }
 
+int rsq_ref_emission_order(const uint64_t* hashes, int64_t n, uint64_t min_size, int32_t parallel, uint32_t* out) {
+    if (n < 0 || (n > 0 && (!hashes || !out))) return RSQ_ERR_INVALID;
+    try {
+        if (parallel) {
+            std::vector<uint32_t> order; ReplayScratch scratch;
+            refEmissionOrderParallel(hashes, (size_t)n, min_size, order, scratch);
+            for (int64_t i = 0; i < n; i++) out[i] = order[(size_t)i];
+        } else {
+            std::vector<size_t> order = refEmissionOrder(std::vector<uint64_t>(hashes, hashes + n), min_size);
+            for (int64_t i = 0; i < n; i++) out[i] = (uint32_t)order[(size_t)i];
+        }
+        return RSQ_OK;
+    } catch (const Error& e) { return e.status; }
+    catch (const std::exception&) { return RSQ_ERR_RUNTIME; }
+}
+
 // ---- SQL front end (sqlfront.cpp) ----
 struct rsq_sql_plan { rsq::ExprPool pool; rsq::sql::Statement st; rsq::sql::PlanDesc plan; std::vector<Table*> db; };
 

@@ -112,6 +112,12 @@ uint64_t opSize(OpNode* o) {   // getSize() estimates (reference src/operators/*
 
 Query::~Query() {
     if (bgCompiler.joinable()) bgCompiler.join();
+    destroyTailState(tailState);
+    if (dtArena.dev || dtArena.pinned) {
+        // the arenas go back to the context for the next query, unless it already holds a pair
+        if (!ctx.spareTailArena.dev && !ctx.spareTailArena.pinned) ctx.spareTailArena = dtArena;
+        else { if (dtArena.dev) ctx.free(dtArena.dev); if (dtArena.pinned) (void)hipHostFree(dtArena.pinned); }
+    }
     if (dGenericCode) ctx.free(dGenericCode);
     if (dAgg && dAggOwned) ctx.free(dAgg);
     if (dAggInit) ctx.free(dAggInit);
@@ -870,7 +876,9 @@ static void enqueueTableReadback(Query& q) {
     else RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
 }
 static void tableFromPinned(Query& q) {
+    q.hAggView = nullptr;
     if (q.aggPad > 1) for (size_t i = 0; i < q.tableWords; i++) q.hAgg[i] = q.hPinned[i * (size_t)q.aggPad];
+    else if (q.tableWords >= (1u << 16)) q.hAggView = q.hPinned;      // tens of MB: the tail reads the pinned buffer itself (a copy is 3 ms of one core)
     else memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
 }
 
@@ -912,6 +920,96 @@ static bool fusedEligible(const Query& q) {
     static const bool off = getenv("RSQ_FUSED_STEP") && atoi(getenv("RSQ_FUSED_STEP")) == 0;
     return !off && q.aggMode == AggMode::DENSE_REG && q.pipelines.size() == 1 && q.pipelines[0].sink == SinkKind::AGGREGATE &&
            !q.pipelines[0].partitioned && q.dFinTicket != nullptr;
+}
+
+// ---- the tail of a large dense aggregation on the device (devtail.hip) --------------------------------------------------
+// The aggregate table stays in HBM.  Device: groups present (in group-id order) -> ordered by first row (radix sort) -> the
+// reference's hash of every group -> [8 bytes per group to the host] -> host: slot order of the reference's table (the cluster-
+// parallel replay, hostref.cpp) -> [4 bytes per group back] -> device: packed result tuples in that order -> [the tuples to the
+// host].  rsq_config.emission_order = RSQ_EMIT_ANY skips everything between "present" and "tuples".
+static bool denseDeviceTailWanted(Query& q) {
+    const bool off = getenv("RSQ_DEVICE_TAIL") && atoi(getenv("RSQ_DEVICE_TAIL")) == 0;      // (read per execution: tests switch it)
+    const int64_t minGroups = getenv("RSQ_DEVICE_TAIL_MIN") ? atoll(getenv("RSQ_DEVICE_TAIL_MIN")) : 65536;
+    if (off || q.holdTail || q.aggPad != 1 || q.denseGroups < minGroups || q.denseGroups >= (1ll << 31) || !q.dAgg) return false;
+    if (q.devTail < 0) q.devTail = planDenseDeviceTail(q, q.dtKeys, q.dtCols, q.dtTupleSize, q.dtLimitRows) ? 1 : 0;
+    return q.devTail == 1;
+}
+
+// returns the ms spent behind the first synchronisation (= behind the pipelines' kernels): the tail proper
+static double runDenseDeviceTail(Query& q) {
+    Context& ctx = q.ctx;
+    const int64_t D = q.denseGroups;
+    const bool trace = getenv("RSQ_TRACE") != nullptr;
+    double tPhase = nowMs();
+    auto phase = [&](const char* what) {
+        if (!trace) return;
+        const double t = nowMs();
+        fprintf(stderr, "[rsq trace]     device tail: %.3f ms  %s\n", t - tPhase, what);
+        tPhase = t;
+    };
+    if (!q.dtFlags) {
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        q.dtSortTempBytes = radixSortTempBytes(D);
+        const size_t sz[] = {up((size_t)(D + 1) * 4), up((size_t)(D + 1) * 8), up(scanTempBytes(D + 1)), up((size_t)D * 8), up((size_t)D * 8), up((size_t)D * 4), up((size_t)D * 4),
+                             up(q.dtSortTempBytes), up((size_t)D * 8), up((size_t)D * 4), up((size_t)D * (size_t)q.dtTupleSize)};
+        size_t devBytes = 0; for (size_t b : sz) devBytes += b;
+        const size_t psz[] = {up((size_t)D * 8), up((size_t)D * 4), up(std::max<size_t>((size_t)D * (size_t)q.dtTupleSize, 8))};
+        size_t pinBytes = 0; for (size_t b : psz) pinBytes += b;
+        Context::TailArena& spare = ctx.spareTailArena;
+        if (spare.dev && spare.devBytes >= devBytes && spare.pinnedBytes >= pinBytes) { q.dtArena = spare; spare = Context::TailArena(); }
+        else {
+            q.dtArena.dev = ctx.alloc(devBytes); q.dtArena.devBytes = devBytes;
+            RSQ_HIP(hipHostMalloc(&q.dtArena.pinned, pinBytes, hipHostMallocDefault)); q.dtArena.pinnedBytes = pinBytes;
+        }
+        char* d = (char*)q.dtArena.dev; size_t at = 0; int k = 0;
+        auto take = [&]() { void* r = d + at; at += sz[k++]; return r; };
+        q.dtFlags = (uint32_t*)take(); q.dtOffs = (uint64_t*)take(); q.dtScanTemp = take();
+        q.dtFirst[0] = (uint64_t*)take(); q.dtFirst[1] = (uint64_t*)take(); q.dtGid[0] = (uint32_t*)take(); q.dtGid[1] = (uint32_t*)take();
+        q.dtSortTemp = take(); q.dtHashes = (uint64_t*)take(); q.dtOrder = (uint32_t*)take(); q.dtRows = (uint8_t*)take();
+        char* h = (char*)q.dtArena.pinned;
+        q.hDtHashes = (uint64_t*)h; q.hDtOrder = (uint32_t*)(h + psz[0]); q.resultPinned = (uint8_t*)(h + psz[0] + psz[1]);
+    }
+    densePresentGroups(ctx, (const int64_t*)(q.dAgg + (size_t)q.accumSlot[0] * (size_t)D), D, q.dtFlags, q.dtOffs, q.dtScanTemp, q.dtFirst[0], q.dtGid[0]);
+    uint64_t nPresent = 0;
+    RSQ_HIP(hipMemcpyAsync(&nPresent, q.dtOffs + D, 8, hipMemcpyDeviceToHost, ctx.stream));
+    RSQ_HIP(hipMemcpyAsync(q.hPinned + q.pinnedWords, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+    waitForStream(ctx);                                    // (this is also where the pipelines' kernels are waited for)
+    q.report.num_kernels += 5;
+    const double tTail0 = nowMs();
+    phase("pipelines done; groups present");
+    const int64_t n = (int64_t)nPresent;
+    int64_t emit = n;
+    if (q.dtLimitRows >= 0) emit = std::min(emit, q.dtLimitRows);
+    const uint32_t* dGids = q.dtGid[0];
+    const uint32_t* dOrder = nullptr;
+    if (ctx.cfg.emission_order != RSQ_EMIT_ANY && n > 1) {
+        // first rows are row numbers of the scanned table: the bits they can use
+        int64_t maxRow = 1;
+        for (auto& p : q.pipelines) if (p.sink == SinkKind::AGGREGATE) maxRow = std::max<int64_t>(maxRow, p.src->row0 + p.src->nRows);
+        int bits = 1; while (bits < 63 && (maxRow >> bits) != 0) bits++;
+        const bool inB = radixSortPairs(ctx, q.dtFirst[0], q.dtGid[0], q.dtFirst[1], q.dtGid[1], n, bits, q.dtSortTemp, q.dtSortTempBytes);
+        dGids = inB ? q.dtGid[1] : q.dtGid[0];
+        denseGroupHashes(ctx, dGids, n, q.dtKeys, q.dtHashes);
+        RSQ_HIP(hipMemcpyAsync(q.hDtHashes, q.dtHashes, (size_t)n * 8, hipMemcpyDeviceToHost, ctx.stream));
+        waitForStream(ctx);
+        q.report.num_kernels += (uint64_t)((bits + 7) / 8) * 5 + 1;
+        phase("groups ordered by first row, hashed (device), hashes read back");
+        std::vector<uint32_t>& order = ctx.replayOrder;
+        refEmissionOrderParallel(q.hDtHashes, (size_t)n, opSize(q.agg), order, ctx.replayScratch);
+        memcpy(q.hDtOrder, order.data(), (size_t)emit * 4);
+        phase("replay of the reference's hash table (host, probe clusters in parallel)");
+        RSQ_HIP(hipMemcpyAsync(q.dtOrder, q.hDtOrder, (size_t)emit * 4, hipMemcpyHostToDevice, ctx.stream));
+        dOrder = q.dtOrder;
+    }
+    denseResultRows(ctx, q.dAgg, D, dGids, dOrder, emit, q.dtKeys, q.dtCols, q.dtTupleSize, q.dtRows);
+    if (emit > 0) RSQ_HIP(hipMemcpyAsync(q.resultPinned, q.dtRows, (size_t)emit * (size_t)q.dtTupleSize, hipMemcpyDeviceToHost, ctx.stream));
+    RSQ_HIP(hipMemcpyAsync(q.hPinned + q.pinnedWords, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+    waitForStream(ctx);
+    q.report.num_kernels += 1;
+    phase("packed tuples (device), read back");
+    q.resultRows = emit;
+    q.resultInPinned = true;
+    return nowMs() - tTail0;
 }
 
 // a shard of a multi-GPU plan that does not end in a dense partial table runs its pipelines and reads the group rows (or the
@@ -961,6 +1059,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             checkDeviceError((uint32_t)q.hPinned[words]);
             if (!partialOnly) {
                 double t1 = nowMs();
+                q.hAggView = nullptr;
                 memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
                 tailUnlessHeld(q);
                 q.report.finalize_time_ms = nowMs() - t1;
@@ -1087,6 +1186,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
         if (!partialOnly) {
             double t1 = nowMs();
+            q.hAggView = nullptr;
             memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
             tailUnlessHeld(q);
             q.report.finalize_time_ms = nowMs() - t1;
@@ -1290,6 +1390,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
     }
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+    bool devTail = false;                   // the rows of a large dense aggregation are made on the device (runDenseDeviceTail)
     {
         const bool wantGroups = !partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH || denseTopk);
         if (q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0)) {
@@ -1302,7 +1403,8 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (anyCompaction) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 8, q.dPipeStats, q.pipelines.size() * 8, hipMemcpyDeviceToHost, ctx.stream));
             if (topkCapacity) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 2, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         }
-        if (!partialOnly && denseMode(q) && !denseTopk) enqueueTableReadback(q);
+        devTail = !partialOnly && !async && denseMode(q) && !denseTopk && denseDeviceTailWanted(q);
+        if (!partialOnly && denseMode(q) && !denseTopk && !devTail) enqueueTableReadback(q);
         if (topkCapacity) RSQ_HIP(hipMemcpyAsync(q.hGroupRows, q.dCandRows, (size_t)topkSpec * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost, ctx.stream));
     }
     if (async && partialOnly) {
@@ -1381,6 +1483,12 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             q.report.execution_time_ms = nowMs() - t0;
             return;
         }
+        if (devTail) {
+            q.report.finalize_time_ms = runDenseDeviceTail(q);
+            checkDeviceError((uint32_t)q.hPinned[words]);
+            q.report.execution_time_ms = nowMs() - t0;
+            return;
+        }
         if (denseMode(q)) tableFromPinned(q);
         else if (q.matOp && !q.agg) {
             q.hMatCols.resize(q.matSchema.size());
@@ -1431,6 +1539,8 @@ void finalizeQuery(Query& q) {
     if (!denseMode(q)) failUnsupported("partial execution / finalize is available for dense aggregations only");
     RSQ_HIP(hipSetDevice(ctx.device));
     double t1 = nowMs();
+    const bool devTail = !q.mergePublishedSeq && denseDeviceTailWanted(q);
+    double devTailMs = 0;
     if (q.mergePublishedSeq) {
         // the merge kernel stored the merged table into host-mapped memory: watch for its sequence number (see the fused step)
         const uint64_t seq = q.mergePublishedSeq;
@@ -1448,6 +1558,8 @@ void finalizeQuery(Query& q) {
         }
         if (*flag != seq) failRuntime("internal error: the merge kernel finished without publishing its table");
         std::atomic_thread_fence(std::memory_order_acquire);
+    } else if (devTail) {
+        devTailMs = runDenseDeviceTail(q);          // (waits for the step's kernels and its merge first)
     } else {
         RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, ctx.stream));
         waitForStream(ctx);
@@ -1462,7 +1574,10 @@ void finalizeQuery(Query& q) {
         if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;
         checkAsyncDeviceError((uint32_t)q.hPinned[q.pinnedWords]);
     }
-    memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
+    if (devTail) { checkDeviceError((uint32_t)q.hPinned[q.pinnedWords]); q.report.finalize_time_ms = devTailMs; return; }
+    t1 = nowMs();          // (the wait for the step's kernels and its merge is not the host tail)
+    if (q.tableWords >= (1u << 16)) q.hAggView = q.hPinned;      // (see tableFromPinned)
+    else { q.hAggView = nullptr; memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8); }
     runTail(q);
     q.report.finalize_time_ms = nowMs() - t1;
 }
@@ -1570,6 +1685,7 @@ void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords) {
     size_t need = q.accums.size() * (size_t)q.denseGroups;
     if (nWords != need) failInvalid("partial table has " + std::to_string(nWords) + " words, expected " + std::to_string(need));
     q.hAgg.assign((const uint64_t*)words, (const uint64_t*)words + nWords);
+    q.hAggView = nullptr;
     runTail(q);
 }
 
@@ -1623,7 +1739,7 @@ void queryResult(Query& q, rsq_result_view* out) {
     out->offsets = q.rvOffsets.data();
     out->tuple_size = off;
     out->n_rows = q.resultRows;
-    out->tuples = q.resultTuples.data();
+    out->tuples = q.resultInPinned ? q.resultPinned : q.resultTuples.data();
 }
 
 void queryReport(const Query& q, rsq_report* out) {

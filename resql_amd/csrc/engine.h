@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "expr.h"
+#include "hostref.h"
 #include "resql_hip.h"
 
 #define RSQ_RANK_CHUNK_BLOCKS 1024       /* 32-byte bitmap blocks one workgroup of the rank index handles (aot_kernels.hip) */
@@ -96,6 +97,14 @@ struct Context {
     void* scratchAlloc(size_t bytes);
     void scratchFree(void* p);
     std::vector<std::pair<void*, size_t>> scratchFreeList, scratchLive;
+    // The device tail of a large dense aggregation (engine.cpp runDenseDeviceTail) works in one device arena and one pinned host
+    // arena per query, tens of MB each.  A query gives its arenas back when it is destroyed and the next one takes them: a host
+    // that runs shard after shard (or statement after statement) pays hipMalloc / hipHostMalloc once, not per query.  The host
+    // side of the replay (hostref.h) keeps its scratch here for the same reason (fresh pages cost more than the work in them).
+    struct TailArena { void* dev = nullptr; size_t devBytes = 0; void* pinned = nullptr; size_t pinnedBytes = 0; };
+    TailArena spareTailArena;
+    ReplayScratch replayScratch;
+    std::vector<uint32_t> replayOrder;
 };
 
 // launch helper: kernel takes one struct of 8-byte slots by value
@@ -154,6 +163,20 @@ void prepareTopCandidatesRange(Context& ctx, void* scratch);
 size_t topkRangeScratchBytes();      // the part of the scratch prepareTopCandidatesRange zeroes (an execution may fold it into its batched fill)
 void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                               uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* cand, uint32_t capacity);
+
+// devtail.hip: the tail of a large dense aggregation on the device (present groups, order by first row, the reference's hashes,
+// packed result tuples); tail.cpp planDenseDeviceTail says whether a plan qualifies and describes keys and columns
+struct DenseTailKey { int64_t min, card, stride; int32_t byteSet, typeTag; uint8_t values[32]; };
+struct DenseTailKeys { int32_t n; DenseTailKey k[4]; };
+struct DenseTailCol { int32_t kind, a, b, width, offset; };      // kind 0: group value of key a; 1: table block a; 2: AVG = block a * 100 / block b
+struct DenseTailCols { int32_t n; DenseTailCol c[24]; };
+void densePresentGroups(Context& ctx, const int64_t* firstBlock, int64_t D, uint32_t* flags /* [D + 1] */, uint64_t* offs /* [D + 1], offs[D] = count */,
+                        void* scanTemp /* scanTempBytes(D + 1) */, uint64_t* outFirst, uint32_t* outGid);
+size_t radixSortTempBytes(int64_t n);
+bool radixSortPairs(Context& ctx, uint64_t* keysA, uint32_t* valsA, uint64_t* keysB, uint32_t* valsB, int64_t n, int keyBits, void* temp, size_t tempBytes);
+void denseGroupHashes(Context& ctx, const uint32_t* gids, int64_t n, const DenseTailKeys& keys, uint64_t* hashes);
+void denseResultRows(Context& ctx, const uint64_t* table, int64_t D, const uint32_t* gids, const uint32_t* order, int64_t nRows, const DenseTailKeys& keys,
+                     const DenseTailCols& cols, int tupleSize, uint8_t* out);
 
 // tbl.cpp: '.tbl' text -> columns with the reference's BULK INSERT semantics (execute.h:332-388)
 void parseTblFile(const std::string& path, const std::vector<Type>& types, char terminator, int nThreads,

@@ -177,6 +177,9 @@ struct Pipeline {
     std::string explain;
 };
 
+struct TailState;
+void destroyTailState(TailState* t);
+
 struct Query {
     Context& ctx;
     ExprPool pool;
@@ -212,6 +215,8 @@ struct Query {
     uint64_t* hPinned = nullptr;           // pinned read-back: aggregate words + error word
     size_t pinnedWords = 0;
     std::vector<uint64_t> hAgg;
+    const uint64_t* hAggView = nullptr;    // where the tail reads the dense table: hAgg, or straight from the pinned read-back buffer (large unpadded tables)
+    struct TailState* tailState = nullptr; // tail.cpp: group arrays and scratch kept between executions
 
     // partitioned aggregation buffers
     uint32_t* dPartCounts = nullptr;       // [workgroups][P] counts, turned into offsets in place
@@ -273,6 +278,18 @@ struct Query {
     bool charGroupsNeedMerge = false;
     bool topkNeedsNoMerge = false;         // the candidate pre-selection is valid only while no merge is needed
 
+    // the tail of a large dense aggregation on the device (engine.cpp runDenseDeviceTail): buffers sized for all D groups
+    int devTail = -1;                      // -1 not analysed yet, 0 no, 1 yes
+    DenseTailKeys dtKeys{}; DenseTailCols dtCols{}; int dtTupleSize = 0; int64_t dtLimitRows = -1;
+    Context::TailArena dtArena;            // everything below is carved out of it
+    uint32_t* dtFlags = nullptr; uint64_t* dtOffs = nullptr; void* dtScanTemp = nullptr;
+    uint64_t* dtFirst[2] = {nullptr, nullptr}; uint32_t* dtGid[2] = {nullptr, nullptr};
+    void* dtSortTemp = nullptr; size_t dtSortTempBytes = 0;
+    uint64_t* dtHashes = nullptr; uint32_t* dtOrder = nullptr; uint8_t* dtRows = nullptr;
+    uint64_t* hDtHashes = nullptr; uint32_t* hDtOrder = nullptr;      // pinned
+    uint8_t* resultPinned = nullptr;       // pinned copy of the result tuples (device tail)
+    bool resultInPinned = false;
+
     // result
     Schema resultSchema;
     std::vector<uint8_t> resultTuples;
@@ -328,6 +345,11 @@ void buildPipelines(Query& q);
 
 // tail.cpp: aggregate table / group rows -> result relation (AVG, projection, materialize, order by, limit)
 void runTail(Query& q);
+// tail.cpp: the tail's buffers that live as long as the query (see TailState)
+std::vector<uint32_t>& tailOrderBuffer(Query& q);
+ReplayScratch& tailReplayScratch(Query& q);
+// tail.cpp: can the rows of this dense aggregation be produced on the device (devtail.hip)?  fills the kernels' descriptions
+bool planDenseDeviceTail(Query& q, DenseTailKeys& keys, DenseTailCols& cols, int& tupleSize, int64_t& limitRows);
 // tail.cpp: is the first ORDER BY key of an `ORDER BY ... LIMIT k` above the aggregation one word of the group rows?
 void planDeviceTopK(Query& q);
 

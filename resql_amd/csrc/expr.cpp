@@ -188,6 +188,10 @@ std::vector<Expr*> ExprPool::build(const rsq_plan_desc& p) {
             int ci = d.child[k];
             if (ci < 0 || ci >= p.n_exprs || ci == i) failInvalid("bad child index in expression " + std::to_string(i));
             Expr* ch = v[ci];
+            // children are chained through their `next` pointers (expressions.h:83-96): one node twice below a parent would chain
+            // it to itself and every walk over the children would never end (the reference's ExprGen cannot build such a tree
+            // either: its binary constructors link two distinct nodes)
+            for (int j = 0; j < k; j++) if (d.child[j] == ci) failInvalid("expression " + std::to_string(i) + " has the same child twice: copy the node (ExprGen::copy)");
             if (k == 0) v[i]->child = ch;
             else {
                 if (prev->next && prev->next != ch) failInvalid("expression node shared as child with different right siblings");
@@ -197,6 +201,12 @@ std::vector<Expr*> ExprPool::build(const rsq_plan_desc& p) {
         }
         if (v[i]->structure == UNARY && d.n_children != 1) failInvalid("unary expression needs one child");
         if (v[i]->structure == BINARY && d.n_children != 2) failInvalid("binary expression needs two children");
+    }
+    // nodes shared between parents may still close a ring of siblings (a below x as [a, b], below y as [b, a]): no chain may be
+    // longer than the plan has expressions
+    for (int i = 0; i < p.n_exprs; i++) {
+        int steps = 0;
+        for (Expr* e = v[i]; e; e = e->next) if (++steps > p.n_exprs) failInvalid("expression nodes shared between parents form a ring of siblings");
     }
     return v;
 }

@@ -1,8 +1,12 @@
 // hostref.cpp — see hostref.h.
 #include <cstring>
 #include "hostref.h"
+#include "hostpar.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 
 namespace rsq {
@@ -153,6 +157,228 @@ std::vector<size_t> refEmissionOrder(const std::vector<uint64_t>& hashes, uint64
     order.reserve(hashes.size());
     for (auto& kv : sim.slots) order.push_back(kv.second.second);
     return order;
+}
+
+// ---- the same replay, cut into its independent probe clusters ------------------------------------------------------
+// Linear probing with first-come-first-served inserts: WHICH slots end up occupied does not depend on the insertion order
+// (slot s is occupied iff carry(s) + home-count(s) > 0 with carry(s+1) = max(0, carry(s) + count(s) - 1)), and an empty slot
+// is a wall no probe sequence crosses.  So the table falls into clusters — maximal runs of occupied slots — that can be
+// replayed independently, each in the order of its items' timestamps.  One level of the reference's table (between two
+// growths) is then: bucket the items by slot chunk, counting-sort every chunk by home slot (cache-sized), reduce every
+// chunk to its carry function x -> max(A, x + B) and chain those (the only sequential step: one multiply-free pass over a
+// few hundred chunk summaries; the cyclic carry into slot 0 is the fixed point A of the whole chain since fewer items than
+// slots make B negative), then walk the chunks in parallel and replay every cluster where it starts.  Growth (a full rehash
+// in slot order of the old table, qlib/hash.h:330-365) makes the next level's timestamps: old entries by their old slot,
+// newer groups behind them in input order.  A million groups: 55 ms as a sequential replay on one core of the GPU box
+// (the table is far larger than the caches and every insert is a dependent miss), a few ms this way.
+namespace {
+
+struct ReplayLevel {
+    uint64_t N = 0;
+    size_t cnt = 0;
+    static constexpr uint64_t CHUNK_BITS = 12, CHUNK = 1ull << CHUNK_BITS;
+};
+
+// items [0, cnt) with hashes h[] and timestamps ts[] into a table of N slots: slotWho[s] = item in slot s or EMPTY
+void replayLevelByClusters(const uint64_t* h, const uint64_t* ts, size_t cnt, uint64_t N, ReplayScratch& S) {
+    constexpr uint32_t EMPTY = 0xffffffffu;
+    constexpr uint64_t CB = ReplayLevel::CHUNK_BITS, CH = ReplayLevel::CHUNK;
+    const size_t nChunks = (size_t)((N + CH - 1) >> CB);
+    const int parts = partsFor(std::max<size_t>(cnt, (size_t)N / 4));
+    if (S.slotWho.size() < N) S.slotWho.resize(N);
+    if (S.start.size() < N + 1) S.start.resize(N + 1);
+    if (S.byChunk.size() < cnt) { S.byChunk.resize(cnt); S.sorted.resize(cnt); }
+    S.chunkStart.assign(nChunks + 1, 0);
+    S.chunkA.assign(nChunks, 0); S.chunkB.assign(nChunks, 0); S.chunkIn.assign(nChunks + 1, 0);
+    const uint64_t magic = (uint64_t)((((__uint128_t)1) << 64) / N);
+    auto mod = [&](uint64_t x) { uint64_t q = (uint64_t)(((__uint128_t)x * magic) >> 64); uint64_t r = x - q * N; while (r >= N) r -= N; return r; };
+    static const bool traceReplay = getenv("RSQ_TRACE_REPLAY") != nullptr;
+    auto nowUs = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tStep = traceReplay ? nowUs() : 0;
+    auto step = [&](const char* what) {
+        if (!traceReplay) return;
+        const double t = nowUs();
+        fprintf(stderr, "[rsq replay]   N=%llu items=%zu  %8.0f us  %s\n", (unsigned long long)N, cnt, t - tStep, what);
+        tStep = t;
+    };
+    // (1) items -> chunk buckets: (home << 32 | item), stable within a bucket is not needed (timestamps order a cluster's items)
+    std::vector<size_t>& hist = S.hist;
+    hist.assign((size_t)parts * nChunks, 0);
+    parallelRanges(cnt, parts, [&](size_t b, size_t e, int p) {
+        size_t* hc = hist.data() + (size_t)p * nChunks;
+        for (size_t i = b; i < e; i++) { const uint64_t home = mod(h[i]); S.byChunk[i] = (home << 32) | (uint64_t)i; hc[home >> CB]++; }
+    });
+    {
+        size_t pos = 0;
+        for (size_t c = 0; c < nChunks; c++) {
+            S.chunkStart[c] = pos;
+            for (int p = 0; p < parts; p++) { size_t k = hist[(size_t)p * nChunks + c]; hist[(size_t)p * nChunks + c] = pos; pos += k; }
+        }
+        S.chunkStart[nChunks] = pos;
+    }
+    uint64_t* bucketed = S.sorted.data();          // first use of `sorted`: the bucketed pairs; the per-chunk sort writes back into byChunk
+    parallelRanges(cnt, parts, [&](size_t b, size_t e, int p) {
+        size_t* hc = hist.data() + (size_t)p * nChunks;
+        for (size_t i = b; i < e; i++) { const uint64_t v = S.byChunk[i]; bucketed[hc[v >> (32 + CB)]++] = v; }
+    });
+    step("items bucketed by slot chunk");
+    // (2) every chunk: counting sort by home slot, start[] offsets, carry summary
+    uint64_t* sorted = S.byChunk.data();
+    const int cparts = (int)std::min<size_t>((size_t)hostThreads(), std::max<size_t>(1, nChunks / 4));
+    parallelRanges(nChunks, cparts, [&](size_t cb, size_t ce, int) {
+        std::vector<uint32_t> local(CH + 1);
+        for (size_t c = cb; c < ce; c++) {
+            const uint64_t s0 = (uint64_t)c << CB, s1 = std::min<uint64_t>(N, s0 + CH);
+            const size_t ib = S.chunkStart[c], ie = S.chunkStart[c + 1];
+            std::fill(local.begin(), local.end(), 0u);
+            for (size_t i = ib; i < ie; i++) local[(size_t)((bucketed[i] >> 32) - s0) + 1]++;
+            int64_t A = 0, B = 0;                   // x -> max(A, x + B) of the slots so far
+            for (uint64_t s = s0; s < s1; s++) {
+                const int64_t k = (int64_t)local[(size_t)(s - s0) + 1] - 1;
+                A = std::max<int64_t>(0, A + k); B += k;
+            }
+            S.chunkA[c] = A; S.chunkB[c] = B;
+            uint32_t run = (uint32_t)ib;
+            for (uint64_t s = s0; s < s1; s++) { const uint32_t k = local[(size_t)(s - s0) + 1]; local[(size_t)(s - s0)] = run; S.start[s] = run; run += k; }
+            for (size_t i = ib; i < ie; i++) { const uint64_t v = bucketed[i]; sorted[local[(size_t)((v >> 32) - s0)]++] = v; }
+        }
+    });
+    S.start[N] = (uint32_t)cnt;
+    step("chunks sorted by home slot");
+    // (3) the carry into every chunk: the cyclic carry into slot 0 is the fixed point of the whole chain
+    {
+        int64_t A = 0;
+        for (size_t c = 0; c < nChunks; c++) A = std::max(S.chunkA[c], A + S.chunkB[c]);
+        int64_t x = A;                               // F(A) = max(A, A + B) = A because B = items - slots < 0
+        for (size_t c = 0; c < nChunks; c++) { S.chunkIn[c] = x; x = std::max(S.chunkA[c], x + S.chunkB[c]); }
+    }
+    step("carries chained");
+    // (4) walk the chunks: empty slots, slots of clusters begun earlier, clusters that begin here (replayed by timestamp)
+    uint32_t* who = S.slotWho.data();
+    const uint32_t* start = S.start.data();
+    auto count = [&](uint64_t s) { return (int64_t)(start[s + 1] - start[s]); };
+    parallelRanges(nChunks, cparts, [&](size_t cb, size_t ce, int) {
+        struct Item { uint64_t ts; uint32_t off; uint32_t item; };
+        std::vector<Item> items;
+        std::vector<uint32_t> occ;
+        for (size_t c = cb; c < ce; c++) {
+            const uint64_t s0 = (uint64_t)c << CB, s1 = std::min<uint64_t>(N, s0 + CH);
+            int64_t x = S.chunkIn[c];
+            uint64_t s = s0;
+            while (s < s1) {
+                const int64_t k = count(s);
+                if (x > 0) { x += k - 1; s++; continue; }
+                if (k == 0) { who[s] = EMPTY; s++; continue; }
+                // a cluster begins at s: it ends at the first slot where as many items have their home in [s, e] as there are slots
+                uint64_t e = s, ew = s; int64_t tot = 0;                  // ew = e modulo N (clusters may run around the table's end)
+                for (;;) { tot += count(ew); if (tot == (int64_t)(e - s + 1)) break; e++; if (++ew == N) ew = 0; }
+                const size_t len = (size_t)(e - s + 1);
+                if (len == 1) { who[s] = (uint32_t)sorted[start[s]]; s = e + 1; continue; }
+                if (len <= 24) {
+                    // the common case: a handful of items — insertion sort by timestamp in registers / stack, no allocation
+                    Item small[24]; uint32_t occS[24];
+                    size_t k = 0;
+                    uint64_t slot = s;
+                    for (uint64_t t = s; t <= e; t++) {
+                        for (uint32_t i = start[slot]; i < start[slot + 1]; i++) {
+                            const uint32_t it = (uint32_t)sorted[i];
+                            const Item x{ts[it], (uint32_t)(t - s), it};
+                            size_t j = k++;
+                            while (j > 0 && small[j - 1].ts > x.ts) { small[j] = small[j - 1]; j--; }
+                            small[j] = x;
+                        }
+                        if (++slot == N) slot = 0;
+                    }
+                    for (size_t j = 0; j < len; j++) occS[j] = EMPTY;
+                    for (size_t i = 0; i < k; i++) { size_t j = small[i].off; while (occS[j] != EMPTY) j++; occS[j] = small[i].item; }
+                    slot = s;
+                    for (size_t j = 0; j < len; j++) { who[slot] = occS[j]; if (++slot == N) slot = 0; }
+                    s = e + 1;
+                    continue;
+                }
+                items.clear();
+                {
+                    uint64_t slot = s;
+                    for (uint64_t t = s; t <= e; t++) {
+                        for (uint32_t i = start[slot]; i < start[slot + 1]; i++) { const uint32_t it = (uint32_t)sorted[i]; items.push_back({ts[it], (uint32_t)(t - s), it}); }
+                        if (++slot == N) slot = 0;
+                    }
+                }
+                std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.ts < b.ts; });
+                occ.assign(len, EMPTY);
+                for (const Item& it : items) { size_t j = it.off; while (occ[j] != EMPTY) j++; occ[j] = it.item; }
+                { uint64_t slot = s; for (size_t j = 0; j < len; j++) { who[slot] = occ[j]; if (++slot == N) slot = 0; } }
+                s = e + 1;                           // (the carry behind a cluster is 0 by construction)
+            }
+        }
+    });
+    step("clusters replayed");
+}
+
+}  // namespace
+
+void refEmissionOrderParallel(const uint64_t* hashes, size_t n, uint64_t minSize, std::vector<uint32_t>& order, ReplayScratch& S) {
+    constexpr uint32_t EMPTY = 0xffffffffu;
+    order.resize(n);
+    if (n == 0) return;
+    uint64_t N = primeAbove(minSize);
+    bool fallback = n < 8192 || n >= 0xfffffff0ull;
+    // the level sizes of the reference's counter (DenseSim::put above: the insert that triggers a growth is not counted again)
+    if (!fallback) {
+        uint64_t c = 0, live = 0, M = N;
+        for (;;) {
+            const uint64_t th = M * 6 / 10;
+            if (th < c || M >= (1ull << 32)) { fallback = true; break; }
+            const uint64_t atGrowth = live + (th - c);
+            if (n <= atGrowth) break;
+            c = atGrowth; live = atGrowth + 1; M = primeAbove(M + 1);
+        }
+    }
+    if (fallback) {
+        std::vector<uint64_t> hv(hashes, hashes + n);
+        std::vector<size_t> o = refEmissionOrder(hv, minSize);
+        for (size_t i = 0; i < n; i++) order[i] = (uint32_t)o[i];
+        return;
+    }
+    if (S.ts.size() < n) S.ts.resize(n);
+    uint64_t* ts = S.ts.data();
+    parallelRanges(n, partsFor(n), [&](size_t b, size_t e, int) { for (size_t i = b; i < e; i++) ts[i] = (uint64_t)i; });
+    uint64_t c = 0, live = 0;
+    for (;;) {
+        const uint64_t th = N * 6 / 10;
+        const uint64_t atGrowth = live + (th - c);
+        const size_t cnt = (size_t)std::min<uint64_t>(n, atGrowth);
+        replayLevelByClusters(hashes, ts, cnt, N, S);
+        const uint32_t* who = S.slotWho.data();
+        if (n <= atGrowth) {
+            // final table: the items in slot order
+            constexpr uint64_t CH = ReplayLevel::CHUNK;
+            const size_t nChunks = (size_t)((N + CH - 1) / CH);
+            const int parts = (int)std::min<size_t>((size_t)hostThreads(), std::max<size_t>(1, nChunks / 4));
+            std::vector<size_t> occupied(nChunks + 1, 0);
+            parallelRanges(nChunks, parts, [&](size_t cb, size_t ce, int) {
+                for (size_t ch = cb; ch < ce; ch++) {
+                    size_t k = 0;
+                    for (uint64_t s = ch * CH, s1 = std::min<uint64_t>(N, s + CH); s < s1; s++) k += who[s] != EMPTY;
+                    occupied[ch + 1] = k;
+                }
+            });
+            for (size_t ch = 0; ch < nChunks; ch++) occupied[ch + 1] += occupied[ch];
+            if (occupied[nChunks] != n) failRuntime("internal error: the replayed hash table holds a different number of groups");
+            parallelRanges(nChunks, parts, [&](size_t cb, size_t ce, int) {
+                for (size_t ch = cb; ch < ce; ch++) {
+                    size_t o = occupied[ch];
+                    for (uint64_t s = ch * CH, s1 = std::min<uint64_t>(N, s + CH); s < s1; s++) if (who[s] != EMPTY) order[o++] = who[s];
+                }
+            });
+            return;
+        }
+        // growth: the old table's entries re-enter in slot order, the groups behind them in input order
+        parallelRanges((size_t)N, partsFor((size_t)N), [&](size_t b, size_t e, int) { for (size_t s = b; s < e; s++) if (who[s] != EMPTY) ts[who[s]] = (uint64_t)s; });
+        parallelRanges(n - cnt, partsFor(n - cnt), [&](size_t b, size_t e, int) { for (size_t i = b; i < e; i++) ts[cnt + i] = N + (uint64_t)(cnt + i); });
+        c = atGrowth; live = atGrowth + 1;
+        N = primeAbove(N + 1);
+    }
 }
 
 void storeValue(uint8_t* addr, Val v, const Type& t) {

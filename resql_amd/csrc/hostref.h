@@ -27,6 +27,17 @@ uint64_t refHashValue(uint64_t h, Val v, const Type& t);
 // every slot in ascending slot order, the index into `hashes` of the group stored there.
 std::vector<size_t> refEmissionOrder(const std::vector<uint64_t>& hashes, uint64_t minSize);
 
+// The same slot order computed on the host's worker pool (hostpar.h): the table is cut into its independent probe clusters
+// (hostref.cpp explains).  hashes[i] in insertion order; order[k] = index into hashes of the group in the k-th occupied slot.
+// The scratch buffers are grown as needed; keep them between calls (a query's executions) to avoid fresh pages every time.
+struct ReplayScratch {
+    std::vector<uint64_t> ts, byChunk, sorted;
+    std::vector<uint32_t> start, slotWho;
+    std::vector<size_t> chunkStart, hist;
+    std::vector<int64_t> chunkA, chunkB, chunkIn;
+};
+void refEmissionOrderParallel(const uint64_t* hashes, size_t n, uint64_t minSize, std::vector<uint32_t>& order, ReplayScratch& scratch);
+
 // Quicksorter (reference src/qlib/sort.h:21-173): Lomuto partition, pivot = last element, over
 // packed tuples.
 struct OrderRequest { int offset; Type type; bool asc; };

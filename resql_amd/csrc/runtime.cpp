@@ -66,6 +66,8 @@ Context::~Context() {
     if (device >= 0) {
         (void)hipSetDevice(device);
         for (auto& kv : kernels) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
+        if (spareTailArena.dev) (void)hipFree(spareTailArena.dev);
+        if (spareTailArena.pinned) (void)hipHostFree(spareTailArena.pinned);
         for (auto& e : scratchFreeList) (void)hipFree(e.first);
         for (auto& e : scratchLive) (void)hipFree(e.first);
         if (dErr) (void)hipFree(dErr);

@@ -11,31 +11,14 @@
 #include <thread>
 
 #include "engine_internal.h"
+#include "hostpar.h"
 
 namespace rsq {
 
-// Run fn(begin, end, part) over [0, n) on up to 16 host threads; small ranges stay on the calling thread.
+// fn(begin, end, part) over [0, n) on the host's worker pool (hostpar.h); small ranges stay on the calling thread.
 // An exception in any part (e.g. a division by zero in a projection) is re-thrown on the calling thread.
-static int tailThreads(size_t n) {
-    if (n < 32768) return 1;
-    unsigned hw = std::thread::hardware_concurrency();
-    unsigned want = (unsigned)std::min<size_t>(16, n / 16384);      // starting a thread costs about as much as 16 K rows
-    return (int)std::max(1u, std::min(want, hw ? hw : 1u));
-}
-static void parallelFor(size_t n, int parts, const std::function<void(size_t, size_t, int)>& fn) {
-    if (parts <= 1) { fn(0, n, 0); return; }
-    std::vector<std::thread> th;
-    std::vector<std::exception_ptr> errs((size_t)parts);
-    const size_t per = (n + (size_t)parts - 1) / (size_t)parts;
-    for (int p = 0; p < parts; p++) {
-        size_t b = std::min(n, per * (size_t)p), e = std::min(n, b + per);
-        th.emplace_back([&fn, &errs, b, e, p] {
-            try { fn(b, e, p); } catch (...) { errs[(size_t)p] = std::current_exception(); }
-        });
-    }
-    for (auto& t : th) t.join();
-    for (auto& e : errs) if (e) std::rethrow_exception(e);
-}
+static int tailThreads(size_t n) { return partsFor(n); }
+static void parallelFor(size_t n, int parts, const std::function<void(size_t, size_t, int)>& fn) { parallelRanges(n, parts, fn); }
 
 int schemaTupleSize(const Schema& s) { int n = 0; for (auto& a : s) n += sizeInTuple(a.type, true); return n; }
 int schemaOffset(const Schema& s, const std::string& name) {
@@ -213,11 +196,29 @@ struct Groups {
     const int64_t* acc(size_t i) const { return accData.data() + i * nAcc; }
 };
 
-Groups groupsFromDense(Query& q) {
+}  // namespace
+
+// What a query's tail keeps between executions: the group arrays and the scratch of the emission order.  A million groups are
+// tens of MB; fresh vectors every execution cost more in page faults than the work done in them.
+struct TailState {
+    Groups groups;
+    SortScratch sort;
+    ReplayScratch replay;
+    std::vector<uint64_t> keys, hashes;
+    std::vector<uint32_t> byFirst, slotOrder, order;
+};
+void destroyTailState(TailState* t) { delete t; }
+static TailState& tailState(Query& q) { if (!q.tailState) q.tailState = new TailState(); return *q.tailState; }
+std::vector<uint32_t>& tailOrderBuffer(Query& q) { return tailState(q).slotOrder; }
+ReplayScratch& tailReplayScratch(Query& q) { return tailState(q).replay; }
+
+namespace {
+
+void groupsFromDense(Query& q, Groups& G) {
     const int64_t D = q.denseGroups;
     const size_t W = q.accums.size();
-    auto word = [&](size_t w, int64_t g) { return (int64_t)q.hAgg[(size_t)(q.accumSlot[w] * D + g)]; };
-    Groups G;
+    const uint64_t* table = q.hAggView ? q.hAggView : q.hAgg.data();
+    auto word = [&](size_t w, int64_t g) { return (int64_t)table[(size_t)(q.accumSlot[w] * D + g)]; };
     G.nKeys = q.denseKeys.size(); G.nAcc = W;
     // two passes over the dense table, both split over the host threads: count the groups present per part, then
     // fill each part's slice (group order = dense id order, as before)
@@ -248,7 +249,6 @@ Groups groupsFromDense(Query& q) {
             o++;
         }
     });
-    return G;
 }
 
 // candidate rows of a dense aggregate table (engine.cpp: ORDER BY ... LIMIT over a large dense table):
@@ -526,10 +526,13 @@ static void runTailOn(Query& q, Groups& G);
 
 void runTail(Query& q) {
     q.tailNeedsAllGroups = false;
+    q.resultInPinned = false;
     if (!q.agg) { runMaterializeTail(q); return; }
     const double t0 = nowMs();
-    Groups G = (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) ? groupsFromJoinEntries(q)
-             : q.candidateRun ? groupsFromDenseRows(q) : groupsFromDense(q);
+    Groups& G = tailState(q).groups;
+    if (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH) G = groupsFromJoinEntries(q);
+    else if (q.candidateRun) G = groupsFromDenseRows(q);
+    else groupsFromDense(q, G);
     if (q.aggMode == AggMode::HASH) mergeSpaceEquivalentGroups(q, G);
     if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     tail: %.3f ms  groups from the device tables\n", nowMs() - t0);
     runTailOn(q, G);
@@ -543,6 +546,7 @@ void runTail(Query& q) {
 // unsharded plan gives on one GPU, whatever the sharding (reference: one hash table all workers reach, aggregation.h:240-343).
 void runTailMerged(Query& root, const std::vector<Query*>& parts) {
     root.tailNeedsAllGroups = false;
+    root.resultInPinned = false;
     root.candidateRun = false;
     if (!root.agg) {
         // materialize.h:78-220 appends in scan order: the parts' columns back to back, parts in shard order
@@ -597,19 +601,29 @@ void runTailMerged(Query& root, const std::vector<Query*>& parts) {
     runTailOn(root, G);
 }
 
-static void runTailOn(Query& q, Groups& G) {
-    OpNode* agg = q.agg;
-    const bool trace = getenv("RSQ_TRACE") != nullptr;
-    double tPhase = nowMs();
-    auto phase = [&](const char* what) {
-        if (!trace) return;
-        double t = nowMs();
-        fprintf(stderr, "[rsq trace]     tail: %.3f ms  %s\n", t - tPhase, what);
-        tPhase = t;
-    };
-
-    // ---- operators above the aggregation (bottom-up) and their schemas ----
+// ---- what sits above the aggregation, analysed once per tail run ------------------------------------------------------
+struct AggOut { bool avg; int sumAcc, cntAcc, slot; };
+struct Proj { std::vector<HostExpr> exprs; std::vector<int> slots; };
+// where an output column comes from when the projections above the aggregation only pass values through (AS, plain symbols)
+struct Src { int kind = 3; int a = 0, b = 0; };     // 0 group value, 1 accumulator, 2 AVG(sum accumulator a, count accumulator b), 3 computed
+struct TailShape {
     OpNode* mat = nullptr; OpNode* orderBy = nullptr;
+    HostCompiler hc;
+    std::vector<int> keySlots;
+    std::vector<AggOut> outs;
+    std::vector<Proj> projs;
+    Schema cur;
+    size_t ts = 0;
+    std::vector<int> offs, matSlots;
+    std::vector<OrderRequest> reqs;
+    std::vector<Src> colSrc;
+    bool directRows = true;          // every output column is a group value, an accumulator or an AVG, none a string
+};
+
+static TailShape buildTailShape(Query& q) {
+    TailShape sh;
+    OpNode* agg = q.agg;
+    OpNode*& mat = sh.mat; OpNode*& orderBy = sh.orderBy;
     std::vector<OpNode*> projections;
     for (OpNode* o = agg->parent; o; o = o->parent) {
         if (o->tag == RSQ_OP_PROJECTION) { if (mat) failUnsupported("projection above materialize"); projections.push_back(o); }
@@ -619,12 +633,11 @@ static void runTailOn(Query& q, Groups& G) {
     }
     if (!mat) failInvalid("plan has no materialization");
 
-    HostCompiler hc;
-    std::vector<int> keySlots, aggSlots;              // symbol slots written per group
+    HostCompiler& hc = sh.hc;
+    std::vector<int>& keySlots = sh.keySlots;
     Schema aggSchema;
     for (Expr* g : agg->exprs2) { keySlots.push_back(hc.define(expressionName(g), g->type)); aggSchema.push_back({expressionName(g), g->type}); }
-    struct AggOut { bool avg; int sumAcc, cntAcc, slot; };
-    std::vector<AggOut> outs;
+    std::vector<AggOut>& outs = sh.outs;
     {
         size_t si = 0;
         for (Expr* a : agg->exprs) {
@@ -644,9 +657,9 @@ static void runTailOn(Query& q, Groups& G) {
         }
     }
     agg->schema = aggSchema;
-    Schema cur = aggSchema;
-    struct Proj { std::vector<HostExpr> exprs; std::vector<int> slots; };
-    std::vector<Proj> projs;
+    Schema& cur = sh.cur;
+    cur = aggSchema;
+    std::vector<Proj>& projs = sh.projs;
     for (OpNode* p : projections) {
         Proj pr; Schema s;
         for (Expr* e : p->exprs) { q.pool.addId(e); pr.exprs.push_back(hc.compile(e)); }
@@ -655,23 +668,96 @@ static void runTailOn(Query& q, Groups& G) {
         projs.push_back(std::move(pr));
     }
     mat->schema = cur;
-    q.resultSchema = cur;
-    const size_t ts = (size_t)schemaTupleSize(cur);
-    std::vector<int> offs, matSlots;
+    sh.ts = (size_t)schemaTupleSize(cur);
     for (auto& a : cur) {
-        offs.push_back(schemaOffset(cur, a.name));
+        sh.offs.push_back(schemaOffset(cur, a.name));
         int s = hc.slotOf(a.name);
         if (s < 0) failType("materialize: symbol " + a.name + " not found");
-        matSlots.push_back(s);
+        sh.matSlots.push_back(s);
     }
-    std::vector<OrderRequest> reqs;
     if (orderBy)
         for (Expr* e : orderBy->exprs) {
             const std::string& n = e->child->symbol;
             bool found = false;
-            for (auto& a : cur) if (a.name == n) { reqs.push_back({schemaOffset(cur, n), a.type, e->tag != RSQ_E_DESC}); found = true; break; }
+            for (auto& a : cur) if (a.name == n) { sh.reqs.push_back({schemaOffset(cur, n), a.type, e->tag != RSQ_E_DESC}); found = true; break; }
             if (!found) failType("Order By attribute not found.");
         }
+    // column sources
+    sh.colSrc.resize(cur.size());
+    std::vector<Src> src(hc.names.size());
+    for (size_t k = 0; k < keySlots.size(); k++) src[(size_t)keySlots[k]] = Src{0, (int)k, 0};
+    for (auto& o : outs) src[(size_t)o.slot] = o.avg ? Src{2, o.sumAcc, o.cntAcc} : Src{1, o.sumAcc, 0};
+    std::function<Src(const HostExpr&)> resolve = [&](const HostExpr& h) -> Src {
+        if (h.kind == 0) return src[(size_t)h.slot];
+        if (h.kind == 2 && (h.tag == RSQ_E_AS || h.tag == RSQ_E_SUM || h.tag == RSQ_E_AVG || h.tag == RSQ_E_MIN || h.tag == RSQ_E_MAX) && h.kids.size() == 1)
+            return resolve(h.kids[0]);
+        return Src{};
+    };
+    for (auto& pr : projs) {
+        std::vector<Src> now(pr.exprs.size());
+        for (size_t i = 0; i < pr.exprs.size(); i++) now[i] = resolve(pr.exprs[i]);
+        for (size_t i = 0; i < pr.exprs.size(); i++) src[(size_t)pr.slots[i]] = now[i];
+    }
+    for (size_t c = 0; c < cur.size(); c++) {
+        sh.colSrc[c] = src[(size_t)sh.matSlots[c]];
+        if (sh.colSrc[c].kind == 3 || cur[c].type.isString()) sh.directRows = false;
+    }
+    return sh;
+}
+
+// Can the rows of this dense aggregation be produced on the device (devtail.hip)?  Yes when every output column is a group
+// value, an accumulator or an AVG (no computed projection, no strings) and nothing sorts the rows afterwards.  Fills the column
+// and key descriptions the kernels take.
+bool planDenseDeviceTail(Query& q, DenseTailKeys& keys, DenseTailCols& cols, int& tupleSize, int64_t& limitRows) {
+    if (!q.agg || q.denseKeys.empty() || q.denseKeys.size() > 4) return false;
+    TailShape sh = buildTailShape(q);
+    if (!sh.directRows || sh.orderBy || sh.cur.size() > 24) return false;
+    keys.n = (int32_t)q.denseKeys.size();
+    for (size_t k = 0; k < q.denseKeys.size(); k++) {
+        const DenseKey& dk = q.denseKeys[k];
+        DenseTailKey& o = keys.k[k];
+        o.min = dk.min; o.card = dk.card; o.stride = dk.stride; o.byteSet = dk.byteSet ? 1 : 0; o.typeTag = dk.type.tag;
+        if (dk.type.isString()) return false;
+        if (dk.byteSet) { if (dk.values.size() > sizeof o.values) return false; memset(o.values, 0, sizeof o.values); memcpy(o.values, dk.values.data(), dk.values.size()); }
+    }
+    cols.n = (int32_t)sh.cur.size();
+    for (size_t c = 0; c < sh.cur.size(); c++) {
+        const Src& s = sh.colSrc[c];
+        DenseTailCol& o = cols.c[c];
+        o.kind = s.kind; o.offset = sh.offs[c]; o.width = sizeInTuple(sh.cur[c].type, true);
+        if (s.kind == 0) { o.a = s.a; o.b = 0; }
+        else { o.a = q.accumSlot[(size_t)s.a]; o.b = s.kind == 2 ? q.accumSlot[(size_t)s.b] : 0; }      // accumulator index -> block of the [block][group] table
+        if (o.width != 8 && o.width != 4 && o.width != 2 && o.width != 1) return false;      // (CHAR(1) takes two bytes of a tuple: the character and a NUL)
+    }
+    tupleSize = (int)sh.ts;
+    limitRows = sh.mat->hasLimit ? std::max<int64_t>(sh.mat->limit, 1) : -1;      // materialize.h:197-206
+    q.resultSchema = sh.cur;
+    return true;
+}
+
+static void runTailOn(Query& q, Groups& G) {
+    OpNode* agg = q.agg;
+    const bool trace = getenv("RSQ_TRACE") != nullptr;
+    double tPhase = nowMs();
+    auto phase = [&](const char* what) {
+        if (!trace) return;
+        double t = nowMs();
+        fprintf(stderr, "[rsq trace]     tail: %.3f ms  %s\n", t - tPhase, what);
+        tPhase = t;
+    };
+    TailShape sh = buildTailShape(q);
+    OpNode* mat = sh.mat; OpNode* orderBy = sh.orderBy;
+    HostCompiler& hc = sh.hc;
+    std::vector<int>& keySlots = sh.keySlots;
+    std::vector<AggOut>& outs = sh.outs;
+    std::vector<Proj>& projs = sh.projs;
+    const Schema& cur = sh.cur;
+    q.resultSchema = cur;
+    const size_t ts = sh.ts;
+    const std::vector<int>& offs = sh.offs; const std::vector<int>& matSlots = sh.matSlots;
+    const std::vector<OrderRequest>& reqs = sh.reqs;
+    const std::vector<Src>& colSrc = sh.colSrc;
+    const bool directRows = sh.directRows;
 
     // ---- per group: dematerialize, AVG, projections, materialize ----
     auto materializeGroupWith = [&](size_t gi, uint8_t* dst, std::vector<Val>& sym) {
@@ -692,56 +778,65 @@ static void runTailOn(Query& q, Groups& G) {
         memset(dst, 0, ts);
         for (size_t c = 0; c < cur.size(); c++) storeValue(dst + offs[c], sym[(size_t)matSlots[c]], cur[c].type);
     };
+    // (sources of pass-through columns: TailShape::colSrc.  A row is then a handful of fixed-width copies and the expression
+    // interpreter stays out of the per-row loop: a million rows 20 ms -> 2 ms on the GPU box's host.)
+    auto materializeDirect = [&](size_t gi, uint8_t* dst) {
+        const Val* gk = G.keys(gi);
+        const int64_t* ga = G.acc(gi);
+        for (size_t c = 0; c < cur.size(); c++) {
+            const Src& sc = colSrc[c];
+            int64_t v;
+            if (sc.kind == 0) v = gk[sc.a].i;
+            else if (sc.kind == 1) v = ga[sc.a];
+            else v = sdiv((int64_t)((uint64_t)ga[sc.a] * 100ull), ga[sc.b]);
+            switch (cur[c].type.tag) {       // (storeValue's widths; no strings on this path)
+                case RSQ_BIGINT: case RSQ_DECIMAL: memcpy(dst + offs[c], &v, 8); break;
+                case RSQ_INT: case RSQ_DATE: { const uint32_t x = (uint32_t)v; memcpy(dst + offs[c], &x, 4); break; }
+                default: dst[offs[c]] = (uint8_t)v; break;
+            }
+        }
+    };
     // many groups: every output row is independent, so the rows are split over the host threads
-    auto materializeMany = [&](size_t count, const std::function<size_t(size_t)>& groupOf, uint8_t* base) {
+    // (groupOf == nullptr: row i is group i)
+    auto materializeMany = [&](size_t count, const uint32_t* groupOf, uint8_t* base) {
         parallelFor(count, tailThreads(count), [&](size_t lo, size_t hi, int) {
+            if (directRows) { for (size_t i = lo; i < hi; i++) materializeDirect(groupOf ? groupOf[i] : i, base + i * ts); return; }
             std::vector<Val> sym(hc.names.size());
-            for (size_t i = lo; i < hi; i++) materializeGroupWith(groupOf(i), base + i * ts, sym);
+            for (size_t i = lo; i < hi; i++) materializeGroupWith(groupOf ? groupOf[i] : i, base + i * ts, sym);
         });
     };
 
     // The reference's order of the materialized rows: groups enter its hash table in the order of their first
-    // input row and leave it in slot order.  Only needed when that order is observable.
-    auto emissionOrder = [&]() {
-        std::vector<size_t> byFirst(G.n);
-        if (G.n < 4096) {
-            for (size_t i = 0; i < G.n; i++) byFirst[i] = i;
-            std::sort(byFirst.begin(), byFirst.end(), [&](size_t a, size_t b) { return G.firstRow[a] < G.firstRow[b]; });
-        } else {
-            // LSD radix sort of (first row, group) pairs, 11 bits per pass over the bits the rows actually use (stable,
-            // so groups that share a first row — matches of one probe row — keep their order)
-            struct KI { uint64_t key; uint32_t idx; };
-            std::vector<KI> a(G.n), b(G.n);
-            uint64_t maxKey = 0;
-            for (size_t i = 0; i < G.n; i++) { a[i].key = (uint64_t)G.firstRow[i]; a[i].idx = (uint32_t)i; maxKey = std::max(maxKey, a[i].key); }
-            for (int shift = 0; shift < 64 && (maxKey >> shift) != 0; shift += 11) {
-                size_t hist[2049] = {0};
-                for (size_t i = 0; i < G.n; i++) hist[((a[i].key >> shift) & 2047) + 1]++;
-                for (int d = 0; d < 2048; d++) hist[d + 1] += hist[d];
-                for (size_t i = 0; i < G.n; i++) b[hist[(a[i].key >> shift) & 2047]++] = a[i];
-                a.swap(b);
-            }
-            for (size_t i = 0; i < G.n; i++) byFirst[i] = a[i].idx;
-        }
+    // input row and leave it in slot order.  Only needed when that order is observable.  rsq_config.emission_order =
+    // RSQ_EMIT_ANY skips it: the rows come in the order the device tables hold them (the reference's own tests compare
+    // un-ordered results as multisets, test/test_common.h:152-190).
+    TailState& T = tailState(q);
+    auto emissionOrder = [&]() -> const uint32_t* {
+        if (G.n >= 0xffffffffull) failUnsupported("more than 4 G groups");
+        if (q.ctx.cfg.emission_order == RSQ_EMIT_ANY) return nullptr;
+        T.keys.resize(G.n);
+        parallelFor(G.n, tailThreads(G.n), [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; i++) T.keys[i] = (uint64_t)G.firstRow[i]; });
+        // (stable: groups that share a first row — the matches of one probe row — keep their order)
+        parallelSortIndex(T.keys.data(), G.n, T.byFirst, T.sort);
         phase("sort groups by first row");
-        std::vector<uint64_t> hashes(G.n);
+        T.hashes.resize(G.n);
         parallelFor(G.n, tailThreads(G.n), [&](size_t lo, size_t hi, int) {
             for (size_t i = lo; i < hi; i++) {
                 uint64_t h = 0;
-                const Val* gk = G.keys(byFirst[i]);
+                const Val* gk = G.keys(T.byFirst[i]);
                 for (size_t k = 0; k < agg->exprs2.size(); k++) h = refHashValue(h, gk[k], agg->exprs2[k]->type);
-                hashes[i] = h;
+                T.hashes[i] = h;
             }
         });
         phase("reference hashes");
-        std::vector<size_t> slotOrder = refEmissionOrder(hashes, opSize(agg));
-        std::vector<size_t> order(G.n);
-        for (size_t i = 0; i < G.n; i++) order[i] = byFirst[slotOrder[i]];
+        refEmissionOrderParallel(T.hashes.data(), G.n, opSize(agg), T.slotOrder, T.replay);
+        T.order.resize(G.n);
+        parallelFor(G.n, tailThreads(G.n), [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; i++) T.order[i] = T.byFirst[T.slotOrder[i]]; });
         phase("replay of the reference's hash table (slot order)");
-        return order;
+        return T.order.data();
     };
 
-    q.resultTuples.clear(); q.resultRows = 0;
+    q.resultRows = 0;                      // (resultTuples keeps its pages: every path below sets its size)
 
     // ---- ORDER BY ... LIMIT k over many groups: the k first rows of the sorted order are determined by the
     // sort keys alone unless rows tie on ALL of them; select them without sorting (or replaying) everything ----
@@ -753,7 +848,7 @@ static void runTailOn(Query& q, Groups& G) {
     if (orderBy && orderBy->hasLimit && !mat->hasLimit && orderBy->limit >= 0 && (size_t)orderBy->limit * 4 < allGroups) {
         const size_t k = (size_t)orderBy->limit;
         std::vector<uint8_t> all(G.n * ts);
-        materializeMany(G.n, [](size_t i) { return i; }, all.data());
+        materializeMany(G.n, nullptr, all.data());
         auto before = [&](const uint8_t* a, const uint8_t* b) {
             for (const auto& o : reqs) {
                 int c = compareTyped(o.type, a + o.offset, b + o.offset);
@@ -780,12 +875,12 @@ static void runTailOn(Query& q, Groups& G) {
         if (q.candidateRun) { q.tailNeedsAllGroups = true; return; }
     }
 
-    std::vector<size_t> order = emissionOrder();
+    const uint32_t* order = emissionOrder();
     // materialize.h:197-206: with a LIMIT the pipeline is left once count >= limit, i.e. after max(limit, 1) tuples
-    size_t emit = order.size();
+    size_t emit = G.n;
     if (mat->hasLimit) emit = std::min(emit, (size_t)std::max<int64_t>(mat->limit, 1));
     q.resultTuples.resize(emit * ts);
-    materializeMany(emit, [&order](size_t i) { return order[i]; }, q.resultTuples.data());
+    materializeMany(emit, order, q.resultTuples.data());
     q.resultRows = (int64_t)emit;
     phase("AVG / projections / materialize");
     if (orderBy) {

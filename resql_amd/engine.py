@@ -24,7 +24,7 @@ STATUS = {0: "OK", 1: "INVALID", 2: "TYPE", 3: "UNSUPPORTED", 4: "DEVICE", 5: "R
 class rsq_config(C.Structure):
     _fields_ = [("print_assembly", C.c_int32), ("print_flounder", C.c_int32), ("print_performance", C.c_int32),
                 ("num_threads", C.c_int32), ("emit_machine_code", C.c_int32), ("optimize", C.c_int32),
-                ("device", C.c_int32), ("kernel_cache_dir", C.c_char_p)]
+                ("device", C.c_int32), ("kernel_cache_dir", C.c_char_p), ("emission_order", C.c_int32)]
 
 
 class rsq_report(C.Structure):
@@ -39,6 +39,7 @@ class rsq_multi_config(C.Structure):
 
 
 MERGE_AUTO, MERGE_RCCL, MERGE_PEER_COPY = 0, 1, 2
+EMIT_REFERENCE, EMIT_ANY = 0, 1
 
 
 class EngineError(RuntimeError):
@@ -108,6 +109,7 @@ def lib():
         L.rsq_result_serialize.restype = vp
         L.rsq_result_serialize.argtypes = [C.POINTER(P.rsq_result_view)]
         L.rsq_free.argtypes = [vp]
+        L.rsq_ref_emission_order.argtypes = [vp, i64, C.c_uint64, i32, vp]
         L.rsq_measure_read_bandwidth.argtypes = [vp, C.c_size_t, i32, C.POINTER(C.c_double)]
         L.rsq_sql_plan_select.argtypes = [vp, C.c_char_p, C.POINTER(vp), i32, C.POINTER(vp)]
         L.rsq_sql_plan_desc.restype = C.POINTER(P.rsq_plan_desc)
@@ -156,7 +158,7 @@ EXPORTED_SYMBOLS = [
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_await_kernels", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
     "rsq_query_finalize", "rsq_query_merge_gathered", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_kernel_time_stats", "rsq_query_source", "rsq_query_explain",
-    "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free",
+    "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free", "rsq_ref_emission_order",
     "rsq_measure_read_bandwidth",
     "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
     "rsq_db_create", "rsq_db_execute", "rsq_db_message", "rsq_db_adopt_table", "rsq_db_report", "rsq_db_destroy",
@@ -182,10 +184,11 @@ class Context:
         self._borrowed = True
         return self
 
-    def __init__(self, device: int = 0, cache_dir: Optional[str] = None, print_source: bool = False):
+    def __init__(self, device: int = 0, cache_dir: Optional[str] = None, print_source: bool = False, emission_order: int = 0):
+        """emission_order: EMIT_REFERENCE (0: rows of an unsorted aggregation in the reference's hash-table order) or EMIT_ANY"""
         self._L = lib()
         self._cache = cache_dir.encode() if cache_dir else None
-        cfg = rsq_config(1 if print_source else 0, 0, 0, 1, 1, 0, device, self._cache)
+        cfg = rsq_config(1 if print_source else 0, 0, 0, 1, 1, 0, device, self._cache, emission_order)
         h = C.c_void_p()
         rc = self._L.rsq_ctx_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -505,7 +508,7 @@ class MultiContext:
         self._L = lib()
         self._devs = (C.c_int32 * len(devices))(*devices)
         self._cache = cache_dir.encode() if cache_dir else None
-        cfg = rsq_multi_config(rsq_config(0, 0, 0, 1, 1, 0, 0, self._cache), self._devs, len(devices), merge)
+        cfg = rsq_multi_config(rsq_config(0, 0, 0, 1, 1, 0, 0, self._cache, 0), self._devs, len(devices), merge)
         h = C.c_void_p()
         rc = self._L.rsq_multi_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -102,6 +102,13 @@ def test_error_codes(compile_ctx):
     cond = p.like(p.constant("ab", P.VARCHAR), p.constant("a%", P.VARCHAR))
     p.set_root(p.materialize(p.aggregation([p.count(p.star())], [], p.selection(cond, p.scan("rel")))))
     compile_ctx.compile(p, [dt]).close()
+    # one node twice below a parent would chain it to itself through the sibling pointer: refused, not walked for ever
+    p = P.Plan([t])
+    sb = p.sum(p.attr("b"))
+    p.set_root(p.materialize(p.projection([p.as_("twice", p.add(sb, sb))], p.aggregation([sb], [], p.scan("rel")))))
+    with pytest.raises(engine.EngineError) as e:
+        compile_ctx.compile(p, [dt])
+    assert e.value.status == 1 and "same child twice" in e.value.message
     # a nested-loops join is valid ReSQL but outside this engine's scope: refused, never emulated
     p = P.Plan([t])
     nl = p._o(P.OpNode("NESTEDLOOPSJOIN", [p.scan("rel"), p.scan("rel")], exprs=[p.eq(p.attr("a"), p.attr("a"))]))
