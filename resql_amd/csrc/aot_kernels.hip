@@ -295,12 +295,17 @@ __global__ void __launch_bounds__(256) k_fill_u64(u64* __restrict__ p, i64 n, u6
 // Several fills in ONE launch (blockIdx.y picks the item).  An execution clears a handful of small things — the error word,
 // counters, the candidate selection's scratch, accumulator blocks — and a stream operation each costs ~5 us of device time
 // whatever its size (TPC-H Q3 at SF10: 7 of them = 30 of 445 us).  Units are 4-byte words; the value is a 64-bit pattern.
-struct FillBatchArgs { unsigned* p[8]; u64 n32[8]; u64 v[8]; };
+#define FILL_BATCH_MAX 24
+// (round 3) one flat grid: item i owns workgroups [first[i], first[i + 1]) — as many as its size deserves (one per 64 KB, at most
+// 1024).  The earlier form gave EVERY item the grid of the largest one (blockIdx.y = item): with a 16 MB accumulator block beside
+// a dozen 4-byte counters that was 24 000 workgroups of which 23 000 had nothing to do, ~25 us of a 300 us query.
+struct FillBatchArgs { unsigned* p[FILL_BATCH_MAX]; u64 n32[FILL_BATCH_MAX]; u64 v[FILL_BATCH_MAX]; unsigned first[FILL_BATCH_MAX + 1]; int n; };
 __global__ void __launch_bounds__(256) k_fill_batch(FillBatchArgs a) {
-    const int it = blockIdx.y;
+    int it = 0;
+    while (it + 1 < a.n && blockIdx.x >= a.first[it + 1]) it++;
     unsigned* p = a.p[it];
     const u64 n = a.n32[it], v = a.v[it];
-    const u64 gtid = (u64)blockIdx.x * blockDim.x + threadIdx.x, gsz = (u64)gridDim.x * blockDim.x;
+    const u64 gtid = (u64)(blockIdx.x - a.first[it]) * blockDim.x + threadIdx.x, gsz = (u64)(a.first[it + 1] - a.first[it]) * blockDim.x;
     if ((reinterpret_cast<unsigned long long>(p) & 15ull) != 0 || n < 256) {
         for (u64 i = gtid; i < n; i += gsz) p[i] = (unsigned)((i & 1) ? (v >> 32) : v);
         return;
@@ -313,22 +318,24 @@ __global__ void __launch_bounds__(256) k_fill_batch(FillBatchArgs a) {
 }
 
 void fillBatchAsync(Context& ctx, const FillItem* items, int count) {
-    for (int base = 0; base < count; base += 8) {
+    for (int base = 0; base < count; base += FILL_BATCH_MAX) {
         FillBatchArgs a;
         memset(&a, 0, sizeof a);
-        const int n = std::min(8, count - base);
-        u64 most = 1;
+        const int n = std::min(FILL_BATCH_MAX, count - base);
         int k = 0;
+        unsigned blocks = 0;
         for (int i = 0; i < n; i++) {
             const FillItem& f = items[base + i];
             if (!f.p || f.bytes == 0) continue;
             if ((f.bytes & 3) || ((uintptr_t)f.p & 3)) throw Error(RSQ_ERR_DEVICE, "fillBatchAsync: a fill must cover whole 4-byte words");
-            a.p[k] = (unsigned*)f.p; a.n32[k] = f.bytes / 4; a.v[k] = f.value; most = std::max<u64>(most, f.bytes / 16);
+            a.p[k] = (unsigned*)f.p; a.n32[k] = f.bytes / 4; a.v[k] = f.value;
+            a.first[k] = blocks;
+            blocks += (unsigned)std::max<u64>(1, std::min<u64>(1024, (f.bytes + 65535) / 65536));
             k++;
         }
         if (k == 0) continue;
-        const unsigned gx = (unsigned)std::min<u64>(2048, (most + 255) / 256);
-        hipLaunchKernelGGL(k_fill_batch, dim3(gx, (unsigned)k), dim3(256), 0, ctx.stream, a);
+        a.first[k] = blocks; a.n = k;
+        hipLaunchKernelGGL(k_fill_batch, dim3(blocks), dim3(256), 0, ctx.stream, a);
         RSQ_HIP(hipGetLastError());
     }
 }
@@ -904,11 +911,79 @@ __global__ void __launch_bounds__(256) k_rank_absolute(unsigned* __restrict__ bm
     for (i64 b = b0 + threadIdx.x; b < b0 + RANK_CHUNK_BLOCKS && b < nBlocks; b += blockDim.x) bm[b * 8] += base;
 }
 
+// The whole index in ONE launch (round 3): the chunks' totals travel through `chain[chunk]` (below) and a workgroup writes its
+// rank words absolute from the start.  The grid is at most 1171 workgroups of 256 threads (a key domain of 2^28 bits), fewer than the chip holds at a time,
+// so a predecessor is always running; a workgroup that nevertheless waits longer than ~1 ms raises `*stuck` and leaves (the host
+// then repeats the index with the two-launch form above — never a hang).  `chain` must be zero before the launch.
+__global__ void __launch_bounds__(256) k_rank_blocks_chained(unsigned* __restrict__ bm, i64 nBlocks, unsigned* __restrict__ chain, int nChunks,
+                                                             unsigned* __restrict__ chunkBase /* [nChunks + 1] */, unsigned* __restrict__ stuck) {
+    __shared__ unsigned s_tot[256];
+    __shared__ unsigned s_base;
+    const i64 b0 = (i64)blockIdx.x * RANK_CHUNK_BLOCKS + (i64)threadIdx.x * RANK_PT;
+    unsigned c[RANK_PT];
+    unsigned mine = 0;
+#pragma unroll
+    for (int j = 0; j < RANK_PT; j++) {
+        unsigned n = 0;
+        if (b0 + j < nBlocks) {
+            const uint4* w = reinterpret_cast<const uint4*>(bm + (b0 + j) * 8);
+            const uint4 lo = w[0], hi = w[1];
+            n = __popc(lo.y) + __popc(lo.z) + __popc(lo.w) + __popc(hi.x) + __popc(hi.y) + __popc(hi.z) + __popc(hi.w);
+        }
+        c[j] = n; mine += n;
+    }
+    s_tot[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                  // inclusive scan of the thread totals
+        unsigned v = threadIdx.x >= (unsigned)off ? s_tot[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_tot[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // chain word = (value << 2) | state: 1 = this chunk's own total, 2 = the total of all chunks up to and including it.
+        // A chunk publishes its own total at once and then looks BACK over its predecessors, adding own totals until it meets an
+        // inclusive one (decoupled look-back): no chunk waits for a chain of 260 hand-overs, which a plain "wait for the chunk
+        // before me" turned into 130 us of serial latency on TPC-H Q3's 60 M-bit orders bitmap.
+        const unsigned total = s_tot[255];
+        unsigned base = 0;
+        if (blockIdx.x == 0) __hip_atomic_store(&chain[0], (total << 2) | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else {
+            __hip_atomic_store(&chain[blockIdx.x], (total << 2) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = wall_clock64();
+            int i = (int)blockIdx.x - 1;
+            for (;;) {
+                const unsigned v = __hip_atomic_load(&chain[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned st = v & 3u;
+                if (st == 2u) { base += v >> 2; break; }
+                if (st == 1u) { base += v >> 2; i--; continue; }           // (chunk 0 publishes state 2 only: i never goes below 0)
+                if (wall_clock64() - t0 > 100000ll) { atomicOr(stuck, 128u); base = 0; break; }          // 100 MHz clock: 1 ms
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __hip_atomic_store(&chain[blockIdx.x], ((base + total) << 2) | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        chunkBase[blockIdx.x] = base;
+        if ((int)blockIdx.x == nChunks - 1) chunkBase[nChunks] = base + total;
+        s_base = base;
+    }
+    __syncthreads();
+    unsigned run = s_base + s_tot[threadIdx.x] - mine;
+#pragma unroll
+    for (int j = 0; j < RANK_PT; j++) { if (b0 + j < nBlocks) bm[(b0 + j) * 8] = run; run += c[j]; }
+}
+
 void rankTableIndex(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chunkTotal, uint32_t* chunkBase) {
     const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
     hipLaunchKernelGGL(k_rank_blocks, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (unsigned*)bitmap, (i64)nBlocks, (unsigned*)chunkTotal);
     hipLaunchKernelGGL(k_rank_absolute, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (unsigned*)bitmap, (i64)nBlocks, (const unsigned*)chunkTotal, nChunks,
                        (unsigned*)chunkBase);
+    RSQ_HIP(hipGetLastError());
+}
+// `chain` = the chunkTotal scratch, zeroed before the launch (the execution's first fill does that)
+void rankTableIndexChained(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chain, uint32_t* chunkBase) {
+    const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
+    hipLaunchKernelGGL(k_rank_blocks_chained, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (unsigned*)bitmap, (i64)nBlocks, (unsigned*)chain, nChunks,
+                       (unsigned*)chunkBase, (unsigned*)ctx.dErr);
     RSQ_HIP(hipGetLastError());
 }
 

@@ -816,9 +816,11 @@ static void buildHashTable(Query& q, Pipeline& p) {
         if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
         if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.rank ? "bitmap-rank dictionary" : "hash table", n);
     }
+    // (an execution whose tables are all sized readies them in its first fill launch — prologueFills below — and h.prepared says so)
+    const bool prepared = h.prepared;
+    h.prepared = false;
     if (h.rank && h.setOnly) {
-        prepareTableAsync(ctx, nullptr, 0, 0, nullptr, 0, h.dBitmap, bmWords, h.dCount);
-        q.report.num_kernels++;
+        if (!prepared) { prepareTableAsync(ctx, nullptr, 0, 0, nullptr, 0, h.dBitmap, bmWords, h.dCount); q.report.num_kernels++; }
         launchPipeline(q, p, -1);
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
         return;
@@ -826,28 +828,32 @@ static void buildHashTable(Query& q, Pipeline& p) {
     if (h.rank) {
         // ONE launch clears the bitmap and both counters' words; the records then arrive in the append buffer, the bitmap
         // becomes the index, the records move to their entries
-        prepareTableAsync(ctx, nullptr, 0, 0, h.dTempUsed, (size_t)h.tempWaves, h.dBitmap, bmWords, h.dCount);
-        q.report.num_kernels++;
+        if (!prepared) { prepareTableAsync(ctx, nullptr, 0, 0, h.dTempUsed, (size_t)h.tempWaves, h.dBitmap, bmWords, h.dCount); q.report.num_kernels++; }
         launchPipeline(q, p, -1);
-        rankTableIndex(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase);
+        // the index in one launch (chunk totals chained between the workgroups) when the prologue has zeroed the chain words
+        static const bool chainedOk = !(getenv("RSQ_RANK_CHAINED") && atoi(getenv("RSQ_RANK_CHAINED")) == 0);
+        if (prepared && chainedOk && !q.chainedIndexOff) { rankTableIndexChained(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase); q.report.num_kernels += 1; }
+        else { rankTableIndex(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase); q.report.num_kernels += 2; }
         rankTablePlace(ctx, h.dTemp, h.dTempUsed, (uint32_t)h.tempWaves, (uint32_t)h.tempRegion, h.dCount, (int)std::max<size_t>(1, nWords), h.dBitmap, h.bmMin,
                        h.bmBits, h.dChunkBase, h.bmBlocks, h.dWords, h.capacity);
-        q.report.num_kernels += 4;
+        q.report.num_kernels += 1;
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
         return;
     }
     // ONE launch readies the table: every key word = EMPTY (with a slot's words next to each other that is a fill of the whole
     // table; the payload words are overwritten by the inserts) or the state words = 0, the key bitmap and the entry counter = 0
-    if (h.keyCas) prepareTableAsync(ctx, (uint64_t*)h.dWords, (size_t)h.capacity * (h.aos ? std::max<size_t>(1, nWords) : 1), 0x8000000000000000ull,
-                                    nullptr, 0, h.dBitmap, bmWords, h.dCount);
-    else prepareTableAsync(ctx, nullptr, 0, 0, h.dState, (size_t)h.capacity, h.dBitmap, bmWords, h.dCount);
-    q.report.num_kernels++;
+    if (!prepared) {
+        if (h.keyCas) prepareTableAsync(ctx, (uint64_t*)h.dWords, (size_t)h.capacity * (h.aos ? std::max<size_t>(1, nWords) : 1), 0x8000000000000000ull,
+                                        nullptr, 0, h.dBitmap, bmWords, h.dCount);
+        else prepareTableAsync(ctx, nullptr, 0, 0, h.dState, (size_t)h.capacity, h.dBitmap, bmWords, h.dCount);
+        q.report.num_kernels++;
+    }
     launchPipeline(q, p, -1);
     q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
 }
 
 static void checkDeviceError(uint32_t err) {
-    err &= ~(32u | 64u);  // NOTE_CHAR_GROUP_ENDS_WITH_SPACE / NOTE_BUILD_KEYS_NOT_UNIQUE are information for the host, not errors
+    err &= ~(32u | 64u | 128u);  // NOTE_CHAR_GROUP_ENDS_WITH_SPACE / NOTE_BUILD_KEYS_NOT_UNIQUE / the chained index's time-out are information for the host, not errors
     if (err & 1) failRuntime("Division by zero");
     if (err & 2) failRuntime("Hash table full");
     if (err & 16) failRuntime("internal error: a hash-table slot stayed in the 'being written' state");
@@ -1209,22 +1215,62 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     ctx.errWordClean = false;      // until this execution has read the word back as 0
     bool anyCompaction = false;
     for (auto& p : q.pipelines) anyCompaction |= p.compact;
+    const bool trace = getenv("RSQ_TRACE") != nullptr;      // per-pipeline wall time (synchronises after each one)
     // everything small this execution wants cleared, in one launch (aot_kernels.hip k_fill_batch): the error word, the pipelines'
     // row counters, the group counter and the candidate selection's scratch of a compaction behind the last pipeline
     bool groupCountCleared = false, topkScratchCleared = false;
+    bool accumulatorsCleared = false;       // the aggregates beside a join table's entries are at their identities (AT_JOIN_ENTRY)
     {
-        FillItem f[5]; int n = 0;
-        f[n++] = FillItem{ctx.dErr, 4, 0};
+        std::vector<FillItem> f;
+        f.push_back(FillItem{ctx.dErr, 4, 0});
         bool anyDynamic = false;
         for (auto& p : q.pipelines) { anyDynamic |= p.dynamicTiles; p.tileCtrClean = p.dynamicTiles; }
-        if (anyDynamic) f[n++] = FillItem{q.dTileCtr, q.pipelines.size() * 256 * 32 * 4, 0};
-        if (anyCompaction) f[n++] = FillItem{q.dPipeStats, q.pipelines.size() * 8, 0};
-        if (q.dGroupCount) { f[n++] = FillItem{q.dGroupCount, 4, 0}; groupCountCleared = true; }
-        if (q.dTopkHists) { f[n++] = FillItem{q.dTopkHists, topkRangeScratchBytes(), 0}; topkScratchCleared = true; }
-        fillBatchAsync(ctx, f, n);
+        if (anyDynamic) f.push_back(FillItem{q.dTileCtr, q.pipelines.size() * 256 * 32 * 4, 0});
+        if (anyCompaction) f.push_back(FillItem{q.dPipeStats, q.pipelines.size() * 8, 0});
+        if (q.dGroupCount) { f.push_back(FillItem{q.dGroupCount, 4, 0}); groupCountCleared = true; }
+        if (q.dTopkHists) { f.push_back(FillItem{q.dTopkHists, topkRangeScratchBytes(), 0}); topkScratchCleared = true; }
+        // Join tables that have been sized (every execution but a query's first) are readied HERE, all of them in this one launch,
+        // instead of one launch in front of every build (TPC-H Q5 builds five tables, Q3 two); likewise the aggregates kept beside
+        // a join table's entries.  Nothing touches a table between this fill and its build pipeline.
+        static const bool prologueOk = !(getenv("RSQ_PROLOGUE") && atoi(getenv("RSQ_PROLOGUE")) == 0);
+        if (prologueOk && !trace)
+            for (auto& p : q.pipelines) {
+                if (p.sink != SinkKind::BUILD) continue;
+                HashTable& h = *q.hashTables[(size_t)p.buildTable];
+                h.prepared = false;
+                if (h.capacity == 0) continue;
+                const size_t nWords = h.keys.size() + h.payload.size();
+                const size_t bmBytes = h.hasBitmap && h.dBitmap ? (size_t)h.bmBlocks * 32 : 0;
+                if (h.rank && h.setOnly) { if (!bmBytes) continue; }
+                else if (h.rank) {
+                    if (!h.dTempUsed || !h.dChunkTotal) continue;
+                    f.push_back(FillItem{h.dTempUsed, (size_t)h.tempWaves * 4, 0});
+                    f.push_back(FillItem{h.dChunkTotal, (size_t)((h.bmBlocks + RSQ_RANK_CHUNK_BLOCKS - 1) / RSQ_RANK_CHUNK_BLOCKS) * 4, 0});      // the chain of the one-launch index
+                } else if (h.keyCas) {
+                    if (!h.dWords) continue;
+                    f.push_back(FillItem{h.dWords, (size_t)h.capacity * (h.aos ? std::max<size_t>(1, nWords) : 1) * 8, 0x8000000000000000ull});
+                } else {
+                    if (!h.dState) continue;
+                    f.push_back(FillItem{h.dState, (size_t)h.capacity * 4, 0});
+                }
+                if (bmBytes) f.push_back(FillItem{h.dBitmap, bmBytes, 0});
+                f.push_back(FillItem{h.dCount, 4, 0});
+                h.prepared = true;
+            }
+        if (prologueOk && !trace && q.aggMode == AggMode::AT_JOIN_ENTRY) {
+            HashTable& h = *q.hashTables[(size_t)q.aggTable];
+            if (h.capacity > 0 && h.dAcc && h.prepared) {       // (sized, and not about to be re-sized by its build)
+                for (int b = 0; b < h.nAccBlocks; b++) {
+                    const uint64_t idv = b < q.nMinBlocks ? 0x7fffffffffffffffull : b < q.nMinBlocks + q.nMaxBlocks ? 0x8000000000000000ull : 0ull;
+                    f.push_back(FillItem{(uint64_t*)h.dAcc + (size_t)b * (size_t)h.capacity, (size_t)h.capacity * 8, idv});
+                }
+                accumulatorsCleared = true;
+            }
+        }
+        fillBatchAsync(ctx, f.data(), (int)f.size());
+        q.report.num_kernels += (f.size() + 23) / 24;
     }
     RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
-    const bool trace = getenv("RSQ_TRACE") != nullptr;      // per-pipeline wall time (synchronises after each one)
     double tPipe = nowMs();
     auto tracePoint = [&](const Pipeline& p) {
         if (!trace) return;
@@ -1251,7 +1297,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             }
             fillBatchAsync(ctx, f.data(), (int)f.size());
         };
-        if (q.aggMode == AggMode::AT_JOIN_ENTRY) resetAccumulators(*q.hashTables[(size_t)q.aggTable]);
+        if (q.aggMode == AggMode::AT_JOIN_ENTRY && !accumulatorsCleared) { resetAccumulators(*q.hashTables[(size_t)q.aggTable]); q.report.num_kernels++; }
         if (q.aggMode == AggMode::HASH) {
             // The number of groups is not known before the scan: start from the reference's own estimate
             // (AggregationOp::getSize, aggregation.h:81-92) and re-run the pipeline with a 4x larger table while
@@ -1397,6 +1443,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             // error word, group count, candidate count and the pipelines' row counters: one kernel writes them into the pinned words
             publishStatusAsync(ctx, q.dPinnedDev + words, ctx.dErr, wantGroups ? q.dGroupCount : nullptr, topkCapacity ? q.dCandCount : nullptr,
                                anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size());
+            q.report.num_kernels++;
         } else {
             RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
             if (wantGroups) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 1, q.dGroupCount, 4, hipMemcpyDeviceToHost, ctx.stream));
@@ -1424,6 +1471,13 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
     ctx.errWordClean = (uint32_t)q.hPinned[words] == 0;
+    if (((uint32_t)q.hPinned[words] & 128u) && !async) {
+        // a workgroup of the one-launch rank index gave up waiting for its predecessor (aot_kernels.hip k_rank_blocks_chained): the
+        // index is wrong (in range, never out of bounds); this query takes the two-launch index from now on and starts over
+        q.chainedIndexOff = true;
+        executeQuery(q, partialOnly, async);
+        return;
+    }
     if (((uint32_t)q.hPinned[words] & 64u) && !async) {
         // a rank dictionary met build rows it was not sized for (two rows with one key, or more rows than the sizing pass saw:
         // the build side's data changed): its tables go back to the hash form and the execution starts over

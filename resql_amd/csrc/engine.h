@@ -130,6 +130,9 @@ void fillBatchAsync(Context& ctx, const FillItem* items, int count);
 // (chunkTotal / chunkBase[ceil(nBlocks / RSQ_RANK_CHUNK_BLOCKS) (+ 1)] are scratch), and the placement of appended build records at the rank of
 // their key
 void rankTableIndex(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chunkTotal, uint32_t* chunkBase);
+// the same index in one launch: chunk totals chained through `chain` (the chunkTotal scratch, zero before the launch); a workgroup
+// that waits too long raises bit 128 of the device error word and the caller repeats with rankTableIndex
+void rankTableIndexChained(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint32_t* chain, uint32_t* chunkBase);
 void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uint32_t nWaves, uint32_t region, const uint32_t* nRecords, int nWords,
                     const uint32_t* bitmap, int64_t bmMin, int64_t bmBits, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
                     int64_t capacity);

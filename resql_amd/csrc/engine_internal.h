@@ -78,6 +78,7 @@ struct HashTable {
     uint32_t* dChunkTotal = nullptr; // [chunks]
     uint32_t* dChunkBase = nullptr;  // [chunks + 1]
     int64_t bmBlocks = 0;            // 32-byte blocks the bitmap is allocated in (256 bits, or 224 bits + the rank word)
+    bool prepared = false;           // this execution's first fill launch has readied the table (engine.cpp: the prologue); buildHashTable then skips its own
 };
 
 // one accumulator the aggregation keeps per group
@@ -322,6 +323,7 @@ struct Query {
     std::atomic<int> bgState{0};           // 0 none, 1 running, 2 done, 3 failed
     std::string bgError;
     bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
+    bool chainedIndexOff = false;          // the one-launch rank index timed out once on this query: two launches from then on
     bool holdTail = false;                 // a shard of a multi-GPU plan: execute reads the group rows / materialised columns back and stops (tail.cpp runTailMerged)
     std::string allSource, explainText;
 

@@ -149,14 +149,16 @@ def region() -> P.Table:
     return tpch.make_table("region", REGION_SCHEMA, cols, 5)
 
 
-def database(sf: float, seed: int = datagen.SEED) -> Dict[str, P.Table]:
+def database(sf: float, seed: int = datagen.SEED, fill_unused: bool = True) -> Dict[str, P.Table]:
     """all tables of tpch/create.sql except partsupp (no query of the reference's set reads it); columns no generator
-    fills (comments, clerks, ...) hold zeros / empty strings so that `select *` has something to read"""
+    fills (comments, clerks, ...) hold zeros / empty strings so that `select *` has something to read — unless
+    fill_unused is False (full sizes: l_comment alone would be 2.6 GB of zeros at SF10; such columns then have no data and
+    no query of QUERIES touches them)"""
     db = {t.name: t for t in (lineitem(sf, seed), orders(sf, seed), customer(sf, seed), part(sf, seed), supplier(sf, seed),
                               nation(), region())}
     for t in db.values():
         for c in t.columns:
-            if c.data is None:
+            if c.data is None and fill_unused:
                 c.data = np.zeros(t.n_rows, dtype=c.type.np_dtype)
     return db
 

@@ -1,0 +1,50 @@
+"""The reference's TPC-H statements with joins into hash aggregations, CASE / LIKE / IN on strings and materialisation
+(tpch/queries/q5, q10, q12, q14, q19 — test/test_queries.h:5-110 runs them at SF0.01) at BASELINE sizes: SF1 and SF10, from SQL
+text through this engine's front end, against the answers of the UNMODIFIED reference (its grammar + planner + asmjit JIT on
+the same token streams and the same rows; tests/golden/make_f2_golden.py), byte for byte, twice per statement (the second
+execution reuses table capacities, rank dictionaries and late-load decisions).
+
+The database is the eight-table numpy generator of resql_amd/tpch_full.py, regenerated here and uploaded (the device generator
+covers lineitem / orders / customer columns of Q1 / Q3 / Q6 only).  SF10: 59 999 996 lineitem rows, 15 M orders, 1.5 M
+customers, 2 M parts — about a minute of host time to generate."""
+import json
+import os
+
+import pytest
+
+from resql_amd import tpch_full
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ("q5", "q10", "q12", "q14", "q19")
+
+
+def _golden(tag):
+    with open(os.path.join(GOLDEN, f"ref_full_{tag}.tbl"), encoding="latin1") as f:
+        return f.read()
+
+
+@pytest.mark.parametrize("sf", [1.0, 10.0])
+def test_join_statements_equal_the_reference_at_full_size(gpu_ctx, sf):
+    with open(os.path.join(GOLDEN, "ref_full_index.json")) as f:
+        index = json.load(f)
+    db = tpch_full.database(sf, fill_unused=False)
+    host = [db[k] for k in sorted(db)]
+    for t in host:
+        assert index[f"q5_sf{sf:g}"]["rows"][t.name] == t.n_rows
+    tabs = [gpu_ctx.table(t) for t in host]
+    del db, host
+    try:
+        for name in NAMES:
+            tag = f"{name}_sf{sf:g}"
+            q = gpu_ctx.sql_compile(tpch_full.QUERIES[name], tabs)
+            try:
+                for _ in range(2):
+                    q.execute()
+                    got = q.result().text
+                    assert got == _golden(tag), f"{name} at SF{sf:g} differs from the reference"
+            finally:
+                q.close()
+    finally:
+        for t in tabs:
+            t.close()

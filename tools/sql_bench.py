@@ -15,7 +15,7 @@ with_ref = "--reference" in sys.argv
 repeat = int(sys.argv[sys.argv.index("--repeat") + 1]) if "--repeat" in sys.argv else 5
 
 t0 = time.time()
-db = tpch_full.database(sf)
+db = tpch_full.database(sf, fill_unused=sf < 1.0)      # (full sizes: columns no statement reads stay without data)
 names = sorted(db)
 host = [db[k] for k in names]
 print(f"# generated SF{sf:g} in {time.time() - t0:.1f} s: " + ", ".join(f"{t.name} {t.n_rows}" for t in host), flush=True)
@@ -45,7 +45,11 @@ for name, sql in tpch_full.QUERIES.items():
         best_e = min(best_e, r.execution_time_ms)
     res = q.result()
     out = {"query": name, "sf": sf, "kernel_ms": round(best_k, 3), "exec_ms": round(best_e, 3), "kernels": r.num_kernels,
-           "rows": res.n_rows, "bytes_read": r.bytes_read, "gbps": round(r.bytes_read / (best_k * 1e-3) / 1e9, 1)}
+           "rows": res.n_rows, "bytes_read": r.bytes_read, "gbps": round(r.bytes_read / (best_k * 1e-3) / 1e9, 1),
+           "frac_of_8TBps": round(r.bytes_read / (best_k * 1e-3) / 8e12, 3)}
+    gold = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", f"ref_full_{name}_sf{sf:g}.tbl")
+    if os.path.exists(gold):
+        out["equals_reference_answer"] = res.text == open(gold, encoding="latin1").read()
     q.close()
     if with_ref:
         import subprocess
