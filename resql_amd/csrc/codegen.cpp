@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <set>
 #include <sstream>
 
 #include "engine_internal.h"
@@ -1064,7 +1065,13 @@ struct Walker {
         if (o->singleMatch) matchSlotTable = ht.id; else { multiMatchAbove = true; }
         explainSteps.push_back(std::string("probe ") + T + (o->singleMatch ? " (single match)" : " (all matches)"));
         selective = true;                       // whatever follows a join probe sees only the matching rows
+        {
+            ProbeInScope ps{ht.id, o->singleMatch, ht.rankCapable, {}};
+            for (Expr* eq : o->exprs) { Expr* r = eq->child->next; ps.keySymbols.push_back(r->tag == RSQ_E_ATTRIBUTE && !r->type.isString() ? r->symbol : std::string()); }
+            probesInScope.push_back(ps);
+        }
         consume(o->parent, o);
+        probesInScope.pop_back();
         matchSlotTable = prevMatch; multiMatchAbove = prevMulti;
     }
 
@@ -1141,6 +1148,10 @@ struct Walker {
         closeScope();
     }
     std::map<std::string, std::pair<int, int>> probeKeyOf;   // probe-side key symbol -> (table, key word)
+    // the join probes whose match is in scope (innermost last): table, single match?, the probe side's key symbols ("" where a key
+    // is not a one-word attribute) — emitHashAggregation's functional dependencies
+    struct ProbeInScope { int table; bool single; bool rankCapable; std::vector<std::string> keySymbols; };
+    std::vector<ProbeInScope> probesInScope;
 
     // ---- aggregation (aggregation.h:240-295) ----------------------------------------------------
     void collectAccumulators(OpNode* o) {
@@ -1281,10 +1292,70 @@ struct Walker {
         std::vector<std::pair<size_t, size_t>> charKeyWords;      // per CHAR(n) group value: [first, last] key word
         openScope("{");
         int k = 0;
-        q.groupSource.clear();
-        for (Expr* g : o->exprs2) {
+        // ---- group values that are functions of other group values -------------------------------------------------------
+        // A single-match probe hands every row with the same probe key the same entry, so the payload values of that entry are
+        // functions of the key.  If the group-by list holds the key of such a table (its build-side key attributes, or the probe-
+        // side attributes equal to them) — or the table is probed with values that are themselves determined this way — the other
+        // group values taken from its entry cannot tell two groups apart: they are CARRIED (stored once, when the group is
+        // created) instead of hashed and compared.  A probe for all matches does the same whenever its table is a bitmap-rank
+        // dictionary in this execution (a.htN_rank: the build keys proved unique — the planner's list of unique attributes,
+        // planner.h:218-241, misses c_custkey): the kernel then takes the short comparison, and the full one when the table fell
+        // back to the hash form.  TPC-H Q10 groups by c_custkey and six more values hanging off the customer and nation entries,
+        // 32 key words of which 31 are carried.  The group rows, and so the result, are the same.  RSQ_GROUP_FD=0 compares every
+        // value as before.
+        std::vector<bool> carried(o->exprs2.size(), false);
+        std::string fdCond;                      // run-time condition of the dependencies ("" = they always hold)
+        if (envInt("RSQ_GROUP_FD", 1, 0, 1)) {
+            std::set<std::string> groupSyms, determined;
+            for (Expr* g : o->exprs2) if (g->tag == RSQ_E_ATTRIBUTE) groupSyms.insert(g->symbol);
+            determined = groupSyms;
+            std::set<int> detTables, condTables; std::set<std::string> covers;
+            for (bool changed = true; changed;) {
+                changed = false;
+                for (auto& ps : probesInScope) {
+                    if ((!ps.single && !ps.rankCapable) || detTables.count(ps.table)) continue;
+                    HashTable& bt = *q.hashTables[(size_t)ps.table];
+                    bool viaProbeKeys = !ps.keySymbols.empty();
+                    for (auto& ks : ps.keySymbols) viaProbeKeys = viaProbeKeys && !ks.empty() && determined.count(ks);
+                    bool viaCover = !bt.keys.empty();
+                    std::vector<std::string> cv;
+                    for (size_t kw = 0; kw < bt.keys.size() && viaCover; kw++) {
+                        std::string hit;
+                        for (auto& gs : groupSyms) {
+                            auto org = symbolOrigin.find(gs);
+                            if (org != symbolOrigin.end() && org->second == ps.table && symbolWord[gs] == (int)kw) { hit = gs; break; }
+                            auto pk = probeKeyOf.find(gs);
+                            if (pk != probeKeyOf.end() && pk->second.first == ps.table && pk->second.second == (int)kw) { hit = gs; break; }
+                        }
+                        if (hit.empty()) viaCover = false; else cv.push_back(hit);
+                    }
+                    if (!viaProbeKeys && !viaCover) continue;
+                    detTables.insert(ps.table);
+                    if (!ps.single) condTables.insert(ps.table);
+                    if (!viaProbeKeys) covers.insert(cv.begin(), cv.end());
+                    for (auto& so : symbolOrigin) if (so.second == ps.table) determined.insert(so.first);
+                    changed = true;
+                }
+            }
+            size_t kept = 0;
+            for (size_t i = 0; i < o->exprs2.size(); i++) {
+                Expr* g = o->exprs2[i];
+                if (g->tag != RSQ_E_ATTRIBUTE) { kept++; continue; }
+                auto org = symbolOrigin.find(g->symbol);
+                carried[i] = org != symbolOrigin.end() && org->second >= 0 && detTables.count(org->second) && !covers.count(g->symbol);
+                if (!carried[i]) kept++;
+            }
+            if (kept == 0) std::fill(carried.begin(), carried.end(), false);      // (cannot happen: a chain of dependencies ends in a kept value)
+            for (int t : condTables) fdCond += (fdCond.empty() ? "" : " && ") + std::string("a.ht") + std::to_string(t) + "_rank != 0";
+        }
+        bool anyCarried = false;
+        for (bool c : carried) anyCarried = anyCarried || c;
+        q.groupSource.assign(o->exprs2.size(), 0);
+        for (size_t gi = 0; gi < o->exprs2.size(); gi++) {
+            if (carried[gi]) continue;
+            Expr* g = o->exprs2[gi];
             const size_t w0 = keyVars.size();
-            q.groupSource.push_back((int)w0);           // first table word of this group value
+            q.groupSource[gi] = (int)w0;                // first table word of this group value
             for (auto& kv : keyWords(g, T + "_g" + std::to_string(k++), false)) keyVars.push_back(kv);
             if (g->type.tag == RSQ_CHAR && g->type.len > 1) charKeyWords.push_back({w0, keyVars.size() - 1});
             for (size_t w = w0; w < keyVars.size(); w++)
@@ -1292,6 +1363,22 @@ struct Walker {
         }
         if (keyVars.empty()) failUnsupported("hash aggregation without group keys");
         const int K = (int)keyVars.size();
+        // carried values: their words follow the key words in the table (HashTable::payload), written by the lane that creates the group
+        struct Carried { Expr* g; std::string var, ctype; int firstWord, nWords; };
+        std::vector<Carried> carriedVals;
+        {
+            int cw = K;
+            for (size_t gi = 0; gi < o->exprs2.size(); gi++) {
+                if (!carried[gi]) continue;
+                Expr* g = o->exprs2[gi];
+                const int nw = g->type.isString() ? (g->type.len + 7) / 8 : 1;
+                q.groupSource[gi] = cw;
+                carriedVals.push_back({g, eg.symbols[g->symbol].var, ExprGen::ctype(g->type), cw, nw});
+                for (int w = 0; w < nw; w++)
+                    ht->payload.push_back({w == 0 ? expressionName(g) : expressionName(g) + "#" + std::to_string(w), w == 0 && !g->type.isString() ? g->type : Type(RSQ_BIGINT)});
+                cw += nw;
+            }
+        }
         for (int w = 1; w < W; w++) line("const i64 in" + std::to_string(w) + " = " + q.accums[(size_t)w].input + ";");
         addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
         addArg(T + "_acc", "u64*", 0);
@@ -1306,7 +1393,7 @@ struct Walker {
         int LS = envInt("RSQ_HASH_LDS_SLOTS", 0, 0, 4096);
         if (LS == 0) LS = slotBytes * 1024 <= 48 * 1024 ? 1024 : slotBytes * 512 <= 48 * 1024 ? 512 : 256;
         while (LS & (LS - 1)) LS &= LS - 1;           // power of two
-        const bool lds = envInt("RSQ_HASH_LDS", 1, 0, 1) && LS >= 64 && slotBytes * LS <= 48 * 1024;
+        const bool lds = envInt("RSQ_HASH_LDS", 1, 0, 1) && LS >= 64 && slotBytes * LS <= 48 * 1024 && !anyCarried;     // (a front-table slot holds no carried values to create its group with)
         if (lds) {
             stateDecl += "    u32* lc_state;\n    i64* lc_key;\n    u64* lc_acc;\n";
             prologue += "    __shared__ u32 s_lc_state[" + std::to_string(LS) + "];\n    __shared__ i64 s_lc_key[" + std::to_string(K * LS) +
@@ -1339,6 +1426,22 @@ struct Walker {
             // stays inside the loop body.  (With `if (won) {publish; hit} if (!hit) continue; ...; break;` the compiler threads
             // the winner straight to the loop exit, the structurizer parks it there until the whole wave has left the loop,
             // and the losers of the same wave spin on a slot that is never published.)
+            // carried group values: their words are needed by the lane that creates a group — and, while the dependencies are not
+            // certain (a table of the chain is in its hash form), by every lane for the full comparison
+            int nCarriedWords = 0;
+            for (auto& c : carriedVals) nCarriedWords += c.nWords;
+            auto carriedWords = [&]() {
+                for (size_t ci = 0; ci < carriedVals.size(); ci++) {
+                    const Carried& c = carriedVals[ci];
+                    std::vector<std::string> words = keyWords(c.g, T + "_c" + std::to_string(ci), false);
+                    for (int w = 0; w < c.nWords; w++) line(T + "_dw[" + std::to_string(c.firstWord - K + w) + "] = " + words[(size_t)w] + ";");
+                }
+            };
+            if (nCarriedWords) {
+                line("const bool " + T + "_fd = " + (fdCond.empty() ? std::string("true") : fdCond) + ";");
+                line("i64 " + T + "_dw[" + std::to_string(nCarriedWords) + "];");
+                if (!fdCond.empty()) { openScope("if (!" + T + "_fd) {"); carriedWords(); closeScope(); }
+            }
             line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0; bool " + T + "_found = false;");
             line("if (rsq::ld_agent(a.err) & (u32)rsq::ERR_HT_FULL) return;      // another lane found the table too small: this run is void");
             openScope("for (;;) {");
@@ -1347,7 +1450,19 @@ struct Walker {
             openScope("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) {");
             for (int i = 0; i < K; i++)
                 line("rsq::st_agent(&a." + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s], " + kp[(size_t)i] + ");");
-            line("__threadfence();");
+            // the carried group values of the new group (written by the lane that creates it; compared only in the full form)
+            if (nCarriedWords) {
+                openScope("if (" + T + "_fd) {"); carriedWords(); closeScope();
+                for (int w = 0; w < nCarriedWords; w++)
+                    line("rsq::st_agent(&a." + T + "_words[" + std::to_string(K + w) + " * a." + T + "_cap + " + T + "_s], " + T + "_dw[" + std::to_string(w) + "]);");
+            }
+            // The key (and carried) words must be visible before the state says "ready".  They are agent-scope stores (write-through
+            // to the level all XCDs see); once the stores have been ACKNOWLEDGED (s_waitcnt vmcnt(0)) a reader that sees state 2
+            // with its own agent-scope loads finds them.  A __threadfence() here instead — buffer_wbl2 + buffer_inv, tens of
+            // microseconds under load — made every NEW group cost a cache write-back: TPC-H Q10 at SF10 creates 380 K groups and
+            // spent 2.5 of its 2.9 ms there (device timestamps; round 3).  RSQ_HASH_FENCE=1 restores the fence.
+            if (envInt("RSQ_HASH_FENCE", 0, 0, 1)) line("__threadfence();");
+            else line("asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");");
             line("rsq::st_agent(&a." + T + "_state[" + T + "_s], 2u);");
             line("st.n_" + T + "++;");
             if (!charKeyWords.empty()) {
@@ -1371,6 +1486,12 @@ struct Walker {
             std::string cond;
             for (int i = 0; i < K; i++)
                 cond += (i ? " && " : "") + std::string("rsq::ld_agent(&a.") + T + "_words[" + std::to_string(i) + " * a." + T + "_cap + " + T + "_s]) == " + kp[(size_t)i];
+            if (nCarriedWords && !fdCond.empty()) {
+                std::string full;
+                for (int w = 0; w < nCarriedWords; w++)
+                    full += (w ? " && " : "") + std::string("rsq::ld_agent(&a.") + T + "_words[" + std::to_string(K + w) + " * a." + T + "_cap + " + T + "_s]) == " + T + "_dw[" + std::to_string(w) + "]";
+                cond = "(" + cond + ") && (" + T + "_fd || (" + full + "))";
+            }
             openScope("if (" + cond + ") {");
             line(T + "_found = true;");
             line("break;");
@@ -1420,6 +1541,7 @@ struct Walker {
             std::string fn = "static RSQ_DEV void " + T + "_upsert(const Args& a, State& st, const i64 x0";
             for (int i = 0; i < K; i++) fn += ", const i64 k" + std::to_string(i);
             for (int w = 1; w < W; w++) fn += ", const i64 x" + std::to_string(w);
+            for (auto& c : carriedVals) fn += ", const " + c.ctype + " " + c.var;          // (named like the row function's symbol: keyWords above refers to it)
             fn += ") {\n" + body + "}\n";
             helperFns += fn;
             body = savedBody; indent = savedIndent;
@@ -1429,6 +1551,7 @@ struct Walker {
         std::string call = T + "_upsert(a, st, row";
         for (int i = 0; i < K; i++) call += ", " + keyVars[(size_t)i];
         for (int w = 1; w < W; w++) call += ", in" + std::to_string(w);
+        for (auto& c : carriedVals) call += ", " + c.var;
         call += ");";
         if (lds) {
             line("bool " + T + "_done = false;");
@@ -1464,7 +1587,8 @@ struct Walker {
         } else line(call);
         closeScope();
         q.aggTable = ht->id;
-        explainSteps.push_back("hash aggregation in " + T + " (" + std::to_string(ht->keys.size()) + " key word(s)" + (lds ? ", LDS front table" : "") +
+        explainSteps.push_back("hash aggregation in " + T + " (" + std::to_string(ht->keys.size()) + " key word(s)" +
+                               (anyCarried ? " + " + std::to_string(ht->payload.size()) + " carried word(s) of group values that depend on them" : "") + (lds ? ", LDS front table" : "") +
                                ") accumulators=" + std::to_string(W - 1) + " (of " + std::to_string(o->splitAgg.size()) + " in the reference)");
         q.hashTables.push_back(std::move(ht));
     }

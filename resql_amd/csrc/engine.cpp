@@ -1312,7 +1312,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             for (;;) {
                 if (!h.dState) {
                     h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
-                    h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * h.keys.size());
+                    h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (h.keys.size() + h.payload.size()));      // key words, then carried group values
                     h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
                 }
                 RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
@@ -1323,6 +1323,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
                 waitForStream(ctx);
                 q.charGroupsNeedMerge = (err & 32u) != 0;
+                if (trace) fprintf(stderr, "[rsq trace]     hash aggregation table ht%d: %lld slots%s\n", h.id, (long long)h.capacity, (err & 2) ? " - too small, four times as many next" : "");
                 if (!(err & 2)) break;
                 if (h.capacity >= ((int64_t)1 << 31)) failRuntime("Hash table full");
                 ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc);

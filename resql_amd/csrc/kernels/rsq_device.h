@@ -299,7 +299,8 @@ RSQ_DEV u8 like(const Str& str, const Str& pattern) {
 // Slots that are inserted AND looked up inside one launch (hash aggregation) are published with agent-scope
 // accesses: a CU's vector L1 is never refreshed by another CU's stores, so plain loads of a freshly written key
 // could be stale (MI355X_MICROARCH.md, inter-workgroup visibility).  Writer: key stores (sc1, write-through) ->
-// __threadfence() -> state = 2.  Reader: state load (sc1) == 2 -> key loads (sc1).
+// s_waitcnt vmcnt(0) (the stores are acknowledged at the level every XCD sees) -> state = 2.  Reader: state load (sc1) == 2 ->
+// key loads (sc1).
 RSQ_DEV u32 ld_agent(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RSQ_DEV i64 ld_agent(const i64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 RSQ_DEV void st_agent(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
