@@ -119,6 +119,10 @@ Query::~Query() {
         else { if (dtArena.dev) ctx.free(dtArena.dev); if (dtArena.pinned) (void)hipHostFree(dtArena.pinned); }
     }
     if (dGenericCode) ctx.free(dGenericCode);
+    for (auto& gp : generic2Progs) { if (gp.dCode) ctx.free(gp.dCode); if (gp.dProbes) ctx.free(gp.dProbes); if (gp.dConstPool) ctx.free(gp.dConstPool); }
+    if (dG2Cnt) ctx.free(dG2Cnt);
+    if (dG2Offs) ctx.free(dG2Offs);
+    if (dG2ScanTemp) ctx.free(dG2ScanTemp);
     if (dAgg && dAggOwned) ctx.free(dAgg);
     if (dAggInit) ctx.free(dAggInit);
     if (dAggWork) ctx.free(dAggWork);
@@ -258,13 +262,32 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     bool cached = true;
     if (allowGeneric) for (const std::string& src : kernelSources(*q)) cached = cached && ctx.kernelCached(src);
     if (allowGeneric && (forceGeneric || !cached)) {
-        std::string why;
-        if (buildGenericProgram(*q, q->generic, why)) {
-            q->genericActive = true; q->genericForced = forceGeneric;
+        std::string why, why2;
+        bool ok = buildGenericProgram(*q, q->generic, why);
+        if (ok) {
             q->dGenericCode = (GenericInstr*)ctx.alloc(std::max<size_t>(1, q->generic.code.size()) * sizeof(GenericInstr));
             RSQ_HIP(hipMemcpy(q->dGenericCode, q->generic.code.data(), q->generic.code.size() * sizeof(GenericInstr), hipMemcpyHostToDevice));
             q->explainText += "generic pre-compiled pipeline (" + std::to_string(q->generic.code.size()) + " instructions, " + std::to_string(q->generic.cols.size()) +
                               " columns)" + (forceGeneric ? " forced" : " until hiprtc has built the specialised kernel") + "\n";
+        } else if (!(getenv("RSQ_GENERIC2") && atoi(getenv("RSQ_GENERIC2")) == 0) && buildGenericPlan(*q, q->generic2Progs, why2)) {
+            // joins, strings, hash aggregation, materialisation: the interpreter for whole pipelines, one program per pipeline
+            ok = true; q->generic2 = true;
+            size_t instr = 0;
+            for (auto& gp : q->generic2Progs) {
+                instr += gp.code.size();
+                gp.dCode = (GenericInstr*)ctx.alloc(std::max<size_t>(1, gp.code.size()) * sizeof(GenericInstr));
+                RSQ_HIP(hipMemcpy(gp.dCode, gp.code.data(), gp.code.size() * sizeof(GenericInstr), hipMemcpyHostToDevice));
+                gp.dProbes = (GenericProbeDesc*)ctx.alloc(std::max<size_t>(1, gp.probes.size()) * sizeof(GenericProbeDesc));
+                if (!gp.probes.empty()) RSQ_HIP(hipMemcpy(gp.dProbes, gp.probes.data(), gp.probes.size() * sizeof(GenericProbeDesc), hipMemcpyHostToDevice));
+                gp.dConstPool = (char*)ctx.alloc(std::max<size_t>(8, gp.constPool.size()));
+                if (!gp.constPool.empty()) RSQ_HIP(hipMemcpy(gp.dConstPool, gp.constPool.data(), gp.constPool.size(), hipMemcpyHostToDevice));
+            }
+            for (auto& h : q->hashTables) q->savedAos.push_back(h->aos);
+            q->explainText += "generic pre-compiled interpreter for " + std::to_string(q->generic2Progs.size()) + " pipeline(s) (" + std::to_string(instr) +
+                              " instructions)" + (forceGeneric ? " forced" : " until hiprtc has built the specialised kernels") + "\n";
+        } else if (!why2.empty() && getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace] not interpreted: %s\n", why2.c_str());
+        if (ok) {
+            q->genericActive = true; q->genericForced = forceGeneric;
             if (!cached) {
                 (void)ctx.cacheKey("");            // fills the header text the compiler thread reads
                 const std::vector<std::string> sources = kernelSources(*q);
@@ -878,14 +901,157 @@ static void enqueueTableInit(Query& q) {
     else RSQ_HIP(hipMemcpyAsync(q.dAgg, q.dAggInit, q.tableWords * 8, hipMemcpyDeviceToDevice, q.ctx.stream));
 }
 static void enqueueTableReadback(Query& q) {
-    if (q.aggPad > 1) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAggWork, q.padWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
+    if (q.aggPad > 1 && !q.flatRun) RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAggWork, q.padWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
     else RSQ_HIP(hipMemcpyAsync(q.hPinned, q.dAgg, q.tableWords * 8, hipMemcpyDeviceToHost, q.ctx.stream));
 }
 static void tableFromPinned(Query& q) {
     q.hAggView = nullptr;
-    if (q.aggPad > 1) for (size_t i = 0; i < q.tableWords; i++) q.hAgg[i] = q.hPinned[i * (size_t)q.aggPad];
+    if (q.aggPad > 1 && !q.flatRun) for (size_t i = 0; i < q.tableWords; i++) q.hAgg[i] = q.hPinned[i * (size_t)q.aggPad];
     else if (q.tableWords >= (1u << 16)) q.hAggView = q.hPinned;      // tens of MB: the tail reads the pinned buffer itself (a copy is 3 ms of one core)
     else memcpy(q.hAgg.data(), q.hPinned, q.tableWords * 8);
+}
+
+// ---- the interpreter for whole pipelines (generic2.cpp, generic_kernels.hip) ---------------------------------------------
+// Its join / aggregation tables live in the HashTable objects the specialised kernels use, in the interpreter's one layout:
+// state[cap], words[cap][keys + payload], acc[block][cap] — which is also what the entry compaction and everything behind it
+// read (HashTable::aos, no rank dictionary).  When the specialised kernels take over, the tables are dropped and sized afresh.
+static void dropTable(Context& ctx, HashTable& h) {
+    for (void* p : {(void*)h.dState, (void*)h.dWords, (void*)h.dAcc, (void*)h.dTemp, (void*)h.dTempUsed, (void*)h.dChunkTotal, (void*)h.dChunkBase})
+        if (p) ctx.free(p);
+    h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr; h.dTemp = nullptr; h.dTempUsed = nullptr; h.dChunkTotal = nullptr; h.dChunkBase = nullptr;
+    h.capacity = 0; h.lastCount = 0; h.rank = false; h.prepared = false;
+}
+static void leaveGeneric2(Query& q) {
+    for (size_t i = 0; i < q.hashTables.size(); i++) {
+        dropTable(q.ctx, *q.hashTables[i]);
+        if (i < q.savedAos.size()) q.hashTables[i]->aos = q.savedAos[i];
+    }
+    for (auto& p : q.pipelines) p.stage2Rows = -1;
+}
+
+static void generic2Launch(Query& q, size_t pi, int matPass) {
+    Context& ctx = q.ctx;
+    Pipeline& p = q.pipelines[pi];
+    GenericProgram2& gp = q.generic2Progs[pi];
+    GenericPipelineLaunch L;
+    memset(&L, 0, sizeof L);
+    L.prog = &gp; L.dCode = gp.dCode; L.dProbes = gp.dProbes; L.dConstPool = gp.dConstPool;
+    for (size_t t = 0; t < q.hashTables.size() && t < G2_MAX_TABLES; t++) {
+        HashTable& h = *q.hashTables[t];
+        L.tables[t] = GenericTableRef{h.dState, h.dWords, h.dAcc, (uint64_t)h.capacity, h.dCount, (int)std::max<size_t>(1, h.keys.size() + h.payload.size())};
+    }
+    L.nRows = p.src->nRows; L.row0 = p.src->row0;
+    L.matCnt = q.dG2Cnt; L.matOffs = q.dG2Offs; L.matLimit = q.matLimit; L.matPass = matPass;
+    for (size_t c = 0; c < q.dMatCols.size() && c < G2_MAX_OUT; c++) L.matOut[c] = q.dMatCols[c];
+    L.dense = q.dAgg; L.denseGroups = q.denseGroups;
+    launchGenericPipeline(ctx, L);
+    q.report.num_kernels++;
+}
+
+static void runGeneric2Pipeline(Query& q, size_t pi) {
+    Context& ctx = q.ctx;
+    Pipeline& p = q.pipelines[pi];
+    const GenericSinkDesc& S = q.generic2Progs[pi].sink;
+    auto identityOfBlock = [&](int b) { return b < q.nMinBlocks ? 0x7fffffffffffffffull : b < q.nMinBlocks + q.nMaxBlocks ? 0x8000000000000000ull : 0ull; };
+    auto clearAcc = [&](HashTable& h) {
+        std::vector<FillItem> f;
+        for (int b = 0; b < h.nAccBlocks; b++) f.push_back(FillItem{(uint64_t*)h.dAcc + (size_t)b * (size_t)h.capacity, (size_t)h.capacity * 8, identityOfBlock(b)});
+        fillBatchAsync(ctx, f.data(), (int)f.size());
+        q.report.num_kernels++;
+    };
+    switch (S.kind) {
+        case G2_SINK_BUILD: {
+            HashTable& h = *q.hashTables[(size_t)S.table];
+            const size_t NW = std::max<size_t>(1, h.keys.size() + h.payload.size());
+            // no sizing pass: twice the scanned rows always hold the entries (a cold first execution may be generous with memory)
+            const int64_t cap = nextPow2(std::max<int64_t>(64, 2 * p.src->nRows));
+            if (h.capacity != cap || !h.dState || !h.dWords) {
+                dropTable(ctx, h);
+                h.capacity = cap;
+                h.dState = (uint32_t*)ctx.alloc((size_t)cap * 4);
+                h.dWords = (int64_t*)ctx.alloc((size_t)cap * 8 * NW);
+                if (q.aggTable == h.id && q.aggMode == AggMode::AT_JOIN_ENTRY) h.dAcc = (int64_t*)ctx.alloc((size_t)cap * 8 * (size_t)h.nAccBlocks);
+            }
+            h.aos = true; h.rank = false;
+            RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)cap * 4, ctx.stream));
+            RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
+            generic2Launch(q, pi, 0);
+            break;
+        }
+        case G2_SINK_DENSE:
+            generic2Launch(q, pi, 0);              // (executeQuery has put the identity image into q.dAgg: this execution is "flat")
+            break;
+        case G2_SINK_ENTRY: {
+            HashTable& h = *q.hashTables[(size_t)S.table];
+            if (!h.dAcc || h.capacity == 0) failRuntime("internal error: the aggregation's join table was not built");
+            clearAcc(h);
+            generic2Launch(q, pi, 0);
+            break;
+        }
+        case G2_SINK_HASH: {
+            HashTable& h = *q.hashTables[(size_t)S.table];
+            const size_t NW = std::max<size_t>(1, h.keys.size() + h.payload.size());
+            h.aos = true;
+            if (h.capacity == 0) h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)opSize(q.agg)));
+            while ((int64_t)h.lastCount * 2 > h.capacity) { if (h.dState) { ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc); } h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr; h.capacity *= 2; }
+            for (;;) {
+                if (!h.dState) {
+                    h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
+                    h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * NW);
+                    h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
+                }
+                RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
+                RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
+                clearAcc(h);
+                generic2Launch(q, pi, 0);
+                uint32_t err = 0;
+                RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+                waitForStream(ctx);
+                q.charGroupsNeedMerge = (err & 32u) != 0;
+                if (!(err & 2)) break;
+                if (h.capacity >= ((int64_t)1 << 31)) failRuntime("Hash table full");
+                ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc);
+                h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
+                h.capacity *= 4;
+                RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
+            }
+            break;
+        }
+        case G2_SINK_MATERIALIZE: {
+            // count per row / exclusive scan / write: the rows keep scan order (materialize.h:78-220 appends with one thread)
+            const int64_t n = p.src->nRows;
+            if (n + 1 > 0x7fffffff) failUnsupported("materialisation over more than 2 G rows in the interpreter");
+            if (q.g2CntRows < n + 1) {
+                if (q.dG2Cnt) { ctx.free(q.dG2Cnt); ctx.free(q.dG2Offs); ctx.free(q.dG2ScanTemp); }
+                q.dG2Cnt = (uint32_t*)ctx.alloc((size_t)(n + 1) * 4);
+                q.dG2Offs = (uint64_t*)ctx.alloc((size_t)(n + 1) * 8);
+                q.dG2ScanTemp = ctx.alloc(scanTempBytes(n + 1));
+                q.g2CntRows = n + 1;
+            }
+            RSQ_HIP(hipMemsetAsync(q.dG2Cnt, 0, (size_t)(n + 1) * 4, ctx.stream));
+            q.matLimit = 0;
+            generic2Launch(q, pi, 1);
+            exclusiveScanCounts(ctx, q.dG2Cnt, q.dG2Offs, n + 1, q.dG2ScanTemp, scanTempBytes(n + 1));
+            q.report.num_kernels += 3;
+            uint64_t total = 0;
+            RSQ_HIP(hipMemcpyAsync(&total, q.dG2Offs + n, 8, hipMemcpyDeviceToHost, ctx.stream));
+            waitForStream(ctx);
+            uint64_t keep = total;
+            if (q.matOp->hasLimit) keep = std::min<uint64_t>(total, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));      // materialize.h:197-206
+            q.matRows = (int64_t)keep;
+            if ((int64_t)keep > q.matCapacity || q.dMatCols.empty()) {
+                for (void* c : q.dMatCols) if (c) ctx.free(c);
+                q.dMatCols.clear();
+                q.matCapacity = std::max<int64_t>((int64_t)keep, 1);
+                for (auto& a : q.matSchema) q.dMatCols.push_back(ctx.alloc((size_t)q.matCapacity * (size_t)columnWidth(a.type)));
+            }
+            q.matLimit = keep;
+            generic2Launch(q, pi, 2);
+            break;
+        }
+        default: failRuntime("internal error: interpreter sink");
+    }
+    q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
 }
 
 // blocks until the query runs on its specialised kernels (joins the compiler thread of a query that started on the generic pipeline)
@@ -895,6 +1061,7 @@ void awaitKernels(Query& q) {
     if (q.bgState.load() == 3) throw Error(RSQ_ERR_DEVICE, q.bgError);
     resolveKernels(q);
     q.genericActive = false;
+    if (q.generic2) leaveGeneric2(q);
     q.report.jit_compiles = (int32_t)kernelSources(q).size();
 }
 
@@ -1041,8 +1208,9 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (q.bgState.load() == 3) throw Error(RSQ_ERR_DEVICE, q.bgError);
             resolveKernels(q);
             q.genericActive = false;
+            if (q.generic2) leaveGeneric2(q);
             q.report.jit_compiles = (int32_t)kernelSources(q).size();       // built by the compiler thread since rsq_query_compile returned
-        } else {
+        } else if (!q.generic2) {
             // ---- the generic pipeline: table init, ONE interpreter launch, read-back ----
             Pipeline& p = q.pipelines[0];
             q.fusedReady = false;
@@ -1074,13 +1242,14 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             return;
         }
     }
-    q.flatRun = partialOnly && q.aggPad > 1;
+    const bool interp = q.genericActive && q.generic2;      // this execution's pipelines run on the interpreter for whole pipelines
+    q.flatRun = (partialOnly || interp) && q.aggPad > 1;      // (the interpreter aggregates into the unpadded table)
     const bool trace0 = getenv("RSQ_TRACE") != nullptr;
     uint32_t topkCapacity = 0, topkSpec = 0;      // > 0: this execution pre-selects ORDER BY ... LIMIT candidates on the device
     bool topkRange = false;                       // ... with the short form (one histogram over the images' range)
     uint32_t groupRowsAllocated = 0;              // rows the group-row buffers of this execution can take
     // ---- the step in one launch: a single register-mode pipeline whose last workgroup publishes the table ----
-    if (fusedEligible(q) && !trace0) {
+    if (fusedEligible(q) && !trace0 && !interp) {
         Pipeline& p = q.pipelines[0];
         // the kernel leaves its working table, the error word and the ticket at their identities; make them so the first
         // time, after an execution that did not come back (an exception between launch and synchronisation), and whenever
@@ -1233,7 +1402,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         // instead of one launch in front of every build (TPC-H Q5 builds five tables, Q3 two); likewise the aggregates kept beside
         // a join table's entries.  Nothing touches a table between this fill and its build pipeline.
         static const bool prologueOk = !(getenv("RSQ_PROLOGUE") && atoi(getenv("RSQ_PROLOGUE")) == 0);
-        if (prologueOk && !trace)
+        if (prologueOk && !trace && !interp)
             for (auto& p : q.pipelines) {
                 if (p.sink != SinkKind::BUILD) continue;
                 HashTable& h = *q.hashTables[(size_t)p.buildTable];
@@ -1257,7 +1426,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 f.push_back(FillItem{h.dCount, 4, 0});
                 h.prepared = true;
             }
-        if (prologueOk && !trace && q.aggMode == AggMode::AT_JOIN_ENTRY) {
+        if (prologueOk && !trace && !interp && q.aggMode == AggMode::AT_JOIN_ENTRY) {
             HashTable& h = *q.hashTables[(size_t)q.aggTable];
             if (h.capacity > 0 && h.dAcc && h.prepared) {       // (sized, and not about to be re-sized by its build)
                 for (int b = 0; b < h.nAccBlocks; b++) {
@@ -1286,6 +1455,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         tPipe = nowMs();
     };
     for (auto& p : q.pipelines) {
+        if (interp) { runGeneric2Pipeline(q, (size_t)(&p - q.pipelines.data())); tracePoint(p); continue; }
         if (p.sink == SinkKind::BUILD) { buildHashTable(q, p); tracePoint(p); continue; }
         if (p.sink == SinkKind::MATERIALIZE) { materializePipeline(q, p); tracePoint(p); continue; }
         auto resetAccumulators = [&](HashTable& h) {

@@ -123,6 +123,50 @@ struct GenericProgram {
     struct Acc { int reg; int merge; int64_t block; };   // reg -1: the row index, -2: the constant 1
     std::vector<Acc> accs;
 };
+// ---- the interpreter for whole pipelines (generic2.cpp, generic_kernels.hip k_generic_pipeline) -------------------------
+// Further instructions of the same 16-byte form: string values are device addresses (of the column's bytes, of a constant in the
+// program's constant pool, or a payload word of a join table — strings travel by address there too).
+enum GenericOp2 : uint8_t { G_COLADDR = 32, G_CONSTADDR, G_MOV, G_CAST16, G_STREQ, G_LIKE, G_STRWORD, G_PROBE };
+enum { G2_REGS = 40, G2_MAX_COLS = 24, G2_MAX_TABLES = 8, G2_MAX_KEYW = 40, G2_MAX_DEPTH = 4, G2_MAX_OUT = 24, G2_MAX_ACCS = 16, G2_MAX_KEYS = 4, G2_MAX_SET = 32,
+       G2_MAX_PAYLOAD = 24, G2_MAX_CHARKEYS = 8 };
+enum { G2_SINK_BUILD = 1, G2_SINK_DENSE, G2_SINK_ENTRY, G2_SINK_HASH, G2_SINK_MATERIALIZE };
+struct GenericProbeDesc {
+    int32_t table, nKeys, nPayload, slotReg, single;
+    uint8_t keyReg[8]; uint8_t payloadReg[G2_MAX_PAYLOAD];
+};
+struct GenericSinkDesc {
+    int32_t kind, table, nKeys, nPayload, slotReg, nAccs, nOut, nCharKeys;
+    uint8_t keyReg[G2_MAX_KEYW];               // BUILD: key words; HASH: all table words (compared keys, then carried values); DENSE: the group values
+    uint8_t payloadReg[G2_MAX_PAYLOAD];
+    int32_t accReg[G2_MAX_ACCS], accMerge[G2_MAX_ACCS], accBlock[G2_MAX_ACCS];      // reg -1: the row number, -2: the constant 1
+    int32_t keyByteSet[G2_MAX_KEYS], keyNValues[G2_MAX_KEYS]; int64_t keyMin[G2_MAX_KEYS], keyCard[G2_MAX_KEYS], keyStride[G2_MAX_KEYS];
+    uint8_t keyValues[G2_MAX_KEYS][G2_MAX_SET];
+    uint8_t charFirst[G2_MAX_CHARKEYS], charLast[G2_MAX_CHARKEYS];                   // HASH: word ranges of CHAR(n) group values (trailing-space note)
+    uint8_t outReg[G2_MAX_OUT]; int32_t outWidth[G2_MAX_OUT], outString[G2_MAX_OUT], outSrcCap[G2_MAX_OUT];
+};
+struct GenericProgram2 {
+    std::vector<GenericInstr> code;
+    struct Col { const void* ptr; int width; };
+    std::vector<Col> cols;
+    std::vector<GenericProbeDesc> probes;
+    std::vector<char> constPool;
+    GenericSinkDesc sink{};
+    // device copies (made when the query is compiled)
+    GenericInstr* dCode = nullptr; GenericProbeDesc* dProbes = nullptr; char* dConstPool = nullptr;
+};
+struct GenericTableRef { uint32_t* state; void* words; void* acc; uint64_t cap; uint32_t* count; int nWords; };
+struct GenericPipelineLaunch {
+    const GenericProgram2* prog; const GenericInstr* dCode; const GenericProbeDesc* dProbes; const char* dConstPool;
+    GenericTableRef tables[G2_MAX_TABLES];
+    int64_t nRows, row0;
+    uint32_t* matCnt; const uint64_t* matOffs; uint64_t matLimit; void* matOut[G2_MAX_OUT]; int matPass;
+    uint64_t* dense; int64_t denseGroups;
+};
+void launchGenericPipeline(Context& ctx, const GenericPipelineLaunch& L);
+struct Query;
+// generic2.cpp: one program per pipeline of the compiled query, or false (+ why) when some shape is not interpreted
+bool buildGenericPlan(Query& q, std::vector<GenericProgram2>& out, std::string& why);
+
 struct Pipeline {
     Table* src = nullptr;
     std::vector<int> cols;           // scanned columns (indices into src->cols)
@@ -319,6 +363,11 @@ struct Query {
     bool genericActive = false, genericForced = false;
     GenericProgram generic;
     GenericInstr* dGenericCode = nullptr;
+    // ... or the interpreter for whole pipelines, one program per pipeline (joins, hash aggregation, materialisation)
+    bool generic2 = false;
+    std::vector<GenericProgram2> generic2Progs;
+    std::vector<bool> savedAos;            // the join tables' own layout flags while the interpreter's (words[slot][w]) are in force
+    uint32_t* dG2Cnt = nullptr; uint64_t* dG2Offs = nullptr; void* dG2ScanTemp = nullptr; int64_t g2CntRows = 0;
     std::thread bgCompiler;                // builds the specialised kernels into the code-object cache
     std::atomic<int> bgState{0};           // 0 none, 1 running, 2 done, 3 failed
     std::string bgError;
