@@ -213,6 +213,7 @@ static std::vector<std::string> kernelSources(const Query& q) {
         if (p.partitioned) { v.push_back(p.sourcePartCount); v.push_back(p.sourcePartScatter); v.push_back(p.sourcePartAgg); }
         if (p.staged) { v.push_back(p.sourceStagedScatter); v.push_back(p.sourceStagedAgg); }
         v.push_back(p.source);
+        if (!p.sourceLazy.empty()) v.push_back(p.sourceLazy);      // (chosen at run time; compiled with the others so that choosing it never blocks an execution)
     }
     return v;
 }
@@ -253,7 +254,9 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     q->exprs = q->pool.build(plan);
     buildOps(*q, plan);
     defineAndDerive(*q, q->root);
+    const double tBuilt0 = nowMs();
     buildPipelines(*q);
+    const double tBuilt = nowMs();
     // A plan shape whose specialised kernels are not in the code-object cache starts on the pre-compiled generic pipeline
     // (generic.cpp) while hiprtc builds them on a host thread; RSQ_FORCE_GENERIC=1 keeps every eligible plan there (tests),
     // RSQ_GENERIC=0 restores the blocking compile.
@@ -261,6 +264,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
     const bool allowGeneric = ctx.device >= 0 && !(getenv("RSQ_GENERIC") && atoi(getenv("RSQ_GENERIC")) == 0);
     bool cached = true;
     if (allowGeneric) for (const std::string& src : kernelSources(*q)) cached = cached && ctx.kernelCached(src);
+    if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace] compile: code-object cache looked up at +%.3f ms\n", nowMs() - tBuilt);
     if (allowGeneric && (forceGeneric || !cached)) {
         std::string why, why2;
         bool ok = buildGenericProgram(*q, q->generic, why);
@@ -273,6 +277,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
             // joins, strings, hash aggregation, materialisation: the interpreter for whole pipelines, one program per pipeline
             ok = true; q->generic2 = true;
             size_t instr = 0;
+            if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace] compile: interpreter programs built at +%.3f ms\n", nowMs() - tBuilt);
             for (auto& gp : q->generic2Progs) {
                 instr += gp.code.size();
                 gp.dCode = (GenericInstr*)ctx.alloc(std::max<size_t>(1, gp.code.size()) * sizeof(GenericInstr));
@@ -283,6 +288,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
                 if (!gp.constPool.empty()) RSQ_HIP(hipMemcpy(gp.dConstPool, gp.constPool.data(), gp.constPool.size(), hipMemcpyHostToDevice));
             }
             for (auto& h : q->hashTables) q->savedAos.push_back(h->aos);
+            if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace] compile: interpreter programs on the device at +%.3f ms\n", nowMs() - tBuilt);
             q->explainText += "generic pre-compiled interpreter for " + std::to_string(q->generic2Progs.size()) + " pipeline(s) (" + std::to_string(instr) +
                               " instructions)" + (forceGeneric ? " forced" : " until hiprtc has built the specialised kernels") + "\n";
         } else if (!why2.empty() && getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace] not interpreted: %s\n", why2.c_str());
@@ -300,7 +306,10 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
             }
         }
     }
+    const double tGeneric = nowMs();
     if (!q->genericActive) resolveKernels(*q);
+    if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace] compile: typing %.3f ms, pipelines + kernel text %.3f ms, cache lookup + interpreter programs %.3f ms, kernels %.3f ms\n",
+                                     tBuilt0 - t0, tBuilt - tBuilt0, tGeneric - tBuilt, nowMs() - tGeneric);
     for (auto& p : q->pipelines) {
         q->allSource += p.source + "\n";
         q->explainText += p.explain + "\n";

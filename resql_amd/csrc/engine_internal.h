@@ -137,6 +137,7 @@ struct GenericProbeDesc {
 struct GenericSinkDesc {
     int32_t kind, table, nKeys, nPayload, slotReg, nAccs, nOut, nCharKeys;
     uint8_t keyReg[G2_MAX_KEYW];               // BUILD: key words; HASH: all table words (compared keys, then carried values); DENSE: the group values
+    uint8_t wordStr[G2_MAX_KEYW], wordOff[G2_MAX_KEYW], wordN[G2_MAX_KEYW];      // HASH: word w = bytes [off, off + n) of the string whose address is in keyReg[w]
     uint8_t payloadReg[G2_MAX_PAYLOAD];
     int32_t accReg[G2_MAX_ACCS], accMerge[G2_MAX_ACCS], accBlock[G2_MAX_ACCS];      // reg -1: the row number, -2: the constant 1
     int32_t keyByteSet[G2_MAX_KEYS], keyNValues[G2_MAX_KEYS]; int64_t keyMin[G2_MAX_KEYS], keyCard[G2_MAX_KEYS], keyStride[G2_MAX_KEYS];

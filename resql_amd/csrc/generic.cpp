@@ -173,10 +173,13 @@ struct Builder {
 
 bool buildGenericProgram(Query& q, GenericProgram& out, std::string& why) {
     out = GenericProgram();
+    // (the two structural tests without an exception: the first C++ exception of a process walks the unwind tables of every loaded
+    // library — 80 ms with the ROCm stack loaded, which a cold TPC-H Q3 then paid on its way to the whole-pipeline interpreter)
+    if (q.pipelines.size() != 1 || q.pipelines[0].sink != SinkKind::AGGREGATE || !q.agg) { why = "not a single scan -> aggregation pipeline"; return false; }
+    if (!(q.aggMode == AggMode::DENSE_REG || q.aggMode == AggMode::DENSE_LDS_PRIVATE || q.aggMode == AggMode::DENSE_LDS_SHARED || q.aggMode == AggMode::DENSE_GLOBAL)) {
+        why = "not a dense aggregation"; return false;
+    }
     try {
-        if (q.pipelines.size() != 1 || q.pipelines[0].sink != SinkKind::AGGREGATE || !q.agg) throw Error(RSQ_ERR_UNSUPPORTED, "not a single scan -> aggregation pipeline");
-        if (!(q.aggMode == AggMode::DENSE_REG || q.aggMode == AggMode::DENSE_LDS_PRIVATE || q.aggMode == AggMode::DENSE_LDS_SHARED || q.aggMode == AggMode::DENSE_GLOBAL))
-            throw Error(RSQ_ERR_UNSUPPORTED, "not a dense aggregation");
         if (q.denseGroups * (int64_t)q.accums.size() > ((int64_t)1 << 27)) throw Error(RSQ_ERR_UNSUPPORTED, "aggregate table too large");
         Builder b(q, out);
         // the operators between the scan and the aggregation: selections only

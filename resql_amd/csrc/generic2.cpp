@@ -320,18 +320,24 @@ void buildOne(Query& q, size_t pi, OpNode* scan, GenericProgram2& prog) {
                     for (size_t gi = 0; gi < o->exprs2.size(); gi++) {
                         Expr* g = o->exprs2[gi];
                         const int first = q.groupSource[gi];
-                        std::vector<int> words;
                         if (g->type.isString()) {
-                            Val2 a = b.gen(g);
-                            b.stringWords(a.reg, g->type, words);
+                            // the words are taken from the string when the row reaches the sink (one register for the address, not one per word:
+                            // TPC-H Q10's seven group values are 32 words)
+                            if (g->type.len > 255) b.no("group value wider than 255 bytes");
+                            const int a = b.pinned(g);
+                            const int nw = (g->type.len + 7) / 8;
+                            for (int w = 0; w < nw; w++) {
+                                if ((size_t)(first + w) >= NW) b.no("group row layout");
+                                wordReg[(size_t)(first + w)] = a;
+                                S.wordStr[first + w] = 1; S.wordOff[first + w] = (uint8_t)(w * 8); S.wordN[first + w] = (uint8_t)std::min(8, g->type.len - w * 8);
+                            }
                             if (g->type.tag == RSQ_CHAR && g->type.len > 1) {
                                 if (S.nCharKeys >= G2_MAX_CHARKEYS) b.no("too many CHAR group values");
-                                S.charFirst[S.nCharKeys] = (uint8_t)first; S.charLast[S.nCharKeys] = (uint8_t)(first + (int)words.size() - 1); S.nCharKeys++;
+                                S.charFirst[S.nCharKeys] = (uint8_t)first; S.charLast[S.nCharKeys] = (uint8_t)(first + nw - 1); S.nCharKeys++;
                             }
-                        } else words.push_back(b.pinned(g));
-                        for (size_t w = 0; w < words.size(); w++) {
-                            if ((size_t)first + w >= NW) b.no("group row layout");
-                            wordReg[(size_t)first + w] = words[w];
+                        } else {
+                            if ((size_t)first >= NW) b.no("group row layout");
+                            wordReg[(size_t)first] = b.pinned(g);
                         }
                     }
                     for (size_t w = 0; w < NW; w++) { if (wordReg[w] < 0) b.no("group row layout"); S.keyReg[w] = (uint8_t)wordReg[w]; }

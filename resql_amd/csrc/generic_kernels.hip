@@ -216,7 +216,15 @@ __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a)
                         const GenericTableDev& T = a.tab[S.table];
                         const int NW = T.nWords;          // compared key words, then carried words: ALL are compared here (the
                         i64 k[G2_MAX_KEYW];               // dependencies codegen.cpp relies on need a rank dictionary, which this path has not)
-                        for (int i = 0; i < NW; i++) k[i] = G2_REG(S.keyReg[i]);
+                        for (int i = 0; i < NW; i++) {
+                            const i64 v = G2_REG(S.keyReg[i]);
+                            if (S.wordStr[i]) {      // a string group value: its bytes where they lie (NUL padded to the column's width)
+                                const char* sp8 = reinterpret_cast<const char*>((unsigned long long)(u64)v) + S.wordOff[i];
+                                u64 w = 0;
+                                for (int bb = 0; bb < (int)S.wordN[i]; bb++) w |= (u64)(u8)sp8[bb] << (8 * bb);
+                                k[i] = (i64)w;
+                            } else k[i] = v;
+                        }
                         const u64 mask = T.cap - 1;
                         u64 s = g2_hash(k, S.nKeys) & mask;
                         u64 adv = 0; u32 spin = 0; bool found = false;
