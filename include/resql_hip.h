@@ -199,6 +199,9 @@ void  rsq_free(void* p);
  * entries: out[k] = index of the group in the k-th occupied slot.  parallel != 0 takes the cluster-parallel replay the engine's
  * tail uses for many groups, 0 the sequential one; both give the same permutation (tests compare them). */
 int   rsq_ref_emission_order(const uint64_t* hashes, int64_t n, uint64_t min_size, int32_t parallel, uint32_t* out);
+/* The same on the GPU of `ctx` (the form the tail of a large dense aggregation uses): hashes and the result travel through device
+ * memory.  RSQ_ERR_UNSUPPORTED for tables beyond the device path's range (2^31 slots). */
+int   rsq_ref_emission_order_device(rsq_ctx* ctx, const uint64_t* hashes, int64_t n, uint64_t min_size, uint32_t* out);
 
 /* ---- SQL text in front of the path --------------------------------------
  * The reference turns SQL text into an operator tree with parseSql (src/parser/parseSql.h:130-166:

@@ -294,6 +294,26 @@ char* rsq_result_serialize(const rsq_result_view* view) {
 
 void rsq_free(void* p) { free(p); }
 
+int rsq_ref_emission_order_device(rsq_ctx* ctx, const uint64_t* hashes, int64_t n, uint64_t min_size, uint32_t* out) {
+    if (!ctx || n < 0 || (n > 0 && (!hashes || !out))) return RSQ_ERR_INVALID;
+    return guarded(C(ctx), [&] {
+        Context& c = *C(ctx);
+        if (c.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
+        if (n == 0) return;
+        std::vector<std::pair<uint64_t, uint64_t>> levels;
+        if (!replayLevels((uint64_t)n, min_size, levels)) failUnsupported("the device replay does not take tables of this size");
+        RSQ_HIP(hipSetDevice(c.device));
+        uint64_t* dH = (uint64_t*)c.alloc((size_t)n * 8);
+        uint32_t* dO = (uint32_t*)c.alloc((size_t)n * 4);
+        void* work = c.alloc(replayDeviceBytes((uint64_t)n, levels.back().first));
+        RSQ_HIP(hipMemcpy(dH, hashes, (size_t)n * 8, hipMemcpyHostToDevice));
+        replayEmissionOrderDevice(c, dH, (uint64_t)n, levels, work, dO);
+        RSQ_HIP(hipStreamSynchronize(c.stream));
+        RSQ_HIP(hipMemcpy(out, dO, (size_t)n * 4, hipMemcpyDeviceToHost));
+        c.free(dH); c.free(dO); c.free(work);
+    });
+}
+
 int rsq_ref_emission_order(const uint64_t* hashes, int64_t n, uint64_t min_size, int32_t parallel, uint32_t* out) {
     if (n < 0 || (n > 0 && (!hashes || !out))) return RSQ_ERR_INVALID;
     try {

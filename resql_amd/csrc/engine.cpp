@@ -1131,10 +1131,13 @@ static double runDenseDeviceTail(Query& q) {
     };
     if (!q.dtFlags) {
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        // (the work area of the replay on the device is sized for all D groups being present)
+        std::vector<std::pair<uint64_t, uint64_t>> lv;
+        q.dtReplayBytes = replayLevels((uint64_t)D, opSize(q.agg), lv) ? replayDeviceBytes((uint64_t)D, lv.back().first) : 0;
         q.dtSortTempBytes = radixSortTempBytes(D);
         const size_t sz[] = {up((size_t)(D + 1) * 4), up((size_t)(D + 1) * 8), up(scanTempBytes(D + 1)), up((size_t)D * 8), up((size_t)D * 8), up((size_t)D * 4), up((size_t)D * 4),
                              up(q.dtSortTempBytes), up((size_t)D * 8), up((size_t)D * 4), up((size_t)D * (size_t)q.dtTupleSize)};
-        size_t devBytes = 0; for (size_t b : sz) devBytes += b;
+        size_t devBytes = up(q.dtReplayBytes); for (size_t b : sz) devBytes += b;
         const size_t psz[] = {up((size_t)D * 8), up((size_t)D * 4), up(std::max<size_t>((size_t)D * (size_t)q.dtTupleSize, 8))};
         size_t pinBytes = 0; for (size_t b : psz) pinBytes += b;
         Context::TailArena& spare = ctx.spareTailArena;
@@ -1148,6 +1151,7 @@ static double runDenseDeviceTail(Query& q) {
         q.dtFlags = (uint32_t*)take(); q.dtOffs = (uint64_t*)take(); q.dtScanTemp = take();
         q.dtFirst[0] = (uint64_t*)take(); q.dtFirst[1] = (uint64_t*)take(); q.dtGid[0] = (uint32_t*)take(); q.dtGid[1] = (uint32_t*)take();
         q.dtSortTemp = take(); q.dtHashes = (uint64_t*)take(); q.dtOrder = (uint32_t*)take(); q.dtRows = (uint8_t*)take();
+        q.dtReplayWork = q.dtReplayBytes ? (void*)(d + at) : nullptr;
         char* h = (char*)q.dtArena.pinned;
         q.hDtHashes = (uint64_t*)h; q.hDtOrder = (uint32_t*)(h + psz[0]); q.resultPinned = (uint8_t*)(h + psz[0] + psz[1]);
     }
@@ -1172,6 +1176,16 @@ static double runDenseDeviceTail(Query& q) {
         const bool inB = radixSortPairs(ctx, q.dtFirst[0], q.dtGid[0], q.dtFirst[1], q.dtGid[1], n, bits, q.dtSortTemp, q.dtSortTempBytes);
         dGids = inB ? q.dtGid[1] : q.dtGid[0];
         denseGroupHashes(ctx, dGids, n, q.dtKeys, q.dtHashes);
+        // the replay of the reference's table: on the device too (devtail.hip), unless switched off or out of its range
+        std::vector<std::pair<uint64_t, uint64_t>> levels;
+        const bool devReplay = !(getenv("RSQ_DEVICE_REPLAY") && atoi(getenv("RSQ_DEVICE_REPLAY")) == 0) && q.dtReplayWork && n >= 4096 &&
+                               replayLevels((uint64_t)n, opSize(q.agg), levels) && replayDeviceBytes((uint64_t)n, levels.back().first) <= q.dtReplayBytes;
+        if (devReplay) {
+            replayEmissionOrderDevice(ctx, q.dtHashes, (uint64_t)n, levels, q.dtReplayWork, q.dtOrder);
+            q.report.num_kernels += (uint64_t)((bits + 7) / 8) * 5 + 1 + levels.size() * 12;
+            dOrder = q.dtOrder;
+            if (trace) { waitForStream(ctx); phase("groups ordered by first row, hashed, the reference's table replayed (device)"); }
+        } else {
         RSQ_HIP(hipMemcpyAsync(q.hDtHashes, q.dtHashes, (size_t)n * 8, hipMemcpyDeviceToHost, ctx.stream));
         waitForStream(ctx);
         q.report.num_kernels += (uint64_t)((bits + 7) / 8) * 5 + 1;
@@ -1182,6 +1196,7 @@ static double runDenseDeviceTail(Query& q) {
         phase("replay of the reference's hash table (host, probe clusters in parallel)");
         RSQ_HIP(hipMemcpyAsync(q.dtOrder, q.hDtOrder, (size_t)emit * 4, hipMemcpyHostToDevice, ctx.stream));
         dOrder = q.dtOrder;
+        }
     }
     denseResultRows(ctx, q.dAgg, D, dGids, dOrder, emit, q.dtKeys, q.dtCols, q.dtTupleSize, q.dtRows);
     if (emit > 0) RSQ_HIP(hipMemcpyAsync(q.resultPinned, q.dtRows, (size_t)emit * (size_t)q.dtTupleSize, hipMemcpyDeviceToHost, ctx.stream));

@@ -181,6 +181,11 @@ void denseGroupHashes(Context& ctx, const uint32_t* gids, int64_t n, const Dense
 void denseResultRows(Context& ctx, const uint64_t* table, int64_t D, const uint32_t* gids, const uint32_t* order, int64_t nRows, const DenseTailKeys& keys,
                      const DenseTailCols& cols, int tupleSize, uint8_t* out);
 
+// the replay of the reference's aggregation hash table on the device (devtail.hip): level sizes on the host, everything else enqueued
+bool replayLevels(uint64_t n, uint64_t minSize, std::vector<std::pair<uint64_t, uint64_t>>& levels);
+size_t replayDeviceBytes(uint64_t n, uint64_t nMax);
+void replayEmissionOrderDevice(Context& ctx, const uint64_t* hashes, uint64_t n, const std::vector<std::pair<uint64_t, uint64_t>>& levels, void* work, uint32_t* order);
+
 // tbl.cpp: '.tbl' text -> columns with the reference's BULK INSERT semantics (execute.h:332-388)
 void parseTblFile(const std::string& path, const std::vector<Type>& types, char terminator, int nThreads,
                   std::vector<std::vector<uint8_t>>& cols, int64_t& nRows);

@@ -332,6 +332,7 @@ struct Query {
     uint64_t* dtFirst[2] = {nullptr, nullptr}; uint32_t* dtGid[2] = {nullptr, nullptr};
     void* dtSortTemp = nullptr; size_t dtSortTempBytes = 0;
     uint64_t* dtHashes = nullptr; uint32_t* dtOrder = nullptr; uint8_t* dtRows = nullptr;
+    void* dtReplayWork = nullptr; size_t dtReplayBytes = 0;           // work area of the replay on the device (0: host replay)
     uint64_t* hDtHashes = nullptr; uint32_t* hDtOrder = nullptr;      // pinned
     uint8_t* resultPinned = nullptr;       // pinned copy of the result tuples (device tail)
     bool resultInPinned = false;

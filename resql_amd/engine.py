@@ -110,6 +110,7 @@ def lib():
         L.rsq_result_serialize.argtypes = [C.POINTER(P.rsq_result_view)]
         L.rsq_free.argtypes = [vp]
         L.rsq_ref_emission_order.argtypes = [vp, i64, C.c_uint64, i32, vp]
+        L.rsq_ref_emission_order_device.argtypes = [vp, vp, i64, C.c_uint64, vp]
         L.rsq_measure_read_bandwidth.argtypes = [vp, C.c_size_t, i32, C.POINTER(C.c_double)]
         L.rsq_sql_plan_select.argtypes = [vp, C.c_char_p, C.POINTER(vp), i32, C.POINTER(vp)]
         L.rsq_sql_plan_desc.restype = C.POINTER(P.rsq_plan_desc)
@@ -158,7 +159,7 @@ EXPORTED_SYMBOLS = [
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_await_kernels", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
     "rsq_query_finalize", "rsq_query_merge_gathered", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_kernel_time_stats", "rsq_query_source", "rsq_query_explain",
-    "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free", "rsq_ref_emission_order",
+    "rsq_query_destroy", "rsq_serialize_expr", "rsq_result_serialize", "rsq_free", "rsq_ref_emission_order", "rsq_ref_emission_order_device",
     "rsq_measure_read_bandwidth",
     "rsq_sql_plan_select", "rsq_sql_plan_desc", "rsq_sql_plan_destroy", "rsq_sql_plan_text", "rsq_sql_compile", "rsq_sql_describe",
     "rsq_db_create", "rsq_db_execute", "rsq_db_message", "rsq_db_adopt_table", "rsq_db_report", "rsq_db_destroy",

@@ -27,7 +27,8 @@ from resql_amd.dist import shard_rows  # noqa: E402
 
 TOTAL_ROWS, SHARDS = 10_000_000_000, 8
 CHUNK = 8 << 20
-CASES = [(0, 8, 0.5), (0, 1 << 20, 0.5), (0, 1 << 20, 0.01), (7, 8, 0.5), (7, 1 << 20, 0.1)]   # (shard, groups, selectivity)
+CASES = [(0, 8, 0.5), (0, 1 << 20, 0.5), (0, 1 << 20, 0.01), (7, 8, 0.5), (7, 1 << 20, 0.1),
+         (0, 1024, 0.1), (7, 1024, 0.5)]   # (shard, groups, selectivity); G = 1024 is the workgroup-LDS table (round 3)
 
 
 def _chunk(args):
@@ -54,6 +55,8 @@ def main():
     result = json.load(open(path)) if os.path.exists(path) else {}
     by_shard = {}
     for shard, g, sel in CASES:
+        if f"shard{shard}_g{g}_thr{int(sel * (1 << 31))}" in result and not os.environ.get("GOLDEN_REDO"):
+            continue                                  # (already recorded: a shard pass takes ~10 minutes)
         by_shard.setdefault(shard, {}).setdefault(g, []).append(int(sel * (1 << 31)))
     for shard, per_g in by_shard.items():
         row0, n = shard_rows(TOTAL_ROWS, SHARDS, shard)

@@ -63,3 +63,29 @@ def test_small_inputs_take_the_sequential_replay():
     h = np.arange(100, dtype=np.uint64) * np.uint64(7919)
     assert np.array_equal(_order(h, 2, True), _order(h, 2, False))
     assert _order(np.empty(0, dtype=np.uint64), 2, True).size == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,min_size,kind", CASES)
+def test_device_replay_equals_the_sequential_one(gpu_ctx, n, min_size, kind):
+    """the same replay as kernels (resql_amd/csrc/devtail.hip: home slots -> counting sort -> running minimum for the carries ->
+    one thread per probe cluster), level by level on the device"""
+    rng = np.random.default_rng(n * 31 + min_size)
+    if kind == "random":
+        h = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, n, dtype=np.uint64)
+    elif kind == "small-range":
+        h = rng.integers(0, 3 * n, n, dtype=np.uint64)
+    elif kind == "multiples":
+        h = rng.integers(0, 1 << 40, n, dtype=np.uint64) * np.uint64(5 * 11 * 23 * 47)
+    elif kind == "identical-runs":
+        h = np.repeat(rng.integers(0, 1 << 62, n // 50 + 1, dtype=np.uint64), 50)[:n]
+        h = h[rng.permutation(n)]
+    else:
+        top = 236897
+        h = (rng.integers(0, 1 << 30, n, dtype=np.uint64) * np.uint64(top) + np.uint64(top) - rng.integers(1, 400, n).astype(np.uint64))
+    seq = _order(h, min_size, False)
+    out = np.empty(n, dtype=np.uint32)
+    hh = np.ascontiguousarray(h, dtype=np.uint64)
+    rc = gpu_ctx._L.rsq_ref_emission_order_device(gpu_ctx.h, hh.ctypes.data, n, min_size, out.ctypes.data)
+    assert rc == 0, gpu_ctx._L.rsq_last_error(gpu_ctx.h)
+    assert np.array_equal(seq, out)

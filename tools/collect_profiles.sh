@@ -5,7 +5,7 @@
 # directly behind `--`; every step runs under a hard timeout and a failed step is reported and skipped, not built upon.
 # usage: bash tools/collect_profiles.sh rNN
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles
 mkdir -p "$OUT"
@@ -17,6 +17,61 @@ found() {   # found DIR PATTERN -> path of the first match, or empty (and a mess
     if [ -z "$f" ]; then echo "   (no $2 under $1: step skipped)" >&2; fi
     echo "$f"
 }
+
+# PART=a (default): bench, Q1 / Q3 / large-group kernel statistics and PMC passes; PART=b: end-to-end tables (config 5, SQL at SF1 / SF10,
+# cold compile latencies, shard tails, late-load traffic, the C-ABI path).  Each part fits one gpurun call.
+PART=${PART:-a}
+if [ "$PART" = "b" ]; then
+step "TPC-H Q3 at SF10 WITHOUT the profiler (what README / DESIGN quote)"
+timeout -k 10 200 python3 "$ROOT/tools/profile_case.py" q3 10 16 2>/dev/null | grep '^q3 ' > "$OUT/${R}_q3_sf10_runs_noprofiler.txt"
+step "one 1.25 B-row shard, 2^20 groups, end to end: cold and warm executions of ONE query (10 % and 50 %, reference emission order and 'any')"
+for s in 0.1 0.5; do
+    timeout -k 10 120 python3 "$ROOT/tools/shard_tail.py" 20 $s 2>/dev/null | grep '^execution' > "$OUT/${R}_shard_g20_sel${s}_end_to_end.txt"
+done
+timeout -k 10 120 python3 "$ROOT/tools/shard_tail.py" 20 0.1 1250000000 any 2>/dev/null | grep '^execution' > "$OUT/${R}_shard_g20_sel0.1_end_to_end_emit_any.txt"
+step "BASELINE config 5: 10 B rows as 8 shards, kernel and end-to-end"
+timeout -k 10 500 python3 "$ROOT/tools/synthetic_10b.py" --out "gpurun_out/profiles/${R}_synthetic_10b.json" > "$OUT/${R}_synthetic_10b.log" 2>&1
+step "late loads: FETCH_SIZE of the scan kernel at 1 % selectivity (1.25 B rows, G = 8) and of TPC-H Q6 at SF10: the traffic-based fraction"
+for w in "synthetic 1250000000 8 0.01 4" "q6 10 4"; do
+    tag=$(echo $w | cut -d' ' -f1)
+    rm -rf /tmp/prof_ll_$tag /tmp/prof_ll_ks_$tag
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ll_ks_$tag -- python3 "$ROOT/tools/profile_case.py" $w > /tmp/ll_ks.log 2>&1
+    timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_ll_$tag -- python3 "$ROOT/tools/profile_case.py" $w > /tmp/ll_pmc.log 2>&1
+done
+python3 - "$OUT/${R}_late_loads_pmc.json" <<'PY'
+import csv, glob, json, sys
+out = {"note": "late loads skip most cache lines of the columns behind a selective leading selection: algorithmic bytes / time then exceeds the HBM peak and is "
+               "NOT a roofline fraction.  traffic_frac = FETCH_SIZE (x2: gfx950 reports half of wide streaming reads, MI355X_MICROARCH.md) / kernel time / 8 TB/s; "
+               "FETCH_SIZE and the kernel time come from separate rocprofv3 runs of the same command", "cases": {}}
+for tag, rows, bpr in (("synthetic", 1250000000, 32), ("q6", 59999996, 28)):
+    fs = glob.glob(f"/tmp/prof_ll_{tag}/*/*counter_collection.csv"); ks = glob.glob(f"/tmp/prof_ll_ks_{tag}/*/*kernel_stats.csv")
+    if not fs or not ks: continue
+    per = {}
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] == "FETCH_SIZE" and r["Kernel_Name"].startswith("rsq_p0"): per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    kb = max(per.values()) if per else 0
+    avg_ns = [float(r["AverageNs"]) for r in csv.DictReader(open(ks[0])) if r["Name"].startswith("rsq_p0")]
+    if not avg_ns or not kb: continue
+    t = min(avg_ns) * 1e-9
+    out["cases"][tag] = {"rows": rows, "algorithmic_bytes": rows * bpr, "kernel_us": round(t * 1e6, 1), "FETCH_SIZE_KB": round(kb, 1),
+                         "hbm_read_bytes_corrected": round(kb * 1024 * 2), "algorithmic_frac_of_8TBps": round(rows * bpr / t / 8e12, 3),
+                         "traffic_frac_of_8TBps": round(kb * 1024 * 2 / t / 8e12, 3)}
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print("   late loads:", {k: (v["algorithmic_frac_of_8TBps"], v["traffic_frac_of_8TBps"]) for k, v in out["cases"].items()})
+PY
+step "the reference's eight TPC-H statements from SQL text at SF1 (with the reference beside them) and at SF10 (answers checked against the reference's goldens)"
+timeout -k 10 300 python3 "$ROOT/tools/sql_bench.py" 1 --reference 2>/dev/null | grep '^{' > "$OUT/${R}_sql_sf1.jsonl"
+timeout -k 10 300 python3 "$ROOT/tools/sql_bench.py" 10 2>/dev/null | grep '^{' > "$OUT/${R}_sql_sf10.jsonl"
+rm -rf /tmp/prof_sql
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sql -- python3 "$ROOT/tools/sql_bench.py" 10 --repeat 5 --only q5,q10,q12,q14,q19 > /tmp/sqlp.log 2>&1
+f=$(found /tmp/prof_sql '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_sql_sf10_kernel_stats.csv"
+step "compile latency, cold and warm (empty code-object cache)"
+RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency.jsonl"
+step "the same Q1 step through the C ABI's one-process path: 8 shards on this one GPU"
+timeout -k 10 200 python3 "$ROOT/bench.py" --path capi --capi-devices 0,0,0,0,0,0,0,0 --steps 20 2>/dev/null | grep '^{' > "$OUT/${R}_bench_capi_8shards_1gpu.json"
+ls -la "$OUT" | tail -n 20
+exit 0
+fi
 
 step "bench line (N = 1)"
 if timeout -k 10 400 python3 "$ROOT/bench.py" > "$OUT/${R}_bench_n1.log" 2>&1; then
@@ -121,11 +176,6 @@ for s in ("0.1", "0.5"):
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print("   large-group pmc:", {s: v["bytes_moved_per_row"] for s, v in out["selectivity"].items()}, "bytes per row")
 PY
-
-step "the reference's eight TPC-H statements from SQL text at SF1"
-timeout -k 10 300 python3 "$ROOT/tools/sql_bench.py" 1 --reference > "$OUT/${R}_sql_sf1.log" 2>&1 && grep '^{' "$OUT/${R}_sql_sf1.log" > "$OUT/${R}_sql_sf1.jsonl"
-step "compile latency, cold and warm"
-timeout -k 10 200 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_run.jsonl"
 
 [ -f "$OUT/${R}_q1_sf10_kernel_stats.csv" ] && head -n 3 "$OUT/${R}_q1_sf10_kernel_stats.csv" | cut -c1-150
 [ -f "$OUT/${R}_q3_sf10_kernel_stats.csv" ] && head -n 5 "$OUT/${R}_q3_sf10_kernel_stats.csv" | cut -c1-150
