@@ -399,7 +399,7 @@ def weak_scaling_extra(args, ctx, dist, world: int, rank: int, device, steps: in
         n_min, n_max, n_sum = q.partial_layout()
         partial = torch.zeros(n_min + n_max + n_sum, dtype=torch.int64, device=device)
         q.bind_partial(partial.data_ptr(), partial.numel() * 8)
-        merger = PartialMerger(dist, partial, n_min, n_max, n_sum, world, query=q) if dist is not None else None
+        merger = PartialMerger(dist, partial, n_min, n_max, n_sum, world, always_collective=args.dist_path, query=q) if dist is not None else None
 
         def step():
             if merger is None:
@@ -587,7 +587,8 @@ def main(argv=None) -> int:
     weak_error = None
     if not args.no_extras:
         try:
-            weak = weak_scaling_extra(args, ctx, dist if (dist is not None and world > 1) else None, world, rank, device)
+            # (--dist-path takes the multi-rank step here too, with a process group of one: partial execution, merge collective, finalize)
+            weak = weak_scaling_extra(args, ctx, dist if (dist is not None and (world > 1 or args.dist_path)) else None, world, rank, device)
         except Exception as e:  # an extra never costs the bench line
             weak_error = f"{type(e).__name__}: {e}"
 

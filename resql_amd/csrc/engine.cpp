@@ -1426,6 +1426,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         // instead of one launch in front of every build (TPC-H Q5 builds five tables, Q3 two); likewise the aggregates kept beside
         // a join table's entries.  Nothing touches a table between this fill and its build pipeline.
         static const bool prologueOk = !(getenv("RSQ_PROLOGUE") && atoi(getenv("RSQ_PROLOGUE")) == 0);
+        for (auto& hp : q.hashTables) hp->prepared = false;       // (an execution that did not come back must not leave a table marked as readied)
         if (prologueOk && !trace && !interp)
             for (auto& p : q.pipelines) {
                 if (p.sink != SinkKind::BUILD) continue;
