@@ -1912,6 +1912,12 @@ struct Walker {
             addArg("fin_err", "u64*", 0);
             addArg("fin_ticket", "u32*", 0);
             addArg("fin_seq", "u64", 0);
+            // RSQ_PERSISTENT_STEP=1 (engine.cpp "the resident step"): the same kernel kept on the chip between steps, started by a
+            // doorbell word in host-mapped memory instead of a launch
+            addArg("pers_bell", "u64*", 0);
+            addArg("pers_idle", "u64", 0);
+            addArg("pers_t0", "u64", 0);          // (the resident form stamps it: the 100 MHz clock when this workgroup saw the doorbell)
+            pipe.persistentForm = true;
             ep << "    if (a.fin_out) {\n        __shared__ u32 s_last;\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        __syncthreads();\n";
             ep << "        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;\n        __syncthreads();\n";
             if (dbgTail) ep << "        if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 4] = (u64)wall_clock64();\n";
@@ -1927,6 +1933,7 @@ struct Walker {
             if (dbgTail) ep << "            if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 5] = (u64)wall_clock64();\n";
             ep << "            if (a.fin_seq) {\n                asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n                __syncthreads();\n";
             if (dbgTail) ep << "                if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 6] = (u64)wall_clock64();\n";
+            ep << "                if (threadIdx.x == 0 && a.pers_t0) a.fin_err[6] = (u64)wall_clock64() - a.pers_t0;      // a resident step's time on the device, for the report\n";
             ep << "                if (threadIdx.x == 0) __hip_atomic_store(a.fin_err + 1, a.fin_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n";
             if (dbgTail) ep << "                if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 7] = (u64)wall_clock64();\n";
             ep << "            }\n";
@@ -2188,6 +2195,7 @@ struct Walker {
         s << "\n";
         if (envInt("RSQ_NT", 1, 0, 1)) s << "#define RSQ_NT_LOADS 1\n";
         s << "#define RSQ_DYN_TILES " << ((envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) != 0 && !pipe.partitioned) ? 1 : 0) << "\n";
+        s << "#ifndef RSQ_PERSISTENT\n#define RSQ_PERSISTENT 0\n#endif\n";
         s << "#include \"rsq_device.h\"\n";
         s << fileScope;
         const bool cq = pipe.compact;
@@ -2298,7 +2306,19 @@ struct Walker {
             pipe.entry = "rsq_p" + std::to_string(q.pipelines.size()) + "_" + tn + "_" + sk;
             if (pipe.sink == SinkKind::BUILD) pipe.entry += "_ht" + std::to_string(pipe.buildTable);
         }
+        if (pipe.persistentForm) {
+            // The resident form: every workgroup's thread 0 watches the doorbell (a sequence number the host stores into mapped pinned
+            // memory); a new value is one step, ~0 or pers_idle ticks (100 MHz) without a ring end the kernel - an exit every wave reaches.
+            s << "#if RSQ_PERSISTENT\nstatic __device__ __attribute__((always_inline)) void rsq_step_body(Args& a);\n";
+            s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n";
+            s << "    __shared__ u64 s_bell;\n    u64 seen = a.fin_seq - 1ull;      // launched for step fin_seq: the host has put that number into the doorbell\n    for (;;) {\n";
+            s << "        if (threadIdx.x == 0) s_bell = rsq::wait_doorbell(a.pers_bell, (u64*)(a.fin_ticket + 2), seen, a.pers_idle);\n        __syncthreads();\n";
+            s << "        const u64 v = s_bell;\n        __syncthreads();\n        if (v == ~0ull) return;\n";
+            s << "        seen = v; a.fin_seq = v; a.pers_t0 = (u64)wall_clock64();\n        rsq_step_body(a);\n        __syncthreads();\n    }\n}\n";
+            s << "static __device__ __attribute__((always_inline)) void rsq_step_body(Args& a) {\n#else\n";
+        }
         s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n";
+        if (pipe.persistentForm) s << "#endif\n";
         s << "    State st;\n" << prologue;
         if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 0] = (u64)wall_clock64();\n";
         s << "    const int lane = threadIdx.x & 63;\n";

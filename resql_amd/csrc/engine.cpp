@@ -110,7 +110,24 @@ uint64_t opSize(OpNode* o) {   // getSize() estimates (reference src/operators/*
     }
 }
 
+// ---- the resident step (RSQ_PERSISTENT_STEP=1, measurement knob) --------------------------------------------------------------
+// The one-launch step's kernel stays on the chip between executions of the same query and is started by a doorbell: a sequence number
+// the host stores into mapped pinned memory (hPinned[pinnedWords + 5]), watched by one thread per workgroup.  ~0 in the doorbell, or
+// RESIDENT_IDLE_MS without a ring, ends the kernel - so a forgotten park delays whatever is queued behind it on the stream, never
+// blocks it.  Everything else that uses the context's stream parks the kernel first.
+static const double RESIDENT_IDLE_MS = 20.0;
+void parkResidentStep(Context& ctx) {
+    Query* q = ctx.residentOwner;
+    if (!q) return;
+    __atomic_store_n(q->hPinned + q->pinnedWords + 5, ~0ull, __ATOMIC_RELEASE);
+    (void)hipSetDevice(ctx.device);
+    (void)hipStreamSynchronize(ctx.stream);
+    q->residentRunning = false;
+    ctx.residentOwner = nullptr;
+}
+
 Query::~Query() {
+    if (ctx.residentOwner == this) parkResidentStep(ctx);
     if (bgCompiler.joinable()) bgCompiler.join();
     destroyTailState(tailState);
     if (dtArena.dev || dtArena.pinned) {
@@ -241,6 +258,7 @@ static void resolveKernels(Query& q) {
 static void prepareStageBuffers(Query& q, const Pipeline& p);
 
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables) {
+    parkResidentStep(ctx);
     double t0 = nowMs();
     std::unique_ptr<Query> q(new Query(ctx));
     int hits0 = ctx.jitCacheHits, comp0 = ctx.jitCompiles;
@@ -352,8 +370,8 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
             void* dv = q->dPinnedDev;
             if (dv) {
                 q->dFinHost = (uint64_t*)dv;
-                q->dFinTicket = (uint32_t*)ctx.alloc(sizeof(uint32_t));
-                RSQ_HIP(hipMemset(q->dFinTicket, 0, sizeof(uint32_t)));
+                q->dFinTicket = (uint32_t*)ctx.alloc(16);        // [0] the ticket, [2..3] the resident step's doorbell as the workgroups see it
+                RSQ_HIP(hipMemset(q->dFinTicket, 0, 16));
             }
         }
     }
@@ -374,6 +392,9 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     if (a.name == "fin_err") return (uint64_t)(uintptr_t)q.finErr;
     if (a.name == "fin_seq") return q.finOut ? q.finSeq : 0;
     if (a.name == "fin_ticket") return (uint64_t)(uintptr_t)(q.finOut ? q.dFinTicket : nullptr);
+    if (a.name == "pers_bell") return (uint64_t)(uintptr_t)(q.dPinnedDev ? q.dPinnedDev + q.pinnedWords + 5 : nullptr);
+    if (a.name == "pers_t0") return 0;
+    if (a.name == "pers_idle") return (uint64_t)(RESIDENT_IDLE_MS * 1e5);          // ticks of the 100 MHz clock
     if (a.name == "part_counts") return (uint64_t)(uintptr_t)q.dPartCounts;
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
@@ -1213,10 +1234,12 @@ static double runDenseDeviceTail(Query& q) {
 // materialised columns) back, but leaves the tail to the root, which merges all shards' groups first (tail.cpp runTailMerged)
 static void tailUnlessHeld(Query& q) { if (!q.holdTail) runTail(q); }
 
-void executeQuery(Query& q, bool partialOnly, bool async) {
+void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     Context& ctx = q.ctx;
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(ctx.device));
+    static const bool residentKnob = getenv("RSQ_PERSISTENT_STEP") && atoi(getenv("RSQ_PERSISTENT_STEP")) == 1;
+    if (ctx.residentOwner && (ctx.residentOwner != &q || partialOnly || async)) parkResidentStep(ctx);
     if (async) {
         if (!partialOnly || !denseMode(q)) failUnsupported("asynchronous execution is available for dense partial aggregation only");
         for (auto& p : q.pipelines)
@@ -1278,6 +1301,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         // the kernel leaves its working table, the error word and the ticket at their identities; make them so the first
         // time, after an execution that did not come back (an exception between launch and synchronisation), and whenever
         // another query of this context may have left the shared error word set
+        static const bool pollOk0 = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
+        const bool resident = residentKnob && pollOk0 && !partialOnly && !async && p.persistentForm && q.dPinnedDev && !p.dynamicTiles &&
+                              pipelineGrid(q, p) <= (unsigned)ctx.numCUs && !q.dDebugStamps;
+        if (q.residentRunning && (!resident || nowMs() - q.residentLastRing > RESIDENT_IDLE_MS / 4 || !q.fusedReady || !ctx.errWordClean)) parkResidentStep(ctx);
+        const bool ringOnly = resident && q.residentRunning;      // the kernel is there: this step is a store into the doorbell
         if (!q.fusedReady || !ctx.errWordClean) {
             RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, ctx.stream));
             RSQ_HIP(hipMemsetAsync(q.dFinTicket, 0, 4, ctx.stream));
@@ -1289,8 +1317,9 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         static const bool stepTrace0 = getenv("RSQ_STEP_TRACE") != nullptr;
         // a step that runs to its end here takes the next pair of the event ring (read when somebody asks, or when the ring is
         // full); an asynchronous partial step keeps the single pair finalize / settle read
-        const bool ringEvents = !(async && partialOnly);
-        if (ringEvents) {
+        const bool ringEvents = !(async && partialOnly) && !resident;      // (no event pair around a step of a resident kernel)
+        if (resident) resolveKernelTime(q);
+        else if (ringEvents) {
             if (q.evRing.empty()) {
                 q.evRing.resize(256);
                 for (auto& e : q.evRing) { RSQ_HIP(hipEventCreate(&e.first)); RSQ_HIP(hipEventCreate(&e.second)); }
@@ -1311,6 +1340,17 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         // two event records around the launch.  (The extended launch that takes the events itself - RSQ_EXT_EVENTS=1 - costs the
         // host 3 us more per step and the tail another 1.5: measured 16 us of step overhead against 11.5.)
         static const bool extEvents = getenv("RSQ_EXT_EVENTS") && atoi(getenv("RSQ_EXT_EVENTS")) == 1;
+        if (resident) {
+            // the doorbell carries the step's sequence number; a kernel launched now finds it there and runs this step at once
+            __atomic_store_n(q.hPinned + q.pinnedWords + 5, seq, __ATOMIC_RELEASE);
+            q.residentLastRing = nowMs();
+            if (!ringOnly) {
+                if (!p.kernelPersistent) p.kernelPersistent = &ctx.getKernel("#define RSQ_PERSISTENT 1\n" + p.source, p.entry);
+                RSQ_HIP(hipMemsetAsync(q.dFinTicket + 2, 0, 8, ctx.stream));
+                launchPipelineKernel(q, p, *p.kernelPersistent, -1);
+                q.residentRunning = true; ctx.residentOwner = &q;
+            } else q.report.num_kernels = 0;
+        } else
         if (extEvents) launchPipelineKernel(q, p, *p.kernel, -1, 0, 0, evA, evB);
         else {
             const double tB = stepTrace0 ? nowMs() : 0;
@@ -1327,7 +1367,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
         q.finOut = nullptr;
         q.finSeq = 0;
-        if (ringEvents) q.evTail++; else q.kernelTimePending = true;
+        if (ringEvents) q.evTail++; else if (!resident) q.kernelTimePending = true;
         static const bool stepTrace = getenv("RSQ_STEP_TRACE") != nullptr;        // host-side phases of the one-launch step, averaged over 64 steps
         const double tLaunched = stepTrace ? nowMs() : 0;
         q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
@@ -1347,14 +1387,30 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 if ((++spins & 1023u) == 0) {
                     hipError_t e = hipStreamQuery(ctx.stream);
                     if (e != hipSuccess && e != hipErrorNotReady) RSQ_HIP(e);
-                    if (e == hipSuccess || nowMs() > deadline) { waitForStream(ctx); break; }
+                    if (resident) { if (e == hipSuccess) break; }       // (a resident kernel ends only by leaving; its steps take as long as they take)
+                    else if (e == hipSuccess || nowMs() > deadline) { waitForStream(ctx); break; }
                 }
                 __builtin_ia32_pause();
+            }
+            if (resident && *flag != seq) {
+                // the kernel - or some of its workgroups - had left when the doorbell rang (the host was away for longer than it
+                // waits): whatever ran of the step is void; make the identities again and take the step with a fresh launch
+                q.residentRunning = false; ctx.residentOwner = nullptr;
+                q.fusedReady = false;
+                if (residentRetry) failRuntime("internal error: the resident step left twice without publishing its table");
+                executeQuery(q, partialOnly, async, true);
+                return;
             }
             if (*flag != seq) failRuntime("internal error: the fused step finished without publishing its table");
             std::atomic_thread_fence(std::memory_order_acquire);
         } else waitForStream(ctx);
         q.fusedReady = true;
+        if (resident) {
+            // (no event pair around a step of a resident kernel: the last workgroup reports doorbell seen -> table published, 100 MHz ticks)
+            const double ms = (double)q.hPinned[q.pinnedWords + 6] * 1e-5;
+            q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
+            q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
+        }
         const double tSeen = stepTrace ? nowMs() : 0;
         if (q.dDebugStamps) {
             static int nPrinted = 0;
@@ -1788,6 +1844,7 @@ void finalizeQuery(Query& q) {
     Context& ctx = q.ctx;
     if (!denseMode(q)) failUnsupported("partial execution / finalize is available for dense aggregations only");
     RSQ_HIP(hipSetDevice(ctx.device));
+    parkResidentStep(ctx);
     double t1 = nowMs();
     const bool devTail = !q.mergePublishedSeq && denseDeviceTailWanted(q);
     double devTailMs = 0;
@@ -1838,6 +1895,7 @@ void settleAsync(Query& q) {
     Context& ctx = q.ctx;
     if (!q.pendingAsync) return;
     RSQ_HIP(hipSetDevice(ctx.device));
+    parkResidentStep(ctx);
     waitForStream(ctx);
     q.pendingAsync = false;
     float ms = 0;

@@ -79,6 +79,7 @@ struct Context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int jitCompiles = 0, jitCacheHits = 0;
     bool errWordClean = false;                 // *dErr is known to be 0 (fused steps reset it themselves and rely on that)
+    struct Query* residentOwner = nullptr;     // the query whose one-launch step is RESIDENT on this stream (RSQ_PERSISTENT_STEP=1; engine.cpp parkResidentStep)
 
     explicit Context(const rsq_config& c);
     ~Context();
@@ -193,7 +194,8 @@ void parseTblFile(const std::string& path, const std::vector<Type>& types, char 
 // ---- query ------------------------------------------------------------------------------------
 struct Query;
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables);
-void executeQuery(Query& q, bool partialOnly, bool async = false);
+void executeQuery(Query& q, bool partialOnly, bool async = false, bool residentRetry = false);
+void parkResidentStep(Context& ctx);          // RSQ_PERSISTENT_STEP=1: end the step kernel that waits on this context's stream (no-op without one)
 void finalizeQuery(Query& q);
 void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords);
 void settleAsync(Query& q);

@@ -212,6 +212,8 @@ struct Pipeline {
     std::vector<int> lazyCols;       // scanned columns only stage 2 needs (codegen.cpp compactThen): RSQ_LAZY 1 reads them by row
     std::string sourceLazy;
     Kernel* kernelLazy = nullptr;    // compiled when first chosen
+    bool persistentForm = false;     // the source holds the resident form of the one-launch step (RSQ_PERSISTENT 1; engine.cpp "the resident step")
+    Kernel* kernelPersistent = nullptr;      // compiled when RSQ_PERSISTENT_STEP=1 first asks for it
     unsigned lastGrid = 0;           // workgroups of the most recent launch
     int64_t stage2Rows = -1;         // rows the previous execution sent to stage 2 (-1: not known yet)
     int extraLdsBytes = 0;           // LDS a pipeline takes besides the compaction queues (hash aggregation's front table)
@@ -356,6 +358,8 @@ struct Query {
     bool fusedReady = false;               // working table, ticket and error word are at their identities
     uint64_t finSeq = 0;                   // > 0 around a launch the host polls for: the number the last workgroup writes behind the error word
     uint64_t finSeqCounter = 0;
+    bool residentRunning = false;        // RSQ_PERSISTENT_STEP=1: this query's step kernel is on the chip, waiting for the doorbell (hPinned[pinnedWords + 5])
+    double residentLastRing = 0;         // ... when the host last rang it (the kernel leaves by itself after RESIDENT_IDLE_MS without a ring)
     uint64_t mergePublishedSeq = 0;        // > 0: rsq_query_merge_gathered also published the merged table to hPinned; finalize polls for this number
     bool kernelTimePending = false;        // the fused step's events have not been read yet (resolveKernelTime)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evRing; size_t evHead = 0, evTail = 0;      // event pairs of the one-launch steps not read yet

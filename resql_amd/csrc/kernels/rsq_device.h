@@ -11,9 +11,9 @@
 //   * coalesced tile loads: one wave owns a tile of 128 consecutive rows, lane l owns rows
 //     2l and 2l+1, so an 8-byte column is ONE global_load_dwordx4 per lane (1 KiB per wave
 //     instruction, unit stride), a 4-byte column one dwordx2, a 1-byte column one ushort
-//   * wave64 butterfly reductions (DPP/ds_swizzle via __shfl_xor) and the block-level flush of
-//     per-thread accumulators: registers -> wave reduce -> LDS -> one global atomic per value
-//     per block
+//   * wave64 reductions in the VALU (DPP row shifts + row broadcasts, wave_reduce_to_lane63; a
+//     __shfl_xor butterfly only where one value per wave is reduced) and the flush of per-thread
+//     accumulators: registers -> wave reduce -> LDS cell -> one global atomic per cell and workgroup
 //   * fixed-width CHAR(n)/VARCHAR(n) comparison (reference src/qlib/scalar.h:16-46)
 //   * open-addressing hash tables in HBM for join build/probe and large group-by
 #pragma once
@@ -334,6 +334,31 @@ RSQ_DEV u32 wave_grab(u32* ctr, u32 n) {
     return (u32)__builtin_amdgcn_readfirstlane((int)v);
 }
 // ... in two halves, so that the atomic's latency can pass behind other work: issue (the answer lands in lane 0's register), value
+// The resident step (codegen.cpp, RSQ_PERSISTENT): the kernel waits for a sequence number the host stores into mapped pinned memory.
+// ONE thread of the whole grid watches that word (reads of host memory from all 256 workgroups queue up one behind the other on
+// their way out of the chip: 130 us per step, measured); it hands the value on through a word in device memory that one thread of
+// every other workgroup watches.  Returns the new value, or ~0 - "leave" - which workgroup 0 also decides after `idle` ticks of the
+// 100 MHz clock without a ring (the kernel's way out when the host went away; the host launches again when it comes back).
+RSQ_DEV u64 wait_doorbell(const u64* bell_host, u64* bell_dev, u64 seen, u64 idle) {
+    const u64 t0 = (u64)wall_clock64();
+    if (blockIdx.x == 0) {
+        u64 v;
+        for (;;) {
+            v = __hip_atomic_load(bell_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v != seen) break;
+            if ((u64)wall_clock64() - t0 > idle) { v = ~0ull; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __hip_atomic_store(bell_dev, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
+    }
+    for (;;) {
+        const u64 v = __hip_atomic_load(bell_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v == ~0ull || v > seen) return v;                       // (sequence numbers only grow; the word is 0 at launch)
+        if ((u64)wall_clock64() - t0 > 4 * idle) return ~0ull;      // (workgroup 0 never came: not reachable, but every wave has its exit)
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
 RSQ_DEV u32 wave_grab_issue(u32* ctr, u32 n) {
     u32 v = 0;
     if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, n);

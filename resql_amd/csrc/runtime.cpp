@@ -65,6 +65,7 @@ Context::Context(const rsq_config& c) : cfg(c), device(c.device) {
 Context::~Context() {
     if (device >= 0) {
         (void)hipSetDevice(device);
+        parkResidentStep(*this);
         for (auto& kv : kernels) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
         if (spareTailArena.dev) (void)hipFree(spareTailArena.dev);
         if (spareTailArena.pinned) (void)hipHostFree(spareTailArena.pinned);
