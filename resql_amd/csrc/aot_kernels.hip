@@ -693,11 +693,103 @@ __global__ void __launch_bounds__(256) k_topk_range_gather(const i64* __restrict
     }
 }
 
-// scratch of both forms: [image range: 2 x u64][candidate count: u32][pad: u32][TOPK_PASSES histograms]
+// ---- the short form in ONE launch, answer delivered ------------------------------------------------------------------
+// histogram -> [all workgroups have added theirs] -> gather -> [all workgroups have gathered] -> status words.  The grid is at most
+// one 256-thread workgroup per CU with 8 KB of LDS, so every workgroup is on the chip at once and the two meeting points are a
+// counter in device memory the workgroups watch (agent-scope loads; the histogram itself is summed with device-scope atomics, which
+// execute at the memory side, and is read back with agent-scope loads).  The candidates go straight into host-mapped pinned memory,
+// and the last workgroup publishes the execution's status words there too: this launch replaces the histogram, the gather, the
+// status kernel and the device-to-host copy of the candidates.  A workgroup that waits longer than 1 ms gives up and sets bit 256 of
+// the error word (the engine then repeats the execution with the separate launches) - every wave has its way out.
+__global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict__ rows, int stride, int keyWord, int is32, int desc,
+                                                           const unsigned* __restrict__ nRows, unsigned maxRows, const u64* __restrict__ imageRange,
+                                                           unsigned* __restrict__ hist, unsigned want, i64* __restrict__ cand, unsigned capacity,
+                                                           unsigned* candCount, unsigned* ticket1, unsigned* ticket2, unsigned* err, u64* __restrict__ host,
+                                                           const unsigned* __restrict__ groupCount, const u64* __restrict__ pipeStats, int nPipelines) {
+    __shared__ unsigned s_hist[TOPK_BINS];
+    __shared__ unsigned s_above[256];
+    __shared__ unsigned s_bin, s_flag;
+    const int t = threadIdx.x;
+    for (int b = t; b < TOPK_BINS; b += 256) s_hist[b] = 0;
+    __syncthreads();
+    const u64 hi = imageRange[0], lo = ~imageRange[1];
+    const int shift = hi > lo ? __builtin_clzll(hi - lo) : 0;
+    const unsigned n = *nRows < maxRows ? *nRows : maxRows;
+    for (unsigned i = blockIdx.x * 256u + t; i < n; i += gridDim.x * 256u)
+        atomicAdd(&s_hist[topk_range_digit(topk_image(rows[(size_t)i * stride + keyWord], is32, desc), lo, shift)], 1u);
+    __syncthreads();
+    for (int b = t; b < TOPK_BINS; b += 256) { const unsigned c = s_hist[b]; if (c) atomicAdd(&hist[b], c); }
+    // meeting point 1: this workgroup's histogram atomics have been performed; wait for everybody's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        __hip_atomic_fetch_add(ticket1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 t0 = (u64)wall_clock64();
+        unsigned ok = 1;
+        while (__hip_atomic_load(ticket1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            if ((u64)wall_clock64() - t0 > 100000ull) { ok = 0; atomicOr(err, 256u); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        s_flag = ok;
+    }
+    __syncthreads();
+    // the lowest bin that still belongs to the candidates: the highest b with (rows in bins >= b) >= want
+    unsigned c[8], local = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) { c[b] = __hip_atomic_load(&hist[t * 8 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); local += c[b]; }
+    if (t == 0) s_bin = 0;                                  // fewer than `want` rows in all: every row qualifies
+    s_above[t] = local;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {                     // inclusive suffix sums over the threads
+        const unsigned v = t + d < 256 ? s_above[t + d] : 0u;
+        __syncthreads();
+        s_above[t] += v;
+        __syncthreads();
+    }
+    unsigned running = s_above[t] - local;                  // rows in bins above this thread's eight
+#pragma unroll
+    for (int b = 7; b >= 0; b--) {
+        if (running < want && want <= running + c[b]) s_bin = (unsigned)(t * 8 + b);
+        running += c[b];
+    }
+    __syncthreads();
+    const unsigned bin = s_bin;
+    const int lane = t & 63;
+    const unsigned rounds = (n + gridDim.x * 256u - 1) / (gridDim.x * 256u);
+    for (unsigned r = 0; r < rounds; r++) {
+        const unsigned i = (r * gridDim.x + blockIdx.x) * 256u + t;
+        const bool take = i < n && topk_range_digit(topk_image(rows[(size_t)i * stride + keyWord], is32, desc), lo, shift) >= bin;
+        const unsigned long long vote = __ballot(take);
+        if (vote == 0) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(candCount, (unsigned)__popcll(vote));
+        base = (unsigned)__shfl((int)base, 0, 64);
+        if (!take) continue;
+        const unsigned pos = base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull));
+        if (pos >= capacity) continue;
+        const i64* src = rows + (size_t)i * stride;
+        i64* dst = cand + (size_t)pos * stride;
+        for (int w = 0; w < stride; w++) dst[w] = src[w];
+    }
+    // meeting point 2: the holder of the last ticket publishes the status words (nobody waits here)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_flag = __hip_atomic_fetch_add(ticket2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (s_flag) {
+        if (t == 0) host[0] = (u64)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == 1 && groupCount) host[1] = (u64)*groupCount;
+        if (t == 2) host[2] = (u64)__hip_atomic_load(candCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pipeStats && t >= 8 && t < 8 + nPipelines) host[t] = pipeStats[t - 8];
+    }
+}
+
+// scratch of both forms: [image range: 2 x u64][candidate count: u32][ticket: u32][TOPK_PASSES histograms]; the one-launch short form
+// keeps its second ticket behind the first histogram
 size_t topkHistBytes() { return 24 + (size_t)TOPK_PASSES * TOPK_BINS * sizeof(unsigned); }
 
 // to be enqueued BEFORE the compaction that collects the image range: clears range, candidate count and the histogram
-size_t topkRangeScratchBytes() { return 24 + TOPK_BINS * sizeof(unsigned); }
+size_t topkRangeScratchBytes() { return 24 + TOPK_BINS * sizeof(unsigned) + 8; }
 void prepareTopCandidatesRange(Context& ctx, void* scratch) { RSQ_HIP(hipMemsetAsync(scratch, 0, topkRangeScratchBytes(), ctx.stream)); }
 
 void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
@@ -710,6 +802,21 @@ void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int
                        (const unsigned*)nRows, (unsigned)rowsUpperBound, range, hist);
     hipLaunchKernelGGL(k_topk_range_gather, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
                        (const unsigned*)nRows, (unsigned)rowsUpperBound, range, (const unsigned*)hist, (unsigned)want, (i64*)cand, (unsigned)capacity, candCount);
+    RSQ_HIP(hipGetLastError());
+}
+
+void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
+                                     uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* candHostMapped, uint32_t capacity,
+                                     uint64_t* hostWords, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines) {
+    if (nPipelines > 56) throw Error(RSQ_ERR_UNSUPPORTED, "more than 56 pipelines in one query");
+    const u64* range = (const u64*)scratch;
+    unsigned* candCount = (unsigned*)((char*)scratch + 16);
+    unsigned* hist = (unsigned*)((char*)scratch + 24);
+    // (the grid must be on the chip as a whole: at most one workgroup per CU)
+    const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx.numCUs, (rowsUpperBound + 2047) / 2048));
+    hipLaunchKernelGGL(k_topk_range_select, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
+                       (const unsigned*)nRows, (unsigned)rowsUpperBound, range, hist, (unsigned)want, (i64*)candHostMapped, (unsigned)capacity, candCount,
+                       (unsigned*)((char*)scratch + 20), (unsigned*)((char*)scratch + 24 + TOPK_BINS * sizeof(unsigned)), err, (u64*)hostWords, (const unsigned*)groupCount, (const u64*)pipeStats, nPipelines);
     RSQ_HIP(hipGetLastError());
 }
 

@@ -906,7 +906,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
 }
 
 static void checkDeviceError(uint32_t err) {
-    err &= ~(32u | 64u | 128u);  // NOTE_CHAR_GROUP_ENDS_WITH_SPACE / NOTE_BUILD_KEYS_NOT_UNIQUE / the chained index's time-out are information for the host, not errors
+    err &= ~(32u | 64u | 128u | 256u);  // NOTE_CHAR_GROUP_ENDS_WITH_SPACE / NOTE_BUILD_KEYS_NOT_UNIQUE / the chained index's time-out are information for the host, not errors
     if (err & 1) failRuntime("Division by zero");
     if (err & 2) failRuntime("Hash table full");
     if (err & 16) failRuntime("internal error: a hash-table slot stayed in the 'being written' state");
@@ -1295,6 +1295,17 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     uint32_t topkCapacity = 0, topkSpec = 0;      // > 0: this execution pre-selects ORDER BY ... LIMIT candidates on the device
     bool topkRange = false;                       // ... with the short form (one histogram over the images' range)
     uint32_t groupRowsAllocated = 0;              // rows the group-row buffers of this execution can take
+    bool selectPublished = false;                 // ... and the selection's launch has delivered candidates and status words to the host
+    auto fusedSelectOk = [&]() {
+        static const bool off = getenv("RSQ_FUSED_SELECT") && atoi(getenv("RSQ_FUSED_SELECT")) == 0;
+        const bool publish = q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0);
+        return !off && !q.fusedSelectOff && publish && q.dHostGroupRows != nullptr && !partialOnly && !async && !getenv("RSQ_TRACE");
+    };
+    auto mapGroupRows = [&]() {
+        void* dv = nullptr;
+        q.dHostGroupRows = nullptr;
+        if (hipHostGetDevicePointer(&dv, q.hGroupRows, 0) == hipSuccess && dv) q.dHostGroupRows = (int64_t*)dv; else (void)hipGetLastError();
+    };
     // ---- the step in one launch: a single register-mode pipeline whose last workgroup publishes the table ----
     if (fusedEligible(q) && !trace0 && !interp) {
         Pipeline& p = q.pipelines[0];
@@ -1616,6 +1627,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             // non-coherent pinned memory: cached on the host (the tail reads every word), valid after the copy's sync
             RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
             q.hGroupRowsWords = need;
+            mapGroupRows();
         }
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
         if (q.topkWord == -2) planDeviceTopK(q);
@@ -1639,12 +1651,22 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         if (preselect) {
             // the short form: the compaction collected the range of the sort key's images, ONE histogram over that range finds
             // the candidates (aot_kernels.hip); the exact radix select runs only if they overflow the buffer (below)
+            topkRange = true;
+            if (fusedSelectOk()) {
+                // ... in one launch that also delivers the candidates and the status words to the host (aot_kernels.hip k_topk_range_select)
+                selectTopCandidatesRangePublish(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated,
+                                                q.topkWant, q.dTopkHists, q.dHostGroupRows, topkCapacity, q.dPinnedDev + words, ctx.dErr, q.dGroupCount,
+                                                anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size());
+                q.report.num_kernels += 1;
+                selectPublished = true;
+                topkSpec = topkCapacity;
+            } else {
             selectTopCandidatesRange(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated, q.topkWant,
                                      q.dTopkHists, q.dCandRows, topkCapacity);
             q.report.num_kernels += 2;
-            topkRange = true;
             // the leading candidates travel with the same synchronisation as the counts (usually that is all of them)
             topkSpec = std::min<uint32_t>(topkCapacity, std::max<uint32_t>(q.topkWant + 64, 65536u / (uint32_t)(q.groupRowWords * 8)));
+            }
         }
     }
     // ORDER BY ... LIMIT k over a large DENSE aggregate table: the groups present are compacted into rows [first row | group id |
@@ -1666,6 +1688,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
                 q.hGroupRows = nullptr;
                 RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
                 q.hGroupRowsWords = need;
+                mapGroupRows();
             }
             if (!q.dGroupCount) q.dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
             topkCapacity = std::min<uint32_t>(D, std::max<uint32_t>(1024, 4 * q.topkWant));
@@ -1679,17 +1702,26 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             if (!groupCountCleared) RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
             compactEntries(ctx, (const int64_t*)q.dAgg /* block 0 = first row */, (int64_t)D, nullptr, 1, false, (const int64_t*)q.dAgg, W,
                            q.dGroupRows, D, q.dGroupCount, false, q.topkWord, q.topkIs32, q.topkDesc, (uint64_t*)q.dTopkHists);
+            topkRange = true;
+            if (fusedSelectOk()) {
+                selectTopCandidatesRangePublish(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, D, q.topkWant,
+                                                q.dTopkHists, q.dHostGroupRows, topkCapacity, q.dPinnedDev + words, ctx.dErr, q.dGroupCount,
+                                                anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size());
+                q.report.num_kernels += 2;
+                selectPublished = true;
+                topkSpec = topkCapacity;
+            } else {
             selectTopCandidatesRange(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, D, q.topkWant,
                                      q.dTopkHists, q.dCandRows, topkCapacity);
-            topkRange = true;
             q.report.num_kernels += 3;
             topkSpec = std::min<uint32_t>(topkCapacity, std::max<uint32_t>(q.topkWant + 64, 65536u / (uint32_t)(q.groupRowWords * 8)));
+            }
             denseTopk = true;
         }
     }
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     bool devTail = false;                   // the rows of a large dense aggregation are made on the device (runDenseDeviceTail)
-    {
+    if (!selectPublished) {
         const bool wantGroups = !partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH || denseTopk);
         if (q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0)) {
             // error word, group count, candidate count and the pipelines' row counters: one kernel writes them into the pinned words
@@ -1723,6 +1755,13 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
     ctx.errWordClean = (uint32_t)q.hPinned[words] == 0;
+    if (((uint32_t)q.hPinned[words] & 256u) && !async && !q.fusedSelectOff) {
+        // a workgroup of the one-launch candidate selection gave up at a meeting point (aot_kernels.hip k_topk_range_select): its
+        // candidates are void; this query takes the separate launches from now on and starts over
+        q.fusedSelectOff = true;
+        executeQuery(q, partialOnly, async);
+        return;
+    }
     if (((uint32_t)q.hPinned[words] & 128u) && !async) {
         // a workgroup of the one-launch rank index gave up waiting for its predecessor (aot_kernels.hip k_rank_blocks_chained): the
         // index is wrong (in range, never out of bounds); this query takes the two-launch index from now on and starts over

@@ -168,6 +168,13 @@ size_t topkRangeScratchBytes();      // the part of the scratch prepareTopCandid
 void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                               uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* cand, uint32_t capacity);
 
+// ... and in ONE launch that also delivers: the candidates are written into host-mapped pinned memory (`candHostMapped`, the device's
+// view of it) and the last workgroup publishes the execution's status words like publishStatusAsync (candidate count = word 2).
+// A meeting point that timed out sets bit 256 of *err.
+void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
+                                     uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* candHostMapped, uint32_t capacity,
+                                     uint64_t* hostWords, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines);
+
 // devtail.hip: the tail of a large dense aggregation on the device (present groups, order by first row, the reference's hashes,
 // packed result tuples); tail.cpp planDenseDeviceTail says whether a plan qualifies and describes keys and columns
 struct DenseTailKey { int64_t min, card, stride; int32_t byteSet, typeTag; uint8_t values[32]; };

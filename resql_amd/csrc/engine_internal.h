@@ -358,6 +358,8 @@ struct Query {
     bool fusedReady = false;               // working table, ticket and error word are at their identities
     uint64_t finSeq = 0;                   // > 0 around a launch the host polls for: the number the last workgroup writes behind the error word
     uint64_t finSeqCounter = 0;
+    int64_t* dHostGroupRows = nullptr;   // the device's view of hGroupRows (the one-launch candidate selection writes the candidates there)
+    bool fusedSelectOff = false;         // a meeting point of the one-launch candidate selection timed out once: separate launches from now on
     bool residentRunning = false;        // RSQ_PERSISTENT_STEP=1: this query's step kernel is on the chip, waiting for the doorbell (hPinned[pinnedWords + 5])
     double residentLastRing = 0;         // ... when the host last rang it (the kernel leaves by itself after RESIDENT_IDLE_MS without a ring)
     uint64_t mergePublishedSeq = 0;        // > 0: rsq_query_merge_gathered also published the merged table to hPinned; finalize polls for this number
