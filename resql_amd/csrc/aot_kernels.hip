@@ -704,7 +704,7 @@ __global__ void __launch_bounds__(256) k_topk_range_gather(const i64* __restrict
 __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict__ rows, int stride, int keyWord, int is32, int desc,
                                                            const unsigned* __restrict__ nRows, unsigned maxRows, const u64* __restrict__ imageRange,
                                                            unsigned* __restrict__ hist, unsigned want, i64* __restrict__ cand, unsigned capacity,
-                                                           unsigned* candCount, unsigned* ticket1, unsigned* ticket2, unsigned* err, u64* __restrict__ host,
+                                                           unsigned* candCount, unsigned* ticket1, unsigned* ticket2, unsigned* err, u64* __restrict__ host, u64 seq,
                                                            const unsigned* __restrict__ groupCount, const u64* __restrict__ pipeStats, int nPipelines) {
     __shared__ unsigned s_hist[TOPK_BINS];
     __shared__ unsigned s_above[256];
@@ -781,6 +781,11 @@ __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict
         if (t == 1 && groupCount) host[1] = (u64)*groupCount;
         if (t == 2) host[2] = (u64)__hip_atomic_load(candCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pipeStats && t >= 8 && t < 8 + nPipelines) host[t] = pipeStats[t - 8];
+        // the sequence number behind them: stored once every store above has been acknowledged (every workgroup waited for its
+        // candidate stores before it took its ticket), system-scope release - the host watches this word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(host + 4, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -807,7 +812,7 @@ void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int
 
 void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                                      uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* candHostMapped, uint32_t capacity,
-                                     uint64_t* hostWords, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines) {
+                                     uint64_t* hostWords, uint64_t seq, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines) {
     if (nPipelines > 56) throw Error(RSQ_ERR_UNSUPPORTED, "more than 56 pipelines in one query");
     const u64* range = (const u64*)scratch;
     unsigned* candCount = (unsigned*)((char*)scratch + 16);
@@ -816,7 +821,7 @@ void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stri
     const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx.numCUs, (rowsUpperBound + 2047) / 2048));
     hipLaunchKernelGGL(k_topk_range_select, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
                        (const unsigned*)nRows, (unsigned)rowsUpperBound, range, hist, (unsigned)want, (i64*)candHostMapped, (unsigned)capacity, candCount,
-                       (unsigned*)((char*)scratch + 20), (unsigned*)((char*)scratch + 24 + TOPK_BINS * sizeof(unsigned)), err, (u64*)hostWords, (const unsigned*)groupCount, (const u64*)pipeStats, nPipelines);
+                       (unsigned*)((char*)scratch + 20), (unsigned*)((char*)scratch + 24 + TOPK_BINS * sizeof(unsigned)), err, (u64*)hostWords, (u64)seq, (const unsigned*)groupCount, (const u64*)pipeStats, nPipelines);
     RSQ_HIP(hipGetLastError());
 }
 

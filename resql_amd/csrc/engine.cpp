@@ -146,6 +146,7 @@ Query::~Query() {
     if (dAggWorkInit) ctx.free(dAggWorkInit);
     if (hPinned) (void)hipHostFree(hPinned);
     if (hGroupRows) (void)hipHostFree(hGroupRows);
+    if (hCandRows) (void)hipHostFree(hCandRows);
     if (dFinTicket) ctx.free(dFinTicket);
     if (gev0) (void)hipEventDestroy(gev0);
     if (gev1) (void)hipEventDestroy(gev1);
@@ -1238,6 +1239,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     Context& ctx = q.ctx;
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(ctx.device));
+    const uint64_t epochAtEntry = ctx.execEpoch++;
     static const bool residentKnob = getenv("RSQ_PERSISTENT_STEP") && atoi(getenv("RSQ_PERSISTENT_STEP")) == 1;
     if (ctx.residentOwner && (ctx.residentOwner != &q || partialOnly || async)) parkResidentStep(ctx);
     if (async) {
@@ -1295,16 +1297,24 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     uint32_t topkCapacity = 0, topkSpec = 0;      // > 0: this execution pre-selects ORDER BY ... LIMIT candidates on the device
     bool topkRange = false;                       // ... with the short form (one histogram over the images' range)
     uint32_t groupRowsAllocated = 0;              // rows the group-row buffers of this execution can take
+    uint64_t selectSeq = 0;                       // ... announced by this sequence number in pinned word 4
     bool selectPublished = false;                 // ... and the selection's launch has delivered candidates and status words to the host
+    auto ensureCandHost = [&]() {        // coherent pinned rows for topkCapacity candidates, and the device's view of them
+        const size_t need = (size_t)topkCapacity * (size_t)q.groupRowWords;
+        if (q.hCandRowsWords >= need && q.dHostCandRows) return;
+        if (q.hCandRows) (void)hipHostFree(q.hCandRows);
+        q.hCandRows = nullptr; q.dHostCandRows = nullptr; q.hCandRowsWords = 0;
+        RSQ_HIP(hipHostMalloc((void**)&q.hCandRows, std::max<size_t>(need, 8) * 8, hipHostMallocDefault));
+        q.hCandRowsWords = need;
+        void* dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, q.hCandRows, 0) == hipSuccess && dv) q.dHostCandRows = (int64_t*)dv; else (void)hipGetLastError();
+    };
     auto fusedSelectOk = [&]() {
         static const bool off = getenv("RSQ_FUSED_SELECT") && atoi(getenv("RSQ_FUSED_SELECT")) == 0;
         const bool publish = q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0);
-        return !off && !q.fusedSelectOff && publish && q.dHostGroupRows != nullptr && !partialOnly && !async && !getenv("RSQ_TRACE");
-    };
-    auto mapGroupRows = [&]() {
-        void* dv = nullptr;
-        q.dHostGroupRows = nullptr;
-        if (hipHostGetDevicePointer(&dv, q.hGroupRows, 0) == hipSuccess && dv) q.dHostGroupRows = (int64_t*)dv; else (void)hipGetLastError();
+        if (off || q.fusedSelectOff || !publish || partialOnly || async || getenv("RSQ_TRACE")) return false;
+        ensureCandHost();
+        return q.dHostCandRows != nullptr;
     };
     // ---- the step in one launch: a single register-mode pipeline whose last workgroup publishes the table ----
     if (fusedEligible(q) && !trace0 && !interp) {
@@ -1480,8 +1490,8 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     // row counters, the group counter and the candidate selection's scratch of a compaction behind the last pipeline
     bool groupCountCleared = false, topkScratchCleared = false;
     bool accumulatorsCleared = false;       // the aggregates beside a join table's entries are at their identities (AT_JOIN_ENTRY)
+    std::vector<FillItem> f;                // (kept: an execution that ends on its candidates enqueues the same clears for the next one)
     {
-        std::vector<FillItem> f;
         f.push_back(FillItem{ctx.dErr, 4, 0});
         bool anyDynamic = false;
         for (auto& p : q.pipelines) { anyDynamic |= p.dynamicTiles; p.tileCtrClean = p.dynamicTiles; }
@@ -1528,10 +1538,25 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
                 accumulatorsCleared = true;
             }
         }
-        fillBatchAsync(ctx, f.data(), (int)f.size());
-        q.report.num_kernels += (f.size() + 23) / 24;
+        // ... unless the previous execution of this query has already enqueued exactly these clears behind its last kernel and
+        // nothing else ran on the context since (RSQ_POST_CLEAR=0: never)
+        auto same = [](const std::vector<FillItem>& a, const std::vector<FillItem>& b) {
+            if (a.size() != b.size()) return false;
+            for (size_t i = 0; i < a.size(); i++) if (a[i].p != b[i].p || a[i].bytes != b[i].bytes || a[i].value != b[i].value) return false;
+            return true;
+        };
+        const bool readied = q.readied && q.readiedEpoch == epochAtEntry && same(f, q.readiedFill);
+        q.readied = false;
+        if (!readied) {
+            fillBatchAsync(ctx, f.data(), (int)f.size());
+            q.report.num_kernels += (f.size() + 23) / 24;
+        }
     }
-    RSQ_HIP(hipEventRecord(ctx.ev0, ctx.stream));
+    // (the execution's event pair is the query's own, read when somebody asks: an execution that ends on the candidate selection's
+    // sequence number returns before the stream has reported the second event)
+    resolveKernelTime(q);
+    if (!q.gev0) { RSQ_HIP(hipEventCreate(&q.gev0)); RSQ_HIP(hipEventCreate(&q.gev1)); }
+    RSQ_HIP(hipEventRecord(q.gev0, ctx.stream));
     double tPipe = nowMs();
     auto tracePoint = [&](const Pipeline& p) {
         if (!trace) return;
@@ -1627,7 +1652,6 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             // non-coherent pinned memory: cached on the host (the tail reads every word), valid after the copy's sync
             RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
             q.hGroupRowsWords = need;
-            mapGroupRows();
         }
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
         if (q.topkWord == -2) planDeviceTopK(q);
@@ -1655,7 +1679,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             if (fusedSelectOk()) {
                 // ... in one launch that also delivers the candidates and the status words to the host (aot_kernels.hip k_topk_range_select)
                 selectTopCandidatesRangePublish(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated,
-                                                q.topkWant, q.dTopkHists, q.dHostGroupRows, topkCapacity, q.dPinnedDev + words, ctx.dErr, q.dGroupCount,
+                                                q.topkWant, q.dTopkHists, q.dHostCandRows, topkCapacity, q.dPinnedDev + words, selectSeq = ++q.finSeqCounter, ctx.dErr, q.dGroupCount,
                                                 anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size());
                 q.report.num_kernels += 1;
                 selectPublished = true;
@@ -1688,8 +1712,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
                 q.hGroupRows = nullptr;
                 RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
                 q.hGroupRowsWords = need;
-                mapGroupRows();
-            }
+                }
             if (!q.dGroupCount) q.dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
             topkCapacity = std::min<uint32_t>(D, std::max<uint32_t>(1024, 4 * q.topkWant));
             if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = q.dTopkHists + 4; }
@@ -1705,7 +1728,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             topkRange = true;
             if (fusedSelectOk()) {
                 selectTopCandidatesRangePublish(ctx, q.dGroupRows, q.groupRowWords, q.topkWord, q.topkIs32, q.topkDesc, q.dGroupCount, D, q.topkWant,
-                                                q.dTopkHists, q.dHostGroupRows, topkCapacity, q.dPinnedDev + words, ctx.dErr, q.dGroupCount,
+                                                q.dTopkHists, q.dHostCandRows, topkCapacity, q.dPinnedDev + words, selectSeq = ++q.finSeqCounter, ctx.dErr, q.dGroupCount,
                                                 anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size());
                 q.report.num_kernels += 2;
                 selectPublished = true;
@@ -1719,7 +1742,8 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             denseTopk = true;
         }
     }
-    RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
+    RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
+    q.kernelTimePending = true;
     bool devTail = false;                   // the rows of a large dense aggregation are made on the device (runDenseDeviceTail)
     if (!selectPublished) {
         const bool wantGroups = !partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH || denseTopk);
@@ -1745,15 +1769,46 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         q.report.execution_time_ms = nowMs() - t0;
         return;
     }
-    waitForStream(ctx);
+    static const bool execTraceOn = getenv("RSQ_EXEC_TRACE") != nullptr;       // host-side phases of an execution of the general path, averaged over 8
+    const double tEnqueued = execTraceOn ? nowMs() : 0;
+    bool sawSequence = false;
+    if (selectPublished) {
+        // candidates and status words are in host memory once the selection's sequence number is: watch that word instead of the
+        // stream's completion (as the one-launch step does); hipStreamQuery now and then notices a failed launch
+        volatile uint64_t* flag = q.hPinned + words + 4;
+        const double deadline = nowMs() + 5.0;
+        unsigned spins = 0;
+        sawSequence = true;
+        while (*flag != selectSeq) {
+            if ((++spins & 1023u) == 0) {
+                hipError_t e = hipStreamQuery(ctx.stream);
+                if (e != hipSuccess && e != hipErrorNotReady) RSQ_HIP(e);
+                if (e == hipSuccess || nowMs() > deadline) { waitForStream(ctx); sawSequence = false; break; }
+            }
+            __builtin_ia32_pause();
+        }
+        if (*flag != selectSeq) failRuntime("internal error: the candidate selection finished without publishing its sequence number");
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else waitForStream(ctx);
+    if (!sawSequence) resolveKernelTime(q);      // (the stream is done: reading the events costs nothing now)
+    const double tSeen = execTraceOn ? nowMs() : 0;
+    auto execTrace = [&]() {
+        if (!execTraceOn) return;
+        static double acc[4] = {0, 0, 0, 0}; static int n = 0;
+        const double tEnd = nowMs();
+        resolveKernelTime(q);
+        acc[0] += tEnqueued - t0; acc[1] += tSeen - tEnqueued; acc[2] += tEnd - tSeen; acc[3] += q.report.kernel_time_ms;
+        if (++n == 8) {
+            fprintf(stderr, "[rsq exec] enqueue %.1f us, enqueued -> stream done %.1f us, checks + tail %.1f us; first to last event on the stream %.1f us, %llu launches\n",
+                    acc[0] / 8 * 1e3, acc[1] / 8 * 1e3, acc[2] / 8 * 1e3, acc[3] / 8 * 1e3, (unsigned long long)q.report.num_kernels);
+            acc[0] = acc[1] = acc[2] = acc[3] = 0; n = 0;
+        }
+    };
     if (anyCompaction)      // a build pipeline that also ran its counting pass reports both passes: only ever an over-estimate
         for (size_t i = 0; i < q.pipelines.size(); i++) {
             Pipeline& p = q.pipelines[i];           // the first 64 workgroups report: scale to the grid
             if (p.compact) p.stage2Rows = (int64_t)((double)q.hPinned[words + 8 + i] * (double)std::max(1u, p.lastGrid) / (double)std::min(64u, std::max(1u, p.lastGrid)));
         }
-    float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
-    q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
-    q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
     ctx.errWordClean = (uint32_t)q.hPinned[words] == 0;
     if (((uint32_t)q.hPinned[words] & 256u) && !async && !q.fusedSelectOff) {
         // a workgroup of the one-launch candidate selection gave up at a meeting point (aot_kernels.hip k_topk_range_select): its
@@ -1786,7 +1841,9 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     }
     checkDeviceError((uint32_t)q.hPinned[words]);
     // the short candidate selection overflowed its buffer (many rows share the leading bin): the exact radix select, now
+    bool candOnHost = selectPublished;      // the candidates are in hCandRows (else: in hGroupRows, copied)
     auto exactCandidates = [&](uint32_t rowsBound) -> int64_t {
+        candOnHost = false;
         if (q.topkImageRows < rowsBound) {
             if (q.dTopkImages) ctx.free(q.dTopkImages);
             q.dTopkImages = (uint64_t*)ctx.alloc((size_t)rowsBound * 8);
@@ -1814,7 +1871,9 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
                                       (size_t)(nCand - topkSpec) * rowBytes, hipMemcpyDeviceToHost));
                 q.candidateRun = true;
                 q.nGroupRows = nCand; q.totalGroups = nGroups;
+                q.hRowsView = candOnHost ? q.hCandRows : nullptr;
                 tailUnlessHeld(q);
+                q.hRowsView = nullptr;
                 q.candidateRun = false;
                 done = !q.tailNeedsAllGroups;
             }
@@ -1856,12 +1915,22 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             const size_t rowBytes = (size_t)q.groupRowWords * 8;
             q.candidateRun = false;
             if (topkCapacity && nCand <= (int64_t)topkCapacity && nCand < nGroups) {
+                static const bool postClear = !(getenv("RSQ_POST_CLEAR") && atoi(getenv("RSQ_POST_CLEAR")) == 0);
+                if (postClear && candOnHost && !trace && !interp && !q.holdTail) {
+                    // the candidates are on the host and decide the answer (or the whole table is read below from buffers the clears
+                    // leave alone): ready the next execution now, while the host does its tail
+                    fillBatchAsync(ctx, f.data(), (int)f.size());
+                    q.report.num_kernels += (f.size() + 23) / 24;
+                    q.readied = true; q.readiedEpoch = ctx.execEpoch; q.readiedFill = f;
+                }
                 if (nCand > (int64_t)topkSpec)
                     RSQ_HIP(hipMemcpy((char*)q.hGroupRows + (size_t)topkSpec * rowBytes, (char*)q.dCandRows + (size_t)topkSpec * rowBytes,
                                       (size_t)(nCand - topkSpec) * rowBytes, hipMemcpyDeviceToHost));
                 q.candidateRun = true;
                 q.nGroupRows = nCand; q.totalGroups = nGroups;
+                q.hRowsView = candOnHost ? q.hCandRows : nullptr;
                 tailUnlessHeld(q);
+                q.hRowsView = nullptr;
                 q.candidateRun = false;
             }
             if (!topkCapacity || q.tailNeedsAllGroups || !(nCand <= (int64_t)topkCapacity && nCand < nGroups)) {
@@ -1871,12 +1940,14 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             }
             q.report.finalize_time_ms = nowMs() - t1;
             q.report.execution_time_ms = nowMs() - t0;
+            execTrace();
             return;
         }
         tailUnlessHeld(q);
         q.report.finalize_time_ms = nowMs() - t1;
     }
     q.report.execution_time_ms = nowMs() - t0;
+    execTrace();
 }
 
 void finalizeQuery(Query& q) {
@@ -1913,8 +1984,8 @@ void finalizeQuery(Query& q) {
     if (q.pendingAsync) {         // the step was enqueued by rsq_query_execute_partial_async: account for it now
         q.pendingAsync = false;
         float ms = 0;
-        if (q.pendingFused) { RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.fusedReady = true; q.kernelTimePending = false; }
-        else RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+        RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.kernelTimePending = false;      // (one-launch step or not: the query's own event pair)
+        if (q.pendingFused) q.fusedReady = true;
         q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
         q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
         if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;
@@ -1938,8 +2009,8 @@ void settleAsync(Query& q) {
     waitForStream(ctx);
     q.pendingAsync = false;
     float ms = 0;
-    if (q.pendingFused) { RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.fusedReady = true; q.kernelTimePending = false; }
-    else RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
+    RSQ_HIP(hipEventElapsedTime(&ms, q.gev0, q.gev1)); q.kernelTimePending = false;
+    if (q.pendingFused) q.fusedReady = true;
     q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
     if (!q.pendingFused) ctx.errWordClean = (uint32_t)q.hPinned[q.pinnedWords] == 0;

@@ -79,6 +79,7 @@ struct Context {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int jitCompiles = 0, jitCacheHits = 0;
     bool errWordClean = false;                 // *dErr is known to be 0 (fused steps reset it themselves and rely on that)
+    uint64_t execEpoch = 0;                    // counts executions on this context (a query's "readied for the next execution" state is good for the very next one only)
     struct Query* residentOwner = nullptr;     // the query whose one-launch step is RESIDENT on this stream (RSQ_PERSISTENT_STEP=1; engine.cpp parkResidentStep)
 
     explicit Context(const rsq_config& c);
@@ -169,11 +170,12 @@ void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int
                               uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* cand, uint32_t capacity);
 
 // ... and in ONE launch that also delivers: the candidates are written into host-mapped pinned memory (`candHostMapped`, the device's
-// view of it) and the last workgroup publishes the execution's status words like publishStatusAsync (candidate count = word 2).
+// view of it) and the last workgroup publishes the execution's status words like publishStatusAsync (candidate count = word 2), then `seq` in
+// word 4 (system-scope release: whoever sees it sees candidates and status words).
 // A meeting point that timed out sets bit 256 of *err.
 void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                                      uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* candHostMapped, uint32_t capacity,
-                                     uint64_t* hostWords, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines);
+                                     uint64_t* hostWords, uint64_t seq, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines);
 
 // devtail.hip: the tail of a large dense aggregation on the device (present groups, order by first row, the reference's hashes,
 // packed result tuples); tail.cpp planDenseDeviceTail says whether a plan qualifies and describes keys and columns

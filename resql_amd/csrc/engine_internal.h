@@ -358,7 +358,18 @@ struct Query {
     bool fusedReady = false;               // working table, ticket and error word are at their identities
     uint64_t finSeq = 0;                   // > 0 around a launch the host polls for: the number the last workgroup writes behind the error word
     uint64_t finSeqCounter = 0;
-    int64_t* dHostGroupRows = nullptr;   // the device's view of hGroupRows (the one-launch candidate selection writes the candidates there)
+    // the one-launch candidate selection delivers the candidates into coherent pinned memory (the host reads them as soon as the
+    // kernel's sequence number arrives, before the stream reports completion)
+    int64_t* hCandRows = nullptr;        // [candidate capacity][groupRowWords]
+    int64_t* dHostCandRows = nullptr;    // ... as the device sees it
+    size_t hCandRowsWords = 0;
+    const int64_t* hRowsView = nullptr;  // the tail reads group rows from here when set (else hGroupRows)
+    // An execution that ended on its candidates enqueues the NEXT execution's clears (error word, counters, join tables, the
+    // aggregates beside their entries) behind its last kernel, where they run while the host does its tail; the next execution of
+    // this query skips its prologue fill if it is the very next execution on the context and wants exactly those clears.
+    bool readied = false;
+    uint64_t readiedEpoch = 0;
+    std::vector<FillItem> readiedFill;
     bool fusedSelectOff = false;         // a meeting point of the one-launch candidate selection timed out once: separate launches from now on
     bool residentRunning = false;        // RSQ_PERSISTENT_STEP=1: this query's step kernel is on the chip, waiting for the doorbell (hPinned[pinnedWords + 5])
     double residentLastRing = 0;         // ... when the host last rang it (the kernel leaves by itself after RESIDENT_IDLE_MS without a ring)

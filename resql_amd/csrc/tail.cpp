@@ -260,7 +260,7 @@ Groups groupsFromDenseRows(Query& q) {
     G.n = (size_t)q.nGroupRows; G.nKeys = q.denseKeys.size(); G.nAcc = W;
     G.firstRow.resize(G.n); G.keyData.resize(G.n * G.nKeys); G.accData.resize(G.n * W);
     for (size_t i = 0; i < G.n; i++) {
-        const int64_t* r = &q.hGroupRows[i * stride];
+        const int64_t* r = &(q.hRowsView ? q.hRowsView : q.hGroupRows)[i * stride];
         const int64_t g = r[1];
         G.firstRow[i] = r[0];
         size_t k = 0;
@@ -289,7 +289,7 @@ Groups groupsFromJoinEntries(Query& q) {
     G.strings.assign(G.n * strBytes, 0);
     parallelFor(G.n, tailThreads(G.n), [&](size_t lo, size_t hi, int) {
         for (size_t i = lo; i < hi; i++) {
-            const int64_t* r = &q.hGroupRows[i * stride];
+            const int64_t* r = &(q.hRowsView ? q.hRowsView : q.hGroupRows)[i * stride];
             size_t sp = i * strBytes;
             G.firstRow[i] = r[0];
             for (size_t k = 0; k < G.nKeys; k++) {
