@@ -469,14 +469,29 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                 if (pos >= maxRows) continue;
                 const i64 s = lo + (i64)s_list[i];
                 i64* o = out + (size_t)pos * stride;
-                o[0] = first[s];
                 // (no word arrays: the one word is the slot index itself — dense aggregate tables, whose slot IS the group id)
                 // (rank dictionaries keep the aggregates of entry r at rank_mix(r), kernels/rsq_device.h: the entry of accumulator
                 // slot s is the inverse)
                 i64 e = s;
                 if (unmix) e = (i64)rank_unmix((u64)s, (u64)cap);
+                if (stride <= 8) {
+                    // all of the row's loads first, then its stores (word by word, every load waited for its predecessor's store:
+                    // a chain of up to eight round trips per row - 18 us for TPC-H Q3's 114 K groups)
+                    i64 v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        v[k] = 0;
+                        if (k == 0) v[k] = first[s];
+                        else if (k - 1 < nWords) v[k] = !words ? s : wordsAos ? words[(size_t)e * nWords + (k - 1)] : words[(size_t)(k - 1) * cap + e];
+                        else if (k < stride) v[k] = acc[(size_t)(k - 1 - nWords) * cap + s];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) if (k < stride) o[k] = v[k];
+                } else {
+                o[0] = first[s];
                 for (int w = 0; w < nWords; w++) o[1 + w] = !words ? s : wordsAos ? words[(size_t)e * nWords + w] : words[(size_t)w * cap + e];
                 for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
+                }
                 if (keyWord >= 0) { const u64 u = topk_image(o[keyWord], keyIs32, keyDesc); imgMax = u > imgMax ? u : imgMax; imgMaxInv = ~u > imgMaxInv ? ~u : imgMaxInv; }
             }
         }
@@ -715,8 +730,30 @@ __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict
     const u64 hi = imageRange[0], lo = ~imageRange[1];
     const int shift = hi > lo ? __builtin_clzll(hi - lo) : 0;
     const unsigned n = *nRows < maxRows ? *nRows : maxRows;
-    for (unsigned i = blockIdx.x * 256u + t; i < n; i += gridDim.x * 256u)
-        atomicAdd(&s_hist[topk_range_digit(topk_image(rows[(size_t)i * stride + keyWord], is32, desc), lo, shift)], 1u);
+    // a thread's rows are (round * gridDim.x + blockIdx.x) * 256 + t; the digits of its first RSEL_KEEP rounds stay in registers for
+    // the gather (their loads are issued together: one round trip instead of one per row - a loop of load, wait, LDS atomic took
+    // 2 us per round)
+    enum { RSEL_KEEP = 8 };
+    const unsigned rounds = (n + gridDim.x * 256u - 1) / (gridDim.x * 256u);
+    unsigned dig[RSEL_KEEP];
+    {
+        i64 key[RSEL_KEEP];
+#pragma unroll
+        for (int r = 0; r < RSEL_KEEP; r++) {
+            const unsigned i = ((unsigned)r * gridDim.x + blockIdx.x) * 256u + t;
+            key[r] = (unsigned)r < rounds && i < n ? rows[(size_t)i * stride + keyWord] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < RSEL_KEEP; r++) {
+            const unsigned i = ((unsigned)r * gridDim.x + blockIdx.x) * 256u + t;
+            dig[r] = 0xffffffffu;                         // no row
+            if ((unsigned)r < rounds && i < n) { dig[r] = topk_range_digit(topk_image(key[r], is32, desc), lo, shift); atomicAdd(&s_hist[dig[r]], 1u); }
+        }
+    }
+    for (unsigned r = RSEL_KEEP; r < rounds; r++) {
+        const unsigned i = (r * gridDim.x + blockIdx.x) * 256u + t;
+        if (i < n) atomicAdd(&s_hist[topk_range_digit(topk_image(rows[(size_t)i * stride + keyWord], is32, desc), lo, shift)], 1u);
+    }
     __syncthreads();
     for (int b = t; b < TOPK_BINS; b += 256) { const unsigned c = s_hist[b]; if (c) atomicAdd(&hist[b], c); }
     // meeting point 1: this workgroup's histogram atomics have been performed; wait for everybody's
@@ -755,21 +792,25 @@ __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict
     __syncthreads();
     const unsigned bin = s_bin;
     const int lane = t & 63;
-    const unsigned rounds = (n + gridDim.x * 256u - 1) / (gridDim.x * 256u);
-    for (unsigned r = 0; r < rounds; r++) {
-        const unsigned i = (r * gridDim.x + blockIdx.x) * 256u + t;
-        const bool take = i < n && topk_range_digit(topk_image(rows[(size_t)i * stride + keyWord], is32, desc), lo, shift) >= bin;
+    auto gather = [&](unsigned i, bool take) {
         const unsigned long long vote = __ballot(take);
-        if (vote == 0) continue;
+        if (vote == 0) return;
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(candCount, (unsigned)__popcll(vote));
         base = (unsigned)__shfl((int)base, 0, 64);
-        if (!take) continue;
+        if (!take) return;
         const unsigned pos = base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull));
-        if (pos >= capacity) continue;
+        if (pos >= capacity) return;
         const i64* src = rows + (size_t)i * stride;
         i64* dst = cand + (size_t)pos * stride;
         for (int w = 0; w < stride; w++) dst[w] = src[w];
+    };
+#pragma unroll
+    for (int r = 0; r < RSEL_KEEP; r++)
+        if ((unsigned)r < rounds) gather(((unsigned)r * gridDim.x + blockIdx.x) * 256u + t, dig[r] != 0xffffffffu && dig[r] >= bin);
+    for (unsigned r = RSEL_KEEP; r < rounds; r++) {
+        const unsigned i = (r * gridDim.x + blockIdx.x) * 256u + t;
+        gather(i, i < n && topk_range_digit(topk_image(rows[(size_t)i * stride + keyWord], is32, desc), lo, shift) >= bin);
     }
     // meeting point 2: the holder of the last ticket publishes the status words (nobody waits here)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -818,7 +859,7 @@ void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stri
     unsigned* candCount = (unsigned*)((char*)scratch + 16);
     unsigned* hist = (unsigned*)((char*)scratch + 24);
     // (the grid must be on the chip as a whole: at most one workgroup per CU)
-    const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx.numCUs, (rowsUpperBound + 2047) / 2048));
+    const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx.numCUs, (rowsUpperBound + 1023) / 1024));
     hipLaunchKernelGGL(k_topk_range_select, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
                        (const unsigned*)nRows, (unsigned)rowsUpperBound, range, hist, (unsigned)want, (i64*)candHostMapped, (unsigned)capacity, candCount,
                        (unsigned*)((char*)scratch + 20), (unsigned*)((char*)scratch + 24 + TOPK_BINS * sizeof(unsigned)), err, (u64*)hostWords, (u64)seq, (const unsigned*)groupCount, (const u64*)pipeStats, nPipelines);
@@ -1100,26 +1141,80 @@ void rankTableIndexChained(Context& ctx, uint32_t* bitmap, int64_t nBlocks, uint
 }
 
 // One workgroup per wave of the build pipeline: its region of the arrival-order buffer holds used[wave] records.
+// Every thread takes two records at a time and issues all their loads before it uses any: the record words, then the 32-byte bitmap
+// block of each key as two 16-byte loads (the rank is the block's rank word + the popcount below the key's bit, computed without
+// branches).  The first form walked the block word by word behind a branch each - eight dependent round trips per record, 27.7 us for
+// TPC-H Q3's 1.45 M records at SF10.
+template <int NW>      // words per record (0: any, at most 8)
 __global__ void __launch_bounds__(256) k_rank_place(const i64* __restrict__ temp, const unsigned* __restrict__ used, unsigned region,
-                                                    const unsigned* __restrict__ nRecords, int nWords, const unsigned* __restrict__ bm, i64 bmMin,
+                                                    const unsigned* __restrict__ nRecords, int nWordsArg, const unsigned* __restrict__ bm, i64 bmMin,
                                                     u64 bmBits, const unsigned* __restrict__ chunkBase, int nChunks, i64* __restrict__ words,
                                                     i64 capacity, unsigned* __restrict__ err) {
     // as many records as distinct keys, and no more than the table was sized for — anything else means the build side changed
     // since the sizing pass (two rows with one key, more rows): the host then falls back to the hash table
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (*nRecords != chunkBase[nChunks] || (i64)*nRecords > capacity)) atomicOr(err, 64u);
+    const int nWords = NW ? NW : nWordsArg;
+    constexpr int MAXW = NW ? NW : 8;
+    const unsigned n = used[blockIdx.x];
+    const i64* base = temp + (i64)blockIdx.x * region * nWords;
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += 2u * blockDim.x) {
+        i64 rec[2][MAXW];
+        bool have[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const unsigned i = i0 + (unsigned)u * blockDim.x;
+            have[u] = i < n;
+#pragma unroll
+            for (int k = 0; k < MAXW; k++) rec[u][k] = have[u] && k < nWords ? base[(i64)i * nWords + k] : 0;
+        }
+        uint4 lo[2], hi[2];
+        unsigned wi[2], bit[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const u64 d = (u64)(rec[u][0] - bmMin);
+            have[u] = have[u] && d < bmBits;          // a key outside the bitmap's domain: the build kernel has raised ERR_GROUP_OVERFLOW for it
+            const unsigned w = (unsigned)(d >> 5), blkI = have[u] ? w / 7u : 0u;
+            wi[u] = 1u + (w % 7u); bit[u] = (unsigned)d & 31u;
+            const uint4* blk = reinterpret_cast<const uint4*>(bm + (i64)blkI * 8);
+            lo[u] = blk[0]; hi[u] = blk[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (!have[u]) continue;
+            const unsigned x[8] = {lo[u].x, lo[u].y, lo[u].z, lo[u].w, hi[u].x, hi[u].y, hi[u].z, hi[u].w};
+            unsigned r = x[0];
+#pragma unroll
+            for (unsigned j = 1; j < 8; j++) {
+                const unsigned m = j < wi[u] ? 0xffffffffu : (j == wi[u] ? (1u << bit[u]) - 1u : 0u);
+                r += __popc(x[j] & m);
+            }
+            if ((i64)r < capacity) {
+#pragma unroll
+                for (int k = 0; k < MAXW; k++) if (k < nWords) words[(i64)r * nWords + k] = rec[u][k];
+            }
+        }
+    }
+}
+
+// ... records wider than 8 words (string payloads): word by word
+__global__ void __launch_bounds__(256) k_rank_place_wide(const i64* __restrict__ temp, const unsigned* __restrict__ used, unsigned region,
+                                                         const unsigned* __restrict__ nRecords, int nWords, const unsigned* __restrict__ bm, i64 bmMin,
+                                                         u64 bmBits, const unsigned* __restrict__ chunkBase, int nChunks, i64* __restrict__ words,
+                                                         i64 capacity, unsigned* __restrict__ err) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && (*nRecords != chunkBase[nChunks] || (i64)*nRecords > capacity)) atomicOr(err, 64u);
     const unsigned n = used[blockIdx.x];
     const i64* base = temp + (i64)blockIdx.x * region * nWords;
     for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
         const i64* rec = base + (i64)i * nWords;
         const u64 d = (u64)(rec[0] - bmMin);
-        if (d >= bmBits) continue;          // a key outside the bitmap's domain (the build kernel has raised ERR_GROUP_OVERFLOW for it)
+        if (d >= bmBits) continue;
         const unsigned w = (unsigned)(d >> 5), blkI = w / 7u, wi = 1u + (w % 7u), bit = (unsigned)d & 31u;
-        const unsigned* blk = bm + (i64)blkI * 8;
-        unsigned r = blk[0];
-        for (unsigned j = 1; j < 8; j++) {
-            const unsigned x = blk[j];
-            r += j < wi ? __popc(x) : (j == wi ? __popc(x & ((1u << bit) - 1u)) : 0u);
-        }
+        const uint4* blk = reinterpret_cast<const uint4*>(bm + (i64)blkI * 8);
+        const uint4 lo = blk[0], hi = blk[1];
+        const unsigned x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        unsigned r = x[0];
+#pragma unroll
+        for (unsigned j = 1; j < 8; j++) r += __popc(x[j] & (j < wi ? 0xffffffffu : (j == wi ? (1u << bit) - 1u : 0u)));
         if ((i64)r < capacity) for (int k = 0; k < nWords; k++) words[(i64)r * nWords + k] = rec[k];
     }
 }
@@ -1128,9 +1223,19 @@ void rankTablePlace(Context& ctx, const int64_t* temp, const uint32_t* used, uin
                     const uint32_t* bitmap, int64_t bmMin, int64_t bmBits, const uint32_t* chunkBase, int64_t nBlocks, int64_t* words,
                     int64_t capacity) {
     const int nChunks = (int)((nBlocks + RANK_CHUNK_BLOCKS - 1) / RANK_CHUNK_BLOCKS);
-    hipLaunchKernelGGL(k_rank_place, dim3(std::max(1u, nWaves)), dim3(256), 0, ctx.stream, (const i64*)temp, (const unsigned*)used, (unsigned)region,
-                       (const unsigned*)nRecords, nWords, (const unsigned*)bitmap, (i64)bmMin, (u64)bmBits, (const unsigned*)chunkBase, nChunks,
-                       (i64*)words, (i64)capacity, (unsigned*)ctx.dErr);
+    if (nWords > 8) {
+        hipLaunchKernelGGL(k_rank_place_wide, dim3(std::max(1u, nWaves)), dim3(256), 0, ctx.stream, (const i64*)temp, (const unsigned*)used, (unsigned)region,
+                           (const unsigned*)nRecords, nWords, (const unsigned*)bitmap, (i64)bmMin, (u64)bmBits, (const unsigned*)chunkBase, nChunks,
+                           (i64*)words, (i64)capacity, (unsigned*)ctx.dErr);
+        RSQ_HIP(hipGetLastError());
+        return;
+    }
+#define RSQ_LAUNCH_PLACE(NW) hipLaunchKernelGGL(k_rank_place<NW>, dim3(std::max(1u, nWaves)), dim3(256), 0, ctx.stream, (const i64*)temp, (const unsigned*)used, \
+                       (unsigned)region, (const unsigned*)nRecords, nWords, (const unsigned*)bitmap, (i64)bmMin, (u64)bmBits, (const unsigned*)chunkBase, nChunks, \
+                       (i64*)words, (i64)capacity, (unsigned*)ctx.dErr)
+    switch (nWords) { case 1: RSQ_LAUNCH_PLACE(1); break; case 2: RSQ_LAUNCH_PLACE(2); break; case 3: RSQ_LAUNCH_PLACE(3); break; case 4: RSQ_LAUNCH_PLACE(4); break;
+                      default: RSQ_LAUNCH_PLACE(0); }
+#undef RSQ_LAUNCH_PLACE
     RSQ_HIP(hipGetLastError());
 }
 

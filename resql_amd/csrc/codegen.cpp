@@ -34,6 +34,7 @@ int64_t nextPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 // ================================================================================================
 struct ExprGen {
     std::map<std::string, Sym> symbols;     // JitContextFlounder::symbolTable of the current pipeline
+    std::set<std::string> strWordVars;      // string columns whose bytes arrive as row-function parameters <var>_w0, _w1 (loaded with the tile)
 
     static std::string ctype(const Type& t) {
         switch (t.tag) {
@@ -168,7 +169,9 @@ struct ExprGen {
                     if (k < text.size()) { cw |= (uint64_t)(uint8_t)text[k] << (8 * i); mask |= 0xFFull << (8 * i); }
                     else mask |= (charSemantics ? 0xDFull : 0xFFull) << (8 * i);
                 }
-                char buf[160];
+                char buf[200];
+                if (strWordVars.count(x)) snprintf(buf, sizeof buf, "((%s_w%d ^ 0x%llxull) & 0x%llxull)", x.c_str(), w, (unsigned long long)cw, (unsigned long long)mask);
+                else
                 snprintf(buf, sizeof buf, "((rsq::ld_bytes<%d>((%s).p + %d) ^ 0x%llxull) & 0x%llxull)", rbytes, x.c_str(), w * 8,
                          (unsigned long long)cw, (unsigned long long)mask);
                 cond += (cond.empty() ? "" : " | ") + std::string(buf);
@@ -364,6 +367,7 @@ struct Walker {
         multiMatchAbove = false;
         selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
         leadCond.clear(); leadCols.clear(); leadPass = 1.0; leadPassComplete = true;
+        strPrefetch.clear(); eg.strWordVars.clear();
         eg.symbols.clear();
         o->schema.clear();
         for (size_t ci = 0; ci < t->cols.size(); ci++) {
@@ -478,6 +482,36 @@ struct Walker {
         }
         for (Expr* c : e->children()) leadColumnsOf(c, out, ok);
     }
+    // Short string columns the selection right above the scan compares with constants: their bytes are loaded WITH the tile (one or
+    // two 8-byte words per row, in flight together with the numeric columns) and reach the row function as parameters, instead of
+    // being fetched inside it row by row - eight dependent round trips per lane and iteration (TPC-H Q3's customer pipeline:
+    // c_mktsegment = 'BUILDING').  RSQ_STRING_PREFETCH=0: never.
+    std::vector<std::pair<int, int>> strPrefetch;         // (scanned column, its width), in the order of the row function's parameters
+    void prefetchComparedStrings(const Expr* e) {
+        if (envInt("RSQ_STRING_PREFETCH", 1, 0, 1) == 0 || envInt("RSQ_STRING_WORDS", 1, 0, 1) == 0) return;
+        if ((e->tag == RSQ_E_EQ || e->tag == RSQ_E_NEQ) && e->child && e->child->next) {
+            const Expr* l = e->child; const Expr* r = e->child->next;
+            const Expr* col = l->tag == RSQ_E_ATTRIBUTE && r->tag == RSQ_E_CONSTANT ? l : r->tag == RSQ_E_ATTRIBUTE && l->tag == RSQ_E_CONSTANT ? r : nullptr;
+            if (!col || !l->type.isString() || !r->type.isString()) return;
+            auto sy = eg.symbols.find(col->symbol);
+            auto so = symbolOrigin.find(col->symbol);
+            if (sy == eg.symbols.end() || so == symbolOrigin.end() || so->second != -1 || sy->second.var.compare(0, 2, "v_") != 0) return;
+            const int k = atoi(sy->second.var.c_str() + 2);
+            const int W = sy->second.type.len;
+            if (k < 0 || k >= (int)colIsString.size() || !colIsString[(size_t)k] || W < 2 || W > 16) return;
+            for (auto& sp : strPrefetch) if (sp.first == k) return;
+            strPrefetch.push_back({k, W});
+            eg.strWordVars.insert(sy->second.var);
+            for (int w = 0; w * 8 < W; w++) {
+                const std::string ld = "rsq::ld_bytes<" + std::to_string(std::min(8, W - w * 8)) + ">(a.c" + std::to_string(k) + " + r * " + std::to_string(W) + " + " + std::to_string(w * 8) + ")";
+                rowParams += ", u64 " + sy->second.var + "_w" + std::to_string(w);
+                rowArgsTail += ", " + ld;
+                rowArgsTailGuarded += ", (valid ? " + ld + " : 0ull)";
+            }
+            return;
+        }
+        if (e->tag == RSQ_E_AND || e->tag == RSQ_E_OR) for (Expr* c : e->children()) prefetchComparedStrings(c);
+    }
     void noteLeadingSelection(const Expr* e, const std::string& cond) {
         bool ok = true;
         std::vector<int> cols;
@@ -496,6 +530,7 @@ struct Walker {
                 q.pool.addId(o->exprs[0]);
                 selective = true;
                 {
+                    if (from->tag == RSQ_OP_SCAN) prefetchComparedStrings(o->exprs[0]);
                     const std::string cond = eg.emit(o->exprs[0]);
                     if (from->tag == RSQ_OP_SCAN && leadCond.empty()) noteLeadingSelection(o->exprs[0], cond);
                     openScope("if (" + cond + ") {");
@@ -2399,7 +2434,15 @@ struct Walker {
             else
             s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2]" << (lateCol[(size_t)k] ? " = {0, 0}" : "") << ";\n";
+            for (auto& sp : strPrefetch)
+                for (int j = 0; j < 2; j++)
+                    for (int w = 0; w * 8 < sp.second; w++) s << "        u64 s" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
             s << "        if (tt" << u << " < tend) {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
+            for (auto& sp : strPrefetch)
+                for (int j = 0; j < 2; j++)
+                    for (int w = 0; w * 8 < sp.second; w++)
+                        s << "            s" << sp.first << "_" << u << "_" << j << "_" << w << " = rsq::ld_bytes<" << std::min(8, sp.second - w * 8) << ">(a.c" << sp.first
+                          << " + (b + " << j << ") * " << sp.second << " + " << w * 8 << ");\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k] && !lateCol[(size_t)k]) {
                 const bool lazy = std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) != pipe.lazyCols.end();
                 if (lazy) s << "#if !RSQ_LAZY\n";
@@ -2425,6 +2468,7 @@ struct Walker {
             for (int j = 0; j < 2; j++) {
                 s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");
                 for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
+                for (auto& sp : strPrefetch) for (int w = 0; w * 8 < sp.second; w++) s << ", s" << sp.first << "_" << u << "_" << j << "_" << w;
                 for (auto& pf : bitmapPrefetch) s << ", pf_" << pf.first << "_" << u << "[" << j << "]";
                 s << ");\n";
                 if (cq && (QCAP < 192 || j == 1)) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";

@@ -96,3 +96,31 @@ def test_repeated_execution_q3(gpu_ctx):
     q.close()
     for t in tabs:
         t.close()
+
+
+def test_interleaved_executions_of_two_join_queries(gpu_ctx):
+    """an execution that ends on its candidates readies the NEXT execution of the same query (the clears run behind its last kernel);
+    that state is good for the very next execution on the context only: other queries in between, repeats, and a query closed in
+    between must all leave every answer as the oracle has it"""
+    sf = 0.05
+    cu, od, li = tpch.customer_table(sf), tpch.orders_table(sf), tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+    li1 = tpch.lineitem_table(sf, tpch.Q1_COLUMNS)
+    plan_a = tpch.q3_plan(cu, od, li)
+    plan_b = tpch.q3_plan(cu, od, li, segment="MACHINERY", date="1995-03-01", limit=25)
+    plan_c = tpch.q1_plan(li1)
+    want = {k: orc.execute(p).text for k, p in (("a", plan_a), ("b", plan_b), ("c", plan_c))}
+    tabs = [gpu_ctx.table(t) for t in (cu, od, li)]
+    t1 = gpu_ctx.table(li1)
+    qs = {"a": gpu_ctx.compile(plan_a, tabs), "b": gpu_ctx.compile(plan_b, tabs), "c": gpu_ctx.compile(plan_c, [t1])}
+    for k in "aababbacaacbbca":
+        qs[k].execute()
+        assert qs[k].result().text == want[k], k
+    qs["b"].close()
+    qs["b"] = gpu_ctx.compile(plan_b, tabs)
+    for k in "abab":
+        qs[k].execute()
+        assert qs[k].result().text == want[k], k
+    for q in qs.values():
+        q.close()
+    for t in tabs + [t1]:
+        t.close()
