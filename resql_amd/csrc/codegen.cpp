@@ -261,7 +261,7 @@ struct Walker {
     std::string rowParams, rowArgsTail, rowArgsTailGuarded;
     // key-bitmap words fetched for both rows of a lane (and all tiles in flight) before the first row is processed:
     // (table name, scanned column index) — see consumeProbe
-    struct BitmapPrefetch { std::string first; int second; bool interleaved; };
+    struct BitmapPrefetch { std::string first; int second; bool interleaved; bool gated = false; };      // gated: only for rows that pass the leading selection
     std::vector<BitmapPrefetch> bitmapPrefetch;
     std::string body;                          // row function body
     std::string closers;                       // closing braces of the open scopes
@@ -1033,6 +1033,7 @@ struct Walker {
             // the two row functions of a lane otherwise run one after the other, each with its own dependent load — a cache
             // round trip per row that nothing overlaps (TPC-H Q3's lineitem pipeline spent a quarter of its time there).
             int pfCol = -1;
+            bool pfGated = false;
             {
                 Expr* r = o->exprs[0]->child->next;
                 auto org = r->tag == RSQ_E_ATTRIBUTE ? symbolOrigin.find(r->symbol) : symbolOrigin.end();
@@ -1043,20 +1044,35 @@ struct Walker {
                 if (!compacted && o->exprs.size() == 1 && org != symbolOrigin.end() && org->second == -1 && sym != eg.symbols.end() &&
                     sym->second.var.compare(0, 2, "v_") == 0 && !r->type.isString()) {
                     const int ci = pipe.src->findCol(r->symbol);
-                    const int mode = envInt("RSQ_BITMAP_PREFETCH", 1, 0, 2);       // 0 never, 1 clustered keys, 2 always
+                    const int mode = envInt("RSQ_BITMAP_PREFETCH", 1, 0, 2);       // 0 never, 1 clustered keys (or gated, below), 2 always
                     if (ci >= 0 && (mode == 2 || (mode == 1 && pipe.src->cols[(size_t)ci].stats.valid && pipe.src->cols[(size_t)ci].stats.ascending)))
                         pfCol = atoi(sym->second.var.c_str() + 2);
+                    // RSQ_BITMAP_PREFETCH_GATED=1 (off by default: measured no gain): keys in random order behind a selection - the words
+                    // are fetched with the tile all the same, but only for the rows the selection passes (the pipeline evaluates it once
+                    // more in front of the loads).  Fetched inside the row function, the eight rows a lane handles per iteration wait
+                    // for their bitmap words one after the other; issuing the eight loads together left TPC-H Q3's orders pipeline where it
+                    // was (0.306-0.308 against 0.305-0.315 ms for the query): what its probes cost - 34 of its 88 us, RSQ_DEBUG_PROBE=1 -
+                    // is the cache lines they move from the L2 (7 M probes of a 187 KB bitmap, one 128-byte line each), not their latency.
+                    // (not where late loads would apply - RSQ_LATE_LOADS, a leading selection that passes few rows: they do better)
+                    else if (ci >= 0 && mode == 1 && !leadCond.empty() && envInt("RSQ_BITMAP_PREFETCH_GATED", 0, 0, 1) &&
+                             !(envInt("RSQ_LATE_LOADS", 1, 0, 2) && leadPass <= (double)envInt("RSQ_LATE_LOADS_BELOW", 12, 0, 100) / 100.0)) {
+                        pfCol = atoi(sym->second.var.c_str() + 2);
+                        pfGated = true;
+                    }
                 }
                 for (auto& pf : bitmapPrefetch) if (pf.first == T) pfCol = -1;        // (one probe per table and pipeline)
             }
             if (pfCol >= 0) {
-                bitmapPrefetch.push_back({T, pfCol, ht.bmInterleaved});
+                bitmapPrefetch.push_back({T, pfCol, ht.bmInterleaved, pfGated});
                 const std::string call = std::string(ht.bmInterleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") + T + "_bm, a." + T + "_bmmin, a." + T + "_bmbits, (i64)";
                 rowParams += ", const u32 pf_" + T;
                 rowArgsTail += ", " + call + "a.c" + std::to_string(pfCol) + "[r])";
                 rowArgsTailGuarded += ", (valid ? " + call + "a.c" + std::to_string(pfCol) + "[r]) : 0u)";
                 openScope("if (" + T + "_d < a." + T + "_bmbits && ((pf_" + T + " >> (" + T + "_d & 31)) & 1u)) {");
             } else
+            if (envInt("RSQ_DEBUG_PROBE", 0, 0, 1) && !ht.unique)       // (measurement only, wrong results: a key set's bit test without its load - one key in five passes)
+                openScope("if (" + T + "_d < a." + T + "_bmbits && ((" + T + "_d * 0x9E3779B97F4A7C15ull) >> 32) % 5u == 0u) {");
+            else
             openScope("if (" + T + "_d < a." + T + "_bmbits && ((a." + T + "_bm[" + (ht.bmInterleaved ? "rsq::bmi_word(" + T + "_d)" : T + "_d >> 5") + "] >> (" + T + "_d & 31)) & 1u)) {");
             selective = true;
         }
@@ -2310,7 +2326,9 @@ struct Walker {
             }
             s << ");\n        st.cq_rows++;\n    }\n    st.cq_n -= count;\n}\n";
         }
-        if (late) {
+        bool gatedPrefetch = false;
+        for (auto& pf : bitmapPrefetch) gatedPrefetch |= pf.gated;
+        if (late || gatedPrefetch) {
             s << "static RSQ_DEV bool lead_pred(const Args& a";
             for (int k : leadCols) s << ", " << colTypes[(size_t)k] << " v_" << k;
             s << ") { return " << leadCond << "; }\n";
@@ -2457,9 +2475,16 @@ struct Walker {
             for (auto& pf : bitmapPrefetch) {
                 s << "        u32 pf_" << pf.first << "_" << u << "[2] = {0u, 0u};\n";
                 s << "        if (tt" << u << " < tend) {\n";
-                for (int j = 0; j < 2; j++)
-                    s << "            pf_" << pf.first << "_" << u << "[" << j << "] = " << (pf.interleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") << pf.first << "_bm, a." << pf.first << "_bmmin, a." << pf.first
+                for (int j = 0; j < 2; j++) {
+                    s << "            pf_" << pf.first << "_" << u << "[" << j << "] = ";
+                    if (pf.gated) {
+                        s << "!lead_pred(a";
+                        for (int k : leadCols) s << ", t" << k << "_" << u << "[" << j << "]";
+                        s << ") ? 0u : ";
+                    }
+                    s << (pf.interleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") << pf.first << "_bm, a." << pf.first << "_bmmin, a." << pf.first
                       << "_bmbits, (i64)t" << pf.second << "_" << u << "[" << j << "]);\n";
+                }
                 s << "        }\n";
             }
         for (int u = 0; u < U; u++) {
