@@ -464,34 +464,53 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                 if (f[r] != 0x7fffffffffffffffll) s_list[lp++] = (unsigned)(r * 256 + t);
             __syncthreads();
             const unsigned base = s_base;
+            if (stride <= 8) {
+                // three rows per thread at a time, all their loads first, then their stores.  (Word by word, every load waited for
+                // its predecessor's store, and the sort key's image was read back from the row just written: chains of up to ten
+                // round trips per row - 18 us for TPC-H Q3's 114 K groups.)
+                for (unsigned i0 = (unsigned)t; i0 < total; i0 += 3u * 256u) {
+                    i64 v[3][8];
+                    bool ok[3];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const unsigned i = i0 + (unsigned)r * 256u;
+                        ok[r] = i < total && base + i < maxRows;
+                        const i64 s = lo + (i64)s_list[ok[r] ? i : 0u];
+                        // (no word arrays: the one word is the slot index itself — dense aggregate tables, whose slot IS the group id)
+                        // (rank dictionaries keep the aggregates of entry r at rank_mix(r), kernels/rsq_device.h: the entry of
+                        // accumulator slot s is the inverse)
+                        i64 e = s;
+                        if (unmix) e = (i64)rank_unmix((u64)s, (u64)cap);
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            v[r][k] = 0;
+                            if (!ok[r]) continue;
+                            if (k == 0) v[r][k] = first[s];
+                            else if (k - 1 < nWords) v[r][k] = !words ? s : wordsAos ? words[(size_t)e * nWords + (k - 1)] : words[(size_t)(k - 1) * cap + e];
+                            else if (k < stride) v[r][k] = acc[(size_t)(k - 1 - nWords) * cap + s];
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        if (!ok[r]) continue;
+                        i64* o = out + (size_t)(base + i0 + (unsigned)r * 256u) * stride;
+                        i64 kv = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) { if (k < stride) o[k] = v[r][k]; if (k == keyWord) kv = v[r][k]; }
+                        if (keyWord >= 0) { const u64 u = topk_image(kv, keyIs32, keyDesc); imgMax = u > imgMax ? u : imgMax; imgMaxInv = ~u > imgMaxInv ? ~u : imgMaxInv; }
+                    }
+                }
+            } else
             for (unsigned i = (unsigned)t; i < total; i += 256u) {
                 const unsigned pos = base + i;
                 if (pos >= maxRows) continue;
                 const i64 s = lo + (i64)s_list[i];
                 i64* o = out + (size_t)pos * stride;
-                // (no word arrays: the one word is the slot index itself — dense aggregate tables, whose slot IS the group id)
-                // (rank dictionaries keep the aggregates of entry r at rank_mix(r), kernels/rsq_device.h: the entry of accumulator
-                // slot s is the inverse)
                 i64 e = s;
                 if (unmix) e = (i64)rank_unmix((u64)s, (u64)cap);
-                if (stride <= 8) {
-                    // all of the row's loads first, then its stores (word by word, every load waited for its predecessor's store:
-                    // a chain of up to eight round trips per row - 18 us for TPC-H Q3's 114 K groups)
-                    i64 v[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        v[k] = 0;
-                        if (k == 0) v[k] = first[s];
-                        else if (k - 1 < nWords) v[k] = !words ? s : wordsAos ? words[(size_t)e * nWords + (k - 1)] : words[(size_t)(k - 1) * cap + e];
-                        else if (k < stride) v[k] = acc[(size_t)(k - 1 - nWords) * cap + s];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) if (k < stride) o[k] = v[k];
-                } else {
                 o[0] = first[s];
                 for (int w = 0; w < nWords; w++) o[1 + w] = !words ? s : wordsAos ? words[(size_t)e * nWords + w] : words[(size_t)w * cap + e];
                 for (int b = 0; b < nAcc; b++) o[1 + nWords + b] = acc[(size_t)b * cap + s];
-                }
                 if (keyWord >= 0) { const u64 u = topk_image(o[keyWord], keyIs32, keyDesc); imgMax = u > imgMax ? u : imgMax; imgMaxInv = ~u > imgMaxInv ? ~u : imgMaxInv; }
             }
         }
@@ -1093,31 +1112,49 @@ __global__ void __launch_bounds__(256) k_rank_blocks_chained(unsigned* __restric
         s_tot[threadIdx.x] += v;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) {
         // chain word = (value << 2) | state: 1 = this chunk's own total, 2 = the total of all chunks up to and including it.
         // A chunk publishes its own total at once and then looks BACK over its predecessors, adding own totals until it meets an
         // inclusive one (decoupled look-back): no chunk waits for a chain of 260 hand-overs, which a plain "wait for the chunk
-        // before me" turned into 130 us of serial latency on TPC-H Q3's 60 M-bit orders bitmap.
+        // before me" turned into 130 us of serial latency on TPC-H Q3's 60 M-bit orders bitmap.  The look-back is done by one WAVE,
+        // lane l reading the l-th predecessor: 64 chain words per round trip (one thread walking them one by one: 19 us for 262 chunks).
+        const int lane = (int)threadIdx.x;
         const unsigned total = s_tot[255];
         unsigned base = 0;
-        if (blockIdx.x == 0) __hip_atomic_store(&chain[0], (total << 2) | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0) { if (lane == 0) __hip_atomic_store(&chain[0], (total << 2) | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         else {
-            __hip_atomic_store(&chain[blockIdx.x], (total << 2) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&chain[blockIdx.x], (total << 2) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const long long t0 = wall_clock64();
-            int i = (int)blockIdx.x - 1;
+            int hi = (int)blockIdx.x - 1;                 // the nearest predecessor not yet accounted for
             for (;;) {
-                const unsigned v = __hip_atomic_load(&chain[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned st = v & 3u;
-                if (st == 2u) { base += v >> 2; break; }
-                if (st == 1u) { base += v >> 2; i--; continue; }           // (chunk 0 publishes state 2 only: i never goes below 0)
-                if (wall_clock64() - t0 > 100000ll) { atomicOr(stuck, 128u); base = 0; break; }          // 100 MHz clock: 1 ms
+                const int idx = hi - lane;
+                // (in front of chunk 0: nothing, inclusive)
+                const unsigned v = idx >= 0 ? __hip_atomic_load(&chain[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2u;
+                const u64 ready = __ballot((v & 3u) != 0u), incl = __ballot((v & 3u) == 2u);
+                unsigned take = 0; bool done = false, moved = false;
+                if (incl) {
+                    const int f = __ffsll((long long)incl) - 1;               // the nearest inclusive total
+                    const u64 below = (1ull << f) - 1ull;
+                    if ((ready & below) == below) { take = lane <= f ? v >> 2 : 0u; done = true; }
+                } else if (ready == ~0ull) { take = v >> 2; moved = true; }           // 64 own totals: add them, look further back
+                if (done || moved) {
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) take += (unsigned)__shfl_xor((int)take, m, 64);
+                    base += take;
+                    if (done) break;
+                    hi -= 64;
+                    continue;
+                }
+                if (wall_clock64() - t0 > 100000ll) { if (lane == 0) atomicOr(stuck, 128u); base = 0; break; }          // 100 MHz clock: 1 ms
                 __builtin_amdgcn_s_sleep(1);
             }
-            __hip_atomic_store(&chain[blockIdx.x], ((base + total) << 2) | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&chain[blockIdx.x], ((base + total) << 2) | 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        chunkBase[blockIdx.x] = base;
-        if ((int)blockIdx.x == nChunks - 1) chunkBase[nChunks] = base + total;
-        s_base = base;
+        if (lane == 0) {
+            chunkBase[blockIdx.x] = base;
+            if ((int)blockIdx.x == nChunks - 1) chunkBase[nChunks] = base + total;
+            s_base = base;
+        }
     }
     __syncthreads();
     unsigned run = s_base + s_tot[threadIdx.x] - mine;
