@@ -84,7 +84,7 @@ fi
 
 step "kernel trace + stats of the bench command"
 rm -rf /tmp/prof_ks
-if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 "$ROOT/bench.py" --no-cpu-baseline > /tmp/ks.log 2>&1; then
+if timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ks -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-extras > /tmp/ks.log 2>&1; then
     f=$(found /tmp/prof_ks '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_q1_sf10_kernel_stats.csv"
 else echo "   rocprofv3 --kernel-trace failed: $(tail -n 2 /tmp/ks.log)"; fi
 
