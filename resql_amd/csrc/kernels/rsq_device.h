@@ -389,6 +389,25 @@ RSQ_DEV u32 bmi_load(const u32* bm, i64 bmmin, u64 bmbits, i64 key) {
     const u64 d = (u64)(key - bmmin);
     return d < bmbits ? bm[bmi_word(d)] : 0u;
 }
+// Set bits `mask` of word `w` of a key bitmap together with the neighbouring lanes that target the same word: a segmented OR over
+// the wave (runs of active lanes with equal w), and the last lane of every run issues the run's one atomic.  For a table scanned
+// in key order a wave's rows fall into a few words - TPC-H orders: eight keys per 32-bit word - and memory-side atomics are what a
+// build over such a table waits for.  Called under any control flow: only the lanes that are here take part.
+RSQ_DEV void bm_set_combined(u32* bm, u32 w, u32 mask) {
+    const u64 act = __ballot(1);
+    const int ln = (int)(threadIdx.x & 63);
+    const u32 wp = (u32)__shfl_up((int)w, 1, 64);
+    const u32 head = (ln == 0 || !((act >> (ln - 1)) & 1ull) || wp != w) ? 1u : 0u;
+    u32 m = mask, f = head;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 mo = (u32)__shfl_up((int)m, d, 64), fo = (u32)__shfl_up((int)f, d, 64);
+        if (ln >= d && !f) { m |= mo; f |= fo; }      // (f == 0: the run began at or before lane ln - d, so that lane is here and in the run)
+    }
+    const u32 nextHead = (u32)__shfl_down((int)head, 1, 64);
+    const bool last = ln == 63 || !((act >> (ln + 1)) & 1ull) || nextHead != 0u;
+    if (last) atomicOr(&bm[w], m);
+}
 struct __attribute__((aligned(16))) u32x4 { u32 x, y, z, w; };
 RSQ_DEV u64 rank_of(const u32* bm, u64 d) {
     const u32 w = (u32)(d >> 5), blk = w / 7u, wi = 1u + (w % 7u), bit = (u32)d & 31u;
