@@ -2377,7 +2377,8 @@ struct Walker {
             s << "        seen = v; a.fin_seq = v; a.pers_t0 = (u64)wall_clock64();\n        rsq_step_body(a);\n        __syncthreads();\n    }\n}\n";
             s << "static __device__ __attribute__((always_inline)) void rsq_step_body(Args& a) {\n#else\n";
         }
-        s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n";
+        s << "#ifdef RSQ_MIN_WG\nextern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS, RSQ_MIN_WG) " << pipe.entry << "(Args a) {\n#else\n";
+        s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n#endif\n";
         if (pipe.persistentForm) s << "#endif\n";
         s << "    State st;\n" << prologue;
         if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 0] = (u64)wall_clock64();\n";
@@ -2553,7 +2554,13 @@ struct Walker {
             const std::string off = "#define RSQ_LAZY 0\n";
             const size_t at = pipe.sourceLazy.find(off);
             if (at == std::string::npos) pipe.sourceLazy.clear();
-            else pipe.sourceLazy.replace(at, off.size(), "#define RSQ_LAZY 1\n");
+            else {
+                // The late-load form runs stage 2 for a few per cent of the rows, but its registers are the kernel's: a hash aggregation
+                // with dozens of carried words holds 160 VGPRs and leaves the scan three waves per SIMD.  RSQ_LAZY_MIN_WG = n asks
+                // the compiler for n resident workgroups per CU (it spills in stage 2 instead).
+                const int minWg = envInt("RSQ_LAZY_MIN_WG", 0, 0, 8);
+                pipe.sourceLazy.replace(at, off.size(), "#define RSQ_LAZY 1\n" + (minWg ? "#define RSQ_MIN_WG " + std::to_string(minWg) + "\n" : std::string()));
+            }
         }
         std::string ex = "pipeline " + std::to_string(q.pipelines.size()) + ": ";
         for (size_t i = 0; i < explainSteps.size(); i++) ex += (i ? " -> " : "") + explainSteps[i];

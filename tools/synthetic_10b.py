@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--shards", type=int, default=8)
     ap.add_argument("--prefix", type=int, default=10_000_000)
     ap.add_argument("--out", default="")
+    ap.add_argument("--groups", default="8,1024,1048576", help="group counts to run (comma separated)")
+    ap.add_argument("--per-shard", action="store_true", help="print every shard's partial-execution kernel time")
     args = ap.parse_args()
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -56,7 +58,7 @@ def main():
     schema_only = tpch.synthetic_table(16, 8)
     results = []
     roof = ctx.read_bandwidth(8 << 30, 5)
-    for groups in (8, 1024, 1 << 20):
+    for groups in [int(g) for g in args.groups.split(",")]:
         # ---- prefix parity against the oracle ----
         from oracle import orc
         host = tpch.synthetic_table(args.prefix, groups)
@@ -90,6 +92,8 @@ def main():
                 q.bind_partial(part.data_ptr(), part.numel() * 8)
                 q.execute_partial()
                 kernel_ms += q.report().kernel_time_ms
+                if args.per_shard:
+                    print(f"# groups {groups} sel {sel} shard {s}: partial execution kernels {q.report().kernel_time_ms:.3f} ms, {q.report().num_kernels} launches", flush=True)
                 if total is None:
                     total = part.clone()
                 else:
