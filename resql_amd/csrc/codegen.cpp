@@ -2455,6 +2455,9 @@ struct Walker {
             s << "    const i64 tend = ntiles;\n";
             s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
         }
+        const bool matSkip = mat && !cq && !late && envInt("RSQ_MAT_SKIP", 1, 0, 1) != 0;
+        pipe.matSkip = matSkip;
+        auto tileLive = [&](int u) { return matSkip ? "live" + std::to_string(u) : "tt" + std::to_string(u) + " < tend"; };
         for (int u = 0; u < U; u++) {
             if (dynamicTiles) s << "        const i64 tt" << u << " = t + " << u << ";\n";
             else
@@ -2463,7 +2466,11 @@ struct Walker {
             for (auto& sp : strPrefetch)
                 for (int j = 0; j < 2; j++)
                     for (int w = 0; w * 8 < sp.second; w++) s << "        u64 s" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
-            s << "        if (tt" << u << " < tend) {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
+            // The write pass of a materialisation skips every tile whose 64 lane slots counted nothing in the count pass: a selective
+            // statement (TPC-H Q19: 1107 rows out of 60 M) then reads its columns once, not twice.
+            if (matSkip) s << "#if RSQ_PASS == 2\n        const bool live" << u << " = tt" << u << " < tend && __ballot(a.cnt[tt" << u << " * 64 + lane] != 0u) != 0ull;\n#else\n"
+                           << "        const bool live" << u << " = tt" << u << " < tend;\n#endif\n";
+            s << "        if (" << tileLive(u) << ") {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
             for (auto& sp : strPrefetch)
                 for (int j = 0; j < 2; j++)
                     for (int w = 0; w * 8 < sp.second; w++)
@@ -2482,7 +2489,7 @@ struct Walker {
         for (int u = 0; u < U; u++)
             for (auto& pf : bitmapPrefetch) {
                 s << "        u32 pf_" << pf.first << "_" << u << "[2] = {0u, 0u};\n";
-                s << "        if (tt" << u << " < tend) {\n";
+                s << "        if (" << tileLive(u) << ") {\n";
                 for (int j = 0; j < 2; j++) {
                     s << "            pf_" << pf.first << "_" << u << "[" << j << "] = ";
                     if (pf.gated) {
@@ -2496,7 +2503,7 @@ struct Walker {
                 s << "        }\n";
             }
         for (int u = 0; u < U; u++) {
-            s << "        if (tt" << u << " < tend) {\n";
+            s << "        if (" << tileLive(u) << ") {\n";
             if (mat) s << "            const i64 slot = tt" << u << " * 64 + lane;\n#if RSQ_PASS == 2\n            st.pos = a.offs[slot];\n#endif\n";
             for (int j = 0; j < 2; j++) {
                 s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");

@@ -815,7 +815,9 @@ static void materializePipeline(Query& q, Pipeline& p) {
     }
     q.matLimit = keep;
     launchPipeline(q, p, -1, false);
-    q.report.bytes_read += 2 * (uint64_t)(p.bytesPerRow * p.src->nRows);
+    // (bytes the passes ask for: both read every row - unless the write pass skips the tiles that counted nothing; then it is the
+    // count pass, the counts, and whatever tiles do hold result rows, which the host cannot know: not counted)
+    q.report.bytes_read += p.matSkip ? (uint64_t)(p.bytesPerRow * p.src->nRows) + (uint64_t)slots * 4 : 2 * (uint64_t)(p.bytesPerRow * p.src->nRows);
 }
 
 // size (by a counting pass of the same pipeline), allocate and clear a join table, then build it

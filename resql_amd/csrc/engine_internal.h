@@ -212,6 +212,7 @@ struct Pipeline {
     std::vector<int> lazyCols;       // scanned columns only stage 2 needs (codegen.cpp compactThen): RSQ_LAZY 1 reads them by row
     std::string sourceLazy;
     Kernel* kernelLazy = nullptr;    // compiled when first chosen
+    bool matSkip = false;            // a materialisation whose write pass skips the tiles that counted nothing (codegen.cpp)
     bool persistentForm = false;     // the source holds the resident form of the one-launch step (RSQ_PERSISTENT 1; engine.cpp "the resident step")
     Kernel* kernelPersistent = nullptr;      // compiled when RSQ_PERSISTENT_STEP=1 first asks for it
     unsigned lastGrid = 0;           // workgroups of the most recent launch
