@@ -34,7 +34,7 @@ int64_t nextPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 // ================================================================================================
 struct ExprGen {
     std::map<std::string, Sym> symbols;     // JitContextFlounder::symbolTable of the current pipeline
-    std::set<std::string> strWordVars;      // string columns whose bytes arrive as row-function parameters <var>_w0, _w1 (loaded with the tile)
+    std::map<std::string, int> strWordVars; // string columns whose first words arrive as row-function parameters <var>_w0, _w1 (loaded with the tile): how many
 
     static std::string ctype(const Type& t) {
         switch (t.tag) {
@@ -160,7 +160,8 @@ struct ExprGen {
             if (text.find('\0') != std::string::npos) return "";
             if (charSemantics) while (!text.empty() && text.back() == ' ') text.pop_back();
             if ((int)text.size() > cap) return "((u8)0)";            // longer than any value of the column
-            std::string cond;
+            std::string cond, condRest;          // (condRest: the words behind the prefetched ones - fetched only if those match)
+            const int nPre = strWordVars.count(x) ? strWordVars[x] : 0;
             for (int w = 0; w * 8 < cap; w++) {
                 const int rbytes = std::min(8, cap - w * 8);
                 uint64_t cw = 0, mask = 0;
@@ -170,12 +171,14 @@ struct ExprGen {
                     else mask |= (charSemantics ? 0xDFull : 0xFFull) << (8 * i);
                 }
                 char buf[200];
-                if (strWordVars.count(x)) snprintf(buf, sizeof buf, "((%s_w%d ^ 0x%llxull) & 0x%llxull)", x.c_str(), w, (unsigned long long)cw, (unsigned long long)mask);
+                if (w < nPre) snprintf(buf, sizeof buf, "((%s_w%d ^ 0x%llxull) & 0x%llxull)", x.c_str(), w, (unsigned long long)cw, (unsigned long long)mask);
                 else
                 snprintf(buf, sizeof buf, "((rsq::ld_bytes<%d>((%s).p + %d) ^ 0x%llxull) & 0x%llxull)", rbytes, x.c_str(), w * 8,
                          (unsigned long long)cw, (unsigned long long)mask);
-                cond += (cond.empty() ? "" : " | ") + std::string(buf);
+                std::string& into = nPre > 0 && w >= nPre ? condRest : cond;
+                into += (into.empty() ? "" : " | ") + std::string(buf);
             }
+            if (!condRest.empty()) return "((u8)(((" + cond + ") == 0ull) && ((" + condRest + ") == 0ull)))";
             return "((u8)((" + cond + ") == 0ull))";
         };
         auto equals = [&]() -> std::string {
@@ -367,7 +370,7 @@ struct Walker {
         multiMatchAbove = false;
         selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
         leadCond.clear(); leadCols.clear(); leadPass = 1.0; leadPassComplete = true;
-        strPrefetch.clear(); eg.strWordVars.clear();
+        strPrefetch.clear(); strPrefetchWidth.clear(); eg.strWordVars.clear();
         eg.symbols.clear();
         o->schema.clear();
         for (size_t ci = 0; ci < t->cols.size(); ci++) {
@@ -486,9 +489,10 @@ struct Walker {
     // two 8-byte words per row, in flight together with the numeric columns) and reach the row function as parameters, instead of
     // being fetched inside it row by row - eight dependent round trips per lane and iteration (TPC-H Q3's customer pipeline:
     // c_mktsegment = 'BUILDING').  RSQ_STRING_PREFETCH=0: never.
-    std::vector<std::pair<int, int>> strPrefetch;         // (scanned column, its width), in the order of the row function's parameters
+    std::vector<std::pair<int, int>> strPrefetch;         // (scanned column, bytes of it that arrive with the tile), in the order of the row function's parameters
+    std::map<int, int> strPrefetchWidth;                   // scanned column -> its width (the row stride)
     void prefetchComparedStrings(const Expr* e) {
-        if (envInt("RSQ_STRING_PREFETCH", 1, 0, 1) == 0 || envInt("RSQ_STRING_WORDS", 1, 0, 1) == 0) return;
+        if (envInt("RSQ_STRING_PREFETCH", 1, 0, 2) == 0 || envInt("RSQ_STRING_WORDS", 1, 0, 1) == 0) return;
         if ((e->tag == RSQ_E_EQ || e->tag == RSQ_E_NEQ) && e->child && e->child->next) {
             const Expr* l = e->child; const Expr* r = e->child->next;
             const Expr* col = l->tag == RSQ_E_ATTRIBUTE && r->tag == RSQ_E_CONSTANT ? l : r->tag == RSQ_E_ATTRIBUTE && l->tag == RSQ_E_CONSTANT ? r : nullptr;
@@ -498,12 +502,16 @@ struct Walker {
             if (sy == eg.symbols.end() || so == symbolOrigin.end() || so->second != -1 || sy->second.var.compare(0, 2, "v_") != 0) return;
             const int k = atoi(sy->second.var.c_str() + 2);
             const int W = sy->second.type.len;
-            if (k < 0 || k >= (int)colIsString.size() || !colIsString[(size_t)k] || W < 2 || W > 16) return;
+            if (k < 0 || k >= (int)colIsString.size() || !colIsString[(size_t)k] || W < 2) return;
             for (auto& sp : strPrefetch) if (sp.first == k) return;
-            strPrefetch.push_back({k, W});
-            eg.strWordVars.insert(sy->second.var);
-            for (int w = 0; w * 8 < W; w++) {
-                const std::string ld = "rsq::ld_bytes<" + std::to_string(std::min(8, W - w * 8)) + ">(a.c" + std::to_string(k) + " + r * " + std::to_string(W) + " + " + std::to_string(w * 8) + ")";
+            // (up to 16 bytes: the whole value; longer: its first word - most values differ there, and the line it sits in is on its
+            // way when the row function asks for the rest)
+            const int PW = W <= 16 ? W : 8;
+            strPrefetch.push_back({k, PW});
+            strPrefetchWidth[k] = W;
+            eg.strWordVars[sy->second.var] = (PW + 7) / 8;
+            for (int w = 0; w * 8 < PW; w++) {
+                const std::string ld = "rsq::ld_bytes<" + std::to_string(std::min(8, PW - w * 8)) + ">(a.c" + std::to_string(k) + " + r * " + std::to_string(W) + " + " + std::to_string(w * 8) + ")";
                 rowParams += ", u64 " + sy->second.var + "_w" + std::to_string(w);
                 rowArgsTail += ", " + ld;
                 rowArgsTailGuarded += ", (valid ? " + ld + " : 0ull)";
@@ -528,9 +536,11 @@ struct Walker {
                 o->schema = from->schema;
                 if (!q.requestAll) o->schema = prune(o->schema, requestOf[o]);
                 q.pool.addId(o->exprs[0]);
+                const bool wasSelective = selective;
                 selective = true;
                 {
-                    if (from->tag == RSQ_OP_SCAN) prefetchComparedStrings(o->exprs[0]);
+                    // (RSQ_STRING_PREFETCH=2, measurement: also behind probes, as long as no selection came before)
+                    if (from->tag == RSQ_OP_SCAN || (envInt("RSQ_STRING_PREFETCH", 1, 0, 2) == 2 && !wasSelective)) prefetchComparedStrings(o->exprs[0]);
                     const std::string cond = eg.emit(o->exprs[0]);
                     if (from->tag == RSQ_OP_SCAN && leadCond.empty()) noteLeadingSelection(o->exprs[0], cond);
                     openScope("if (" + cond + ") {");
@@ -2475,7 +2485,7 @@ struct Walker {
                 for (int j = 0; j < 2; j++)
                     for (int w = 0; w * 8 < sp.second; w++)
                         s << "            s" << sp.first << "_" << u << "_" << j << "_" << w << " = rsq::ld_bytes<" << std::min(8, sp.second - w * 8) << ">(a.c" << sp.first
-                          << " + (b + " << j << ") * " << sp.second << " + " << w * 8 << ");\n";
+                          << " + (b + " << j << ") * " << strPrefetchWidth[sp.first] << " + " << w * 8 << ");\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k] && !lateCol[(size_t)k]) {
                 const bool lazy = std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) != pipe.lazyCols.end();
                 if (lazy) s << "#if !RSQ_LAZY\n";
