@@ -1242,6 +1242,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(ctx.device));
     const uint64_t epochAtEntry = ctx.execEpoch++;
+    q.hRowsView = nullptr;          // (set around a candidate run of the tail only; an execution that did not come back must not leave it)
     static const bool residentKnob = getenv("RSQ_PERSISTENT_STEP") && atoi(getenv("RSQ_PERSISTENT_STEP")) == 1;
     if (ctx.residentOwner && (ctx.residentOwner != &q || partialOnly || async)) parkResidentStep(ctx);
     if (async) {
