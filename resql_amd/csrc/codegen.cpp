@@ -2295,8 +2295,12 @@ struct Walker {
         // 63 left over + 128 pushed by one tile, rounded up.  (RSQ_QCAP=128 drains after every row_fn call instead: smaller
         // queues, 7 instead of 4 workgroups of a five-word pipeline per CU — measured slower: Q3's orders pipeline 0.24 ->
         // 0.31 ms, its inserts do not want more waves.)
-        const int QCAP = envInt("RSQ_QCAP", 192, 128, 192);
         const int NV = 1 + pipe.compactWords;       // the row index + the carried values
+        // (... unless the queues are what limits the workgroups per CU: with six or more words per row three workgroups fit next to each
+        // other at 192 entries; at 128 four or five do, and TPC-H Q5's lineitem pipeline - five probes per surviving row - went from
+        // 0.55 to 0.46 ms.  Pipelines whose registers set the limit - Q10, Q3 - lose 2-3 % to the extra drains and keep 192.)
+        const bool queuesLimit = (144 * 1024) / std::max(1, (pipe.blockThreads / 64) * NV * 192 * 8 + pipe.extraLdsBytes) < 4;
+        const int QCAP = envInt("RSQ_QCAP", queuesLimit ? 128 : 192, 128, 192);
         const int NVL = 1 + pipe.compactWordsLazy;  // ... in the RSQ_LAZY 1 form
         const bool twoForms = !pipe.lazyCols.empty();
         if (cq) {
