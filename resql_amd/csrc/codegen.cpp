@@ -1509,17 +1509,9 @@ struct Walker {
             // certain (a table of the chain is in its hash form), by every lane for the full comparison
             int nCarriedWords = 0;
             for (auto& c : carriedVals) nCarriedWords += c.nWords;
-            auto carriedWords = [&]() {
-                for (size_t ci = 0; ci < carriedVals.size(); ci++) {
-                    const Carried& c = carriedVals[ci];
-                    std::vector<std::string> words = keyWords(c.g, T + "_c" + std::to_string(ci), false);
-                    for (int w = 0; w < c.nWords; w++) line(T + "_dw[" + std::to_string(c.firstWord - K + w) + "] = " + words[(size_t)w] + ";");
-                }
-            };
             if (nCarriedWords) {
                 line("const bool " + T + "_fd = " + (fdCond.empty() ? std::string("true") : fdCond) + ";");
-                line("i64 " + T + "_dw[" + std::to_string(nCarriedWords) + "];");
-                if (!fdCond.empty()) { openScope("if (!" + T + "_fd) {"); carriedWords(); closeScope(); }
+
             }
             line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0; bool " + T + "_found = false;");
             line("if (rsq::ld_agent(a.err) & (u32)rsq::ERR_HT_FULL) return;      // another lane found the table too small: this run is void");
@@ -1531,9 +1523,16 @@ struct Walker {
                 line("rsq::st_agent(&" + aggWord(i) + ", " + kp[(size_t)i] + ");");
             // the carried group values of the new group (written by the lane that creates it; compared only in the full form)
             if (nCarriedWords) {
-                openScope("if (" + T + "_fd) {"); carriedWords(); closeScope();
-                for (int w = 0; w < nCarriedWords; w++)
-                    line("rsq::st_agent(&" + aggWord(K + w) + ", " + T + "_dw[" + std::to_string(w) + "]);");
+                // (with the dependencies certain the words go from their loads straight into the table, value by value: staged in
+                // the array first, 31 words of TPC-H Q10's group values were 62 more live VGPRs - the kernel held 163 and ran three
+                // waves per SIMD)
+                for (size_t ci = 0; ci < carriedVals.size(); ci++) {
+                    const Carried& c = carriedVals[ci];
+                    openScope("{");
+                    std::vector<std::string> words = keyWords(c.g, T + "_n" + std::to_string(ci), false);
+                    for (int w = 0; w < c.nWords; w++) line("rsq::st_agent(&" + aggWord(c.firstWord + w) + ", " + words[(size_t)w] + ");");
+                    closeScope();
+                }
             }
             // The key (and carried) words must be visible before the state says "ready".  They are agent-scope stores (write-through
             // to the level all XCDs see); once the stores have been ACKNOWLEDGED (s_waitcnt vmcnt(0)) a reader that sees state 2
@@ -1566,10 +1565,20 @@ struct Walker {
             for (int i = 0; i < K; i++)
                 cond += (i ? " && " : "") + std::string("rsq::ld_agent(&") + aggWord(i) + ") == " + kp[(size_t)i];
             if (nCarriedWords && !fdCond.empty()) {
-                std::string full;
-                for (int w = 0; w < nCarriedWords; w++)
-                    full += (w ? " && " : "") + std::string("rsq::ld_agent(&") + aggWord(K + w) + ") == " + T + "_dw[" + std::to_string(w) + "]";
-                cond = "(" + cond + ") && (" + T + "_fd || (" + full + "))";
+                // (the full comparison, while a table of the dependency chain is in its hash form: the values' words are made here, where
+                // they are compared - kept in an array across the loop they were 62 live VGPRs for TPC-H Q10's 31 words)
+                line("bool " + T + "_eq = " + cond + ";");
+                openScope("if (" + T + "_eq && !" + T + "_fd) {");
+                for (size_t ci = 0; ci < carriedVals.size(); ci++) {
+                    const Carried& c = carriedVals[ci];
+                    openScope("{");
+                    std::vector<std::string> words = keyWords(c.g, T + "_m" + std::to_string(ci), false);
+                    for (int w = 0; w < c.nWords; w++)
+                        line(T + "_eq = " + T + "_eq && rsq::ld_agent(&" + aggWord(c.firstWord + w) + ") == " + words[(size_t)w] + ";");
+                    closeScope();
+                }
+                closeScope();
+                cond = T + "_eq";
             }
             openScope("if (" + cond + ") {");
             line(T + "_found = true;");
