@@ -1011,6 +1011,86 @@ __global__ void __launch_bounds__(256) k_scan_chunks(const unsigned* __restrict_
     }
     if (t == 0) chunkTotal[blockIdx.x] = carry;
 }
+// The same scan in ONE launch, offsets absolute from the start: the chunks' totals travel through chain[chunk] = (value << 2) | state
+// (1: the chunk's own total, 2: the total of all chunks up to and including it) by decoupled look-back, a wave reading 64 predecessors
+// per round trip - as in k_rank_blocks_chained below.  Workgroups are dispatched in the order of their index, so whatever a chunk
+// waits for is running or done; a wave that nevertheless waits longer than 1 ms sets bit 512 of *stuck and leaves (the host repeats
+// the scan with the three launches).  `chain` must be zero before the launch.  Saves the pass that adds the chunk bases (87 us of
+// reading and re-writing the 240 MB of offsets of a 60 M-row materialisation) and the single-workgroup scan of the totals.
+__global__ void __launch_bounds__(256) k_scan_chained(const unsigned* __restrict__ counts, u64* __restrict__ offs, i64 n, u64* __restrict__ chain,
+                                                      unsigned* __restrict__ stuck) {
+    __shared__ u64 s_wave[2][4];
+    __shared__ u64 s_base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned c[4][4];
+    u64 loc[4];
+    u64 carry = 0;
+#pragma unroll
+    for (int sb = 0; sb < 4; sb++) {
+        const i64 i0 = (i64)blockIdx.x * SCAN_CHUNK + (i64)sb * 1024 + (i64)t * 4;
+        c[sb][0] = c[sb][1] = c[sb][2] = c[sb][3] = 0u;
+        if (i0 + 3 < n) { const uint4 v = *reinterpret_cast<const uint4*>(counts + i0); c[sb][0] = v.x; c[sb][1] = v.y; c[sb][2] = v.z; c[sb][3] = v.w; }
+        else for (int j = 0; j < 4; j++) if (i0 + j < n) c[sb][j] = counts[i0 + j];
+        const u64 mine = (u64)c[sb][0] + c[sb][1] + c[sb][2] + c[sb][3];
+        u64 incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u64 v = (u64)__shfl_up((long long)incl, d, 64); if (lane >= d) incl += v; }
+        if (lane == 63) s_wave[sb & 1][wave] = incl;
+        __syncthreads();
+        u64 before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const u64 x = s_wave[sb & 1][w]; if (w < wave) before += x; total += x; }
+        loc[sb] = carry + before + incl - mine;
+        carry += total;
+    }
+    if (t < 64) {
+        const u64 total = carry;
+        u64 base = 0;
+        if (blockIdx.x == 0) { if (lane == 0) __hip_atomic_store(&chain[0], (total << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else {
+            if (lane == 0) __hip_atomic_store(&chain[blockIdx.x], (total << 2) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long t0 = wall_clock64();
+            i64 hi = (i64)blockIdx.x - 1;
+            for (;;) {
+                const i64 idx = hi - lane;
+                const u64 v = idx >= 0 ? __hip_atomic_load(&chain[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 2ull;      // (in front of chunk 0: nothing, inclusive)
+                const u64 ready = __ballot((v & 3ull) != 0ull), incl = __ballot((v & 3ull) == 2ull);
+                u64 take = 0; bool done = false, moved = false;
+                if (incl) {
+                    const int f = __ffsll((long long)incl) - 1;
+                    const u64 below = (1ull << f) - 1ull;
+                    if ((ready & below) == below) { take = lane <= f ? v >> 2 : 0ull; done = true; }
+                } else if (ready == ~0ull) { take = v >> 2; moved = true; }
+                if (done || moved) {
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) take += (u64)__shfl_xor((long long)take, m, 64);
+                    base += take;
+                    if (done) break;
+                    hi -= 64;
+                    continue;
+                }
+                if (wall_clock64() - t0 > 100000ll) { if (lane == 0) atomicOr(stuck, 512u); base = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) __hip_atomic_store(&chain[blockIdx.x], ((base + total) << 2) | 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_base = base;
+    }
+    __syncthreads();
+    const u64 base = s_base;
+#pragma unroll
+    for (int sb = 0; sb < 4; sb++) {
+        const i64 i0 = (i64)blockIdx.x * SCAN_CHUNK + (i64)sb * 1024 + (i64)t * 4;
+        const u64 r0 = base + loc[sb], r1 = r0 + c[sb][0], r2 = r1 + c[sb][1], r3 = r2 + c[sb][2];
+        if (i0 + 3 < n) {
+            ulonglong2* o = reinterpret_cast<ulonglong2*>(offs + i0);
+            o[0] = make_ulonglong2(r0, r1); o[1] = make_ulonglong2(r2, r3);
+        } else {
+            const u64 r[4] = {r0, r1, r2, r3};
+            for (int j = 0; j < 4; j++) if (i0 + j < n) offs[i0 + j] = r[j];
+        }
+    }
+}
 __global__ void __launch_bounds__(1024) k_scan_chunk_totals(const u64* __restrict__ chunkTotal, i64 nChunks, u64* __restrict__ chunkBase) {
     __shared__ u64 s[1024];
     u64 carry = 0;
@@ -1036,6 +1116,17 @@ __global__ void __launch_bounds__(256) k_scan_add_base(u64* __restrict__ offs, i
 
 size_t scanTempBytes(int64_t n) { return (size_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 1) * 16; }
 
+// one launch (k_scan_chained); `temp` as for exclusiveScanCounts.  A look-back that timed out sets bit 512 of the context's error word:
+// the caller then repeats with exclusiveScanCounts.
+void exclusiveScanCountsChained(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes) {
+    if (n > 0x7fffffff) throw Error(RSQ_ERR_UNSUPPORTED, "materialisation of more than 2^31 lane slots");
+    if (n <= 0) return;
+    const i64 nChunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (tempBytes < (size_t)(nChunks + 1) * 16) throw Error(RSQ_ERR_DEVICE, "exclusiveScanCountsChained: temporary buffer too small");
+    RSQ_HIP(hipMemsetAsync(temp, 0, (size_t)nChunks * 8, ctx.stream));
+    hipLaunchKernelGGL(k_scan_chained, dim3((unsigned)nChunks), dim3(256), 0, ctx.stream, (const unsigned*)counts, (u64*)offs, (i64)n, (u64*)temp, (unsigned*)ctx.dErr);
+    RSQ_HIP(hipGetLastError());
+}
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes) {
     if (n > 0x7fffffff) throw Error(RSQ_ERR_UNSUPPORTED, "materialisation of more than 2^31 lane slots");
     if (n <= 0) return;

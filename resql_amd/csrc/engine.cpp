@@ -798,11 +798,27 @@ static void materializePipeline(Query& q, Pipeline& p) {
     RSQ_HIP(hipMemsetAsync(q.dMatCnt, 0, (size_t)slots * 4, ctx.stream));
     q.matLimit = 0;
     launchPipeline(q, p, -1, true);
-    exclusiveScanCounts(ctx, q.dMatCnt, q.dMatOffs, slots, q.dScanTemp, q.scanTempBytes);
+    static const bool chainedOk = !(getenv("RSQ_SCAN_CHAINED") && atoi(getenv("RSQ_SCAN_CHAINED")) == 0);
+    // (worth it for many lane slots: 30 M of them 1.43 -> 1.39 ms for TPC-H Q19 at SF10; at SF1 - 3 M slots - the look-back's latency
+    // costs more than the two small launches it replaces: 0.210 -> 0.227 ms)
+    const bool chained = chainedOk && !q.scanChainedOff && slots >= (8ll << 20);
+    if (chained) exclusiveScanCountsChained(ctx, q.dMatCnt, q.dMatOffs, slots, q.dScanTemp, q.scanTempBytes);
+    else exclusiveScanCounts(ctx, q.dMatCnt, q.dMatOffs, slots, q.dScanTemp, q.scanTempBytes);
     q.report.num_kernels++;
     uint64_t total = 0;
+    uint32_t scanErr = 0;
     RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + (slots - 1), 8, hipMemcpyDeviceToHost, ctx.stream));
+    if (chained) RSQ_HIP(hipMemcpyAsync(&scanErr, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
     waitForStream(ctx);
+    if (scanErr & 512u) {
+        // a look-back of the one-launch scan gave up: its offsets are void.  The three-launch scan from now on, and now.
+        q.scanChainedOff = true;
+        scanErr &= ~512u;
+        RSQ_HIP(hipMemcpyAsync(ctx.dErr, &scanErr, 4, hipMemcpyHostToDevice, ctx.stream));
+        exclusiveScanCounts(ctx, q.dMatCnt, q.dMatOffs, slots, q.dScanTemp, q.scanTempBytes);
+        RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + (slots - 1), 8, hipMemcpyDeviceToHost, ctx.stream));
+        waitForStream(ctx);
+    }
     // MaterializeOp with a LIMIT leaves the pipeline once count >= limit, i.e. after max(limit, 1) tuples (materialize.h:197-206)
     uint64_t keep = total;
     if (q.matOp->hasLimit) keep = std::min<uint64_t>(total, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));
@@ -909,7 +925,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
 }
 
 static void checkDeviceError(uint32_t err) {
-    err &= ~(32u | 64u | 128u | 256u);  // NOTE_CHAR_GROUP_ENDS_WITH_SPACE / NOTE_BUILD_KEYS_NOT_UNIQUE / the chained index's time-out are information for the host, not errors
+    err &= ~(32u | 64u | 128u | 256u | 512u);  // NOTE_CHAR_GROUP_ENDS_WITH_SPACE / NOTE_BUILD_KEYS_NOT_UNIQUE / the chained index's time-out are information for the host, not errors
     if (err & 1) failRuntime("Division by zero");
     if (err & 2) failRuntime("Hash table full");
     if (err & 16) failRuntime("internal error: a hash-table slot stayed in the 'being written' state");

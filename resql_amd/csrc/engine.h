@@ -120,6 +120,7 @@ void generateTable(Context& ctx, Table& t, int kind, int64_t row0, int64_t nRows
 double measureReadBandwidth(Context& ctx, size_t bytes, int iters);
 size_t scanTempBytes(int64_t n);
 void exclusiveScanCounts(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);
+void exclusiveScanCountsChained(Context& ctx, const uint32_t* counts, uint64_t* offs, int64_t n, void* temp, size_t tempBytes);      // one launch; bit 512 of *ctx.dErr: repeat with the above
 void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
 // several fills in one launch: whole 4-byte words, `value` a 64-bit pattern (aot_kernels.hip k_fill_batch)
 struct FillItem { void* p; size_t bytes; uint64_t value; };

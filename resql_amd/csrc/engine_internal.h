@@ -371,6 +371,7 @@ struct Query {
     bool readied = false;
     uint64_t readiedEpoch = 0;
     std::vector<FillItem> readiedFill;
+    bool scanChainedOff = false;         // a look-back of the one-launch offset scan timed out once: three launches from now on
     bool fusedSelectOff = false;         // a meeting point of the one-launch candidate selection timed out once: separate launches from now on
     bool residentRunning = false;        // RSQ_PERSISTENT_STEP=1: this query's step kernel is on the chip, waiting for the doorbell (hPinned[pinnedWords + 5])
     double residentLastRing = 0;         // ... when the host last rang it (the kernel leaves by itself after RESIDENT_IDLE_MS without a ring)
