@@ -109,6 +109,7 @@ void Context::scratchFree(void* p) {
 void Context::setStream(hipStream_t s, bool callers) {
     if (device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(device));
+    parkResidentStep(*this);
     RSQ_HIP(hipStreamSynchronize(stream));     // nothing of ours may still be in flight on the stream we leave
     stream = callers ? s : ownStream;          // a caller's stream may be the null stream (0)
 }
