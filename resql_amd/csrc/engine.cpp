@@ -1880,6 +1880,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         double t1 = nowMs();
         if (denseTopk) {
             const int64_t nGroups = (int64_t)(uint32_t)q.hPinned[words + 1];
+            if (nGroups == 0xffffffffll) failRuntime("internal error: the group-row compaction's look-back timed out");
             int64_t nCand = (int64_t)(uint32_t)q.hPinned[words + 2];
             if (topkRange && nCand > (int64_t)topkCapacity) { nCand = exactCandidates(groupRowsAllocated); topkSpec = topkCapacity; }
             const size_t rowBytes = (size_t)q.groupRowWords * 8;
@@ -1922,6 +1923,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             }
         } else {
             const int64_t nGroups = (int64_t)(uint32_t)q.hPinned[words + 1];
+            if (nGroups == 0xffffffffll) failRuntime("internal error: the group-row compaction's look-back timed out");
             if (nGroups > (int64_t)groupRowsAllocated) {
                 // more groups than the remembered entry count provided for (the build side changed under us): start over
                 q.hashTables[(size_t)q.aggTable]->lastCount = 0;

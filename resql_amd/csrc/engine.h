@@ -104,6 +104,11 @@ struct Context {
     // that runs shard after shard (or statement after statement) pays hipMalloc / hipHostMalloc once, not per query.  The host
     // side of the replay (hostref.h) keeps its scratch here for the same reason (fresh pages cost more than the work in them).
     struct TailArena { void* dev = nullptr; size_t devBytes = 0; void* pinned = nullptr; size_t pinnedBytes = 0; };
+    // chain words of the group-row compaction's look-back (aot_kernels.hip k_compact_entries): [value:32 | launch number:30 | state:2];
+    // a word of an earlier launch carries an earlier number and reads as "nothing yet", so the buffer is zeroed once, when it is made
+    uint64_t* dCompactChain = nullptr;
+    size_t compactChainWords = 0;
+    uint32_t compactLaunch = 0;
     TailArena spareTailArena;
     ReplayScratch replayScratch;
     std::vector<uint32_t> replayOrder;

@@ -67,6 +67,7 @@ Context::~Context() {
         (void)hipSetDevice(device);
         parkResidentStep(*this);
         for (auto& kv : kernels) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
+        if (dCompactChain) (void)hipFree(dCompactChain);
         if (spareTailArena.dev) (void)hipFree(spareTailArena.dev);
         if (spareTailArena.pinned) (void)hipHostFree(spareTailArena.pinned);
         for (auto& e : scratchFreeList) (void)hipFree(e.first);
