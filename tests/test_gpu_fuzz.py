@@ -11,7 +11,7 @@ import fuzzplans
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = list(range(240))
+SEEDS = list(range(320))
 
 
 @pytest.mark.parametrize("block", range(0, len(SEEDS), 20))

@@ -86,7 +86,7 @@ def make(seed, with_spec=False):
     return (plan, what, spec) if with_spec else (plan, what)
 
 
-@pytest.mark.parametrize("block", range(0, 100, 20))
+@pytest.mark.parametrize("block", range(0, 120, 20))
 def test_join_shapes_engine_matches_oracle(gpu_ctx, block):
     failures = []
     for seed in range(block, block + 20):
