@@ -123,3 +123,49 @@ def test_decoupled_look_back_gives_every_chunk_its_exclusive_prefix():
             acc += t
         assert bases == want, (trial, n, resident)
         assert [c & 3 for c in chain] == [2] * n and chain[-1] >> 2 == acc
+
+
+def range_select(images, want, bins=2048):
+    """the short candidate selection of aot_kernels.hip (k_topk_range_hist / _gather, k_topk_range_select): ONE histogram of the images
+    stretched to their range; the bin that holds the `want`-th largest image and the bins above it are the candidates"""
+    hi, lo = max(images), min(images)
+    shift = 0
+    if hi > lo:
+        shift = 64 - (hi - lo).bit_length()                 # __builtin_clzll(hi - lo)
+    digit = lambda u: (((u - lo) << shift) & ((1 << 64) - 1)) >> 53
+    hist = [0] * bins
+    for u in images:
+        hist[digit(u)] += 1
+    # the highest b with (rows in bins >= b) >= want; bin 0 (every row) when there are fewer than `want` rows
+    chosen, running = 0, 0
+    for b in range(bins - 1, -1, -1):
+        if running < want <= running + hist[b]:
+            chosen = b
+        running += hist[b]
+    return [i for i, u in enumerate(images) if digit(u) >= chosen]
+
+
+def test_range_selection_returns_a_superset_of_the_leading_rows():
+    rnd = random.Random(99)
+    for trial in range(400):
+        n = rnd.choice([1, 5, 100, 3000])
+        kind = trial % 4
+        if kind == 0:
+            images = [rnd.getrandbits(64) for _ in range(n)]
+        elif kind == 1:        # a narrow range high up (sums of similar magnitude)
+            base = rnd.getrandbits(63) | (1 << 63)
+            images = [base + rnd.randrange(1 << rnd.choice([3, 20, 40])) for _ in range(n)]
+        elif kind == 2:        # heavy ties
+            vals = [rnd.getrandbits(64) for _ in range(max(1, n // 50))]
+            images = [rnd.choice(vals) for _ in range(n)]
+        else:                  # all equal
+            images = [rnd.getrandbits(64)] * n
+        want = rnd.choice([1, 10, 100, 5000])
+        cand = set(range_select(images, want))
+        order = sorted(range(n), key=lambda i: -images[i])
+        if want >= n:
+            assert cand == set(range(n))
+            continue
+        threshold = images[order[want - 1]]
+        must = {i for i in range(n) if images[i] >= threshold}        # the leading `want` rows and every tie of the last one
+        assert must <= cand, trial
