@@ -903,7 +903,9 @@ __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict
         if (pos >= capacity) return;
         const i64* src = rows + (size_t)i * stride;
         i64* dst = cand + (size_t)pos * stride;
-        for (int w = 0; w < stride; w++) dst[w] = src[w];
+        // (host-mapped memory, read by the host as soon as the sequence number arrives: system-scope stores, waited for before this
+        // workgroup takes its second ticket)
+        for (int w = 0; w < stride; w++) __hip_atomic_store(dst + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
 #pragma unroll
     for (int r = 0; r < RSEL_KEEP; r++)
@@ -918,10 +920,10 @@ __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict
     if (t == 0) s_flag = __hip_atomic_fetch_add(ticket2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
     __syncthreads();
     if (s_flag) {
-        if (t == 0) host[0] = (u64)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == 1 && groupCount) host[1] = (u64)*groupCount;
-        if (t == 2) host[2] = (u64)__hip_atomic_load(candCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (pipeStats && t >= 8 && t < 8 + nPipelines) host[t] = pipeStats[t - 8];
+        if (t == 0) __hip_atomic_store(host + 0, (u64)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (t == 1 && groupCount) __hip_atomic_store(host + 1, (u64)*groupCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (t == 2) __hip_atomic_store(host + 2, (u64)__hip_atomic_load(candCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (pipeStats && t >= 8 && t < 8 + nPipelines) __hip_atomic_store(host + t, pipeStats[t - 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // the sequence number behind them: stored once every store above has been acknowledged (every workgroup waited for its
         // candidate stores before it took its ticket), system-scope release - the host watches this word
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
