@@ -216,40 +216,49 @@ std::string expressionName(const Expr* e) {
     return "expr" + std::to_string(e->id);
 }
 
+// ---- value text (what the reference prints for a value of each type, values.h:30-127), one small writer per type ----------------
+namespace {
+
+// CHAR(n): the value's characters, then blanks up to n.  n > 1 is a NUL-terminated string, n <= 1 a single byte (a NUL prints nothing)
+void writePaddedChars(std::string& out, const Val& v, int n) {
+    size_t have;
+    if (n > 1) { have = strlen(v.s); out.append(v.s, have); }
+    else { const char c = (char)v.i; have = c ? 1 : 0; if (c) out.push_back(c); }
+    if (have < (size_t)std::max(n, 0)) out.append((size_t)n - have, ' ');
+}
+
+// DATE: the integer yyyymmdd as y/mm/dd
+void writeDate(std::string& out, uint32_t yyyymmdd) {
+    const unsigned day = yyyymmdd % 100, month = yyyymmdd / 100 % 100;
+    out += std::to_string(yyyymmdd / 10000);
+    const char tail[6] = {'/', (char)('0' + month / 10), (char)('0' + month % 10), '/', (char)('0' + day / 10), (char)('0' + day % 10)};
+    out.append(tail, 6);
+}
+
+// DECIMAL(p, s): sign, then the magnitude's digits with the point s places from the right (zeros in front where the digits run out)
+void writeDecimal(std::string& out, int64_t raw, int scale) {
+    if (raw < 0) out.push_back('-');
+    // (the magnitude is formed the reference's way, as a signed negation: the smallest value keeps its sign in the digit string)
+    std::string digits = std::to_string((long long)(raw < 0 ? (int64_t)(0 - (uint64_t)raw) : raw));
+    const size_t places = (size_t)std::max(scale, 0);
+    if (digits.size() <= places) digits.insert((size_t)0, places + 1 - digits.size(), '0');
+    if (places > 0) digits.insert(digits.size() - places, 1, '.');
+    out += digits;
+}
+
+}  // namespace
+
 std::string serializeSqlValue(Val v, const Type& t) {
-    std::ostringstream ser;
-    switch (t.tag) {
-        case RSQ_CHAR: {
-            size_t i = 0;
-            if (t.len > 1) { while (v.s[i] != '\0') { ser << v.s[i]; i++; } }
-            else if ((char)v.i != '\0') { ser << (char)v.i; i = 1; }
-            for (; i < (size_t)t.len; i++) ser << " ";
-            break;
-        }
-        case RSQ_VARCHAR: ser << v.s; break;
-        case RSQ_DATE: {
-            unsigned d = (unsigned)(uint32_t)v.i;
-            char buf[32]; snprintf(buf, sizeof buf, "%u/%02u/%02u", d / 10000, d / 100 % 100, d % 100);
-            ser << buf;
-            break;
-        }
-        case RSQ_INT: ser << (int32_t)v.i; break;
-        case RSQ_BIGINT: ser << (long long)v.i; break;
-        case RSQ_BOOL: ser << (((unsigned char)v.i) ? "true" : "false"); break;
-        case RSQ_DECIMAL: {
-            int64_t x = v.i;
-            if (x < 0) { x = (int64_t)(0 - (uint64_t)x); ser << "-"; }
-            std::string dec = std::to_string((long long)x);
-            if (dec.length() <= (size_t)t.scale) {
-                ser << "0.";
-                for (size_t i = dec.length(); i < (size_t)t.scale; i++) ser << "0";
-            } else if (t.scale > 0) dec.insert(dec.length() - (size_t)t.scale, ".");
-            ser << dec;
-            break;
-        }
-        default: failType("serializeSqlValue(..) not implemented for datatype.");
-    }
-    return ser.str();
+    std::string out;
+    if (t.tag == RSQ_VARCHAR) out = v.s;
+    else if (t.tag == RSQ_CHAR) writePaddedChars(out, v, t.len);
+    else if (t.tag == RSQ_DATE) writeDate(out, (uint32_t)v.i);
+    else if (t.tag == RSQ_DECIMAL) writeDecimal(out, v.i, t.scale);
+    else if (t.tag == RSQ_INT) out = std::to_string((int32_t)v.i);
+    else if (t.tag == RSQ_BIGINT) out = std::to_string((long long)v.i);
+    else if (t.tag == RSQ_BOOL) out = (unsigned char)v.i ? "true" : "false";
+    else failType("serializeSqlValue(..) not implemented for datatype.");
+    return out;
 }
 
 std::string serializeExpr(const Expr* e) {
@@ -281,22 +290,16 @@ void requiredAttributes(const Expr* e, std::vector<std::string>& out) {
 // ---- type derivation -------------------------------------------------------------------------
 namespace {
 
-// Put `insert` between parent and child in the linked representation.
+// `insert` takes `child`'s place among `parent`'s children and becomes its only parent: the link that points at `child` - the
+// parent's child pointer or a sibling's next pointer - is redirected
 void insertBetween(Expr* parent, Expr* child, Expr* insert) {
-    if (parent->child == child) {
-        parent->child = insert;
-        insert->child = child;
-        insert->next = child->next;
-        child->next = nullptr;
-    } else {
-        Expr* prev = parent->child;
-        while (prev->next != child && prev->next != nullptr) prev = prev->next;
-        if (prev->next != child) failType("Child in insertUnaryBetweenParentAndChild(..) not found.");
-        prev->next = insert;
-        insert->next = child->next;
-        child->next = nullptr;
-        insert->child = child;
-    }
+    Expr** link = &parent->child;
+    while (*link != nullptr && *link != child) link = &(*link)->next;
+    if (*link == nullptr) failType("Child in insertUnaryBetweenParentAndChild(..) not found.");
+    *link = insert;
+    insert->next = child->next;
+    insert->child = child;
+    child->next = nullptr;
 }
 
 struct Deriver {
