@@ -257,7 +257,22 @@ def dry_run(args, world: int, rank: int) -> int:
     row0, n_rows = shard_rows(n_total, world, rank)
     ctx = engine.Context(device=-1)
     schema_only = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
-    shard = ctx.table(tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=1024))   # statistics -> the 6-group layout
+    # a small stand-in shard with REAL rows (rows [s0, s0 + sn) of a 6144-row table), so that every rank has its own column
+    # statistics; RSQ_BENCH_DRY_DROP="rank:char,..." removes the rows with that l_returnflag / l_linestatus value from a rank's
+    # shard (test hook: shards whose statistics differ).  The statistics are unified across the ranks before compiling — the
+    # step the measured path takes too — so every rank derives the same 6-group layout.
+    from resql_amd.dist import unify_shard_stats
+    s0, sn = shard_rows(6144, world, rank)
+    cols = datagen.lineitem_columns(s0, sn, 0.001, columns=set(tpch.Q1_COLUMNS))
+    for item in filter(None, os.environ.get("RSQ_BENCH_DRY_DROP", "").split(",")):
+        r, ch = item.split(":")
+        if int(r) == rank:
+            keep = (cols["l_returnflag"] != ord(ch)) & (cols["l_linestatus"] != ord(ch))
+            cols = {k: v[keep] for k, v in cols.items()}
+    shard = ctx.table(tpch.make_table("lineitem", tpch.LINEITEM_SCHEMA, cols, len(cols["l_quantity"])))
+    shard.set_row0(s0)
+    own_layout_values = sorted({int(v) for v in cols["l_returnflag"]}), sorted({int(v) for v in cols["l_linestatus"]})
+    unify_shard_stats(dist if grouped else None, shard, world)
     q = ctx.compile(tpch.q1_plan(schema_only), [shard])
     n_min, n_max, n_sum = q.partial_layout()
     words = n_min + n_max + n_sum
@@ -266,12 +281,14 @@ def dry_run(args, world: int, rank: int) -> int:
     partial[:n_min] = row0 + torch.arange(n_min)
     partial[n_min:n_min + n_max] = rank
     partial[n_min + n_max:] = (rank + 1) * (torch.arange(n_sum) + 1)
+    layout = [l for l in q.explain.splitlines() if l.startswith("partial table:")]
+    every_layout, every_values = [layout], [own_layout_values]
     if grouped and world > 1:
-        layout = [l for l in q.explain.splitlines() if l.startswith("partial table:")]
-        every = [None] * world
-        dist.all_gather_object(every, layout)
-        if any(e != every[0] for e in every):
-            raise SystemExit(f"rank {rank}: shards disagree on the partial aggregate table layout: {every}")
+        every_layout, every_values = [None] * world, [None] * world
+        dist.all_gather_object(every_layout, layout)
+        dist.all_gather_object(every_values, own_layout_values)
+        if any(e != every_layout[0] for e in every_layout):      # cannot happen after unify_shard_stats: a defect, not a property of the data
+            raise SystemExit(f"rank {rank}: internal error: ranks planned from the same statistics disagree on the layout: {every_layout}")
     merger = PartialMerger(dist if grouped else None, partial, n_min, n_max, n_sum, world)
     for _ in range(args.warmup + args.steps):
         mine = partial.clone()
@@ -296,6 +313,8 @@ def dry_run(args, world: int, rank: int) -> int:
                                      "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
                                      "shards": [list(shard_rows(n_total, world, r)) for r in range(world)],
                                      "merge": merger.strategy, "merged_ok": bool(ok), "result_groups": res.n_rows,
+                                     "layout": layout[0] if layout else None, "shard_rows_total": shard.total_rows,
+                                     "shard_group_values": every_values,
                                      "phases": {"kernel_ms_per_rank": per_rank}}}),
               flush=True)
         if not ok:
@@ -342,11 +361,13 @@ def run_capi(args) -> int:
         probe = max(1, min(args.steps, 20))
         per = [0.0] * n_dev
         fin = 0.0
+        coll = 0.0
         for _ in range(probe):
             q.execute()
             rep, k = q.report()
             per = [a + b for a, b in zip(per, k)]
             fin += rep.finalize_time_ms
+            coll += q.collective_ms
         per = [v / probe for v in per]
         result = q.result()
         rows_per = [t.n_rows for t in shards]
@@ -361,7 +382,7 @@ def run_capi(args) -> int:
                                    f"row-range sharded over {n_dev} shard(s) on devices {devices}",
                        "rows": n_total, "rows_per_shard": rows_per, "result_groups": result.n_rows, "path": "capi",
                        "parallelism": f"one host process, rsq_multi_* over {n_dev} shard(s): {m.merge_name}; {q.merge_name}",
-                       "phases": {"kernel_ms_per_rank": per, "finalize_ms": fin / probe,
+                       "phases": {"kernel_ms_per_rank": per, "collective_ms": coll / probe, "finalize_ms": fin / probe,
                                   "step_minus_slowest_kernel_ms": elapsed / args.steps * 1e3 - slowest}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None, "traffic_source": None,
@@ -492,6 +513,10 @@ def main(argv=None) -> int:
     row0, n_rows = shard_rows(n_total, world, rank)   # shard boundaries on 128-row tiles
     ctx = engine.Context(device=local_rank if world > 1 else 0)
     table = ctx.generate(engine.GEN_LINEITEM, n_rows, args.sf, row0=row0)
+    # every rank plans its shard as the WHOLE table (union of the shards' column statistics, summed row count): one dense group
+    # layout on all ranks whatever their rows hold — the reference has one hash table all workers reach (aggregation.h:240-295)
+    from resql_amd.dist import unify_shard_stats
+    unify_shard_stats(dist if world > 1 else None, table, world, device)
     schema_only = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
     q = ctx.compile(tpch.q1_plan(schema_only), [table])
     q.await_kernels()          # the measured path is the specialised kernel, never the generic pipeline a cold cache starts on
@@ -502,14 +527,19 @@ def main(argv=None) -> int:
 
     multi = dist is not None
     merger = None
+    ranks_seen = 1
+    if multi:
+        # how many ranks the collectives of this run really span: one word of ones, all-reduced over RCCL
+        ones = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
     if multi and world > 1:
-        # the partial tables are only mergeable if every rank derived the same dense group layout from its shard's
-        # column statistics (same byte-value sets / ranges): compare the layout line of `explain` across the ranks
+        # (after unify_shard_stats every rank derives the same layout; a difference would be a defect, not a property of the data)
         layout = [l for l in q.explain.splitlines() if l.startswith("partial table:")]
         every = [None] * world
         dist.all_gather_object(every, layout)
         if any(e != every[0] for e in every):
-            raise SystemExit(f"rank {rank}: shards disagree on the partial aggregate table layout: {every}")
+            raise SystemExit(f"rank {rank}: internal error: ranks planned from the same statistics disagree on the layout: {every}")
     if multi:
         # one stream for the whole step: scan+aggregate kernel -> merge collective (RCCL over xGMI) -> read-back, with a
         # single host synchronisation (inside finalize) per step on rank 0 and none on the other ranks
@@ -609,6 +639,7 @@ def main(argv=None) -> int:
                               f"resident in HBM, row-range sharded over {world} GPU(s)",
                   "rows": n_total, "rows_per_gpu": n_rows, "result_groups": result.n_rows, "path": "dist",
                   "world_size": dist.get_world_size() if dist is not None else 1,
+                  "rccl_ranks_seen": ranks_seen,
                   "backend": (dist.get_backend() + " (RCCL)") if dist is not None else "none (single process, single GPU)",
                   "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
                   "parallelism": f"row-range shards x{world}, group-by merge over RCCL: {merger.strategy}"

@@ -125,6 +125,21 @@ int64_t rsq_table_rows(const rsq_table* t);
  * is observable — the order in which groups first occur decides the emission order of an aggregation (operators/aggregation.h:
  * 298-343 scans the hash table the groups entered in input order).  Set before queries are compiled over the table. */
 int  rsq_table_set_first_row(rsq_table* t, int64_t row0);
+/* Shards of ONE table must plan as that table.  The reference has one Relation and one hash table all its workers reach
+ * (src/operators/aggregation.h:240-295, src/JitContextFlounder.h:459-487), so it never sees a "shard"; here the planner reads column
+ * statistics (dense group ids come from a column's byte-value set or [min, max] range) and the row count (the reference sizes its
+ * aggregation table from Relation::tupleNum(), which decides the emission order) of the table it is handed.  Before compiling
+ * a plan over a shard, give it every shard's statistics: rsq_table_stats_export writes this table's fixed-size blob
+ * (rsq_table_stats_bytes; the same size on every shard of a schema), the host moves the blobs (one all-gather between rank
+ * processes), and rsq_table_unify_shard_stats(t, blobs of ALL shards incl. t's own, back to back) makes t plan with the union of the
+ * value sets / ranges and the summed row count.  All shards then derive the same partial-table layout whatever their rows hold
+ * (a shard without any 'R' row still keeps a cell for 'R'); where the union is not dense the plan takes the hash aggregation on
+ * every shard alike.  rsq_multi_query_compile does this itself for the shards it is given.  rsq_table_total_rows: the summed count
+ * (before unification: this table's own). */
+int64_t rsq_table_stats_bytes(const rsq_table* t);
+int  rsq_table_stats_export(const rsq_table* t, void* buf, int64_t bytes);
+int  rsq_table_unify_shard_stats(rsq_table* t, const void* blobs, int32_t n_shards, int64_t blob_bytes);
+int64_t rsq_table_total_rows(const rsq_table* t);
 /* Copy one device column back (tests). */
 int  rsq_table_read_column(rsq_ctx* ctx, const rsq_table* t, const char* name, void* host_dst, size_t bytes);
 void rsq_table_destroy(rsq_table* t);
@@ -310,6 +325,9 @@ int  rsq_multi_query_execute(rsq_multi_query* q);                /* blocking, li
 int  rsq_multi_query_result(rsq_multi_query* q, rsq_result_view* out);
 /* kernel_time_ms = the slowest shard's; shard_kernel_ms (may be NULL) receives every shard's */
 int  rsq_multi_query_report(const rsq_multi_query* q, rsq_report* out, double* shard_kernel_ms /* [n_devices] */);
+/* device time of the last execution's group-by merge (RCCL reduce / peer copies + merge kernel): an event pair on the root GPU's
+ * stream around it, so it includes the root's wait for the slowest shard; 0 for one shard without a collective and for host merges */
+double rsq_multi_query_collective_ms(const rsq_multi_query* q);
 /* which merge the query takes and why (dense partial tables / ordered merge of LIMIT-ed rows / general merge), for logs and tests */
 const char* rsq_multi_query_merge_name(const rsq_multi_query* q);
 void rsq_multi_query_destroy(rsq_multi_query* q);

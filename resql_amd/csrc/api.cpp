@@ -58,7 +58,78 @@ Table* makeTable(Context& ctx, const rsq_table_desc& d, bool adopt) {
 }
 }  // namespace
 
+// ---- shard statistics -------------------------------------------------------------------------------------------------------
+// One blob per table: [magic | columns | row0 | rows] then per column [valid | ascending | min | max | number of byte values | 256 byte
+// values].  Fixed size for a schema, plain little-endian words: what one all-gather between the rank processes moves.
+namespace rsq {
+namespace {
+const uint64_t STATS_MAGIC = 0x3174617473717372ull;      // "rsqstat1"
+struct StatsHead { uint64_t magic; int64_t nCols, row0, nRows; };
+struct StatsCol { int32_t valid, ascending; int64_t min, max; int32_t nBytes, pad; uint8_t bytes[256]; };
+}  // namespace
+size_t tableStatsBytes(const Table& t) { return sizeof(StatsHead) + t.cols.size() * sizeof(StatsCol); }
+void exportTableStats(const Table& t, void* buf, size_t bytes) {
+    if (bytes < tableStatsBytes(t)) failInvalid("statistics buffer too small");
+    StatsHead h{STATS_MAGIC, (int64_t)t.cols.size(), t.row0, t.nRows};
+    memcpy(buf, &h, sizeof h);
+    for (size_t i = 0; i < t.cols.size(); i++) {
+        const ColumnStats& st = t.shardStats(i);
+        StatsCol c{};
+        c.valid = st.valid; c.ascending = st.ascending; c.min = st.min; c.max = st.max; c.nBytes = (int32_t)st.distinctBytes.size();
+        for (size_t k = 0; k < st.distinctBytes.size() && k < 256; k++) c.bytes[k] = st.distinctBytes[k];
+        memcpy((char*)buf + sizeof h + i * sizeof c, &c, sizeof c);
+    }
+}
+void unifyShardStats(Table& t, const void* blobs, int nShards, size_t blobBytes) {
+    if (!blobs || nShards < 1 || blobBytes < tableStatsBytes(t)) failInvalid("shard statistics: " + std::to_string(nShards) + " blob(s) of " + std::to_string(blobBytes) + " bytes do not describe table " + t.name);
+    if (t.ownStats.empty()) for (auto& c : t.cols) t.ownStats.push_back(c.stats);
+    int64_t total = 0;
+    bool mine = false;
+    std::vector<ColumnStats> u(t.cols.size());
+    std::vector<bool> unknown(t.cols.size(), false), any(t.cols.size(), false);
+    for (int s = 0; s < nShards; s++) {
+        const char* b = (const char*)blobs + (size_t)s * blobBytes;
+        StatsHead h; memcpy(&h, b, sizeof h);
+        if (h.magic != STATS_MAGIC || h.nCols != (int64_t)t.cols.size() || h.nRows < 0) failInvalid("shard statistics: blob " + std::to_string(s) + " is not a statistics blob of table " + t.name);
+        if (h.row0 == t.row0 && h.nRows == t.nRows) mine = true;
+        total += h.nRows;
+        if (h.nRows == 0) continue;                      // an empty shard says nothing about the values
+        for (size_t i = 0; i < t.cols.size(); i++) {
+            StatsCol c; memcpy(&c, b + sizeof h + i * sizeof c, sizeof c);
+            if (!c.valid) { unknown[i] = true; continue; }
+            if (c.nBytes < 0 || c.nBytes > 256) failInvalid("shard statistics: malformed byte-value set");
+            ColumnStats& o = u[i];
+            if (!any[i]) { o.min = c.min; o.max = c.max; any[i] = true; }
+            else { o.min = std::min(o.min, c.min); o.max = std::max(o.max, c.max); }
+            for (int k = 0; k < c.nBytes; k++) o.distinctBytes.push_back(c.bytes[k]);
+        }
+    }
+    if (!mine) failInvalid("shard statistics: none of the blobs is this shard's own (rows " + std::to_string(t.row0) + " + " + std::to_string(t.nRows) + " of " + t.name + ")");
+    for (size_t i = 0; i < t.cols.size(); i++) {
+        ColumnStats& o = u[i];
+        std::sort(o.distinctBytes.begin(), o.distinctBytes.end());
+        o.distinctBytes.erase(std::unique(o.distinctBytes.begin(), o.distinctBytes.end()), o.distinctBytes.end());
+        o.valid = any[i] && !unknown[i];
+        o.ascending = t.ownStats[i].ascending;           // (a property of this shard's own rows: it shapes kernels, never a layout)
+        t.cols[i].stats = o;
+    }
+    t.nRowsTotal = total;
+}
+}  // namespace rsq
+
 extern "C" {
+
+int64_t rsq_table_stats_bytes(const rsq_table* t) { return t ? (int64_t)tableStatsBytes(*reinterpret_cast<const Table*>(t)) : -1; }
+int rsq_table_stats_export(const rsq_table* t, void* buf, int64_t bytes) {
+    if (!t || !buf || bytes < 0) return RSQ_ERR_INVALID;
+    const Table* tb = reinterpret_cast<const Table*>(t);
+    return guarded(tb->ctx, [&] { exportTableStats(*tb, buf, (size_t)bytes); });
+}
+int rsq_table_unify_shard_stats(rsq_table* t, const void* blobs, int32_t n_shards, int64_t blob_bytes) {
+    if (!t || !blobs || blob_bytes < 0) return RSQ_ERR_INVALID;
+    return guarded(T(t)->ctx, [&] { unifyShardStats(*T(t), blobs, n_shards, (size_t)blob_bytes); });
+}
+int64_t rsq_table_total_rows(const rsq_table* t) { return t ? reinterpret_cast<const Table*>(t)->totalRows() : -1; }
 
 int rsq_ctx_create(const rsq_config* cfg, rsq_ctx** out) {
     if (!out) return RSQ_ERR_INVALID;
@@ -221,9 +292,8 @@ int rsq_ctx_set_stream(rsq_ctx* ctx, void* hip_stream, int32_t use_callers_strea
 
 int rsq_query_partial_layout(const rsq_query* q, int64_t* n_min_words, int64_t* n_max_words, int64_t* n_sum_words) {
     if (!q || !n_min_words || !n_max_words || !n_sum_words) return RSQ_ERR_INVALID;
-    void* p = nullptr;
-    partialBuffer(*reinterpret_cast<const QueryHandle*>(q)->q, &p, n_min_words, n_max_words, n_sum_words);
-    return RSQ_OK;
+    const QueryHandle* h = reinterpret_cast<const QueryHandle*>(q);
+    return guarded(h->ctx, [&] { void* p = nullptr; partialBuffer(*h->q, &p, n_min_words, n_max_words, n_sum_words); });
 }
 
 int rsq_query_bind_partial(rsq_query* q, void* dev_ptr, size_t bytes) {

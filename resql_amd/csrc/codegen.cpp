@@ -1271,7 +1271,8 @@ struct Walker {
             const TableColumn& c = t->cols[(size_t)ci];
             if (c.type.isString()) return false;               // string keys: generic hash aggregation (bytes as key words)
             DenseKey k; k.expr = g; k.type = c.type;
-            if (t->nRows == 0) { k.card = 1; k.min = 0; }      // empty input: no row reaches the aggregation
+            // (an empty SHARD of a table plans with the statistics of the whole table, like every other shard: Table::nRowsTotal)
+            if (t->nRows == 0 && !c.stats.valid) { k.card = 1; k.min = 0; }      // empty input: no row reaches the aggregation
             else if (!c.stats.valid) return false;
             else if (!c.stats.distinctBytes.empty()) { k.byteSet = true; k.values = c.stats.distinctBytes; k.card = (int64_t)k.values.size(); }
             else {

@@ -93,19 +93,21 @@ void defineAndDerive(Query& q, OpNode* o) {
 
 }  // namespace
 
-uint64_t opSize(OpNode* o) {   // getSize() estimates (reference src/operators/*.h)
+// getSize() estimates (reference src/operators/*.h).  local: over this shard's own rows (sizing of the device's tables) instead of the
+// whole table's (everything that replays the reference: its table sizes decide the emission order)
+uint64_t opSize(OpNode* o, bool local) {
     switch (o->tag) {
-        case RSQ_OP_SCAN: return (uint64_t)o->table->nRows;
-        case RSQ_OP_SELECTION: return opSize(o->child[0]) / 2;
-        case RSQ_OP_PROJECTION: case RSQ_OP_ORDERBY: return opSize(o->child[0]);
-        case RSQ_OP_HASHJOIN: return opSize(o->child[0]) + opSize(o->child[1]) / 2;
+        case RSQ_OP_SCAN: return (uint64_t)(local ? o->table->nRows : o->table->totalRows());      // a shard sizes like the table it is a range of (Table::nRowsTotal)
+        case RSQ_OP_SELECTION: return opSize(o->child[0], local) / 2;
+        case RSQ_OP_PROJECTION: case RSQ_OP_ORDERBY: return opSize(o->child[0], local);
+        case RSQ_OP_HASHJOIN: return opSize(o->child[0], local) + opSize(o->child[1], local) / 2;
         case RSQ_OP_AGGREGATION: {
             if (o->exprs2.empty()) return 1;
             int red = 512;
             for (size_t i = 1; i < o->exprs2.size() && red > 2; i++) red /= 2;
-            return opSize(o->child[0]) / (uint64_t)red;
+            return opSize(o->child[0], local) / (uint64_t)red;
         }
-        case RSQ_OP_MATERIALIZE: { uint64_t s = opSize(o->child[0]); if (o->hasLimit && (uint64_t)o->limit < s) s = (uint64_t)o->limit; return s; }
+        case RSQ_OP_MATERIALIZE: { uint64_t s = opSize(o->child[0], local); if (o->hasLimit && (uint64_t)o->limit < s) s = (uint64_t)o->limit; return s; }
         default: return 0;
     }
 }
@@ -1041,7 +1043,7 @@ static void runGeneric2Pipeline(Query& q, size_t pi) {
             HashTable& h = *q.hashTables[(size_t)S.table];
             const size_t NW = std::max<size_t>(1, h.keys.size() + h.payload.size());
             h.aos = true;
-            if (h.capacity == 0) h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)opSize(q.agg)));
+            if (h.capacity == 0) h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)opSize(q.agg, true)));
             while ((int64_t)h.lastCount * 2 > h.capacity) { if (h.dState) { ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc); } h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr; h.capacity *= 2; }
             for (;;) {
                 if (!h.dState) {
@@ -1211,7 +1213,9 @@ static double runDenseDeviceTail(Query& q) {
     if (ctx.cfg.emission_order != RSQ_EMIT_ANY && n > 1) {
         // first rows are row numbers of the scanned table: the bits they can use
         int64_t maxRow = 1;
-        for (auto& p : q.pipelines) if (p.sink == SinkKind::AGGREGATE) maxRow = std::max<int64_t>(maxRow, p.src->row0 + p.src->nRows);
+        // (over the WHOLE table: the root of a multi-GPU step finalises the merged table, whose first rows come from every shard)
+        for (auto& p : q.pipelines) if (p.sink == SinkKind::AGGREGATE) maxRow = std::max<int64_t>(maxRow, std::max(p.src->row0 + p.src->nRows, p.src->totalRows()));
+        if (q.firstRowsForeign) maxRow = std::max<int64_t>(maxRow, (int64_t)1 << 40);      // merged from shards this table knows nothing about: all 40 row bits
         int bits = 1; while (bits < 63 && (maxRow >> bits) != 0) bits++;
         const bool inB = radixSortPairs(ctx, q.dtFirst[0], q.dtGid[0], q.dtFirst[1], q.dtGid[1], n, bits, q.dtSortTemp, q.dtSortTempBytes);
         dGids = inB ? q.dtGid[1] : q.dtGid[0];
@@ -1609,7 +1613,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             // (AggregationOp::getSize, aggregation.h:81-92) and re-run the pipeline with a 4x larger table while
             // the kernel reports a full table.
             HashTable& h = *q.hashTables[(size_t)q.aggTable];
-            if (h.capacity == 0) h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)opSize(q.agg)));
+            if (h.capacity == 0) h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)opSize(q.agg, true)));
             if ((int64_t)h.lastCount * 2 > h.capacity) {        // the previous execution filled more than half of the table
                 if (h.dState) { ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc); }
                 h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
@@ -2104,7 +2108,7 @@ bool shardGroupsDisjoint(const std::vector<Query*>& parts, std::string& why) {
             for (Table* t : parts[i]->tables) { int c = t->findCol(g->symbol); if (c >= 0) { tab = t; col = c; break; } }
             if (!tab) { usable = false; break; }
             if (tab->nRows == 0) continue;
-            const ColumnStats& st = tab->cols[(size_t)col].stats;
+            const ColumnStats& st = tab->shardStats((size_t)col);      // what THIS shard's rows hold (stats may be the union over all shards)
             if (!st.valid || !st.distinctBytes.empty() || tab->cols[(size_t)col].type.isString()) { usable = false; break; }
             ranges.emplace_back(st.min, st.max);
         }
@@ -2135,6 +2139,7 @@ void bindPartial(Query& q, void* dptr, size_t bytes) {
     if (q.dAgg && q.dAggOwned) q.ctx.free(q.dAgg);
     q.dAgg = (uint64_t*)dptr;
     q.dAggOwned = false;
+    for (auto& p : q.pipelines) if (p.sink == SinkKind::AGGREGATE && p.src->nRowsTotal < 0) q.firstRowsForeign = true;      // (the caller's collectives write into it)
 }
 
 // the kernel behind the merge collective: `gathered` = every rank's partial table back to back (one all-gather), reduced by
@@ -2145,6 +2150,7 @@ void mergeGathered(Query& q, const void* gathered, int nRanks) {
     if (q.ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(q.ctx.device));
     const int64_t G = q.denseGroups;
+    if (nRanks > 1) for (auto& p : q.pipelines) if (p.sink == SinkKind::AGGREGATE && p.src->nRowsTotal < 0) q.firstRowsForeign = true;
     // small tables: the merge kernel also publishes the result to host-mapped memory (finalizeQuery polls for it)
     static const bool pollOk = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
     const bool publish = pollOk && q.dFinHost && q.tableWords <= 2048;

@@ -48,6 +48,14 @@ struct Table {
     std::string name;
     int64_t nRows = 0;
     int64_t row0 = 0;                          // global index of the first row (row-range shards)
+    // A shard of a larger table plans as that table: rsq_table_unify_shard_stats / rsq_multi_query_compile give every shard the row
+    // count of the whole table (the reference sizes its hash tables from Relation::tupleNum(), and first rows are numbered over the
+    // whole table) and the UNION of the shards' column statistics in cols[i].stats, so that all shards derive one dense group layout.
+    // ownStats keeps what this shard's own rows say (empty: never unified) - the proof that shards are disjoint in a key needs it.
+    int64_t nRowsTotal = -1;
+    std::vector<ColumnStats> ownStats;
+    int64_t totalRows() const { return nRowsTotal >= 0 ? nRowsTotal : nRows; }
+    const ColumnStats& shardStats(size_t col) const { return ownStats.empty() ? cols[col].stats : ownStats[col]; }
     std::vector<TableColumn> cols;
     int findCol(const std::string& n) const {
         for (size_t i = 0; i < cols.size(); i++) if (cols[i].name == n) return (int)i;
@@ -221,6 +229,10 @@ void mergeShardResults(Query& into, const std::vector<Query*>& parts);
 void setHoldTail(Query& q, bool hold);                  // execute stops in front of the host tail
 void runTailMerged(Query& root, const std::vector<Query*>& parts);   // all parts' groups (or materialised rows) merged by key, then root's tail
 bool shardGroupsDisjoint(const std::vector<Query*>& parts, std::string& why);   // provably no group in two shards (column statistics)
+// shard statistics (api.cpp): one fixed-size blob per table; unify = plan this shard as the whole table (see Table::nRowsTotal)
+size_t tableStatsBytes(const Table& t);
+void exportTableStats(const Table& t, void* buf, size_t bytes);
+void unifyShardStats(Table& t, const void* blobs, int nShards, size_t blobBytes);
 bool queryOrderedWithLimit(const Query& q);             // ORDER BY ... LIMIT k at the root
 bool queryAsyncCapable(const Query& q);                 // every pipeline can be enqueued without the host in between
 bool queryIsDense(const Query& q);              // its aggregation ends in a dense partial table ([min | max | sum] words)

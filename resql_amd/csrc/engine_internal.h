@@ -394,6 +394,7 @@ struct Query {
     std::string bgError;
     bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
     bool chainedIndexOff = false;          // the one-launch rank index timed out once on this query: two launches from then on
+    bool firstRowsForeign = false;         // the partial table may hold first rows of shards whose size this query's table does not know (bound / gathered partials, table never unified)
     bool holdTail = false;                 // a shard of a multi-GPU plan: execute reads the group rows / materialised columns back and stops (tail.cpp runTailMerged)
     std::string allSource, explainText;
 
@@ -405,7 +406,7 @@ bool buildGenericProgram(Query& q, GenericProgram& out, std::string& why);
 void launchGenericAggregate(Context& ctx, const GenericProgram& prog, const GenericInstr* dCode, int64_t nRows, int64_t row0, uint64_t* dTable,
                             int64_t denseGroups, int64_t tableWords);
 
-uint64_t opSize(OpNode* o);      // getSize() estimates of the reference's operators
+uint64_t opSize(OpNode* o, bool local = false);      // getSize() estimates of the reference's operators
 
 inline double nowMs() {
     using namespace std::chrono;

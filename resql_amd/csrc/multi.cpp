@@ -94,7 +94,10 @@ struct rsq_multi_query {
     std::vector<hipEvent_t> ready;      // peer-copy mode: shard i's partial table is complete
     rsq_report report{};
     std::vector<double> shardKernelMs;
+    hipEvent_t evMerge0 = nullptr, evMerge1 = nullptr;      // on the root's stream, around the group-by merge of the last execution
+    double collectiveMs = 0;
     ~rsq_multi_query() {
+        if (evMerge0 && m && !m->ctxs.empty()) { (void)hipSetDevice(m->ctxs[0]->device); (void)hipEventDestroy(evMerge0); (void)hipEventDestroy(evMerge1); }
         if (gathered && m && !m->ctxs.empty()) { (void)hipSetDevice(m->ctxs[0]->device); m->ctxs[0]->free(gathered); }
         for (size_t i = 0; i < ready.size(); i++) if (ready[i]) { (void)hipSetDevice(m->ctxs[i]->device); (void)hipEventDestroy(ready[i]); }
         for (Query* q : qs) destroyQuery(q);
@@ -111,8 +114,22 @@ int guardedM(rsq_multi* m, F&& f) {
     catch (const std::exception& e) { if (m) m->lastError = e.what(); else g_multiCreateError = e.what(); return RSQ_ERR_INVALID; }
 }
 
-// the group-by merge of one step, enqueued behind every shard's kernels; returns after enqueueing
+void enqueueMergeUntimed(rsq_multi_query& mq);
+// the group-by merge of one step, enqueued behind every shard's kernels; returns after enqueueing.  An event pair on the root's
+// stream brackets it: rsq_multi_query_collective_ms (from the root's last kernel to the merged table, i.e. including the wait for
+// the slowest shard)
 void enqueueMerge(rsq_multi_query& mq) {
+    rsq_multi& m = *mq.m;
+    if (m.ctxs.size() == 1 && m.comms.empty()) return;
+    Context& root = *m.ctxs[0];
+    RSQ_HIP(hipSetDevice(root.device));
+    if (!mq.evMerge0) { RSQ_HIP(hipEventCreate(&mq.evMerge0)); RSQ_HIP(hipEventCreate(&mq.evMerge1)); }
+    RSQ_HIP(hipEventRecord(mq.evMerge0, root.stream));
+    enqueueMergeUntimed(mq);
+    RSQ_HIP(hipSetDevice(root.device));
+    RSQ_HIP(hipEventRecord(mq.evMerge1, root.stream));
+}
+void enqueueMergeUntimed(rsq_multi_query& mq) {
     rsq_multi& m = *mq.m;
     const int n = (int)m.ctxs.size();
     const int64_t words = mq.nMin + mq.nMax + mq.nSum;
@@ -295,22 +312,40 @@ int rsq_multi_query_compile(rsq_multi* m, const rsq_plan_desc* plan, rsq_table* 
         const int n = (int)m->ctxs.size();
         std::unique_ptr<rsq_multi_query> mq(new rsq_multi_query());
         mq->m = m;
-        for (int i = 0; i < n; i++) {
+        for (int i = 0; i < n; i++)
             for (int t = 0; t < n_tables; t++) {
                 const Table* tb = reinterpret_cast<const Table*>(tables[(size_t)i * (size_t)n_tables + (size_t)t]);
                 if (!tb) failInvalid("null table");
                 if (tb->ctx != m->ctxs[(size_t)i]) failInvalid("table " + tb->name + " of shard " + std::to_string(i) + " does not live on that shard's context");
             }
-            mq->qs.push_back(compileQuery(*m->ctxs[(size_t)i], *plan, tables + (size_t)i * (size_t)n_tables, n_tables));
-        }
+        // The reference has ONE relation and ONE hash table all workers reach (aggregation.h:240-295, JitContextFlounder.h:459-487): any
+        // data works.  Here every shard plans from column statistics, so the shards of a table first receive the statistics of the WHOLE
+        // table (union of the byte-value sets, min / max over the shards, summed row count): all of them then derive the same dense
+        // group layout whatever their own rows hold, or all of them the hash aggregation where the union is not dense.  A table whose
+        // instances are the same rows on every shard (a replicated build side: equal row range and statistics) is left as it is.
+        if (n > 1)
+            for (int t = 0; t < n_tables; t++) {
+                auto tab = [&](int i) { return reinterpret_cast<Table*>(tables[(size_t)i * (size_t)n_tables + (size_t)t]); };
+                const size_t bb = tableStatsBytes(*tab(0));
+                std::vector<char> blobs((size_t)n * bb);
+                bool replicated = true;
+                for (int i = 0; i < n; i++) {
+                    if (tableStatsBytes(*tab(i)) != bb) failInvalid("table " + tab(i)->name + " has another schema on shard " + std::to_string(i));
+                    exportTableStats(*tab(i), blobs.data() + (size_t)i * bb, bb);
+                    if (memcmp(blobs.data(), blobs.data() + (size_t)i * bb, bb) != 0) replicated = false;
+                }
+                if (replicated) continue;
+                for (int i = 0; i < n; i++) unifyShardStats(*tab(i), blobs.data(), n, bb);
+            }
+        for (int i = 0; i < n; i++) mq->qs.push_back(compileQuery(*m->ctxs[(size_t)i], *plan, tables + (size_t)i * (size_t)n_tables, n_tables));
         mq->dense = queryIsDense(*mq->qs[0]);
         if (mq->dense) {
-            // mergeable only if every shard derived the same dense group layout from its column statistics
+            // (with unified statistics every shard derives the same layout; anything else is a defect of this library, not of the data)
             const std::string l0 = queryPartialLayoutText(*mq->qs[0]);
             for (int i = 1; i < n; i++)
                 if (!queryIsDense(*mq->qs[(size_t)i]) || queryPartialLayoutText(*mq->qs[(size_t)i]) != l0)
-                    failUnsupported("shards disagree on the partial aggregate table layout: shard 0 has \"" + l0 + "\", shard " + std::to_string(i) +
-                                    " has \"" + queryPartialLayoutText(*mq->qs[(size_t)i]) + "\"");
+                    throw Error(RSQ_ERR_RUNTIME, "internal: shards planned from the same statistics disagree on the partial aggregate table layout: shard 0 has \"" + l0 +
+                                                 "\", shard " + std::to_string(i) + " has \"" + queryPartialLayoutText(*mq->qs[(size_t)i]) + "\"");
             void* p;
             queryDenseLayout(*mq->qs[0], &mq->nMin, &mq->nMax, &mq->nSum, &p);
             if (n > 1 && m->merge == RSQ_MERGE_PEER_COPY) {
@@ -323,7 +358,7 @@ int rsq_multi_query_compile(rsq_multi* m, const rsq_plan_desc* plan, rsq_table* 
             for (Query* q : mq->qs) mq->async = mq->async && queryAsyncCapable(*q);
             mq->mergeText = std::string("dense partial tables: ") + rsq_multi_merge_name(m) + (mq->async ? "" : " (join builds: the shards run on host threads)");
         } else {
-            for (int i = 1; i < n; i++) if (queryIsDense(*mq->qs[(size_t)i])) failUnsupported("shards disagree on the aggregation strategy");
+            for (int i = 1; i < n; i++) if (queryIsDense(*mq->qs[(size_t)i])) throw Error(RSQ_ERR_RUNTIME, "internal: shards planned from the same statistics disagree on the aggregation strategy");
             // Groups may straddle shard boundaries (the reference has ONE hash table all workers reach, aggregation.h:240-295):
             // the general merge reads every shard's group rows back and re-aggregates them by key before the root's tail runs.
             // Only when the column statistics PROVE that no group lives in two shards (the caller sharded on a boundary of a
@@ -397,6 +432,12 @@ int rsq_multi_query_execute(rsq_multi_query* mq) {
             mq->shardKernelMs[(size_t)i] = r.kernel_time_ms;
         }
         if (!mq->dense && n > 1) rep.finalize_time_ms = r0.finalize_time_ms + mq->report.finalize_time_ms;
+        mq->collectiveMs = 0;
+        if (mq->dense && mq->evMerge0) {
+            float ms = 0;
+            RSQ_HIP(hipSetDevice(m->ctxs[0]->device));
+            if (hipEventSynchronize(mq->evMerge1) == hipSuccess && hipEventElapsedTime(&ms, mq->evMerge0, mq->evMerge1) == hipSuccess) mq->collectiveMs = ms;
+        }
         rep.execution_time_ms = now() - t0;
         rep.hbm_gbps = rep.kernel_time_ms > 0 ? (double)rep.bytes_read / (rep.kernel_time_ms * 1e-3) / 1e9 : 0;
         mq->report = rep;
@@ -414,6 +455,8 @@ int rsq_multi_query_report(const rsq_multi_query* mq, rsq_report* out, double* s
     if (shard_kernel_ms) for (size_t i = 0; i < mq->shardKernelMs.size(); i++) shard_kernel_ms[i] = mq->shardKernelMs[i];
     return RSQ_OK;
 }
+
+double rsq_multi_query_collective_ms(const rsq_multi_query* mq) { return mq ? mq->collectiveMs : 0; }
 
 const char* rsq_multi_query_merge_name(const rsq_multi_query* mq) { return mq ? mq->mergeText.c_str() : ""; }
 

@@ -578,7 +578,7 @@ struct Planner {
     typedef std::pair<Expr*, Expr*> ExprPair;
     typedef std::pair<RelationPair, std::vector<ExprPair>> JoinEntry;
 
-    int64_t tupleNum(const std::string& name) { return planTables[name].table->nRows; }
+    int64_t tupleNum(const std::string& name) { return planTables[name].table->totalRows(); }      // (a shard plans as the table it is a range of)
 
     // planner.h:268-392
     ExprVec addEqualityHashJoins(const ExprVec& where) {

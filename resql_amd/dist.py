@@ -28,6 +28,24 @@ def shard_rows(n_total: int, world: int, rank: int, tile: int = 128) -> Tuple[in
     return row0, n
 
 
+def unify_shard_stats(dist, table, world: int, device=None) -> None:
+    """Every rank holds one shard (`table`, an engine.DeviceTable) of the same table: all-gather the shards' statistics blobs
+    and make each shard plan as the whole table (include/resql_hip.h rsq_table_unify_shard_stats) — one dense group layout on
+    all ranks whatever their rows hold, the whole table's row count where the reference's table sizes matter.  Call before
+    compiling; a no-op for one rank."""
+    import torch
+    if dist is None or world == 1:
+        return
+    blob = table.stats_blob()
+    mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+    if device is not None:
+        mine = mine.to(device)
+    every = torch.empty(world * len(blob), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(every, mine)
+    raw = every.cpu().numpy().tobytes()
+    table.unify_shard_stats([raw[i * len(blob):(i + 1) * len(blob)] for i in range(world)])
+
+
 def allreduce_partial(dist, partial, n_min: int, n_max: int, n_sum: int) -> None:
     """in-place merge of a partial aggregate table (1-D int64 tensor) across the ranks of `dist`:
     one all-reduce per non-empty segment"""

@@ -84,6 +84,12 @@ def lib():
         L.rsq_table_rows.argtypes = [vp]
         L.rsq_table_read_column.argtypes = [vp, vp, C.c_char_p, vp, C.c_size_t]
         L.rsq_table_set_first_row.argtypes = [vp, i64]
+        L.rsq_table_stats_bytes.restype = i64
+        L.rsq_table_stats_bytes.argtypes = [vp]
+        L.rsq_table_stats_export.argtypes = [vp, vp, i64]
+        L.rsq_table_unify_shard_stats.argtypes = [vp, vp, i32, i64]
+        L.rsq_table_total_rows.restype = i64
+        L.rsq_table_total_rows.argtypes = [vp]
         L.rsq_table_destroy.argtypes = [vp]
         L.rsq_query_compile.argtypes = [vp, C.POINTER(P.rsq_plan_desc), C.POINTER(vp), i32, C.POINTER(vp)]
         L.rsq_query_execute.argtypes = [vp]
@@ -148,6 +154,8 @@ def lib():
         L.rsq_multi_query_execute.argtypes = [vp]
         L.rsq_multi_query_result.argtypes = [vp, C.POINTER(P.rsq_result_view)]
         L.rsq_multi_query_report.argtypes = [vp, C.POINTER(rsq_report), C.POINTER(C.c_double)]
+        L.rsq_multi_query_collective_ms.restype = C.c_double
+        L.rsq_multi_query_collective_ms.argtypes = [vp]
         L.rsq_multi_query_destroy.argtypes = [vp]
         _lib = L
     return _lib
@@ -156,6 +164,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
     "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_set_first_row", "rsq_table_read_column",
+    "rsq_table_stats_bytes", "rsq_table_stats_export", "rsq_table_unify_shard_stats", "rsq_table_total_rows",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_await_kernels", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
     "rsq_query_finalize", "rsq_query_merge_gathered", "rsq_query_finalize_host", "rsq_query_bind_partial", "rsq_query_partial_layout", "rsq_query_result", "rsq_query_report", "rsq_query_kernel_time_stats", "rsq_query_source", "rsq_query_explain",
@@ -165,7 +174,7 @@ EXPORTED_SYMBOLS = [
     "rsq_db_create", "rsq_db_execute", "rsq_db_message", "rsq_db_adopt_table", "rsq_db_report", "rsq_db_destroy",
     "rsq_multi_create", "rsq_multi_destroy", "rsq_multi_last_error", "rsq_multi_devices", "rsq_multi_ctx", "rsq_multi_merge_name",
     "rsq_multi_shard_rows", "rsq_multi_table_generate", "rsq_multi_table_generate_on_key", "rsq_multi_query_merge_name", "rsq_multi_query_compile", "rsq_multi_query_execute",
-    "rsq_multi_query_result", "rsq_multi_query_report", "rsq_multi_query_destroy",
+    "rsq_multi_query_result", "rsq_multi_query_report", "rsq_multi_query_collective_ms", "rsq_multi_query_destroy",
 ]
 
 GEN_LINEITEM, GEN_ORDERS, GEN_CUSTOMER, GEN_SYNTHETIC = 0, 1, 2, 3
@@ -359,6 +368,23 @@ class DeviceTable:
     def set_row0(self, row0: int):
         """this table is rows [row0, row0 + n_rows) of a larger one (a shard); before queries are compiled over it"""
         self.ctx._check(self.ctx._L.rsq_table_set_first_row(self.h, row0))
+
+    @property
+    def total_rows(self) -> int:
+        """rows of the whole table this one is a shard of (its own count before unify_shard_stats)"""
+        return self.ctx._L.rsq_table_total_rows(self.h)
+
+    def stats_blob(self) -> bytes:
+        """this shard's column statistics + row range as a fixed-size blob (the same size on every shard of a schema)"""
+        n = self.ctx._L.rsq_table_stats_bytes(self.h)
+        buf = C.create_string_buffer(n)
+        self.ctx._check(self.ctx._L.rsq_table_stats_export(self.h, buf, n))
+        return buf.raw
+
+    def unify_shard_stats(self, blobs: Sequence[bytes]):
+        """plan this shard as the whole table: `blobs` = stats_blob() of ALL shards (this one's included).  Before compiling."""
+        joined = b"".join(blobs)
+        self.ctx._check(self.ctx._L.rsq_table_unify_shard_stats(self.h, joined, len(blobs), len(blobs[0]) if blobs else 0))
 
     def read_column(self, name: str, dtype, count: Optional[int] = None) -> np.ndarray:
         n = self.n_rows if count is None else count
@@ -597,6 +623,11 @@ class MultiQuery:
     @property
     def merge_name(self) -> str:
         return self.m._L.rsq_multi_query_merge_name(self.h).decode()
+
+    @property
+    def collective_ms(self) -> float:
+        """device time of the last execution's group-by merge (event pair on the root's stream)"""
+        return self.m._L.rsq_multi_query_collective_ms(self.h)
 
     def report(self):
         """(rsq_report, [kernel ms of every shard])"""

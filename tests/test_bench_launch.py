@@ -44,6 +44,23 @@ def test_bench_starts_its_own_ranks():
     _check(_line(pr.stdout), 2, True)
 
 
+def test_ranks_whose_shards_hold_different_group_values_agree_on_the_layout():
+    """rank 0's stand-in shard has no 'R' line, rank 1's no 'O' line, rank 2's no 'A' line: planned from their own statistics the
+    ranks would derive three different dense layouts (round 3 ended the run with "shards disagree"); the statistics are unified
+    across the ranks before compiling, so all plan the 6-group table of the whole"""
+    env = _env()
+    env["RSQ_BENCH_DRY_DROP"] = "0:R,1:O,2:A"
+    pr = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--backend", "gloo", "--no-gpu", "--steps", "2", "--warmup", "1"],
+                        env=env, capture_output=True, text=True, timeout=240)
+    assert pr.returncode == 0, pr.stderr[-2000:]
+    rec = _line(pr.stdout)
+    _check(rec, 3, True)
+    cfg = rec["config"]
+    assert "groups=6" in cfg["layout"] and "l_returnflag{65,78,82} x l_linestatus{70,79}" in cfg["layout"]
+    assert cfg["shard_group_values"] == [[[65, 78], [70, 79]], [[65, 78, 82], [70]], [[78, 82], [70, 79]]]
+    assert 0 < cfg["shard_rows_total"] < 6144                       # the summed row count of the (thinned) shards
+
+
 def test_bench_under_torch_distributed_run():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

@@ -6,8 +6,14 @@ communicator.  Results == the oracle on the unsharded table, byte for byte."""
 import numpy as np
 import pytest
 
+import os
+import sys
+
 from resql_amd import datagen, engine, plan as P, tpch
 from oracle import orc
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import shardcases  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 SF = 0.05
@@ -85,20 +91,151 @@ def test_large_partial_tables_merge(groups):
         m.close()
 
 
-def test_shards_that_disagree_on_the_layout_are_refused():
-    """the dense group layout comes from each shard's column statistics: a shard that misses a group value cannot be merged"""
-    li = tpch.lineitem_table(0.01, tpch.Q1_COLUMNS)
-    m = engine.MultiContext([0, 0])
+def _shard_tables(m, shards, row0):
+    tabs = []
+    for i, (c, r0) in enumerate(zip(shards, row0)):
+        t = m.shards[i].table(shardcases.shard_table(c))
+        t.set_row0(r0)
+        tabs.append(t)
+    return tabs
+
+
+@pytest.mark.parametrize("plan_of,cols", [(tpch.q1_plan, tpch.Q1_COLUMNS), (tpch.q6_plan, tpch.Q6_COLUMNS)])
+def test_shards_with_different_value_sets_merge_through_peer_copies(plan_of, cols):
+    """a time-clustered table: shard 1 holds no 'R' line, shard 2 no 'O' line.  The reference has one hash table every worker
+    reaches (aggregation.h:240-295) and answers whatever the distribution; rsq_multi_query_compile gives every shard the whole
+    table's statistics, so all three derive ONE dense layout (round 3 refused this) and the peer-copy merge adds them up"""
+    want_cols = sorted(set(tpch.Q1_COLUMNS) | set(cols))
+    shards, row0, whole = shardcases.lineitem_shards(n_rows=30_000, columns=want_cols)
+    want = orc.execute(plan_of(whole))
+    m = engine.MultiContext([0, 0, 0])
     try:
-        a = m.shards[0].table(li)
-        cols = {c.name: c.data for c in li.columns if c.data is not None}
-        keep = cols["l_returnflag"] != ord("R")
-        sub = tpch.make_table("lineitem", tpch.LINEITEM_SCHEMA, {k: v[keep] for k, v in cols.items()}, int(keep.sum()))
-        b = m.shards[1].table(sub)
-        with pytest.raises(engine.EngineError) as e:
-            m.compile(tpch.q1_plan(_schema(tpch.Q1_COLUMNS)), [[a], [b]])
-        assert e.value.status == 3 and "disagree" in str(e.value)
-        a.close(); b.close()
+        tabs = _shard_tables(m, shards, row0)
+        q = m.compile(plan_of(_schema(cols)), [[t] for t in tabs])
+        assert "dense partial tables" in q.merge_name and "peer copies" in q.merge_name
+        assert [t.total_rows for t in tabs] == [whole.n_rows] * 3
+        for _ in range(2):
+            q.execute()
+            got = q.result()
+            assert got.text == want.text and got.tuples == want.tuples
+        q.close()
+        for t in tabs:
+            t.close()
+    finally:
+        m.close()
+
+
+def test_a_shard_planned_as_the_whole_table_through_the_rccl_handle():
+    """the RCCL handle (one-device communicator: grouped ncclReduce per segment) over a shard that lacks 'R' and was given the
+    statistics of all three shards: its partial table has the whole table's 6 cells, the 'R' cells stay at their identities, and
+    the answer is the oracle's on that shard's rows"""
+    shards, row0, _ = shardcases.lineitem_shards(n_rows=30_000)
+    m = engine.MultiContext([0], merge=engine.MERGE_RCCL)
+    ctx = engine.Context(device=0)
+    try:
+        others = [ctx.table(shardcases.shard_table(c)) for c in shards]
+        for t, r0 in zip(others, row0):
+            t.set_row0(r0)
+        t1 = m.shards[0].table(shardcases.shard_table(shards[1]))
+        t1.set_row0(row0[1])
+        t1.unify_shard_stats([t.stats_blob() for t in others])
+        q = m.compile(tpch.q1_plan(_schema(tpch.Q1_COLUMNS)), [[t1]])
+        q.execute()
+        got = q.result()
+        want = orc.execute(tpch.q1_plan(shardcases.shard_table(shards[1])))
+        assert got.text == want.text and 0 < got.n_rows <= 4
+        q.close(); t1.close()
+        for t in others:
+            t.close()
+    finally:
+        ctx.close()
+        m.close()
+
+
+def test_where_the_union_of_the_shards_is_not_dense_the_general_merge_answers():
+    """every shard's group key spans 1024 values (dense on its own), the union spans 2^26: all shards take the hash aggregation
+    and the general re-aggregating merge gives the single-table answer (round 3: RSQ_ERR_UNSUPPORTED)"""
+    from resql_amd import datagen
+    n, groups = 60_000, 1024
+    parts = []
+    for i, shift in enumerate((0, 1 << 26, 0)):
+        c = datagen.synthetic_columns(i * n, n, groups)
+        c["b"] = c["b"] + shift
+        parts.append(c)
+    whole = tpch.make_table("t", tpch.SYNTH_SCHEMA, {k: np.concatenate([c[k] for c in parts]) for k in parts[0]}, 3 * n)
+    want = orc.execute(tpch.synthetic_plan(whole, 1 << 30))
+    m = engine.MultiContext([0, 0, 0])
+    try:
+        tabs = []
+        for i, c in enumerate(parts):
+            t = m.shards[i].table(tpch.make_table("t", tpch.SYNTH_SCHEMA, c, n))
+            t.set_row0(i * n)
+            tabs.append(t)
+        q = m.compile(tpch.synthetic_plan(tpch.synthetic_table(0, groups), 1 << 30), [[t] for t in tabs])
+        assert "general merge" in q.merge_name
+        q.execute()
+        got = q.result()
+        assert got.n_rows == want.n_rows == 2 * groups
+        assert got.text == want.text
+        q.close()
+        for t in tabs:
+            t.close()
+    finally:
+        m.close()
+
+
+def test_device_tail_orders_groups_that_first_occur_in_late_shards():
+    """65536 dense groups over 16 shards of 62 500 rows: the root's own rows need 16 bits, the first rows of the merged table 20.
+    The radix sort by first row must cover the WHOLE table's row numbers (round-3 advisor: it covered the root shard's), or the
+    replay of the reference's hash table sees another insertion order.  No ORDER BY: the text is the emission order, byte for byte"""
+    n, groups, n_shards = 1_000_000, 1 << 16, 16
+    host = tpch.synthetic_table(n, groups)
+    want = orc.execute(tpch.synthetic_plan(host, 1 << 30))
+    m = engine.MultiContext([0] * n_shards)
+    try:
+        shards = m.generate(engine.GEN_SYNTHETIC, n, 1.0, param=groups)
+        assert shards[0].n_rows < (1 << 16) < n
+        q = m.compile(tpch.synthetic_plan(tpch.synthetic_table(0, groups), 1 << 30), [[t] for t in shards])
+        assert "dense partial tables" in q.merge_name
+        q.execute()
+        got = q.result()
+        assert got.n_rows == want.n_rows
+        assert got.text == want.text
+        q.close()
+        for t in shards:
+            t.close()
+    finally:
+        m.close()
+
+
+def test_general_merge_of_a_few_dozen_groups_sizes_the_replay_from_the_whole_table():
+    """40 groups of a computed key over 4 shards: the reference allocates its aggregation table for the WHOLE input
+    (aggregation.h:81-92 getSize = child / 512 -> the prime above it); with so few groups no growth evens the sizes out, so a replay
+    sized from the root shard's rows (round-3 advisor) would emit the groups in another order"""
+    n, groups = 400_000, 40
+    host = tpch.synthetic_table(n, groups)
+
+    def plan_of(t):
+        p = P.Plan([t])
+        key = p.add(p.mul(p.attr("b"), p.constant("7", P.BIGINT)), p.constant("3", P.BIGINT))
+        sc, cnt = p.sum(p.attr("c")), p.count(p.star())
+        node = p.selection(p.lt(p.attr("a"), p.constant(str(1 << 30), P.BIGINT)), p.scan("t"))
+        node = p.aggregation([sc, cnt], [key], node)
+        return p.set_root(p.materialize(p.projection([p.as_("k", key), p.as_("s", sc), p.as_("n", cnt)], node)))
+
+    want = orc.execute(plan_of(host))
+    m = engine.MultiContext([0, 0, 0, 0])
+    try:
+        shards = m.generate(engine.GEN_SYNTHETIC, n, 1.0, param=groups)
+        q = m.compile(plan_of(tpch.synthetic_table(0, groups)), [[t] for t in shards])
+        assert "general merge" in q.merge_name
+        q.execute()
+        got = q.result()
+        assert got.n_rows == want.n_rows == groups
+        assert got.text == want.text
+        q.close()
+        for t in shards:
+            t.close()
     finally:
         m.close()
 

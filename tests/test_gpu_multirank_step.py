@@ -79,6 +79,58 @@ def test_async_partial_merge_finalize(nccl_world1, plan_of):
     assert got.text == want.text
 
 
+def test_shards_with_different_value_sets_through_the_rank_step(nccl_world1):
+    """the dist-path step (asynchronous partial execution, RCCL collective of a world of one forced to run, merge kernel, finalize)
+    over three shards whose statistics differ — shard 1 has no 'R' line, shard 2 no 'O' line — after the exchange bench.py's ranks
+    make (stats_blob of every shard -> unify_shard_stats): one 6-group layout, the gathered tables reduce to the oracle's answer on
+    the concatenated table.  The reference: one hash table all workers reach (aggregation.h:240-295)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import shardcases
+    from resql_amd.dist import PartialMerger
+    dist = nccl_world1
+    shards, row0, whole = shardcases.lineitem_shards(n_rows=30_000)
+    dev = torch.device("cuda", 0)
+    ctx = engine.Context(device=0)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        ctx.set_stream(stream.cuda_stream)
+        tabs = [ctx.table(shardcases.shard_table(c)) for c in shards]
+        for t, r0 in zip(tabs, row0):
+            t.set_row0(r0)
+        blobs = [t.stats_blob() for t in tabs]
+        schema_only = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
+        queries, partials = [], []
+        for t in tabs:
+            t.unify_shard_stats(blobs)
+            q = ctx.compile(tpch.q1_plan(schema_only), [t])
+            n_min, n_max, n_sum = q.partial_layout()
+            assert (n_min, n_max, n_sum) == (6, 0, 36)
+            partial = torch.zeros(42, dtype=torch.int64, device=dev)
+            q.bind_partial(partial.data_ptr(), partial.numel() * 8)
+            queries.append(q); partials.append(partial)
+        for q, partial in zip(queries, partials):
+            q.execute_partial_async()
+            PartialMerger(dist, partial, 6, 0, 36, 1, always_collective=True).merge()
+        stream.synchronize()
+        # what one all-gather delivers on three real ranks: the three tables back to back -> the engine's merge kernel on the root
+        gathered = torch.cat(partials).contiguous()
+        queries[0].merge_gathered(gathered.data_ptr(), 3)
+        queries[0].finalize()
+        got = queries[0].result()
+        for q in queries[1:]:
+            q.finalize()
+        for q in queries:
+            q.close()
+        for t in tabs:
+            t.close()
+    ctx.set_stream(None)
+    ctx.close()
+    want = orc.execute(tpch.q1_plan(whole))
+    assert got.text == want.text and got.tuples == want.tuples
+
+
 def test_async_needs_a_plain_dense_plan(gpu_ctx):
     sf = 0.01
     li = tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
