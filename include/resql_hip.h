@@ -50,8 +50,12 @@ enum rsq_status {
     RSQ_ERR_NOMEM = 6
 };
 
-/* Mirrors JitConfig (reference src/JitContextFlounder.h:86-109) field for field, plus the device. */
+/* Mirrors JitConfig (reference src/JitContextFlounder.h:86-109) field for field — behind `struct_size` — plus the device and the
+ * engine's own settings.  struct_size = sizeof(rsq_config) of the header the HOST was compiled against: the library reads that many
+ * bytes and takes every later field as 0, so the struct can grow without a host built against an older header handing over
+ * garbage (0 is refused: an uninitialised struct). */
 typedef struct rsq_config {
+    uint32_t struct_size;        /* sizeof(rsq_config) */
     int32_t print_assembly;      /* JitConfig::printAssembly  -> dump generated HIP source */
     int32_t print_flounder;      /* JitConfig::printFlounder  -> dump the pipeline description */
     int32_t print_performance;   /* JitConfig::printPerformance */
@@ -61,7 +65,18 @@ typedef struct rsq_config {
     int32_t device;              /* HIP device ordinal this context drives (one context per GPU / process) */
     const char* kernel_cache_dir;/* directory with pre-built code objects (NULL: <library dir>/../_kcache) */
     int32_t emission_order;      /* rsq_emission_order: order of an aggregation's rows when the plan does not sort them */
+    uint32_t compat_flags;       /* rsq_compat bits: where "as the reference's source says" and "as its JIT executes" differ */
 } rsq_config;
+
+/* Semantics switches.  The default (0) computes what the reference's SOURCE specifies; a bit selects what its asmjit back end
+ * actually executes where the two differ, for a drop-in host that must return the JIT's own answers:
+ *   RSQ_COMPAT_JIT_INT16_CAST — TYPECAST INT -> BIGINT is a 32 -> 64-bit sign extension in ExpressionsJitFlounder.h:818-824 (`movsx`);
+ *     the asmjit translation encodes the 16-bit form, so the JIT extends the LOW 16 BITS (`l_orderkey < 3` also keeps key 65537).
+ *     With the bit set device code, interpreter and host tail do the same.
+ * Not selectable: ht_get's missing wrap-around (src/qlib/hash.h:427-477) reads one entry past the table's allocation, so what the
+ * reference returns for a probe chain that crosses the table's end depends on heap contents; the engine always walks the chain
+ * (tests/test_reference_defect.py pins the difference on the live reference). */
+enum rsq_compat { RSQ_COMPAT_JIT_INT16_CAST = 1u };
 
 /* Without ORDER BY the reference emits an aggregation's groups in the slot order of its hash table (operators/aggregation.h:
  * 298-343), which depends on the order the groups first occur in the input, its hash function, prime table sizes and growth rule.

@@ -20,6 +20,7 @@
 int main(int argc, char** argv) {
     rsq_config cfg;
     memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
     cfg.device = getenv("RSQ_DEVICE") ? atoi(getenv("RSQ_DEVICE")) : 0;
     rsq_ctx* ctx = NULL;
     if (rsq_ctx_create(&cfg, &ctx) != RSQ_OK) { fprintf(stderr, "context: %s\n", rsq_last_error(NULL)); return 2; }

@@ -153,8 +153,12 @@ private:
 // One engine context + the device copies of the Relations it has seen.
 class JitContextHip {
 public:
-    explicit JitContextHip(const JitConfig& cfg, int device = 0) {
+    // compat: rsq_compat bits — a host that must return exactly what ReSQL's asmjit JIT returns today passes
+    // RSQ_COMPAT_JIT_INT16_CAST; 0 computes what the reference's source specifies
+    explicit JitContextHip(const JitConfig& cfg, int device = 0, uint32_t compat = 0) {
         rsq_config c{};
+        c.struct_size = sizeof c;
+        c.compat_flags = compat;
         c.print_assembly = cfg.printAssembly; c.print_flounder = cfg.printFlounder; c.print_performance = cfg.printPerformance;
         c.num_threads = cfg.numThreads; c.emit_machine_code = cfg.emitMachineCode; c.optimize = cfg.optimizeFlounder;
         c.device = device;

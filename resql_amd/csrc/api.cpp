@@ -58,6 +58,23 @@ Table* makeTable(Context& ctx, const rsq_table_desc& d, bool adopt) {
 }
 }  // namespace
 
+// rsq_config as the host's header declared it: struct_size bytes are the host's, everything behind them reads as 0
+namespace rsq {
+rsq_config readConfig(const rsq_config* cfg) {
+    rsq_config c{};
+    c.struct_size = (uint32_t)sizeof(rsq_config);
+    if (!cfg) return c;
+    const uint32_t have = cfg->struct_size;
+    if (have < offsetof(rsq_config, kernel_cache_dir) || have > 4096)
+        failInvalid("rsq_config.struct_size is " + std::to_string(have) + ": set it to sizeof(rsq_config) (" + std::to_string(sizeof(rsq_config)) + " in this library)");
+    memcpy(&c, cfg, std::min<size_t>(have, sizeof c));
+    c.struct_size = (uint32_t)sizeof(rsq_config);
+    if (c.emission_order != RSQ_EMIT_REFERENCE && c.emission_order != RSQ_EMIT_ANY) failInvalid("rsq_config.emission_order must be RSQ_EMIT_REFERENCE (0) or RSQ_EMIT_ANY (1)");
+    if (c.compat_flags & ~(uint32_t)RSQ_COMPAT_JIT_INT16_CAST) failInvalid("rsq_config.compat_flags has bits this library does not know");
+    return c;
+}
+}  // namespace rsq
+
 // ---- shard statistics -------------------------------------------------------------------------------------------------------
 // One blob per table: [magic | columns | row0 | rows] then per column [valid | ascending | min | max | number of byte values | 256 byte
 // values].  Fixed size for a schema, plain little-endian words: what one all-gather between the rank processes moves.
@@ -134,9 +151,7 @@ int64_t rsq_table_total_rows(const rsq_table* t) { return t ? reinterpret_cast<c
 int rsq_ctx_create(const rsq_config* cfg, rsq_ctx** out) {
     if (!out) return RSQ_ERR_INVALID;
     *out = nullptr;
-    rsq_config c{};
-    if (cfg) c = *cfg;
-    return guarded(nullptr, [&] { *out = reinterpret_cast<rsq_ctx*>(new Context(c)); });
+    return guarded(nullptr, [&] { *out = reinterpret_cast<rsq_ctx*>(new Context(readConfig(cfg))); });
 }
 
 void rsq_ctx_destroy(rsq_ctx* ctx) { delete C(ctx); }

@@ -35,6 +35,7 @@ int64_t nextPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 struct ExprGen {
     std::map<std::string, Sym> symbols;     // JitContextFlounder::symbolTable of the current pipeline
     std::map<std::string, int> strWordVars; // string columns whose first words arrive as row-function parameters <var>_w0, _w1 (loaded with the tile): how many
+    bool int16Cast = false;                 // rsq_config.compat_flags & RSQ_COMPAT_JIT_INT16_CAST
 
     static std::string ctype(const Type& t) {
         switch (t.tag) {
@@ -122,8 +123,8 @@ struct ExprGen {
                 if (to.tag == RSQ_BIGINT) {
                     // INT -> BIGINT is a 32 -> 64 sign extension (ExpressionsJitFlounder.h:818-824 `movsx`).  The reference's
                     // asmjit back end encodes the 16-bit movsx for it, so its JIT extends the low 16
-                    // bits; RSQ_REFERENCE_INT16_CAST=1 reproduces exactly that for hosts that need the JIT's answers.
-                    if (from.tag == RSQ_INT) return envInt("RSQ_REFERENCE_INT16_CAST", 0, 0, 1) ? "((i64)(short)(" + c + "))" : "((i64)(" + c + "))";
+                    // bits; rsq_config.compat_flags & RSQ_COMPAT_JIT_INT16_CAST reproduces exactly that for hosts that need the JIT's answers.
+                    if (from.tag == RSQ_INT) return int16Cast ? "((i64)(short)(" + c + "))" : "((i64)(" + c + "))";
                     if (from.tag == RSQ_DECIMAL) {
                         if (from.scale > 8) failType("typecast beyond the supported scale");
                         return "((i64)((" + c + ") / " + lit64(pow10(from.scale)) + "))";
@@ -286,7 +287,7 @@ struct Walker {
     std::string stage2Body;
     std::vector<std::pair<std::string, Sym>> cqLive;     // carried symbols: name -> stage-1 variable and type
 
-    explicit Walker(Query& q_) : q(q_) {}
+    explicit Walker(Query& q_) : q(q_) { eg.int16Cast = jitInt16Cast(q_.ctx); }
 
     void line(const std::string& s) { body += std::string((size_t)indent * 4, ' ') + s + "\n"; }
     void openScope(const std::string& head) { line(head); indent++; }

@@ -122,6 +122,9 @@ struct Context {
     std::vector<uint32_t> replayOrder;
 };
 
+rsq_config readConfig(const rsq_config* cfg);      // api.cpp: the host's struct (struct_size bytes), validated
+inline bool jitInt16Cast(const Context& c) { return (c.cfg.compat_flags & RSQ_COMPAT_JIT_INT16_CAST) != 0; }
+
 // launch helper: kernel takes one struct of 8-byte slots by value
 // start / stop (optional): events that take the kernel's own begin and end (hipExtModuleLaunchKernel)
 void launch(Context& ctx, Kernel& k, unsigned grid, unsigned block, const std::vector<uint64_t>& args, hipEvent_t start = nullptr,

@@ -100,7 +100,7 @@ struct Builder {
                             } else failType("emitTypecastToDECIMAL(..) code generation not implemented for datatype");
                         } else if (to.tag == RSQ_BIGINT) {
                             if (from.tag == RSQ_INT) {
-                                if (getenv("RSQ_REFERENCE_INT16_CAST") && atoi(getenv("RSQ_REFERENCE_INT16_CAST"))) no("the 16-bit cast switch");
+                                if (jitInt16Cast(q.ctx)) no("the 16-bit cast switch");
                                 return c;                      // values travel sign-extended to 64 bits already
                             }
                             if (from.tag == RSQ_BIGINT) return c;

@@ -106,7 +106,7 @@ struct Builder2 {
                             } else failType("emitTypecastToDECIMAL(..) code generation not implemented for datatype");
                         } else if (to.tag == RSQ_BIGINT) {
                             if (from.tag == RSQ_INT) {
-                                if (!(getenv("RSQ_REFERENCE_INT16_CAST") && atoi(getenv("RSQ_REFERENCE_INT16_CAST")))) return c;      // values travel sign-extended already
+                                if (!jitInt16Cast(q.ctx)) return c;      // values travel sign-extended already
                                 const int r = alloc(); emit(G_CAST16, r, c.reg); release(c); return {r, true};
                             }
                             if (from.tag == RSQ_BIGINT) return c;

@@ -10,6 +10,8 @@
 #include <mutex>
 #include <thread>
 
+#include <pthread.h>
+
 namespace rsq {
 
 namespace {
@@ -24,7 +26,8 @@ struct Pool {
     std::atomic<int> next{0};
     int pending = 0;                    // workers that have not finished the current region yet
     std::exception_ptr error;
-    std::mutex region;                  // one parallel region at a time
+    std::atomic<bool> busy{false};      // one parallel region at a time; whoever finds it taken (another thread's region, or a
+                                        // nested call from inside this thread's own region) runs its parts itself
     bool stop = false;
 
     explicit Pool(int nWorkers) {
@@ -82,9 +85,20 @@ int configuredThreads() {
     return n;
 }
 
+// (kept until the process ends: no shutdown-order games with a library that Python unloads late)
+std::atomic<Pool*> g_pool{nullptr};
+std::once_flag g_poolOnce;
+// worker threads do not survive fork(): the child forgets the pool (its threads, mutexes and condition variables belong to the
+// parent) and runs serially — a region started in a forked child would otherwise wait for workers that do not exist
+std::atomic<bool> g_forked{false};
+
 Pool* pool() {
-    static Pool* p = configuredThreads() > 1 ? new Pool(configuredThreads() - 1) : nullptr;      // (kept until the process ends: no shutdown-order games with a library that Python unloads late)
-    return p;
+    if (g_forked.load(std::memory_order_relaxed)) return nullptr;
+    std::call_once(g_poolOnce, [] {
+        if (configuredThreads() > 1) g_pool.store(new Pool(configuredThreads() - 1));
+        pthread_atfork(nullptr, nullptr, [] { g_forked.store(true); });
+    });
+    return g_pool.load();
 }
 
 }  // namespace
@@ -99,8 +113,9 @@ int partsFor(size_t n) {
 void parallelRun(int parts, const std::function<void(int)>& fn) {
     if (parts <= 0) return;
     Pool* p = parts > 1 ? pool() : nullptr;
-    if (!p || !p->region.try_lock()) { for (int i = 0; i < parts; i++) fn(i); return; }
-    std::lock_guard<std::mutex> g(p->region, std::adopt_lock);
+    bool expected = false;
+    if (!p || !p->busy.compare_exchange_strong(expected, true, std::memory_order_acquire)) { for (int i = 0; i < parts; i++) fn(i); return; }
+    struct Release { Pool* p; ~Release() { p->busy.store(false, std::memory_order_release); } } release{p};
     p->run(parts, fn);
 }
 

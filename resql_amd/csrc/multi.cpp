@@ -193,7 +193,7 @@ int rsq_multi_create(const rsq_multi_config* cfg, rsq_multi** out) {
         if (m->merge == RSQ_MERGE_RCCL && m->sharedDevice)
             failInvalid("an RCCL communicator cannot hold the same device twice: use RSQ_MERGE_PEER_COPY for shards that share a GPU");
         for (int i = 0; i < cfg->n_devices; i++) {
-            rsq_config c = cfg->base;
+            rsq_config c = readConfig(&cfg->base);
             c.device = cfg->devices[i];
             m->ctxs.push_back(new Context(c));
         }

@@ -36,12 +36,14 @@ struct HostExpr {
     int tag = 0;
     Type type, opType;
     Val constant{};
+    bool int16Cast = false;    // TYPECAST INT -> BIGINT as the reference's JIT executes it (RSQ_COMPAT_JIT_INT16_CAST)
     std::vector<HostExpr> kids;
 };
 
 struct HostCompiler {
     std::vector<std::string> names;      // symbol table: slot -> name
     std::vector<Type> types;
+    bool int16Cast = false;
 
     int slotOf(const std::string& n) const {
         for (size_t i = 0; i < names.size(); i++) if (names[i] == n) return (int)i;
@@ -55,7 +57,7 @@ struct HostCompiler {
     }
 
     HostExpr compile(Expr* e) {
-        HostExpr h; h.type = e->type;
+        HostExpr h; h.type = e->type; h.int16Cast = int16Cast;
         int s = slotOf(expressionName(e));
         if (s >= 0) { h.kind = 0; h.slot = s; return h; }
         switch (e->structure) {
@@ -149,8 +151,7 @@ Val evalHost(const HostExpr& h, const std::vector<Val>& sym) {
                 else failType("emitTypecastToDECIMAL(..) code generation not implemented for datatype");
             } else if (to.tag == RSQ_BIGINT) {
                 if (from.tag == RSQ_INT) {
-                    static const bool int16Cast = getenv("RSQ_REFERENCE_INT16_CAST") && atoi(getenv("RSQ_REFERENCE_INT16_CAST")) == 1;
-                    r.i = int16Cast ? (int64_t)(int16_t)c.i : (int64_t)(int32_t)c.i;      // see codegen.cpp emitUnary
+                    r.i = h.int16Cast ? (int64_t)(int16_t)c.i : (int64_t)(int32_t)c.i;      // see codegen.cpp emitUnary
                 }
                 else if (from.tag == RSQ_DECIMAL) r.i = sdiv(c.i, pow10i(from.scale));
                 else r = c;
@@ -634,6 +635,7 @@ static TailShape buildTailShape(Query& q) {
     if (!mat) failInvalid("plan has no materialization");
 
     HostCompiler& hc = sh.hc;
+    hc.int16Cast = jitInt16Cast(q.ctx);
     std::vector<int>& keySlots = sh.keySlots;
     Schema aggSchema;
     for (Expr* g : agg->exprs2) { keySlots.push_back(hc.define(expressionName(g), g->type)); aggSchema.push_back({expressionName(g), g->type}); }

@@ -22,9 +22,15 @@ STATUS = {0: "OK", 1: "INVALID", 2: "TYPE", 3: "UNSUPPORTED", 4: "DEVICE", 5: "R
 
 
 class rsq_config(C.Structure):
-    _fields_ = [("print_assembly", C.c_int32), ("print_flounder", C.c_int32), ("print_performance", C.c_int32),
+    _fields_ = [("struct_size", C.c_uint32),
+                ("print_assembly", C.c_int32), ("print_flounder", C.c_int32), ("print_performance", C.c_int32),
                 ("num_threads", C.c_int32), ("emit_machine_code", C.c_int32), ("optimize", C.c_int32),
-                ("device", C.c_int32), ("kernel_cache_dir", C.c_char_p), ("emission_order", C.c_int32)]
+                ("device", C.c_int32), ("kernel_cache_dir", C.c_char_p), ("emission_order", C.c_int32),
+                ("compat_flags", C.c_uint32)]
+
+    @classmethod
+    def make(cls, device: int, cache_dir=None, print_source: bool = False, emission_order: int = 0, compat_flags: int = 0):
+        return cls(C.sizeof(cls), 1 if print_source else 0, 0, 0, 1, 1, 0, device, cache_dir, emission_order, compat_flags)
 
 
 class rsq_report(C.Structure):
@@ -40,6 +46,7 @@ class rsq_multi_config(C.Structure):
 
 MERGE_AUTO, MERGE_RCCL, MERGE_PEER_COPY = 0, 1, 2
 EMIT_REFERENCE, EMIT_ANY = 0, 1
+COMPAT_JIT_INT16_CAST = 1      # rsq_compat: TYPECAST INT -> BIGINT as the reference's asmjit JIT executes it (low 16 bits)
 
 
 class EngineError(RuntimeError):
@@ -194,11 +201,13 @@ class Context:
         self._borrowed = True
         return self
 
-    def __init__(self, device: int = 0, cache_dir: Optional[str] = None, print_source: bool = False, emission_order: int = 0):
-        """emission_order: EMIT_REFERENCE (0: rows of an unsorted aggregation in the reference's hash-table order) or EMIT_ANY"""
+    def __init__(self, device: int = 0, cache_dir: Optional[str] = None, print_source: bool = False, emission_order: int = 0,
+                 compat_flags: int = 0):
+        """emission_order: EMIT_REFERENCE (0: rows of an unsorted aggregation in the reference's hash-table order) or EMIT_ANY;
+        compat_flags: rsq_compat bits (COMPAT_JIT_INT16_CAST)"""
         self._L = lib()
         self._cache = cache_dir.encode() if cache_dir else None
-        cfg = rsq_config(1 if print_source else 0, 0, 0, 1, 1, 0, device, self._cache, emission_order)
+        cfg = rsq_config.make(device, self._cache, print_source, emission_order, compat_flags)
         h = C.c_void_p()
         rc = self._L.rsq_ctx_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -531,11 +540,12 @@ class Database:
 class MultiContext:
     """one host process, N GPUs (include/resql_hip.h rsq_multi_*): shard contexts + the RCCL (or peer-copy) group-by merge"""
 
-    def __init__(self, devices: Sequence[int], merge: int = MERGE_AUTO, cache_dir: Optional[str] = None):
+    def __init__(self, devices: Sequence[int], merge: int = MERGE_AUTO, cache_dir: Optional[str] = None, emission_order: int = 0,
+                 compat_flags: int = 0):
         self._L = lib()
         self._devs = (C.c_int32 * len(devices))(*devices)
         self._cache = cache_dir.encode() if cache_dir else None
-        cfg = rsq_multi_config(rsq_config(0, 0, 0, 1, 1, 0, 0, self._cache, 0), self._devs, len(devices), merge)
+        cfg = rsq_multi_config(rsq_config.make(0, self._cache, False, emission_order, compat_flags), self._devs, len(devices), merge)
         h = C.c_void_p()
         rc = self._L.rsq_multi_create(C.byref(cfg), C.byref(h))
         if rc != 0:

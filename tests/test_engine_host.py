@@ -223,3 +223,21 @@ def test_resident_form_of_the_one_launch_step_compiles_for_gfx950(compile_ctx, t
         p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-DRSQ_PERSISTENT=1", "-include", "hip/hip_runtime.h", "-I", inc,
                             "--cuda-device-only", "-c", "-o", str(tmp_path / "step.o"), str(src)], capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-2000:]
+
+
+def test_config_struct_is_validated_without_a_gpu():
+    """rsq_config.struct_size / emission_order / compat_flags are checked by rsq_ctx_create (compile-only context: no device needed)"""
+    import ctypes as C
+    L = engine.lib()
+    h = C.c_void_p()
+    cfg = engine.rsq_config.make(-1)
+    cfg.struct_size = 0
+    assert L.rsq_ctx_create(C.byref(cfg), C.byref(h)) == 1 and b"struct_size" in L.rsq_last_error(None)
+    for bad in (engine.rsq_config.make(-1, emission_order=2), engine.rsq_config.make(-1, compat_flags=6)):
+        assert L.rsq_ctx_create(C.byref(bad), C.byref(h)) == 1
+    old_host = engine.rsq_config.make(-1, emission_order=2, compat_flags=6)      # fields its header never had are not read
+    old_host.struct_size = engine.rsq_config.emission_order.offset
+    assert L.rsq_ctx_create(C.byref(old_host), C.byref(h)) == 0
+    L.rsq_ctx_destroy(h)
+    ok = engine.Context(device=-1, compat_flags=engine.COMPAT_JIT_INT16_CAST)
+    ok.close()

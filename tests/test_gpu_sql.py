@@ -114,19 +114,46 @@ def test_statement_loop_create_load_select(gpu_ctx, tmp_path):
         db.close()
 
 
-def test_reference_int16_cast_switch_reproduces_the_jit(gpu_ctx, small_db, monkeypatch):
-    """RSQ_REFERENCE_INT16_CAST=1: INT -> BIGINT casts extend the low 16 bits, as the reference's asmjit back end does
-     — the engine then returns the JIT's own answer for `l_orderkey < 3` (keys 32769.. included)"""
-    host, tabs = small_db
+def test_reference_int16_cast_switch_reproduces_the_jit(small_db):
+    """rsq_config.compat_flags = RSQ_COMPAT_JIT_INT16_CAST: INT -> BIGINT casts extend the low 16 bits, as the reference's asmjit
+    back end does — a context created with the bit returns the JIT's own answer for `l_orderkey < 3`
+    (keys 65537.. included), on the specialised kernels and on the interpreter; the default context returns what the source says"""
+    host, _ = small_db
     cases = [g for g in GOLD["results"].values() if "reference_text" in g]
     assert cases
-    monkeypatch.setenv("RSQ_REFERENCE_INT16_CAST", "1")
-    for g in cases:
-        q = gpu_ctx.sql_compile(g["sql"], tabs)
-        q.execute()
-        got = q.result()
-        q.close()
-        assert got.text == g["reference_text"] and got.text != g["text"]
+    for interpreter in ("0", "1"):
+        os.environ["RSQ_FORCE_GENERIC"] = interpreter
+        try:
+            ctx = engine.Context(device=0, compat_flags=engine.COMPAT_JIT_INT16_CAST)
+            tabs = [ctx.table(t) for t in host]
+            for g in cases:
+                q = ctx.sql_compile(g["sql"], tabs)
+                q.execute()
+                got = q.result()
+                q.close()
+                assert got.text == g["reference_text"] and got.text != g["text"]
+            ctx.close()
+        finally:
+            os.environ.pop("RSQ_FORCE_GENERIC", None)
+
+
+def test_config_is_validated():
+    """struct_size says how much of rsq_config the host's header knew; unknown settings are refused instead of guessed"""
+    import ctypes as C
+    L = engine.lib()
+    h = C.c_void_p()
+    cfg = engine.rsq_config.make(0)
+    cfg.struct_size = 0                                            # an uninitialised struct
+    assert L.rsq_ctx_create(C.byref(cfg), C.byref(h)) == 1 and b"struct_size" in L.rsq_last_error(None)
+    cfg = engine.rsq_config.make(0, emission_order=7)
+    assert L.rsq_ctx_create(C.byref(cfg), C.byref(h)) == 1 and b"emission_order" in L.rsq_last_error(None)
+    cfg = engine.rsq_config.make(0, compat_flags=1 << 9)
+    assert L.rsq_ctx_create(C.byref(cfg), C.byref(h)) == 1 and b"compat_flags" in L.rsq_last_error(None)
+    # a host built against the header before emission_order / compat_flags existed: garbage behind its struct is never read
+    cfg = engine.rsq_config.make(0, emission_order=7, compat_flags=1 << 9)
+    cfg.struct_size = engine.rsq_config.emission_order.offset
+    assert L.rsq_ctx_create(C.byref(cfg), C.byref(h)) == 0
+    L.rsq_ctx_destroy(h)
 
 
 def test_random_valid_statements(gpu_ctx, small_db):
