@@ -42,6 +42,11 @@ Extra objects on the JSON line:
                  accumulators, 3 merged words) and G = 2^20 (HBM table, 32 MB all-reduced) — rows/s of the whole job and
                  the fraction of N x 8 TB/s in algorithmic bytes (32 B/row).  Untimed for `value`; skipped with --no-extras.
 
+  extras.q1_sf1 / q6_sf10 / q3_sf10 (N = 1) — the other single-GPU BASELINE configurations (2: Q1 at SF1; 3: Q3 at SF10) and Q6 at
+                 SF10, whole executions through the C ABI after the timed region: exec_ms / ms_per_step, kernel_ms (HIP events),
+                 launches, fraction of 8 TB/s in algorithmic bytes (for Q3: streaming bytes, an upper bound; for Q6 also the
+                 FETCH_SIZE-based traffic_frac of the committed PMC pass), each answer compared with the reference's recorded one.
+
 `--backend gloo --no-gpu` is a dry mode for machines without a GPU (the CPU test of the launch path): every rank takes a
 compile-only engine context, a deterministic stand-in partial table goes through the same sharding, layout check, merge
 and finalisation calls, and the line carries "dry_run": true instead of a measurement.
@@ -469,6 +474,98 @@ def weak_scaling_extra(args, ctx, dist, world: int, rank: int, device, steps: in
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# extras.q1_sf1 / q6_sf10 / q3_sf10: the other single-GPU BASELINE configurations, untimed for `value`
+# ------------------------------------------------------------------------------------------------------------------
+LATE_LOAD_PROFILES = ("profiles/r04_late_loads_pmc.json", "profiles/r03_late_loads_pmc.json")
+
+
+def _golden_text(name: str):
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", f"ref_full_{name}.tbl")) as f:
+            return f.read()
+    except OSError:
+        return None
+
+
+def _committed_late_load_traffic(case: str, rows: int):
+    """FETCH_SIZE-based fraction of a late-load plan from the committed rocprofv3 --pmc pass (same rows only), or (None, None)"""
+    for rel in LATE_LOAD_PROFILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                c = json.load(f)["cases"][case]
+            if c["rows"] == rows:
+                return c["traffic_frac_of_8TBps"], f"{rel} (committed --pmc FETCH_SIZE pass x 2 / kernel time / 8 TB/s; not measured by this run)"
+        except Exception:
+            continue
+    return None, None
+
+
+def _measure_plan(q, steps: int, golden: str, bytes_alg: int):
+    """whole executions of one compiled query: exec_ms (host wall time of rsq_query_execute, launches to result relation),
+    kernel_ms (HIP events on the engine's stream), launches, fraction of the 8 TB/s peak in ALGORITHMIC bytes, parity"""
+    q.await_kernels()
+    for _ in range(3):
+        q.execute()
+    q.kernel_time_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        q.execute()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ksum, kn = q.kernel_time_stats()
+    rep = q.report()
+    kernel_ms = ksum / max(1, kn) if kn else rep.kernel_time_ms
+    want = _golden_text(golden)
+    return {"exec_ms": ms, "kernel_ms": kernel_ms, "launches": int(rep.num_kernels), "finalize_ms": rep.finalize_time_ms,
+            "algorithmic_bytes": bytes_alg, "algorithmic_frac": bytes_alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kernel_ms > 0 else None,
+            "parity_checked": (q.result().text == want) if want is not None else None,
+            "parity_source": f"tests/golden/ref_full_{golden}.tbl (the unmodified reference's answer on the same rows)"}
+
+
+def config_extras(ctx, sf10_table, sf: float):
+    """BASELINE configs 2 (Q1 SF1) and 3 (Q3 SF10) and Q6 at SF10 on this GPU; each result is compared with the reference's
+    recorded answer.  Q1 at SF1 is a 228 MB scan (~30 us at peak): launch-latency shaped, ms_per_step says so."""
+    from resql_amd import datagen, engine, tpch
+    out = {}
+    schema_q1 = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
+    # ---- config 2: Q1 at SF1 ----
+    n1 = datagen.n_lineitem(1.0)
+    t1 = ctx.generate(engine.GEN_LINEITEM, n1, 1.0)
+    q = ctx.compile(tpch.q1_plan(schema_q1), [t1])
+    m = _measure_plan(q, 200, "q1_sf1", tpch.Q1_BYTES_PER_ROW * n1)
+    out["q1_sf1"] = {"workload": f"TPC-H Q1 over lineitem SF1 ({n1} rows) on one GPU (BASELINE config 2)", "ms_per_step": m["exec_ms"],
+                     "rows_per_s": n1 / (m["exec_ms"] * 1e-3), "kernel_ms": m["kernel_ms"], "frac": m["algorithmic_frac"], "launches": m["launches"],
+                     "parity_checked": m["parity_checked"], "parity_source": m["parity_source"]}
+    q.close(); t1.close()
+    # ---- Q6 at SF10 (late loads behind the selective date filter: fewer bytes fetched than the columns hold) ----
+    if sf == 10.0:
+        n = sf10_table.n_rows
+        q = ctx.compile(tpch.q6_plan(schema_q1), [sf10_table])
+        m = _measure_plan(q, 50, "q6_sf10", tpch.Q6_BYTES_PER_ROW * n)
+        tf, src = _committed_late_load_traffic("q6", n)
+        m.update({"workload": f"TPC-H Q6 over lineitem SF10 ({n} rows): scan + 5 comparisons + ungrouped sum", "traffic_frac": tf, "traffic_source": src,
+                  "note": "algorithmic_frac can exceed what the bytes actually fetched allow (late loads skip cache lines): traffic_frac is the roofline figure"})
+        out["q6_sf10"] = m
+        q.close()
+        # ---- config 3: Q3 at SF10 ----
+        nL, nO, nC = datagen.n_lineitem(10.0), datagen.n_orders(10.0), datagen.n_customer(10.0)
+        li = ctx.generate(engine.GEN_LINEITEM, nL, 10.0, param=1)
+        od = ctx.generate(engine.GEN_ORDERS, nO, 10.0)
+        cu = ctx.generate(engine.GEN_CUSTOMER, nC, 10.0)
+        plan = tpch.q3_plan(tpch.customer_table(0.001), tpch.orders_table(0.001), tpch.lineitem_table(0.001, tpch.Q3_LINEITEM_COLUMNS, n_rows=0))
+        q = ctx.compile(plan, [cu, od, li])
+        streaming = (4 + 10) * nC + (4 + 4 + 4 + 4) * nO + (4 + 4 + 8 + 8) * nL          # SURVEY.md §8d
+        m = _measure_plan(q, 30, "q3_sf10", streaming)
+        m.update({"workload": f"TPC-H Q3 at SF10 (customer {nC}, orders {nO}, lineitem {nL}): 2 joins + aggregation at the join entry + ORDER BY ... LIMIT 10 "
+                              f"(BASELINE config 3)",
+                  "note": "algorithmic_frac is against the STREAMING bytes of the three scans: an upper-bound figure, the probes are random accesses (SURVEY.md §8d)"})
+        out["q3_sf10"] = m
+        q.close()
+        for t in (li, od, cu):
+            t.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
@@ -622,7 +719,14 @@ def main(argv=None) -> int:
         except Exception as e:  # an extra never costs the bench line
             weak_error = f"{type(e).__name__}: {e}"
 
-    _mark(f"extras done ({weak_error})")
+    configs = None
+    configs_error = None
+    if not args.no_extras and world == 1 and rank == 0:
+        try:
+            configs = config_extras(ctx, table, args.sf)
+        except Exception as e:
+            configs_error = f"{type(e).__name__}: {e}"
+    _mark(f"extras done ({weak_error}, {configs_error})")
     rc = 0
     if rank == 0:
         result = q.result()
@@ -668,10 +772,16 @@ def main(argv=None) -> int:
                          "frac_of_measured_read_roofline": (achieved / measured) if measured else None},
         }
         rc = check_parity(result.text, args.sf, out)
+        if configs is not None or configs_error is not None:
+            out.setdefault("extras", {}).update(configs if configs is not None else {"configs_error": configs_error})
+            bad = [k for k, v in (configs or {}).items() if v.get("parity_checked") is False]
+            if bad:
+                print(f"bench.py: extras {bad} differ from the reference's recorded answers", file=sys.stderr)
+                rc = rc or 4
         if weak is not None or weak_error is not None:
-            out["extras"] = {"weak_scaling": weak if weak is not None else {"error": weak_error},
+            out.setdefault("extras", {}).update({"weak_scaling": weak if weak is not None else {"error": weak_error},
                              "weak_scaling_note": "BASELINE config 5: one synthetic 4 x int64 shard per GPU (rows_per_gpu), a < tau at 10 %, "
-                                                  "group by b, 2 sums + count; whole step incl. merge and rank 0's host tail; untimed for `value`"}
+                                                  "group by b, 2 sums + count; whole step incl. merge and rank 0's host tail; untimed for `value`"})
         if world == 1 and not args.no_cpu_baseline:
             want_sf = args.cpu_baseline_sf if args.cpu_baseline_sf is not None else args.sf
             try:

@@ -2259,7 +2259,6 @@ struct Walker {
         // values address — and few of its rows go further: it wants several tiles in flight per wave.  TPC-H Q3 at SF10, all kernels:
         // 0.415 ms with one tile, 0.381 with two, 0.367 with three, 0.363 with four (RSQ_COMPACT_UNROLL).
         if (!getenv("RSQ_UNROLL") && pipe.compact) pipe.unroll = envInt("RSQ_COMPACT_UNROLL", 4, 1, 8);
-        const int U = pipe.unroll;
         const bool mat = pipe.sink == SinkKind::MATERIALIZE;
         std::ostringstream s;
         s << "// generated by resql_amd/csrc/codegen.cpp\n//   ";
@@ -2302,7 +2301,25 @@ struct Walker {
             }
         }
         pipe.lateLoads = late;
+        // The late-load form keeps the LEADING columns in flight, so its tiles per wave follow their width, not the row's (1.25 B
+        // synthetic rows: 8 of 32 bytes lead -> four tiles).  It is software-pipelined (the main loop below): not for the few
+        // shapes whose tile loads carry more than plain columns.
+        // Measured (MI355X, 1.25 B synthetic rows, G = 8; kernel ms, plain order with two tiles -> pipelined with 2 / 3 / 4 tiles):
+        // 1 %: 3.51 -> 2.48 / 2.40 / 2.24; 10 %: 5.86 -> 5.17 / 5.21 / 5.35; TPC-H Q6 SF10 (2 %, 20 leading bytes): 0.206 -> 0.192 / 0.191
+        // / 0.197.  The more rows pass, the more of the late registers are really in use and the fewer tiles pay.
+        const bool latePipelined = late && envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) == 0;
+        bool anyGated = false;
+        for (auto& pf : bitmapPrefetch) anyGated |= pf.gated;
+        // ... and so is the loop of a pipeline behind a wave compaction (measurement switch RSQ_CQ_PIPELINE while it is being judged)
+        const bool cqPipelined = pipe.compact && !late && pipe.sink != SinkKind::MATERIALIZE && !anyGated && envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) == 0 &&
+                                 envInt("RSQ_CQ_PIPELINE", 1, 0, 1) != 0;
+        if (late && !getenv("RSQ_UNROLL") && pipe.gridPerCU == 2) {
+            int64_t leadBytes = 0;
+            for (int k : leadCols) leadBytes += colTypes[(size_t)k] == "i64" ? 8 : colTypes[(size_t)k] == "i32" ? 4 : 1;
+            if (leadBytes > 0) pipe.unroll = (int)std::max<int64_t>(1, std::min<int64_t>(leadPass <= 0.04 ? 4 : 2, (4608 + leadBytes * 128 - 1) / (leadBytes * 128)));
+        }
         pipe.leadPass = leadCond.empty() || !leadPassComplete ? -1.0 : leadPass;      // (for the engine's first layout of staged regions: only a complete estimate)
+        const int U = pipe.unroll;
         // 63 left over + 128 pushed by one tile, rounded up.  (RSQ_QCAP=128 drains after every row_fn call instead: smaller
         // queues, 7 instead of 4 workgroups of a five-word pipeline per CU — measured slower: Q3's orders pipeline 0.24 ->
         // 0.31 ms, its inserts do not want more waves.)
@@ -2463,6 +2480,89 @@ struct Walker {
         // were dispatched first run ahead (the SIMDs favour older waves: device timestamps show TPC-H Q3's lineitem workgroups
         // finishing between 61 and 97 us in the order of their index) and the launch ends on the few that are left alone with a
         // CU; sharing a pool between workgroups of different age lets the fast ones take the rest.
+        auto emitPipelinedLoop = [&]() {
+            // The software-pipelined main loop.  Per iteration a wave
+            //   (1) works on its U tiles whose columns were requested ONE ITERATION AGO: the late-load form decides the leading
+            //       selection and requests the other columns for the lanes that hold a passing row; a pipeline behind a wave
+            //       compaction requests the key-bitmap words its rows address;
+            //   (2) requests the NEXT iteration's tile columns;
+            //   (3) runs the row function (and the drains of the compaction queues).
+            // Memory operations return in issue order, so (2) must stand behind (1): whoever waits for the dependent loads of (1) waits
+            // for everything issued before them, never for what was issued after.  The wave then stalls once per iteration with the
+            // next tiles' stream in flight the whole time; the plain order - tile loads, wait, dependent loads, wait, rows - had
+            // nothing streaming during the second wait and the drains (1.25 B rows at 1 %: 3.69 ms for 14.5 GB fetched, 0.49 of peak).
+            // The loads of (2) are unconditional, their tile index clamped to the last tile: the compiler counts the loads it KNOWS
+            // stand behind the dependent ones when it places the wait in front of the row function - a load under a condition
+            // would not count and the wait would cover the next tiles too.
+            std::vector<int> tileCols;
+            if (late) tileCols = leadCols;
+            else for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) tileCols.push_back(k);
+            auto isLazy = [&](int k) { return std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) != pipe.lazyCols.end(); };
+            auto tileLoads = [&](const std::string& ind, const char* pre, int u) {      // pre: "t" / "s" (this iteration's) or "n" / "ns" (the next one's)
+                const std::string spre = pre[0] == 'n' ? "ns" : "s";
+                for (auto& sp : strPrefetch)
+                    for (int j = 0; j < 2; j++)
+                        for (int w = 0; w * 8 < sp.second; w++)
+                            s << ind << spre << sp.first << "_" << u << "_" << j << "_" << w << " = rsq::ld_bytes<" << std::min(8, sp.second - w * 8) << ">(a.c" << sp.first
+                              << " + (b + " << j << ") * " << strPrefetchWidth[sp.first] << " + " << w * 8 << ");\n";
+                for (int k : tileCols) {
+                    if (isLazy(k)) s << "#if !RSQ_LAZY\n";
+                    s << ind << "rsq::ld2(a.c" << k << " + b, " << pre << k << "_" << u << ");\n";
+                    if (isLazy(k)) s << "#endif\n";
+                }
+            };
+            s << "    const i64 tend = ntiles;\n";
+            for (int u = 0; u < U; u++) {
+                for (int k : tileCols) s << "    " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2] = {0, 0};\n";
+                for (auto& sp : strPrefetch) for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++) s << "    u64 s" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
+            }
+            for (int u = 0; u < U; u++) {
+                s << "    {\n        const i64 p = wave * tstep + " << u << " * nwaves * tstep;\n        if (p < tend) {\n            const i64 b = (p << 7) + lane * 2;\n";
+                tileLoads("            ", "t", u);
+                s << "        }\n    }\n";
+            }
+            s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
+            for (int u = 0; u < U; u++) {
+                s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
+                for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k] && lateCol[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2] = {0, 0};\n";
+            }
+            if (late) for (int u = 0; u < U; u++) emitLateLoads(s, "tt" + std::to_string(u), u, lateCol, "tend");
+            for (int u = 0; u < U; u++)
+                for (auto& pf : bitmapPrefetch) {
+                    s << "        u32 pf_" << pf.first << "_" << u << "[2] = {0u, 0u};\n";
+                    s << "        if (tt" << u << " < tend) {\n";
+                    for (int j = 0; j < 2; j++)
+                        s << "            pf_" << pf.first << "_" << u << "[" << j << "] = " << (pf.interleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") << pf.first << "_bm, a." << pf.first
+                          << "_bmmin, a." << pf.first << "_bmbits, (i64)t" << pf.second << "_" << u << "[" << j << "]);\n";
+                    s << "        }\n";
+                }
+            for (int u = 0; u < U; u++) {
+                for (int k : tileCols) s << "        " << colTypes[(size_t)k] << " n" << k << "_" << u << "[2] = {0, 0};\n";
+                for (auto& sp : strPrefetch) for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++) s << "        u64 ns" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
+                s << "        {\n            const i64 nt = tt" << u << " + nwaves * tstep * " << U << ";\n            const i64 b = ((nt < tend ? nt : tend - 1) << 7) + lane * 2;\n";
+                tileLoads("            ", "n", u);
+                s << "        }\n";
+            }
+            for (int u = 0; u < U; u++) {
+                s << "        if (tt" << u << " < tend) {\n";
+                for (int j = 0; j < 2; j++) {
+                    s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");
+                    for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
+                    for (auto& sp : strPrefetch) for (int w = 0; w * 8 < sp.second; w++) s << ", s" << sp.first << "_" << u << "_" << j << "_" << w;
+                    for (auto& pf : bitmapPrefetch) s << ", pf_" << pf.first << "_" << u << "[" << j << "]";
+                    s << ");\n";
+                    if (cq && (QCAP < 192 || j == 1)) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";
+                }
+                s << "        }\n";
+            }
+            for (int u = 0; u < U; u++) {
+                for (int k : tileCols) s << "        t" << k << "_" << u << "[0] = n" << k << "_" << u << "[0]; t" << k << "_" << u << "[1] = n" << k << "_" << u << "[1];\n";
+                for (auto& sp : strPrefetch) for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++)
+                    s << "        s" << sp.first << "_" << u << "_" << j << "_" << w << " = ns" << sp.first << "_" << u << "_" << j << "_" << w << ";\n";
+            }
+            s << "    }\n";
+        };
+        auto emitPlainLoop = [&]() {
         if (dynamicTiles) {
             // chunks of U consecutive tiles, dealt to the pools round-robin (chunk c belongs to pool c % pools): at any moment the
             // pools work on neighbouring chunks, i.e. the chip reads one contiguous window of the table, spread over all HBM
@@ -2542,6 +2642,24 @@ struct Walker {
             s << "        }\n";
         }
         s << "    }\n";
+        };
+        // Double-buffered tile registers pay where the tiles are narrow: the late-load form (leading columns only), the RSQ_LAZY 1
+        // form of a compaction pipeline (the columns stage 1 reads), any compaction pipeline whose tiles take few registers.  A
+        // wide eager tile set would cost the occupancy the plan needs (TPC-H Q5 / Q10 lineitem: 133 -> 183 VGPRs).
+        {
+            int eagerRegs = 0, lazyRegs = 0;      // VGPRs of one tile's columns: all of them / without the lazily loaded ones
+            for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) {
+                const int r = colTypes[(size_t)k] == "i64" ? 4 : colTypes[(size_t)k] == "i32" ? 2 : 1;
+                eagerRegs += r;
+                if (std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) == pipe.lazyCols.end()) lazyRegs += r;
+            }
+            for (auto& sp : strPrefetch) { eagerRegs += 4 * ((sp.second + 7) / 8); lazyRegs += 4 * ((sp.second + 7) / 8); }
+            const int budget = envInt("RSQ_CQ_PIPELINE_REGS", 24, 0, 256);
+            const bool eagerOk = cqPipelined && eagerRegs * U <= budget, lazyOk = cqPipelined && lazyRegs * U <= budget;
+            if (latePipelined || (eagerOk && (lazyOk || pipe.lazyCols.empty()))) emitPipelinedLoop();
+            else if (lazyOk && !pipe.lazyCols.empty()) { s << "#if RSQ_LAZY\n"; emitPipelinedLoop(); s << "#else\n"; emitPlainLoop(); s << "#endif\n"; }
+            else emitPlainLoop();
+        }
         if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 1] = (u64)wall_clock64();\n";
         if (cq) {
             // tail rows with a wave-uniform trip count (the push votes across the wave)

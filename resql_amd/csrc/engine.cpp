@@ -240,7 +240,9 @@ static std::vector<std::string> kernelSources(const Query& q) {
 static void resolveKernels(Query& q) {
     Context& ctx = q.ctx;
     // (compiling a query's kernels on one host thread each was tried: hiprtc serialises internally, TPC-H Q3's three kernels took
-    // 548 ms in parallel against 448 ms one after the other)
+    // 548 ms in parallel against 448 ms one after the other.  What is not in the cache is therefore compiled in helper PROCESSES
+    // first, all at once - runtime.cpp compileManyToCache - and the loop below finds it there)
+    ctx.compileManyToCache(kernelSources(q));
     for (auto& p : q.pipelines) {
         if (!p.sourcePass1.empty()) p.kernelPass1 = &ctx.getKernel(p.sourcePass1, p.entry);
         if (!p.sourceFlat.empty()) p.kernelFlat = &ctx.getKernel(p.sourceFlat, p.entry);
@@ -321,7 +323,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
                 Query* qp = q.get();
                 q->bgState = 1;
                 q->bgCompiler = std::thread([qp, sources] {
-                    try { for (const std::string& src : sources) if (!qp->ctx.kernelCachedOnDisk(src)) qp->ctx.compileToCache(src); qp->bgState = 2; }
+                    try { qp->ctx.compileManyToCache(sources); qp->bgState = 2; }      // (one helper process per kernel: hiprtc serialises inside a process)
                     catch (const std::exception& e) { qp->bgError = e.what(); qp->bgState = 3; }
                 });
             }

@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -98,6 +100,10 @@ struct Context {
     bool kernelCachedOnDisk(const std::string& source);      // (no access to the table of loaded kernels: for the compiler thread)
     // compile `source` into the on-disk cache without touching the context's tables: safe on another host thread
     void compileToCache(const std::string& source);
+    // ... several at once, in parallel helper processes (runtime.cpp); returns with every source in the on-disk cache
+    void compileManyToCache(const std::vector<std::string>& sources);
+    std::set<std::string> freshlyCompiled;      // keys compileManyToCache built and getKernel has not loaded yet
+    std::mutex freshMutex;
     std::string cacheKey(const std::string& source);
     void* alloc(size_t bytes);
     void free(void* p);

@@ -5,11 +5,14 @@
 // object via hiprtc, in process, with an on-disk cache so that a pipeline shape is compiled once
 // (the cache is pre-populated at build time, __graft_entry__.build()).
 #include "engine.h"
+#include "kernel_compile_options.h"
 
 #include <dlfcn.h>
 #include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -17,6 +20,9 @@
 #include <atomic>
 #include <fstream>
 #include <sstream>
+#include <thread>
+
+extern char** environ;
 
 namespace rsq {
 
@@ -139,9 +145,9 @@ static bool readFile(const std::string& path, std::string& out) {
     return true;
 }
 
-static const char* const kHiprtcArch = "--offload-arch=gfx950";
-static const char* const kHiprtcOpt = "-O3";
-static const char* const kHiprtcStd = "-std=c++17";
+static const char* const kHiprtcArch = RSQ_HIPRTC_ARCH;
+static const char* const kHiprtcOpt = RSQ_HIPRTC_OPT;
+static const char* const kHiprtcStd = RSQ_HIPRTC_STD;
 
 static std::string compileWithHiprtc(Context& ctx, const std::string& source) {
     hiprtcProgram prog;
@@ -204,6 +210,59 @@ static void writeCacheEntry(const std::string& cacheDir, const std::string& key,
     publish(cacheDir + "/" + key + ".hsaco", code);
 }
 
+// Several kernels at once: one helper process per kernel (kernel_compiler.cpp), because hiprtc serialises inside a process.  The
+// helpers are fresh processes started with posix_spawn - children of this one, never a replacement of it -, load hiprtc only and
+// touch no GPU; their results arrive in the on-disk cache.  Whatever a helper did not deliver (no helper binary, a spawn that
+// failed, a crash) is compiled in process afterwards, so the function always ends with every source cached or an exception.
+void Context::compileManyToCache(const std::vector<std::string>& sources) {
+    (void)cacheKey("");
+    std::vector<std::pair<std::string, const std::string*>> todo;      // (key, source) of what is not cached yet, each key once
+    for (const std::string& src : sources) {
+        if (kernelCachedOnDisk(src)) continue;
+        const std::string key = cacheKey(src);
+        bool seen = false;
+        for (auto& t : todo) seen = seen || t.first == key;
+        if (!seen) todo.emplace_back(key, &src);
+    }
+    static const bool helpersOff = getenv("RSQ_COMPILE_HELPERS") && atoi(getenv("RSQ_COMPILE_HELPERS")) == 0;
+    const std::string helper = libraryDir() + "/rsq_kernel_compiler";
+    if (todo.size() > 1 && !helpersOff && access(helper.c_str(), X_OK) == 0) {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t nProc = std::min<size_t>(todo.size(), std::max<size_t>(1, std::min<size_t>(hw, 32)));
+        std::vector<std::vector<std::string>> share(nProc);
+        for (size_t i = 0; i < todo.size(); i++) {
+            // the source goes first (a code object is only trusted beside its own source), and is what the helper reads
+            const std::string path = cacheDir + "/" + todo[i].first + ".hip";
+            const std::string tmp = path + ".tmp" + std::to_string((long)getpid()) + "_" + std::to_string(i);
+            std::ofstream f(tmp, std::ios::binary);
+            f.write(todo[i].second->data(), (std::streamsize)todo[i].second->size());
+            f.close();
+            if (!f || rename(tmp.c_str(), path.c_str()) != 0) { (void)remove(tmp.c_str()); continue; }
+            (void)remove((cacheDir + "/" + todo[i].first + ".err").c_str());
+            share[i % nProc].push_back(todo[i].first);
+        }
+        std::vector<pid_t> pids;
+        for (auto& keys : share) {
+            if (keys.empty()) continue;
+            std::vector<char*> argv;
+            argv.push_back(const_cast<char*>(helper.c_str()));
+            argv.push_back(const_cast<char*>(includeDir.c_str()));
+            argv.push_back(const_cast<char*>(cacheDir.c_str()));
+            for (auto& k : keys) argv.push_back(const_cast<char*>(k.c_str()));
+            argv.push_back(nullptr);
+            pid_t pid = 0;
+            if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) == 0) pids.push_back(pid);
+        }
+        for (pid_t pid : pids) { int st = 0; while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {} }
+        for (auto& t : todo) {          // a compile error is an error of the kernel text, the same in any process: report it, do not repeat it
+            std::string log;
+            if (readFile(cacheDir + "/" + t.first + ".err", log)) { (void)remove((cacheDir + "/" + t.first + ".err").c_str()); throw Error(RSQ_ERR_DEVICE, "hiprtc compilation failed:\n" + log); }
+        }
+    }
+    for (auto& t : todo) if (!kernelCachedOnDisk(*t.second)) compileToCache(*t.second);
+    { std::lock_guard<std::mutex> g(freshMutex); for (auto& t : todo) freshlyCompiled.insert(t.first); }      // (the report counts them as compiles, not as cache hits)
+}
+
 void Context::compileToCache(const std::string& source) {
     // (cacheKey reads headerText, which the calling thread has filled before it started this one)
     const std::string key = cacheKey(source);
@@ -220,8 +279,10 @@ Kernel& Context::getKernel(const std::string& source, const std::string& entry) 
     Kernel k;
     std::string storedSource;
     if (readFile(path, code) && !code.empty() && (!readFile(cacheDir + "/" + key + ".hip", storedSource) || storedSource == source)) {
-        k.fromCache = true;              // (the source stored beside the code object is compared: a key collision compiles afresh)
-        jitCacheHits++;
+        bool fresh;
+        { std::lock_guard<std::mutex> g(freshMutex); fresh = freshlyCompiled.erase(key) != 0; }
+        k.fromCache = !fresh;            // (the source stored beside the code object is compared: a key collision compiles afresh)
+        if (fresh) jitCompiles++; else jitCacheHits++;
     } else {
         code = compileWithHiprtc(*this, source);
         jitCompiles++;
