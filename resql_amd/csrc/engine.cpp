@@ -1674,6 +1674,16 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
                 h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
                 while ((int64_t)h.lastCount * 2 > h.capacity) h.capacity *= 2;
             }
+            // ... or a small corner of it: the reference's estimate knows nothing of the joins' selectivity (TPC-H Q10 at SF10: 16 M slots
+            // of 32 words = 4 GB for 380 K groups).  Every new group then sits alone on its pages and cache lines, and the
+            // compaction of the group rows reads 16 M state words to find them: once the group count is known the table
+            // is cut to four times that.  (The table's size is invisible in the result: the emission order is the REFERENCE table's,
+            // replayed from the reference's hashes.)
+            else if (h.lastCount > 0 && h.capacity > 4096 && (int64_t)h.lastCount * 16 < h.capacity) {
+                if (h.dState) { ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc); }
+                h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
+                h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)h.lastCount));
+            }
             for (;;) {
                 if (!h.dState) {
                     h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
