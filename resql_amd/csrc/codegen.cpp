@@ -283,7 +283,6 @@ struct Walker {
     // the selection directly above the scan: its text over the row's column variables, the columns it reads and the fraction of
     // rows it is expected to pass (column statistics, values taken as uniform) - the late-load form of the tile loop (below)
     std::string leadCond; std::vector<int> leadCols; double leadPass = 1.0;
-    std::string prologueCq;                 // the part of the kernel prologue that sets up the compaction queues (finishPipeline)
     bool leadPassComplete = true;       // every part of the predicate was understood (else the estimate is an upper bound only)
     std::string stage2Body;
     std::vector<std::pair<std::string, Sym>> cqLive;     // carried symbols: name -> stage-1 variable and type
@@ -371,7 +370,7 @@ struct Walker {
         explainSteps.clear(); indent = 1; matchSlotTable = -1; slotVar.clear(); symbolOrigin.clear(); symbolWord.clear();
         multiMatchAbove = false;
         selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
-        leadCond.clear(); leadCols.clear(); leadPass = 1.0; leadPassComplete = true; prologueCq.clear();
+        leadCond.clear(); leadCols.clear(); leadPass = 1.0; leadPassComplete = true;
         strPrefetch.clear(); strPrefetchWidth.clear(); eg.strWordVars.clear();
         eg.symbols.clear();
         o->schema.clear();
@@ -2311,9 +2310,10 @@ struct Walker {
         const bool latePipelined = late && envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) == 0;
         bool anyGated = false;
         for (auto& pf : bitmapPrefetch) anyGated |= pf.gated;
-        // ... and so is the loop of a pipeline behind a wave compaction (measurement switch RSQ_CQ_PIPELINE while it is being judged)
-        const bool cqPipelined = pipe.compact && !late && pipe.sink != SinkKind::MATERIALIZE && !anyGated && envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) == 0 &&
-                                 envInt("RSQ_CQ_PIPELINE", 1, 0, 1) != 0;
+        // ... and so is the loop of a pipeline behind a wave compaction, where its tiles are narrow (below).  Measured at SF10, whole
+        // statements: TPC-H Q5 0.707 -> 0.687 ms, Q14 0.289 -> 0.276, Q3 0.289 -> 0.285, the others within noise: these pipelines are
+        // bound by the dependent accesses of stage 2 (Q5's lineitem pipeline as two kernels: scan 81 us, stage 2 363 us), not by the stream.
+        const bool cqPipelined = pipe.compact && !late && pipe.sink != SinkKind::MATERIALIZE && !anyGated && envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) == 0;
         if (late && !getenv("RSQ_UNROLL") && pipe.gridPerCU == 2) {
             int64_t leadBytes = 0;
             for (int k : leadCols) leadBytes += colTypes[(size_t)k] == "i64" ? 8 : colTypes[(size_t)k] == "i32" ? 4 : 1;
@@ -2349,27 +2349,8 @@ struct Walker {
             addArg("cq_total", "unsigned long long*", 0);
             epilogue += "    if (blockIdx.x < 64) {\n        const u64 v = rsq::wave_sum((u64)st.cq_rows);\n        if ((threadIdx.x & 63) == 0 && v) atomicAdd(a.cq_total, (unsigned long long)v);\n    }\n";
             const std::string nv = twoForms ? "RSQ_CQ_NV" : std::to_string(NV);
-            // The SPLIT form (RSQ_SPLIT 1 / 2; 0 = this one kernel): stage 1 and stage 2 as two kernels with the survivors in a queue in
-            // HBM between them.  A fused kernel runs its scan at the register count and occupancy of everything behind the compaction
-            // point, and its waves alternate between streaming tiles and chains of dependent random accesses; apart, the scan
-            // kernel is a narrow streaming kernel and the stage-2 kernel does nothing but probe, every lane busy.  The queue costs
-            // 8 bytes per carried word and survivor, written and read once, coalesced (TPC-H Q5's lineitem pipeline: 9.1 M of 60 M
-            // rows x 16 bytes).  Same source text: RSQ_SPLIT 1 replaces the drain by an append to the queue and drops everything
-            // that belongs to stage 2 (its LDS tables, the epilogue); RSQ_SPLIT 2 replaces the scan by a loop over the queue.
-            // (aggregation sinks only: the build of a bitmap-rank dictionary appends its records to one region per WAVE OF ITS GRID,
-            // HashTable::dTemp - a stage-2 kernel with a grid of its own would write past them)
-            pipe.splitCapable = !mat && pipe.sink != SinkKind::BUILD && !pipe.partitioned && !pipe.persistentForm && envInt("RSQ_SPLIT_STAGES", 1, 0, 2) != 0;
-            // The queue is one REGION per wave of the scan kernel (gq_region entries, enough for every row the wave is dealt; word w of
-            // entry e of region r at gq[w * gq_cap + r * gq_region + e]), filled front to back by that wave alone, its length in
-            // gq_count[r]: no atomics.  (One shared cursor was tried first: 142 K appends of TPC-H Q5's lineitem pipeline to ONE
-            // word serialise at the memory side - 0.69 -> 1.97 ms.)  A wave of the stage-2 kernel takes every n-th region.
-            if (pipe.splitCapable) {
-                addArg("gq", "i64*", 0); addArg("gq_cap", "u64", 0); addArg("gq_count", "unsigned long long*", 0); addArg("gq_region", "u64", 0); addArg("gq_nreg", "u64", 0);
-                stateDecl += "    u64 gq_base = 0;\n    u32 gq_n = 0;\n";
-            }
-            prologueCq = "    __shared__ i64 s_cq[(RSQ_BLOCK_THREADS / 64) * " + nv + " * " + std::to_string(QCAP) + "];\n";
-            prologueCq += "    st.cq = s_cq + (threadIdx.x >> 6) * " + nv + " * " + std::to_string(QCAP) + ";\n";
-            if (pipe.splitCapable) prologueCq += "#if RSQ_SPLIT == 1\n    st.gq_base = ((u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * a.gq_region;\n#endif\n";
+            prologue += "    __shared__ i64 s_cq[(RSQ_BLOCK_THREADS / 64) * " + nv + " * " + std::to_string(QCAP) + "];\n";
+            prologue += "    st.cq = s_cq + (threadIdx.x >> 6) * " + nv + " * " + std::to_string(QCAP) + ";\n";
         }
         if (twoForms) s << "#if RSQ_LAZY\n#define RSQ_CQ_NV " << NVL << "\n#else\n#define RSQ_CQ_NV " << NV << "\n#endif\n";
         s << "#ifndef RSQ_BLOCK_THREADS\n#define RSQ_BLOCK_THREADS " << pipe.blockThreads << "\n#endif\n";
@@ -2382,14 +2363,6 @@ struct Walker {
             s << "static RSQ_DEV void stage2(const Args& a, State& st, const i64 row";
             for (int k = 0; k < pipe.compactWords; k++) s << ", const i64 qw_" << k;
             s << ") {\n" << stage2Body << "}\n";
-            if (pipe.splitCapable) {
-                s << "#if RSQ_SPLIT == 1\n";
-                s << "static RSQ_DEV void cq_drain(const Args& a, State& st, const int count) {      // append to this wave's region of the queue in HBM\n";
-                s << "    const int lane = threadIdx.x & 63;\n    const int i = st.cq_n - count + lane;\n";
-                s << "    if (lane < count) {\n        if ((u64)st.gq_n + (u64)lane < a.gq_region) {\n            const u64 at = st.gq_base + st.gq_n + lane;\n";
-                for (int k = 0; k <= pipe.compactWordsLazy; k++) s << "            a.gq[" << k << "ull * a.gq_cap + at] = st.cq[" << k * QCAP << " + i];\n";
-                s << "        } else atomicOr(a.err, (u32)rsq::ERR_STUCK);\n    }\n    st.gq_n += (u32)count;\n    st.cq_n -= count;\n}\n#else\n";
-            }
             s << "static RSQ_DEV void cq_drain(const Args& a, State& st, const int count) {\n";
             s << "    const int lane = threadIdx.x & 63;\n    const int i = st.cq_n - count + lane;\n";
             s << "    if (lane < count) {\n        stage2(a, st, st.cq[i]";
@@ -2402,7 +2375,6 @@ struct Walker {
                 s << "\n#endif\n        ";
             }
             s << ");\n        st.cq_rows++;\n    }\n    st.cq_n -= count;\n}\n";
-            if (pipe.splitCapable) s << "#endif\n";
         }
         bool gatedPrefetch = false;
         for (auto& pf : bitmapPrefetch) gatedPrefetch |= pf.gated;
@@ -2451,9 +2423,7 @@ struct Walker {
         s << "#ifdef RSQ_MIN_WG\nextern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS, RSQ_MIN_WG) " << pipe.entry << "(Args a) {\n#else\n";
         s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n#endif\n";
         if (pipe.persistentForm) s << "#endif\n";
-        s << "    State st;\n";
-        if (pipe.splitCapable) s << "#if RSQ_SPLIT != 1\n" << prologue << "#endif\n#if RSQ_SPLIT != 2\n" << prologueCq << "#endif\n";
-        else s << prologue << prologueCq;
+        s << "    State st;\n" << prologue;
         if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 0] = (u64)wall_clock64();\n";
         s << "    const int lane = threadIdx.x & 63;\n";
         s << "    const i64 wave = (i64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);\n";
@@ -2677,16 +2647,6 @@ struct Walker {
         // Double-buffered tile registers pay where the tiles are narrow: the late-load form (leading columns only), the RSQ_LAZY 1
         // form of a compaction pipeline (the columns stage 1 reads), any compaction pipeline whose tiles take few registers.  A
         // wide eager tile set would cost the occupancy the plan needs (TPC-H Q5 / Q10 lineitem: 133 -> 183 VGPRs).
-        if (pipe.splitCapable) {
-            s << "#if RSQ_SPLIT == 2\n";
-            s << "    for (u64 r = (u64)wave; r < a.gq_nreg; r += (u64)nwaves) {\n";
-            s << "        const u64 rn = (u64)a.gq_count[r] < a.gq_region ? (u64)a.gq_count[r] : a.gq_region;\n";
-            s << "        for (u64 e = (u64)lane; e < rn; e += 64) {\n            const u64 i = r * a.gq_region + e;\n";
-            s << "            stage2(a, st, a.gq[i]";
-            for (int k = 1; k <= pipe.compactWordsLazy; k++) s << ", a.gq[" << k << "ull * a.gq_cap + i]";
-            for (int k = pipe.compactWordsLazy; k < pipe.compactWords; k++) s << ", 0";
-            s << ");\n            st.cq_rows++;\n        }\n    }\n#else\n";
-        }
         {
             int eagerRegs = 0, lazyRegs = 0;      // VGPRs of one tile's columns: all of them / without the lazily loaded ones
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) {
@@ -2695,7 +2655,7 @@ struct Walker {
                 if (std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) == pipe.lazyCols.end()) lazyRegs += r;
             }
             for (auto& sp : strPrefetch) { eagerRegs += 4 * ((sp.second + 7) / 8); lazyRegs += 4 * ((sp.second + 7) / 8); }
-            const int budget = envInt("RSQ_CQ_PIPELINE_REGS", 24, 0, 256);
+            const int budget = 24;      // (64: TPC-H Q5 0.69 -> 0.78 ms, the eager form's 133 -> 183 VGPRs)
             const bool eagerOk = cqPipelined && eagerRegs * U <= budget, lazyOk = cqPipelined && lazyRegs * U <= budget;
             if (latePipelined || (eagerOk && (lazyOk || pipe.lazyCols.empty()))) emitPipelinedLoop();
             else if (lazyOk && !pipe.lazyCols.empty()) { s << "#if RSQ_LAZY\n"; emitPipelinedLoop(); s << "#else\n"; emitPlainLoop(); s << "#endif\n"; }
@@ -2709,7 +2669,6 @@ struct Walker {
             s << "        row_fn(a, st, r, valid" << rowArgsTailGuarded << ");\n";
             s << "        while (st.cq_n >= 64) cq_drain(a, st, 64);\n    }\n";
             s << "    while (st.cq_n > 0) cq_drain(a, st, st.cq_n < 64 ? st.cq_n : 64);\n";
-            if (pipe.splitCapable) s << "#if RSQ_SPLIT == 1\n    if (lane == 0) a.gq_count[wave] = (unsigned long long)st.gq_n;\n#endif\n#endif\n";
         } else {
             s << "    for (i64 r = (ntiles << 7) + (i64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (i64)gridDim.x * blockDim.x) {\n";
             if (mat) s << "        const i64 slot = ntiles * 64 + (r - (ntiles << 7));\n#if RSQ_PASS == 2\n        st.pos = a.offs[slot];\n#endif\n";
@@ -2719,7 +2678,7 @@ struct Walker {
         }
         if (pipe.staged) s << "#endif\n";
         if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 2] = (u64)wall_clock64();\n";
-        if (pipe.splitCapable) s << "#if RSQ_SPLIT != 1\n" << epilogue << "#endif\n"; else s << epilogue;
+        s << epilogue;
         if (dbgStamps) s << "    __syncthreads();\n    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 3] = (u64)wall_clock64();\n";
         s << "}\n";
         pipe.source = s.str();
@@ -2740,17 +2699,6 @@ struct Walker {
             pipe.sourcePartScatter = "#define RSQ_AGG_VARIANT 2\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
             if (pipe.staged) pipe.sourceStagedScatter = "#define RSQ_AGG_VARIANT 3\n#define RSQ_BLOCK_THREADS 1024\n" + pipe.source;
             pipe.source = "#define RSQ_AGG_VARIANT 0\n" + pipe.source;
-        }
-        if (pipe.splitCapable) {
-            // (the split kernels are the late-load form where there is one: only what stage 1 reads travels with the tiles and through the queue)
-            std::string base = pipe.source;
-            const std::string off = "#define RSQ_LAZY 0\n";
-            const size_t at = base.find(off);
-            if (at != std::string::npos) base.replace(at, off.size(), "#define RSQ_LAZY 1\n");
-            pipe.sourceSplitScan = "#define RSQ_SPLIT 1\n" + base;
-            pipe.sourceSplitStage2 = "#define RSQ_SPLIT 2\n" + base;
-            pipe.source = "#define RSQ_SPLIT 0\n" + pipe.source;
-            pipe.splitWords = 1 + pipe.compactWordsLazy;
         }
         if (!pipe.lazyCols.empty()) {          // the late-load form of the full-execution kernel: same text, RSQ_LAZY 1
             pipe.sourceLazy = pipe.source;

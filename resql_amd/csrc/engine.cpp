@@ -159,7 +159,6 @@ Query::~Query() {
     for (void* p : dMatCols) if (p) ctx.free(p);
     if (dGroupRows) ctx.free(dGroupRows);
     if (dPipeStats) ctx.free(dPipeStats);
-    for (auto& sq : split) { if (sq.words) ctx.scratchFree(sq.words); if (sq.counts) ctx.free(sq.counts); }
     if (dGroupCount) ctx.free(dGroupCount);
     if (dTopkImages) ctx.free(dTopkImages);
     if (dTopkHists) ctx.free(dTopkHists);
@@ -235,7 +234,6 @@ static std::vector<std::string> kernelSources(const Query& q) {
         if (p.staged) { v.push_back(p.sourceStagedScatter); v.push_back(p.sourceStagedAgg); }
         v.push_back(p.source);
         if (!p.sourceLazy.empty()) v.push_back(p.sourceLazy);      // (chosen at run time; compiled with the others so that choosing it never blocks an execution)
-        if (p.splitCapable) { v.push_back(p.sourceSplitScan); v.push_back(p.sourceSplitStage2); }
     }
     return v;
 }
@@ -259,7 +257,6 @@ static void resolveKernels(Query& q) {
         }
         p.kernel = &ctx.getKernel(p.source, p.entry);
         if (!p.sourceLazy.empty() && ctx.device < 0) (void)ctx.getKernel(p.sourceLazy, p.entry);      // build(): warm the cache with both forms
-        if (p.splitCapable && ctx.device < 0) { (void)ctx.getKernel(p.sourceSplitScan, p.entry); (void)ctx.getKernel(p.sourceSplitStage2, p.entry); }
     }
 }
 
@@ -421,16 +418,6 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     if (a.name == "sp_nwg") return (uint64_t)q.stageWorkgroups;
     (void)p;
     if (a.name == "cq_total") return (uint64_t)(uintptr_t)(q.dPipeStats + (&p - q.pipelines.data()));
-    if (a.name.compare(0, 3, "gq_") == 0 || a.name == "gq") {
-        const size_t pi = (size_t)(&p - q.pipelines.data());
-        if (pi >= q.split.size()) return 0;
-        const Query::SplitQueue& sq = q.split[pi];
-        if (a.name == "gq") return (uint64_t)(uintptr_t)sq.words;
-        if (a.name == "gq_cap") return sq.regions * sq.region;
-        if (a.name == "gq_region") return sq.region;
-        if (a.name == "gq_nreg") return sq.regions;
-        return (uint64_t)(uintptr_t)sq.counts;
-    }
     if (a.name == "cnt") return (uint64_t)(uintptr_t)q.dMatCnt;
     if (a.name == "offs") return (uint64_t)(uintptr_t)q.dMatOffs;
     if (a.name == "out_limit") return (uint64_t)q.matLimit;
@@ -564,47 +551,7 @@ static void debugStamps(Query& q, Pipeline& p) {
             p.entry.c_str(), p.lastGrid, early, dist(0).c_str(), dist(1).c_str(), dist(2).c_str(), dist(3).c_str());
 }
 
-// The split form of a compaction pipeline (codegen.cpp finishPipeline): scan kernel -> survivors' queue in HBM -> stage-2 kernel.
-// Taken when the previous execution sent less than a third of the rows to stage 2 (more, and the queue's traffic and the second
-// launch cost what the separation gains) and the queue - sized for EVERY row, so that it cannot overflow - stays below 4 GB.
-static bool launchPipelineSplit(Query& q, Pipeline& p, int countOnlyTable) {
-    static const int mode = getenv("RSQ_SPLIT_STAGES") ? atoi(getenv("RSQ_SPLIT_STAGES")) : 1;      // 0 never, 1 by the previous execution, 2 always (tests)
-    if (!p.splitCapable || mode == 0 || countOnlyTable >= 0 || q.flatRun) return false;
-    // (below ~16 M rows the pipeline is launch- and latency-shaped: TPC-H Q3's lineitem pipeline at SF1 took 97 us split, 49 us fused)
-    if (mode != 2 && !(p.stage2Rows >= 0 && p.stage2Rows * 3 < p.src->nRows && p.src->nRows >= (16 << 20))) return false;
-    if (p.sink != SinkKind::AGGREGATE) return false;
-    const size_t pi = (size_t)(&p - q.pipelines.data());
-    Context& ctx = q.ctx;
-    if (!p.kernelSplitScan) p.kernelSplitScan = &ctx.getKernel(p.sourceSplitScan, p.entry);
-    if (!p.kernelSplitStage2) p.kernelSplitStage2 = &ctx.getKernel(p.sourceSplitStage2, p.entry);
-    // the scan: as many workgroups as are resident (a narrow streaming kernel; the tiles in flight per wave do the rest)
-    const int64_t tiles = p.src->nRows >> 7;
-    const int wavesPerBlock = p.blockThreads / 64;
-    const int64_t want = std::max<int64_t>(1, (tiles + (int64_t)wavesPerBlock * p.unroll - 1) / ((int64_t)wavesPerBlock * p.unroll));
-    const int64_t scanGrid = std::min<int64_t>(want, (int64_t)std::min(8, residentWorkgroupsPerCU(p.kernelSplitScan, p.blockThreads)) * ctx.numCUs);
-    // one region of the queue per wave of the scan grid, large enough for every row the wave is dealt (tiles round-robin + its share of the tail rows)
-    const uint64_t regions = (uint64_t)scanGrid * (uint64_t)wavesPerBlock;
-    const uint64_t region = (((uint64_t)tiles + regions - 1) / regions) * 128 + 128;
-    const size_t bytes = (size_t)(regions * region) * (size_t)p.splitWords * 8;
-    if (bytes > ((size_t)4 << 30)) return false;
-    if (q.split.size() < q.pipelines.size()) q.split.resize(q.pipelines.size());
-    Query::SplitQueue& sq = q.split[pi];
-    if (sq.bytes < bytes) { if (sq.words) ctx.scratchFree(sq.words); sq.words = ctx.scratchAlloc(bytes); sq.bytes = bytes; }
-    if (sq.countsFor < regions) { if (sq.counts) ctx.free(sq.counts); sq.counts = (unsigned long long*)ctx.alloc((size_t)regions * 8); sq.countsFor = regions; }
-    sq.regions = regions; sq.region = region;
-    launchPipelineKernel(q, p, *p.kernelSplitScan, countOnlyTable, (unsigned)scanGrid);
-    // stage 2: every lane one survivor at a time; the grid covers what the last execution sent there, at most what is resident
-    const int64_t expect = std::max<int64_t>(p.stage2Rows, 1);
-    const int64_t s2Grid = std::max<int64_t>(1, std::min<int64_t>((expect + p.blockThreads - 1) / p.blockThreads,
-                                                                  (int64_t)residentWorkgroupsPerCU(p.kernelSplitStage2, p.blockThreads) * ctx.numCUs));
-    launchPipelineKernel(q, p, *p.kernelSplitStage2, countOnlyTable, (unsigned)s2Grid);
-    if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     %s: split form, scan %lld + stage 2 %lld workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(),
-                                     (long long)scanGrid, (long long)s2Grid, (long long)p.stage2Rows);
-    return true;
-}
-
 static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
-    if (!pass1 && launchPipelineSplit(q, p, countOnlyTable)) { debugStamps(q, p); return; }
     Kernel* k = pass1 ? p.kernelPass1 : (q.flatRun && p.kernelFlat ? p.kernelFlat : p.kernel);
     // late column loads (codegen.cpp compactThen): worth it when the previous execution sent few rows to stage 2
     static const int64_t lazyDen = getenv("RSQ_LAZY_THRESHOLD") ? std::max(1, atoi(getenv("RSQ_LAZY_THRESHOLD"))) : 32;
@@ -1673,16 +1620,6 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
                 if (h.dState) { ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc); }
                 h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
                 while ((int64_t)h.lastCount * 2 > h.capacity) h.capacity *= 2;
-            }
-            // ... or a small corner of it: the reference's estimate knows nothing of the joins' selectivity (TPC-H Q10 at SF10: 16 M slots
-            // of 32 words = 4 GB for 380 K groups).  Every new group then sits alone on its pages and cache lines, and the
-            // compaction of the group rows reads 16 M state words to find them: once the group count is known the table
-            // is cut to four times that.  (The table's size is invisible in the result: the emission order is the REFERENCE table's,
-            // replayed from the reference's hashes.)
-            else if (h.lastCount > 0 && h.capacity > 4096 && (int64_t)h.lastCount * 16 < h.capacity) {
-                if (h.dState) { ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc); }
-                h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
-                h.capacity = nextPow2(std::max<int64_t>(4096, 4 * (int64_t)h.lastCount));
             }
             for (;;) {
                 if (!h.dState) {

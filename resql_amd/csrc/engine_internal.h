@@ -212,11 +212,6 @@ struct Pipeline {
     std::vector<int> lazyCols;       // scanned columns only stage 2 needs (codegen.cpp compactThen): RSQ_LAZY 1 reads them by row
     std::string sourceLazy;
     Kernel* kernelLazy = nullptr;    // compiled when first chosen
-    // the split form of a compaction pipeline (codegen.cpp finishPipeline): stage 1 and stage 2 as two kernels, survivors in an HBM queue
-    bool splitCapable = false;
-    std::string sourceSplitScan, sourceSplitStage2;
-    Kernel* kernelSplitScan = nullptr; Kernel* kernelSplitStage2 = nullptr;
-    int splitWords = 0;              // words per queue entry: the row + the values stage 1 hands over
     bool matSkip = false;            // a materialisation whose write pass skips the tiles that counted nothing (codegen.cpp)
     bool persistentForm = false;     // the source holds the resident form of the one-launch step (RSQ_PERSISTENT 1; engine.cpp "the resident step")
     Kernel* kernelPersistent = nullptr;      // compiled when RSQ_PERSISTENT_STEP=1 first asks for it
@@ -291,10 +286,6 @@ struct Query {
     uint32_t stageMode = 0, stageWorkgroups = 0;
 
     uint64_t* dPipeStats = nullptr;        // per pipeline: rows that reached stage 2 (behind the wave compaction)
-    // per pipeline: the survivors' queue of the split form - [words][regions x region] i64 (from the context's scratch cache), one region
-    // per wave of the scan grid, its length in counts[region]
-    struct SplitQueue { void* words = nullptr; size_t bytes = 0; unsigned long long* counts = nullptr; uint64_t countsFor = 0, regions = 0, region = 0; };
-    std::vector<SplitQueue> split;
 
     // device-side materialisation (plans without aggregation)
     OpNode* matOp = nullptr;
