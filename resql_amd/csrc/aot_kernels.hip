@@ -596,32 +596,15 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix, int keyWord, bool keyIs32,
                     bool keyDesc, uint64_t* imageRange) {
     // slots per thread: every chunk costs one reservation atomic on the same word (they serialise), so large tables take
-    // large chunks; swept on the box through RSQ_COMPACT_PT for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us
-    static const int forced = getenv("RSQ_COMPACT_PT") ? atoi(getenv("RSQ_COMPACT_PT")) : 0;
-    const int perThread = forced ? forced : capacity >= (1 << 22) ? 64 : capacity >= (1 << 20) ? 32 : 16;
+    // large chunks; swept on the box for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us.  (Row positions by look-back through
+    // a chain of chunk totals instead of the reservation atomics were tried and measured no gain - TPC-H Q3 at SF10 0.305 against
+    // 0.300 ms, Q10 0.939 either way: the 177 / 256 same-word atomics are not what these 19 / 119 us kernels wait for.)
+    const int perThread = capacity >= (1 << 22) ? 64 : capacity >= (1 << 20) ? 32 : 16;
     const int64_t chunkSlots = 256 * (int64_t)perThread;
     const int64_t nChunks = std::max<int64_t>(1, (capacity + chunkSlots - 1) / chunkSlots);
     unsigned grid = (unsigned)std::min<int64_t>(8 * (int64_t)ctx.numCUs, nChunks);
-    // RSQ_COMPACT_CHAINED=1 (off by default: measured no gain): row positions by look-back through a chain of chunk totals instead of one
-    // reservation atomic per chunk (one chunk per workgroup, as many workgroups as chunks: a chunk only ever waits for workgroups with a
-    // smaller index, which started before it).  Same box, TPC-H Q3 at SF10 0.305 against 0.300 ms, Q10 0.939 either way: the 177 / 256
-    // same-word atomics are not what these 19 / 119 us kernels wait for.  (The rows do come out in slot order with it.)
-    static const bool chainedOk = getenv("RSQ_COMPACT_CHAINED") && atoi(getenv("RSQ_COMPACT_CHAINED")) == 1;
     u64* chain = nullptr;
     unsigned launchNo = 0;
-    if (chainedOk && nChunks <= (1 << 20)) {
-        if (ctx.compactChainWords < (size_t)nChunks) {
-            if (ctx.dCompactChain) ctx.free(ctx.dCompactChain);
-            ctx.dCompactChain = nullptr; ctx.compactChainWords = 0;
-            const size_t words64 = std::max<size_t>((size_t)nChunks, 4096);
-            ctx.dCompactChain = (uint64_t*)ctx.alloc(words64 * 8);
-            RSQ_HIP(hipMemsetAsync(ctx.dCompactChain, 0, words64 * 8, ctx.stream));
-            ctx.compactChainWords = words64;
-        }
-        ctx.compactLaunch = (ctx.compactLaunch % 0x3ffffffeu) + 1u;      // 1 .. 2^30 - 2: never 0, the number of a word nobody has written
-        chain = (u64*)ctx.dCompactChain; launchNo = ctx.compactLaunch;
-        grid = (unsigned)nChunks;
-    }
 #define RSQ_LAUNCH_COMPACT(PT) hipLaunchKernelGGL(k_compact_entries<PT>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, \
                        (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0, imageRange ? keyWord : -1, keyIs32 ? 1 : 0, keyDesc ? 1 : 0, (u64*)imageRange, chain, launchNo)
     if (perThread >= 64) RSQ_LAUNCH_COMPACT(64); else if (perThread >= 32) RSQ_LAUNCH_COMPACT(32); else RSQ_LAUNCH_COMPACT(16);

@@ -153,7 +153,7 @@ struct ExprGen {
         auto equalsConstant = [&](bool charSemantics) -> std::string {
             Expr* lc = e->child; Expr* rc = e->child->next;
             const bool lConst = lc->tag == RSQ_E_CONSTANT, rConst = rc->tag == RSQ_E_CONSTANT;
-            if (lConst == rConst || !lc->type.isString() || !rc->type.isString() || envInt("RSQ_STRING_WORDS", 1, 0, 1) == 0) return "";
+            if (lConst == rConst || !lc->type.isString() || !rc->type.isString() || 1 == 0) return "";
             const Expr* cst = lConst ? lc : rc;
             const std::string& x = lConst ? r : l;
             const int cap = (lConst ? rc : lc)->type.len;
@@ -265,7 +265,7 @@ struct Walker {
     std::string rowParams, rowArgsTail, rowArgsTailGuarded;
     // key-bitmap words fetched for both rows of a lane (and all tiles in flight) before the first row is processed:
     // (table name, scanned column index) — see consumeProbe
-    struct BitmapPrefetch { std::string first; int second; bool interleaved; bool gated = false; };      // gated: only for rows that pass the leading selection
+    struct BitmapPrefetch { std::string first; int second; bool interleaved; };
     std::vector<BitmapPrefetch> bitmapPrefetch;
     std::string body;                          // row function body
     std::string closers;                       // closing braces of the open scopes
@@ -360,11 +360,11 @@ struct Walker {
         pipe.src = t;
         // tuned on MI355X with TPC-H Q1 SF10 (profiles/): 1 tile in flight per wave + non-temporal loads
         // 0.395 ms; 2 tiles 0.42 ms; 4 tiles 0.47 ms (fewer resident waves); without nt loads 0.45-0.47 ms
-        pipe.unroll = envInt("RSQ_UNROLL", 1, 1, 8);
-        pipe.blockThreads = envInt("RSQ_BLOCK", 256, 64, 1024);
+        pipe.unroll = 1;
+        pipe.blockThreads = 256;
         // workgroups (of 256 threads) per launch; 0 = 2 per CU.  Measured on MI355X (Q1 SF10): 512 workgroups 0.348 ms,
         // 768: 0.367, 1024: 0.374, 2048: 0.395, 4096: 0.448 - a streaming kernel wants exactly 2 resident workgroups per CU
-        pipe.maxGrid = (unsigned)envInt("RSQ_MAXGRID", 0, 0, 1 << 20);
+        pipe.maxGrid = (unsigned)0;
         colTypes.clear(); colIsString.clear(); rowParams.clear(); rowArgsTail.clear(); rowArgsTailGuarded.clear(); bitmapPrefetch.clear();
         body.clear(); stateDecl.clear(); stateInit.clear(); prologue.clear(); epilogue.clear(); fileScope.clear(); helperFns.clear();
         explainSteps.clear(); indent = 1; matchSlotTable = -1; slotVar.clear(); symbolOrigin.clear(); symbolWord.clear();
@@ -493,7 +493,7 @@ struct Walker {
     std::vector<std::pair<int, int>> strPrefetch;         // (scanned column, bytes of it that arrive with the tile), in the order of the row function's parameters
     std::map<int, int> strPrefetchWidth;                   // scanned column -> its width (the row stride)
     void prefetchComparedStrings(const Expr* e) {
-        if (envInt("RSQ_STRING_PREFETCH", 1, 0, 2) == 0 || envInt("RSQ_STRING_WORDS", 1, 0, 1) == 0) return;
+        if (1 == 0 || 1 == 0) return;
         if ((e->tag == RSQ_E_EQ || e->tag == RSQ_E_NEQ) && e->child && e->child->next) {
             const Expr* l = e->child; const Expr* r = e->child->next;
             const Expr* col = l->tag == RSQ_E_ATTRIBUTE && r->tag == RSQ_E_CONSTANT ? l : r->tag == RSQ_E_ATTRIBUTE && l->tag == RSQ_E_CONSTANT ? r : nullptr;
@@ -541,7 +541,7 @@ struct Walker {
                 selective = true;
                 {
                     // (RSQ_STRING_PREFETCH=2, measurement: also behind probes, as long as no selection came before)
-                    if (from->tag == RSQ_OP_SCAN || (envInt("RSQ_STRING_PREFETCH", 1, 0, 2) == 2 && !wasSelective)) prefetchComparedStrings(o->exprs[0]);
+                    if (from->tag == RSQ_OP_SCAN || (1 == 2 && !wasSelective)) prefetchComparedStrings(o->exprs[0]);
                     const std::string cond = eg.emit(o->exprs[0]);
                     if (from->tag == RSQ_OP_SCAN && leadCond.empty()) noteLeadingSelection(o->exprs[0], cond);
                     openScope("if (" + cond + ") {");
@@ -609,7 +609,7 @@ struct Walker {
         // l_extendedprice and l_discount, 16 of the 24 bytes per row) — gathers for a few rows beat streaming for all, but
         // only then: a row gathered costs a 64-byte request per column.
         std::vector<int> lazyOf(cqLive.size(), -1);
-        if (envInt("RSQ_LAZY_COLUMNS", 1, 0, 1)) {
+        if (1) {
             for (size_t k = 0; k < cqLive.size(); k++) {
                 const std::string& var = cqLive[k].second.var;
                 auto org = symbolOrigin.find(cqLive[k].first);
@@ -801,11 +801,7 @@ struct Walker {
     // cache lines, and atomics on one line serialise at the memory side just like atomics on one word.  Scattering the
     // inserts over the table is what keeps them fast.
     std::string slotOf(const HashTable& ht, const std::string& T, const std::vector<std::string>& keyVars) {
-        if (ht.hasBitmap && keyVars.size() == 1 && envInt("RSQ_BLOCKED_HASH", 0, 0, 1)) {
-            addArg(T + "_bmmin", "i64", (uint64_t)ht.bmMin);
-            addArg(T + "_hm", "u64", 0);
-            return "rsq::blocked_slot((u64)(" + keyVars[0] + " - a." + T + "_bmmin), a." + T + "_hm, " + T + "_mask)";
-        }
+        (void)ht;
         return hashOf(keyVars) + " & " + T + "_mask";
     }
 
@@ -863,13 +859,13 @@ struct Walker {
         // capacity: the reference sizes its table lChild.getSize() * 5 / 3 and grows it; ours cannot grow
         // inside a kernel, so it is sized for twice the rows the build pipeline can deliver and re-run
         // at double size if it still overflows (engine.cpp).
-        ht->aos = envInt("RSQ_JOIN_AOS", 1, 0, 1) != 0;
+        ht->aos = 1 != 0;
         ht->capacity = 0;     // decided by the sizing pass at execute time (engine.cpp)
         // One integer key word whose values can never be INT64_MIN: the key word itself is the slot's state.  A 64-bit CAS
         // from the EMPTY sentinel claims the slot and publishes the key in one memory request (instead of a CAS on a state
         // word plus a key store), a probe step reads one word instead of two dependent ones.  Scattered HBM requests are what
         // a build costs.
-        if (keyVars.size() == 1 && o->exprs.size() == 1 && envInt("RSQ_KEY_CAS", 1, 0, 1)) {
+        if (keyVars.size() == 1 && o->exprs.size() == 1 && 1) {
             Expr* l = o->exprs[0]->child;
             const int tg = l->type.tag;
             if (tg == RSQ_INT || tg == RSQ_DATE || tg == RSQ_BOOL || (tg == RSQ_CHAR && l->type.len == 1)) ht->keyCas = true;   // widened 32-bit / 8-bit values
@@ -885,7 +881,7 @@ struct Walker {
         // forms behind a uniform branch on a.<T>_rank; the host decides once, from the sizing pass.
         // (A join probed for ALL matches qualifies too: with unique build keys every probe has at most one.  If such a table carries
         // nothing but its key - TPC-H Q3's customer side - the bitmap IS the table in the rank form: a KEY SET, no entries at all.)
-        ht->rankCapable = (ht->unique || envInt("RSQ_JOIN_RANK_MULTI", 1, 0, 1)) && ht->hasBitmap && ht->keyCas && ht->aos && keyVars.size() == 1 &&
+        ht->rankCapable = (ht->unique || 1) && ht->hasBitmap && ht->keyCas && ht->aos && keyVars.size() == 1 &&
                           envInt("RSQ_JOIN_RANK", 1, 0, 1) != 0;
         ht->setOnly = ht->rankCapable && !ht->unique && ht->payload.empty();
         // (a table that may become a rank dictionary keeps its bitmap in the interleaved layout, rsq_device.h bmi_word)
@@ -899,7 +895,7 @@ struct Walker {
             // a table scanned in the order of its build key (column statistics): the rows of a wave fall into a few bitmap words, and
             // the lanes that meet in one word set their bits with ONE atomic (rsq_device.h bm_set_combined).  Memory-side atomics
             // run at ~25 G/s chip-wide: a build over all 15 M orders (TPC-H Q12) spent 0.6 of its 0.73 ms on them.
-            if (ci >= 0 && pipe.src->cols[(size_t)ci].stats.valid && pipe.src->cols[(size_t)ci].stats.ascending && envInt("RSQ_BITMAP_COMBINE", 1, 0, 1))
+            if (ci >= 0 && pipe.src->cols[(size_t)ci].stats.valid && pipe.src->cols[(size_t)ci].stats.ascending && 1)
                 combineBits = true;
         }
         const std::string setBit = combineBits ? "rsq::bm_set_combined(a." + T + "_bm, (u32)(" + bmw + "), 1u << (d & 31));"
@@ -973,7 +969,7 @@ struct Walker {
         line("u64 " + T + "_n = 0;");
         // (measurement only, wrong results: 1 no payload stores, 2 a plain store into the home slot instead of the CAS loop,
         // 4 no insert at all — to see what each part of an insert costs)
-        const int dbgBuild = envInt("RSQ_DEBUG_BUILD", 0, 0, 7);
+        const int dbgBuild = 0;
         openScope("for (;; " + T + "_n++) {");
         line("if (" + T + "_n > " + T + "_mask) { atomicOr(a.err, (u32)rsq::ERR_HT_FULL); break; }");
         if (dbgBuild & 4) line("break;");
@@ -996,8 +992,7 @@ struct Walker {
         }
         line("st.n_" + T + "++;");
         if (ht->hasBitmap) {
-            if (envInt("RSQ_DEBUG_NO_BITMAP_SET", 0, 0, 64) != ht->id + 1)      // (measurement only: table id + 1 builds no bitmap; its probes then find nothing)
-                line("{ " + bitSet + setBit + " }");
+            line("{ " + bitSet + setBit + " }");
         }
         closeScope();
         closeScope();
@@ -1051,7 +1046,6 @@ struct Walker {
             // the two row functions of a lane otherwise run one after the other, each with its own dependent load — a cache
             // round trip per row that nothing overlaps (TPC-H Q3's lineitem pipeline spent a quarter of its time there).
             int pfCol = -1;
-            bool pfGated = false;
             {
                 Expr* r = o->exprs[0]->child->next;
                 auto org = r->tag == RSQ_E_ATTRIBUTE ? symbolOrigin.find(r->symbol) : symbolOrigin.end();
@@ -1062,35 +1056,24 @@ struct Walker {
                 if (!compacted && o->exprs.size() == 1 && org != symbolOrigin.end() && org->second == -1 && sym != eg.symbols.end() &&
                     sym->second.var.compare(0, 2, "v_") == 0 && !r->type.isString()) {
                     const int ci = pipe.src->findCol(r->symbol);
-                    const int mode = envInt("RSQ_BITMAP_PREFETCH", 1, 0, 2);       // 0 never, 1 clustered keys (or gated, below), 2 always
+                    const int mode = 1;       // 0 never, 1 clustered keys (or gated, below), 2 always
                     if (ci >= 0 && (mode == 2 || (mode == 1 && pipe.src->cols[(size_t)ci].stats.valid && pipe.src->cols[(size_t)ci].stats.ascending)))
                         pfCol = atoi(sym->second.var.c_str() + 2);
-                    // RSQ_BITMAP_PREFETCH_GATED=1 (off by default: measured no gain): keys in random order behind a selection - the words
-                    // are fetched with the tile all the same, but only for the rows the selection passes (the pipeline evaluates it once
-                    // more in front of the loads).  Fetched inside the row function, the eight rows a lane handles per iteration wait
-                    // for their bitmap words one after the other; issuing the eight loads together left TPC-H Q3's orders pipeline where it
-                    // was (0.306-0.308 against 0.305-0.315 ms for the query): what its probes cost - 34 of its 88 us, RSQ_DEBUG_PROBE=1 -
-                    // is the cache lines they move from the L2 (7 M probes of a 187 KB bitmap, one 128-byte line each), not their latency.
-                    // (not where late loads would apply - RSQ_LATE_LOADS, a leading selection that passes few rows: they do better)
-                    else if (ci >= 0 && mode == 1 && !leadCond.empty() && envInt("RSQ_BITMAP_PREFETCH_GATED", 0, 0, 1) &&
-                             !(envInt("RSQ_LATE_LOADS", 1, 0, 2) && leadPass <= (double)envInt("RSQ_LATE_LOADS_BELOW", 12, 0, 100) / 100.0)) {
-                        pfCol = atoi(sym->second.var.c_str() + 2);
-                        pfGated = true;
-                    }
+                    // (Keys in random order behind a selection: fetching their bitmap words with the tile for the rows the selection passes
+                    // was tried and measured no gain - TPC-H Q3's orders pipeline 0.306-0.308 against 0.305-0.315 ms for the query: what
+                    // its probes cost, 34 of its 88 us, is the cache lines they move from the L2 - 7 M probes of a 187 KB bitmap, one
+                    // 128-byte line each - not their latency.)
                 }
                 for (auto& pf : bitmapPrefetch) if (pf.first == T) pfCol = -1;        // (one probe per table and pipeline)
             }
             if (pfCol >= 0) {
-                bitmapPrefetch.push_back({T, pfCol, ht.bmInterleaved, pfGated});
+                bitmapPrefetch.push_back({T, pfCol, ht.bmInterleaved});
                 const std::string call = std::string(ht.bmInterleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") + T + "_bm, a." + T + "_bmmin, a." + T + "_bmbits, (i64)";
                 rowParams += ", const u32 pf_" + T;
                 rowArgsTail += ", " + call + "a.c" + std::to_string(pfCol) + "[r])";
                 rowArgsTailGuarded += ", (valid ? " + call + "a.c" + std::to_string(pfCol) + "[r]) : 0u)";
                 openScope("if (" + T + "_d < a." + T + "_bmbits && ((pf_" + T + " >> (" + T + "_d & 31)) & 1u)) {");
             } else
-            if (envInt("RSQ_DEBUG_PROBE", 0, 0, 1) && !ht.unique)       // (measurement only, wrong results: a key set's bit test without its load - one key in five passes)
-                openScope("if (" + T + "_d < a." + T + "_bmbits && ((" + T + "_d * 0x9E3779B97F4A7C15ull) >> 32) % 5u == 0u) {");
-            else
             openScope("if (" + T + "_d < a." + T + "_bmbits && ((a." + T + "_bm[" + (ht.bmInterleaved ? "rsq::bmi_word(" + T + "_d)" : T + "_d >> 5") + "] >> (" + T + "_d & 31)) & 1u)) {");
             selective = true;
         }
@@ -1153,7 +1136,7 @@ struct Walker {
             line("u64 " + T + "_s = 0; bool " + T + "_hit = false;");
             openScope("if (a." + T + "_rank) {");
             {
-                const int dbgRank = envInt("RSQ_DEBUG_RANK", 0, 0, 2);      // (measurement only, wrong results: 1 the key offset, 2 its hash instead of the rank)
+                const int dbgRank = 0;      // (measurement only, wrong results: 1 the key offset, 2 its hash instead of the rank)
                 const std::string dd = "(u64)(" + keyVars[0] + " - a." + T + "_bmmin)";
                 if (dbgRank == 1) line(T + "_s = " + dd + " & (a." + T + "_cap - 1);");
                 else if (dbgRank == 2) line(T + "_s = rsq::hash64(" + dd + ") & (a." + T + "_cap - 1);");
@@ -1333,7 +1316,7 @@ struct Walker {
             // The HBM-table forms could sit behind the compaction too; measured (200 M rows, 2^20 groups): 3 % faster at 1 %
             // selectivity, 15-25 % SLOWER at 10 / 50 % (the count / scatter passes pay for the queue without needing it),
             // so it stays off unless asked for.
-            if (!(q.aggMode == AggMode::DENSE_GLOBAL && envInt("RSQ_COMPACT_DENSE", 0, 0, 1) &&
+            if (!(q.aggMode == AggMode::DENSE_GLOBAL && 0 &&
                   compactThen(o, [&] { collectAccumulators(o); emitDenseAggregation(o); })))
                 emitDenseAggregation(o);
         } else if (forced != 5 && tryJoinEntry(o)) {
@@ -1375,7 +1358,7 @@ struct Walker {
         // value as before.
         std::vector<bool> carried(o->exprs2.size(), false);
         std::string fdCond;                      // run-time condition of the dependencies ("" = they always hold)
-        if (envInt("RSQ_GROUP_FD", 1, 0, 1)) {
+        if (1) {
             std::set<std::string> groupSyms, determined;
             for (Expr* g : o->exprs2) if (g->tag == RSQ_E_ATTRIBUTE) groupSyms.insert(g->symbol);
             determined = groupSyms;
@@ -1457,7 +1440,7 @@ struct Walker {
         // cache lines instead of 32 stores a table-length apart (TPC-H Q10 at SF10: 380 K new groups per execution).
         int NWtab = K;
         for (auto& c : carriedVals) NWtab += c.nWords;
-        ht->aos = NWtab > 1 && envInt("RSQ_AGG_AOS", 1, 0, 1) != 0;
+        ht->aos = NWtab > 1 && 1 != 0;
         const bool aggAos = ht->aos;
         auto aggWord = [&, NWtab, aggAos](int w) {
             return aggAos ? "a." + T + "_words[" + T + "_s * " + std::to_string(NWtab) + " + " + std::to_string(w) + "]"
@@ -1471,10 +1454,10 @@ struct Walker {
         // itself).  At the end of the kernel every occupied slot is merged into the HBM table by the same upsert.  With
         // few groups (TPC-H Q12: 2, Q5: 5) nearly every row stays in LDS; with many, nearly every row pays one LDS probe.
         const int slotBytes = 8 * (K + W) + 4;
-        int LS = envInt("RSQ_HASH_LDS_SLOTS", 0, 0, 4096);
+        int LS = 0;
         if (LS == 0) LS = slotBytes * 1024 <= 48 * 1024 ? 1024 : slotBytes * 512 <= 48 * 1024 ? 512 : 256;
         while (LS & (LS - 1)) LS &= LS - 1;           // power of two
-        const bool lds = envInt("RSQ_HASH_LDS", 1, 0, 1) && LS >= 64 && slotBytes * LS <= 48 * 1024 && !anyCarried;     // (a front-table slot holds no carried values to create its group with)
+        const bool lds = 1 && LS >= 64 && slotBytes * LS <= 48 * 1024 && !anyCarried;     // (a front-table slot holds no carried values to create its group with)
         if (lds) {
             stateDecl += "    u32* lc_state;\n    i64* lc_key;\n    u64* lc_acc;\n";
             prologue += "    __shared__ u32 s_lc_state[" + std::to_string(LS) + "];\n    __shared__ i64 s_lc_key[" + std::to_string(K * LS) +
@@ -1541,7 +1524,7 @@ struct Walker {
             // with its own agent-scope loads finds them.  A __threadfence() here instead — buffer_wbl2 + buffer_inv, tens of
             // microseconds under load — made every NEW group cost a cache write-back: TPC-H Q10 at SF10 creates 380 K groups and
             // spent 2.5 of its 2.9 ms there (device timestamps; round 3).  RSQ_HASH_FENCE=1 restores the fence.
-            if (envInt("RSQ_HASH_FENCE", 0, 0, 1)) line("__threadfence();");
+            if (0) line("__threadfence();");
             else line("asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");");
             line("rsq::st_agent(&a." + T + "_state[" + T + "_s], 2u);");
             line("st.n_" + T + "++;");
@@ -1607,7 +1590,7 @@ struct Walker {
                               op + ">(" + dst + ", r); }");
                 }
             };
-            if (envInt("RSQ_WAVE_FOLD", 1, 0, 1)) {
+            if (1) {
                 line("const int wl_lane = (int)(threadIdx.x & 63);");
                 line("bool wl_mine = " + T + "_found;");
                 line("u64 wl_todo = __ballot(wl_mine);");
@@ -1785,7 +1768,7 @@ struct Walker {
         const int ncolsNow = (int)colTypes.size();
         // rows per thread and round: 4 (2 for wide rows: registers); 8 when few rows are expected to pass - the rounds' barriers then
         // weigh more than the records (1.25 B rows, 2^20 groups: 10 % 7.54 -> 7.15 ms; at 50 % 8 rows cost 11.1 instead of 9.6 ms)
-        const int RPT = envInt("RSQ_STAGED_ROWS", ncolsNow <= 6 ? (!leadCond.empty() && leadPass <= 0.15 ? 8 : 4) : 2, 2, 8) & ~1;
+        const int RPT = ncolsNow <= 6 ? (!leadCond.empty() && leadPass <= 0.15 ? 8 : 4) : 2;
         pipe.staged = true; pipe.stagedRecWords = RECW; pipe.stagedRows = RPT;
         const std::string Ps = std::to_string(P), Rs = std::to_string(RECW), Ts = std::to_string(RPT);
         const std::string LDS = "rsq::StageLds<" + Rs + ", " + Ps + ">";
@@ -1869,7 +1852,7 @@ struct Walker {
         k << "    const u64 base = a.sp_base[p]; const u32 cap = a.sp_cap[p];\n";
         k << "    for (u32 wg = threadIdx.x >> 6; wg < a.sp_nwg; wg += blockDim.x >> 6) {\n";
         k << "        const u64 st = base + (u64)wg * cap;\n        const u32 cnt = min(a.sp_counts[(u64)wg * " << P << " + p], cap);\n";
-        const int AU = envInt("RSQ_STAGED_AGG_UNROLL", 4, 1, 16);
+        const int AU = 4;
         // AU 16-byte loads per lane in flight (one per lane leaves a CU with 16 KB outstanding: 4.8 TB/s; four: see DESIGN §4)
         const int step = RECW == 1 ? 128 : 64;              // records one wave-load covers
         k << "        for (u32 i0 = 0; i0 < cnt; i0 += " << AU * step << ") {\n";
@@ -1908,7 +1891,7 @@ struct Walker {
             for (int w = 0; w < W; w++)
                 for (int64_t g = 0; g < D; g++)
                     stateDecl += "    i64 acc_" + std::to_string(w) + "_" + std::to_string((long long)g) + " = (i64)" + identityOf(q.accums[(size_t)w].merge) + ";\n";
-            const bool branchy = envInt("RSQ_REG_UPDATE", D > 1 ? 1 : 0, 0, 1) == 1;
+            const bool branchy = (D > 1 ? 1 : 0) == 1;
             for (int64_t g = 0; g < D; g++) {
                 if (branchy) {
                     // EXEC-masked update of one group's accumulators (2 VALU per 64-bit add instead of the
@@ -1943,7 +1926,7 @@ struct Walker {
             if (dbgTail) { addArg("dbg", "u64*", 0); prologue += "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 0] = (u64)wall_clock64();\n"; }
             stamp(1);
             ep << "    __shared__ u64 s_acc[" << W * D << "];\n";
-            if (envInt("RSQ_FLUSH_LANES", 1, 0, 1)) {
+            if (1) {
                 // The workgroup's accumulators meet LANE BY LANE first: every wave merges its cells into s_lane[cell][lane] (LDS
                 // atomics, no two lanes on one word), then each wave folds a share of the cells across the 64 lanes (DPP, rsq_device.h
                 // wave_reduce_to_lane63).  One cross-lane reduction per cell and workgroup instead of one per cell and WAVE: the
@@ -1973,7 +1956,7 @@ struct Walker {
             }
             // The workgroups flush into a PADDED copy of the table, one cell per 64-byte line (engine.cpp unpads it):
             // memory-side atomics serialise per line, and the 42 cells of TPC-H Q1 otherwise share six lines.
-            q.aggPad = envInt("RSQ_AGG_PAD", 8, 1, 16);
+            q.aggPad = 8;
             stamp(2);
             emitGlobalFlush(ep, std::to_string((long long)(W * D)), "s_acc[i]", D, q.aggPad);
             stamp(3);
@@ -1991,12 +1974,6 @@ struct Walker {
             addArg("fin_err", "u64*", 0);
             addArg("fin_ticket", "u32*", 0);
             addArg("fin_seq", "u64", 0);
-            // RSQ_PERSISTENT_STEP=1 (engine.cpp "the resident step"): the same kernel kept on the chip between steps, started by a
-            // doorbell word in host-mapped memory instead of a launch
-            addArg("pers_bell", "u64*", 0);
-            addArg("pers_idle", "u64", 0);
-            addArg("pers_t0", "u64", 0);          // (the resident form stamps it: the 100 MHz clock when this workgroup saw the doorbell)
-            pipe.persistentForm = true;
             ep << "    if (a.fin_out) {\n        __shared__ u32 s_last;\n        asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n        __syncthreads();\n";
             ep << "        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.fin_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;\n        __syncthreads();\n";
             if (dbgTail) ep << "        if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 4] = (u64)wall_clock64();\n";
@@ -2004,7 +1981,6 @@ struct Walker {
             ep << "            for (int i = threadIdx.x; i < " << W * D << "; i += blockDim.x) {\n                const int blk = i / " << D << ";\n";
             ep << "                const u64 idv = " << blockIdentityExpr("blk") << ";\n";
             ep << "                a.fin_out[i] = __hip_atomic_exchange(a.out + i" << (q.aggPad > 1 ? " * RSQ_OUT_STRIDE" : "") << ", idv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n            }\n";
-            ep << "#if RSQ_DYN_TILES\n            for (int i = threadIdx.x; i < 256; i += blockDim.x) a.tile_ctr[i * 32] = 0u;      // every workgroup is done drawing tiles\n#endif\n";
             ep << "            if (threadIdx.x == 0) {\n                a.fin_err[0] = (u64)atomicExch(a.err, 0u);\n";
             ep << "                __hip_atomic_store(a.fin_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n            }\n";
             // a full execution is announced to the polling host by a sequence number behind the table: written after every
@@ -2012,7 +1988,6 @@ struct Walker {
             if (dbgTail) ep << "            if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 5] = (u64)wall_clock64();\n";
             ep << "            if (a.fin_seq) {\n                asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n                __syncthreads();\n";
             if (dbgTail) ep << "                if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 6] = (u64)wall_clock64();\n";
-            ep << "                if (threadIdx.x == 0 && a.pers_t0) a.fin_err[6] = (u64)wall_clock64() - a.pers_t0;      // a resident step's time on the device, for the report\n";
             ep << "                if (threadIdx.x == 0) __hip_atomic_store(a.fin_err + 1, a.fin_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);\n";
             if (dbgTail) ep << "                if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 7] = (u64)wall_clock64();\n";
             ep << "            }\n";
@@ -2022,7 +1997,7 @@ struct Walker {
             // 512 to 256 workgroups took 8 us off the 352 us SF10 kernel and 9 off the 67 us SF1 kernel (1024 and 2048
             // workgroups: +25 / +75 us).  A slab-per-workgroup + ticket + last-workgroup reduction was tried instead of
             // the atomics and measured 28 us SLOWER (write-through slab stores, a serial reducer), so it is not here.
-            if (!getenv("RSQ_BLOCK")) pipe.blockThreads = 512;
+            pipe.blockThreads = 512;
         } else if (q.aggMode == AggMode::DENSE_LDS_PRIVATE) {
             // one private copy of the [block][group] table per LANE in LDS, laid out [cell][thread] so that a
             // wave's 64 accesses to one cell are 64 consecutive 8-byte words: conflict-free, no contention,
@@ -2176,11 +2151,11 @@ struct Walker {
         // atomics would queue on a handful of cache lines.  The accumulators of entry r therefore live at rsq::rank_mix(r), a
         // bijection of [0, capacity) (rsq_device.h; the capacity of a dictionary that carries aggregates is a power of two).
         std::string accIdx = slotVar[ht.id];
-        if (ht.rankCapable && envInt("RSQ_RANK_SCRAMBLE", 1, 0, 1)) {
+        if (ht.rankCapable && 1) {
             line("const u64 " + T + "_ai = a." + T + "_rank ? rsq::rank_mix(" + slotVar[ht.id] + ", a." + T + "_cap) : " + slotVar[ht.id] + ";");
             accIdx = T + "_ai";
         }
-        const int dbgAcc = envInt("RSQ_DEBUG_ENTRY_ACC", 0, 0, 3);      // (measurement only: 1 no first-row tracker, 2 no aggregates, 3 neither)
+        const int dbgAcc = 0;      // (measurement only: 1 no first-row tracker, 2 no aggregates, 3 neither)
         for (int w = 0; w < W; w++) {
             if ((w == 0 && (dbgAcc & 1)) || (w > 0 && (dbgAcc & 2))) continue;
             std::string in = w == 0 ? "row" : q.accums[(size_t)w].input;
@@ -2253,12 +2228,12 @@ struct Walker {
         // Bytes in flight: a CU streams fastest with ~40 KB of loads outstanding (8 waves x one 128-row tile of TPC-H Q1's
         // 38 B rows).  Narrower rows keep the same amount in flight with more tiles per wave: Q6 (28 B/row) went
         // 0.293 -> 0.254 ms with two tiles, the 32 B synthetic rows gained ~1.5 %; Q1 itself is slower with two (0.363 vs 0.348).
-        if (!getenv("RSQ_UNROLL") && pipe.gridPerCU == 2 && pipe.bytesPerRow > 0)
+        if (pipe.gridPerCU == 2 && pipe.bytesPerRow > 0)
             pipe.unroll = (int)std::max<int64_t>(1, std::min<int64_t>(4, (4608 + pipe.bytesPerRow * 128 - 1) / (pipe.bytesPerRow * 128)));
         // A pipeline behind a wave compaction waits twice per tile — for the key columns, then (join probes) for the bitmap words their
         // values address — and few of its rows go further: it wants several tiles in flight per wave.  TPC-H Q3 at SF10, all kernels:
         // 0.415 ms with one tile, 0.381 with two, 0.367 with three, 0.363 with four (RSQ_COMPACT_UNROLL).
-        if (!getenv("RSQ_UNROLL") && pipe.compact) pipe.unroll = envInt("RSQ_COMPACT_UNROLL", 4, 1, 8);
+        if (pipe.compact) pipe.unroll = 4;
         const bool mat = pipe.sink == SinkKind::MATERIALIZE;
         std::ostringstream s;
         s << "// generated by resql_amd/csrc/codegen.cpp\n//   ";
@@ -2271,17 +2246,13 @@ struct Walker {
             s << (i ? " -> " : "") << step;
         }
         s << "\n";
-        if (envInt("RSQ_NT", 1, 0, 1)) s << "#define RSQ_NT_LOADS 1\n";
-        s << "#define RSQ_DYN_TILES " << ((envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) != 0 && !pipe.partitioned) ? 1 : 0) << "\n";
-        s << "#ifndef RSQ_PERSISTENT\n#define RSQ_PERSISTENT 0\n#endif\n";
+        if (1) s << "#define RSQ_NT_LOADS 1\n";
         s << "#include \"rsq_device.h\"\n";
         s << fileScope;
         const bool cq = pipe.compact;
         // (measurement only, RSQ_DEBUG_TAIL=1: device timestamps per workgroup - [0] start, [1] rows done, [2] drains done, [3] end)
         const bool dbgStamps = envInt("RSQ_DEBUG_TAIL", 0, 0, 1) != 0 && !(pipe.sink == SinkKind::AGGREGATE && q.aggMode == AggMode::DENSE_REG);
         if (dbgStamps) addArg("dbg", "u64*", 0);
-        const bool dynamicTiles = envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) != 0 && !pipe.partitioned;       // (see the main loop below)
-        if (dynamicTiles) { addArg("tile_ctr", "u32*", 0); addArg("tile_pools", "u32", 1); pipe.dynamicTiles = true; }
         // (the staged form's round loop knows neither the compaction queues nor prefetched bitmap words nor string columns)
         if (pipe.staged && (cq || mat || !bitmapPrefetch.empty() || !pipe.lazyCols.empty() ||
                             std::find(colIsString.begin(), colIsString.end(), true) != colIsString.end())) pipe.staged = false;
@@ -2294,7 +2265,7 @@ struct Walker {
         bool late = false;
         {
             const int mode = envInt("RSQ_LATE_LOADS", 1, 0, 2);
-            const double below = (double)envInt("RSQ_LATE_LOADS_BELOW", 12, 0, 100) / 100.0;
+            const double below = (double)12 / 100.0;
             if (mode && !cq && !mat && !leadCond.empty() && bitmapPrefetch.empty() && pipe.lazyCols.empty() && (mode == 2 || leadPass <= below)) {
                 for (size_t k = 0; k < colTypes.size(); k++)
                     if (!colIsString[k] && std::find(leadCols.begin(), leadCols.end(), (int)k) == leadCols.end()) { lateCol[k] = 1; late = true; }
@@ -2307,14 +2278,12 @@ struct Walker {
         // Measured (MI355X, 1.25 B synthetic rows, G = 8; kernel ms, plain order with two tiles -> pipelined with 2 / 3 / 4 tiles):
         // 1 %: 3.51 -> 2.48 / 2.40 / 2.24; 10 %: 5.86 -> 5.17 / 5.21 / 5.35; TPC-H Q6 SF10 (2 %, 20 leading bytes): 0.206 -> 0.192 / 0.191
         // / 0.197.  The more rows pass, the more of the late registers are really in use and the fewer tiles pay.
-        const bool latePipelined = late && envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) == 0;
-        bool anyGated = false;
-        for (auto& pf : bitmapPrefetch) anyGated |= pf.gated;
+        const bool latePipelined = late;
         // ... and so is the loop of a pipeline behind a wave compaction, where its tiles are narrow (below).  Measured at SF10, whole
         // statements: TPC-H Q5 0.707 -> 0.687 ms, Q14 0.289 -> 0.276, Q3 0.289 -> 0.285, the others within noise: these pipelines are
         // bound by the dependent accesses of stage 2 (Q5's lineitem pipeline as two kernels: scan 81 us, stage 2 363 us), not by the stream.
-        const bool cqPipelined = pipe.compact && !late && pipe.sink != SinkKind::MATERIALIZE && !anyGated && envInt("RSQ_DYNAMIC_TILES", 0, 0, 1) == 0;
-        if (late && !getenv("RSQ_UNROLL") && pipe.gridPerCU == 2) {
+        const bool cqPipelined = pipe.compact && !late && pipe.sink != SinkKind::MATERIALIZE;
+        if (late && pipe.gridPerCU == 2) {
             int64_t leadBytes = 0;
             for (int k : leadCols) leadBytes += colTypes[(size_t)k] == "i64" ? 8 : colTypes[(size_t)k] == "i32" ? 4 : 1;
             if (leadBytes > 0) pipe.unroll = (int)std::max<int64_t>(1, std::min<int64_t>(leadPass <= 0.04 ? 4 : 2, (4608 + leadBytes * 128 - 1) / (leadBytes * 128)));
@@ -2329,7 +2298,7 @@ struct Walker {
         // other at 192 entries; at 128 four or five do, and TPC-H Q5's lineitem pipeline - five probes per surviving row - went from
         // 0.55 to 0.46 ms.  Pipelines whose registers set the limit - Q10, Q3 - lose 2-3 % to the extra drains and keep 192.)
         const bool queuesLimit = (144 * 1024) / std::max(1, (pipe.blockThreads / 64) * NV * 192 * 8 + pipe.extraLdsBytes) < 4;
-        const int QCAP = envInt("RSQ_QCAP", queuesLimit ? 128 : 192, 128, 192);
+        const int QCAP = (queuesLimit ? 128 : 192);
         const int NVL = 1 + pipe.compactWordsLazy;  // ... in the RSQ_LAZY 1 form
         const bool twoForms = !pipe.lazyCols.empty();
         if (cq) {
@@ -2340,8 +2309,8 @@ struct Walker {
             // whatever the occupancy query says - TPC-H Q3's lineitem pipeline started 256 of 1792 workgroups 67 us late; the
             // engine also clamps every grid to the query's answer, engine.cpp residentWorkgroupsPerCU)
             const int wgCap = pipe.unroll >= 3 ? 6 : 8;
-            pipe.gridPerCU = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(wgCap, (144 * 1024) / std::max(1, ldsPerWG))), 1, 16);
-            pipe.gridPerCULazy = envInt("RSQ_COMPACT_GRID", std::max(2, std::min(wgCap, (144 * 1024) / std::max(1, ldsPerWGLazy))), 1, 16);
+            pipe.gridPerCU = std::max(2, std::min(wgCap, (144 * 1024) / std::max(1, ldsPerWG)));
+            pipe.gridPerCULazy = std::max(2, std::min(wgCap, (144 * 1024) / std::max(1, ldsPerWGLazy)));
             stateDecl += "    int cq_n = 0;\n    u32 cq_rows = 0;\n    i64* cq;\n";
             // rows that reached stage 2, for the host's choice between the two forms of the kernel (see compactThen).  Only
             // the first 64 workgroups report (tiles are dealt round-robin, so they are a fair sample; the host scales): every
@@ -2376,9 +2345,7 @@ struct Walker {
             }
             s << ");\n        st.cq_rows++;\n    }\n    st.cq_n -= count;\n}\n";
         }
-        bool gatedPrefetch = false;
-        for (auto& pf : bitmapPrefetch) gatedPrefetch |= pf.gated;
-        if (late || gatedPrefetch) {
+        if (late) {
             s << "static RSQ_DEV bool lead_pred(const Args& a";
             for (int k : leadCols) s << ", " << colTypes[(size_t)k] << " v_" << k;
             s << ") { return " << leadCond << "; }\n";
@@ -2409,20 +2376,8 @@ struct Walker {
             pipe.entry = "rsq_p" + std::to_string(q.pipelines.size()) + "_" + tn + "_" + sk;
             if (pipe.sink == SinkKind::BUILD) pipe.entry += "_ht" + std::to_string(pipe.buildTable);
         }
-        if (pipe.persistentForm) {
-            // The resident form: every workgroup's thread 0 watches the doorbell (a sequence number the host stores into mapped pinned
-            // memory); a new value is one step, ~0 or pers_idle ticks (100 MHz) without a ring end the kernel - an exit every wave reaches.
-            s << "#if RSQ_PERSISTENT\nstatic __device__ __attribute__((always_inline)) void rsq_step_body(Args& a);\n";
-            s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n";
-            s << "    __shared__ u64 s_bell;\n    u64 seen = a.fin_seq - 1ull;      // launched for step fin_seq: the host has put that number into the doorbell\n    for (;;) {\n";
-            s << "        if (threadIdx.x == 0) s_bell = rsq::wait_doorbell(a.pers_bell, (u64*)(a.fin_ticket + 2), seen, a.pers_idle);\n        __syncthreads();\n";
-            s << "        const u64 v = s_bell;\n        __syncthreads();\n        if (v == ~0ull) return;\n";
-            s << "        seen = v; a.fin_seq = v; a.pers_t0 = (u64)wall_clock64();\n        rsq_step_body(a);\n        __syncthreads();\n    }\n}\n";
-            s << "static __device__ __attribute__((always_inline)) void rsq_step_body(Args& a) {\n#else\n";
-        }
         s << "#ifdef RSQ_MIN_WG\nextern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS, RSQ_MIN_WG) " << pipe.entry << "(Args a) {\n#else\n";
         s << "extern \"C\" __global__ void __launch_bounds__(RSQ_BLOCK_THREADS) " << pipe.entry << "(Args a) {\n#endif\n";
-        if (pipe.persistentForm) s << "#endif\n";
         s << "    State st;\n" << prologue;
         if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 0] = (u64)wall_clock64();\n";
         s << "    const int lane = threadIdx.x & 63;\n";
@@ -2472,15 +2427,9 @@ struct Walker {
             s << "#else\n";
         }
         // main loop, textually unrolled: the loads of U tiles are issued before the first row is processed
-        // (RSQ_DYNAMIC_TILES=1, OFF by default: measured slower - TPC-H Q1 SF10 370 instead of 338 us, Q3 0.341 instead of 0.302 ms,
-        // Q6 0.24 instead of 0.207 ms - although the counters sit one per cache line, the tickets are taken two chunks ahead and
-        // behind the loads, and the pools interleave their chunks; the returning atomics still cost more than the tail they remove.)
-        // Tiles are handed out DYNAMICALLY (RSQ_DYNAMIC_TILES): the table is cut into one range per pool (up to 256 pools;
-        // workgroup b draws from pool b % pools), and a wave takes the next U consecutive tiles of its pool with one atomic, issued
-        // an iteration ahead so that its latency hides behind the loads.  With tiles dealt to the waves up front, the waves that
-        // were dispatched first run ahead (the SIMDs favour older waves: device timestamps show TPC-H Q3's lineitem workgroups
-        // finishing between 61 and 97 us in the order of their index) and the launch ends on the few that are left alone with a
-        // CU; sharing a pool between workgroups of different age lets the fast ones take the rest.
+        // (Tiles handed out DYNAMICALLY - per-pool counters, a wave drawing its next chunk one iteration ahead - were built and measured
+        // slower: TPC-H Q1 SF10 370 instead of 338 us, Q3 0.341 instead of 0.302 ms, Q6 0.24 instead of 0.207 ms; the returning atomics
+        // cost more than the tail they remove.  Tiles are dealt to the waves round-robin.)
         auto emitPipelinedLoop = [&]() {
             // The software-pipelined main loop.  Per iteration a wave
             //   (1) works on its U tiles whose columns were requested ONE ITERATION AGO: the late-load form decides the leading
@@ -2564,29 +2513,12 @@ struct Walker {
             s << "    }\n";
         };
         auto emitPlainLoop = [&]() {
-        if (dynamicTiles) {
-            // chunks of U consecutive tiles, dealt to the pools round-robin (chunk c belongs to pool c % pools): at any moment the
-            // pools work on neighbouring chunks, i.e. the chip reads one contiguous window of the table, spread over all HBM
-            // channels.  (One contiguous RANGE per pool - 256 sequential streams 1.8 MB apart - halved the bandwidth.)
-            s << "    const u32 tpool = blockIdx.x % a.tile_pools;\n";
-            s << "    const i64 tend = ntiles, tchunks = (ntiles + " << (U - 1) << ") / " << U << ";\n";
-            // (one counter per 128-byte line: atomics on one LINE serialise at the memory side like atomics on one word - with the
-            // 256 counters in eight lines TPC-H Q1 took 608 us instead of 338)
-            // (two tickets in flight, the new one issued BEHIND the chunk's loads: memory operations return in order, and loads
-            // issued behind a returning atomic wait for it)
-            s << "    u32 tgrab = rsq::wave_grab_issue(a.tile_ctr + tpool * 32u, 1u), tgrab2 = rsq::wave_grab_issue(a.tile_ctr + tpool * 32u, 1u);\n";
-            s << "    for (;;) {\n        const i64 tchunk = (i64)tpool + (i64)a.tile_pools * (i64)rsq::wave_grab_value(tgrab);\n        if (tchunk >= tchunks) break;\n";
-            s << "        const i64 t = tchunk * " << U << ";\n";
-        } else {
-            s << "    const i64 tend = ntiles;\n";
-            s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
-        }
-        const bool matSkip = mat && !cq && !late && envInt("RSQ_MAT_SKIP", 1, 0, 1) != 0;
+        s << "    const i64 tend = ntiles;\n";
+        s << "    for (i64 t = wave * tstep; t < ntiles; t += nwaves * tstep * " << U << ") {\n";
+        const bool matSkip = mat && !cq && !late && 1 != 0;
         pipe.matSkip = matSkip;
         auto tileLive = [&](int u) { return matSkip ? "live" + std::to_string(u) : "tt" + std::to_string(u) + " < tend"; };
         for (int u = 0; u < U; u++) {
-            if (dynamicTiles) s << "        const i64 tt" << u << " = t + " << u << ";\n";
-            else
             s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2]" << (lateCol[(size_t)k] ? " = {0, 0}" : "") << ";\n";
             for (auto& sp : strPrefetch)
@@ -2610,7 +2542,6 @@ struct Walker {
             }
             s << "        }\n";
         }
-        if (dynamicTiles) s << "        tgrab = tgrab2; tgrab2 = rsq::wave_grab_issue(a.tile_ctr + tpool * 32u, 1u);\n";
         if (late) for (int u = 0; u < U; u++) emitLateLoads(s, "tt" + std::to_string(u), u, lateCol, "tend");
         for (int u = 0; u < U; u++)
             for (auto& pf : bitmapPrefetch) {
@@ -2618,11 +2549,6 @@ struct Walker {
                 s << "        if (" << tileLive(u) << ") {\n";
                 for (int j = 0; j < 2; j++) {
                     s << "            pf_" << pf.first << "_" << u << "[" << j << "] = ";
-                    if (pf.gated) {
-                        s << "!lead_pred(a";
-                        for (int k : leadCols) s << ", t" << k << "_" << u << "[" << j << "]";
-                        s << ") ? 0u : ";
-                    }
                     s << (pf.interleaved ? "rsq::bmi_load(a." : "rsq::bm_word(a.") << pf.first << "_bm, a." << pf.first << "_bmmin, a." << pf.first
                       << "_bmbits, (i64)t" << pf.second << "_" << u << "[" << j << "]);\n";
                 }
@@ -2709,7 +2635,7 @@ struct Walker {
                 // The late-load form runs stage 2 for a few per cent of the rows, but its registers are the kernel's: a hash aggregation
                 // with dozens of carried words holds 160 VGPRs and leaves the scan three waves per SIMD.  RSQ_LAZY_MIN_WG = n asks
                 // the compiler for n resident workgroups per CU (it spills in stage 2 instead).
-                const int minWg = envInt("RSQ_LAZY_MIN_WG", 0, 0, 8);
+                const int minWg = 0;
                 pipe.sourceLazy.replace(at, off.size(), "#define RSQ_LAZY 1\n" + (minWg ? "#define RSQ_MIN_WG " + std::to_string(minWg) + "\n" : std::string()));
             }
         }

@@ -112,24 +112,7 @@ uint64_t opSize(OpNode* o, bool local) {
     }
 }
 
-// ---- the resident step (RSQ_PERSISTENT_STEP=1, measurement knob) --------------------------------------------------------------
-// The one-launch step's kernel stays on the chip between executions of the same query and is started by a doorbell: a sequence number
-// the host stores into mapped pinned memory (hPinned[pinnedWords + 5]), watched by one thread per workgroup.  ~0 in the doorbell, or
-// RESIDENT_IDLE_MS without a ring, ends the kernel - so a forgotten park delays whatever is queued behind it on the stream, never
-// blocks it.  Everything else that uses the context's stream parks the kernel first.
-static const double RESIDENT_IDLE_MS = 20.0;
-void parkResidentStep(Context& ctx) {
-    Query* q = ctx.residentOwner;
-    if (!q) return;
-    __atomic_store_n(q->hPinned + q->pinnedWords + 5, ~0ull, __ATOMIC_RELEASE);
-    (void)hipSetDevice(ctx.device);
-    (void)hipStreamSynchronize(ctx.stream);
-    q->residentRunning = false;
-    ctx.residentOwner = nullptr;
-}
-
 Query::~Query() {
-    if (ctx.residentOwner == this) parkResidentStep(ctx);
     if (bgCompiler.joinable()) bgCompiler.join();
     destroyTailState(tailState);
     if (dtArena.dev || dtArena.pinned) {
@@ -165,7 +148,6 @@ Query::~Query() {
     if (dCandRows) ctx.free(dCandRows);
     if (dPartCounts) ctx.free(dPartCounts);
     if (dPartStart) ctx.free(dPartStart);
-    if (dTileCtr) ctx.free(dTileCtr);
     if (dDebugStamps) ctx.free(dDebugStamps);
     if (dStageBase) ctx.free(dStageBase);
     if (dStageCap) ctx.free(dStageCap);
@@ -263,7 +245,6 @@ static void resolveKernels(Query& q) {
 static void prepareStageBuffers(Query& q, const Pipeline& p);
 
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables) {
-    parkResidentStep(ctx);
     double t0 = nowMs();
     std::unique_ptr<Query> q(new Query(ctx));
     int hits0 = ctx.jitCacheHits, comp0 = ctx.jitCompiles;
@@ -363,7 +344,6 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         }
         if (q->aggMode == AggMode::AT_JOIN_ENTRY || q->aggMode == AggMode::HASH) q->dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
         q->dPipeStats = (uint64_t*)ctx.alloc(std::max<size_t>(1, q->pipelines.size()) * 8);
-        q->dTileCtr = (uint32_t*)ctx.alloc(std::max<size_t>(1, q->pipelines.size()) * 256 * 32 * 4);       // [pipeline][256 pools], one counter per 128-byte line
         size_t pw = q->pinnedWords + 8 + q->pipelines.size();
         RSQ_HIP(hipHostMalloc((void**)&q->hPinned, pw * 8, hipHostMallocDefault));
         memset(q->hPinned, 0, pw * 8);
@@ -397,15 +377,10 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     if (a.name == "fin_err") return (uint64_t)(uintptr_t)q.finErr;
     if (a.name == "fin_seq") return q.finOut ? q.finSeq : 0;
     if (a.name == "fin_ticket") return (uint64_t)(uintptr_t)(q.finOut ? q.dFinTicket : nullptr);
-    if (a.name == "pers_bell") return (uint64_t)(uintptr_t)(q.dPinnedDev ? q.dPinnedDev + q.pinnedWords + 5 : nullptr);
-    if (a.name == "pers_t0") return 0;
-    if (a.name == "pers_idle") return (uint64_t)(RESIDENT_IDLE_MS * 1e5);          // ticks of the 100 MHz clock
     if (a.name == "part_counts") return (uint64_t)(uintptr_t)q.dPartCounts;
     if (a.name == "part_start") return (uint64_t)(uintptr_t)q.dPartStart;
     if (a.name == "tile_step") return (uint64_t)q.partTileStep;
     if (a.name == "rec" || a.name == "sp_rec") return q.dPartRecords.empty() ? 0 : (uint64_t)(uintptr_t)q.dPartRecords[0];
-    if (a.name == "tile_ctr") return (uint64_t)(uintptr_t)(q.dTileCtr + (size_t)(&p - q.pipelines.data()) * 256 * 32);
-    if (a.name == "tile_pools") return (uint64_t)std::max(1u, std::min(256u, p.lastGrid));
     if (a.name == "dbg") {          // RSQ_DEBUG_TAIL: [workgroup][8] device timestamps (100 MHz), printed by the one-launch step
         if (!q.dDebugStamps) { q.dDebugStamps = (uint64_t*)q.ctx.alloc(4096 * 8 * 8); RSQ_HIP(hipMemset(q.dDebugStamps, 0, 4096 * 8 * 8)); }
         return (uint64_t)(uintptr_t)q.dDebugStamps;
@@ -441,12 +416,6 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
         if (f == "temp") return (uint64_t)(uintptr_t)h.dTemp;
         if (f == "treg") return (uint64_t)h.tempRegion;
         if (f == "tused") return (uint64_t)(uintptr_t)h.dTempUsed;
-        if (f == "hm") {      // slots per key value as a 32.32 fixed-point number, at most 4 (small ranges in large tables)
-            if (h.bmBits <= 0) return 0;
-            unsigned __int128 m = (((unsigned __int128)(uint64_t)h.capacity) << 32) / (unsigned __int128)(uint64_t)h.bmBits;
-            const unsigned __int128 cap4 = ((unsigned __int128)4) << 32;
-            return (uint64_t)(m < cap4 ? m : cap4);
-        }
     }
     return a.value;
 }
@@ -471,7 +440,7 @@ static unsigned pipelineGrid(const Query& q, const Pipeline& p, bool lazyForm = 
     int64_t want = (tiles + (int64_t)wavesPerBlock * p.unroll - 1) / ((int64_t)wavesPerBlock * p.unroll);
     const int64_t maxGrid = p.maxGrid ? (int64_t)p.maxGrid : (int64_t)(lazyForm ? p.gridPerCULazy : p.gridPerCU) * (int64_t)q.ctx.numCUs;
     int64_t grid = std::min<int64_t>(maxGrid * 256 / p.blockThreads, want);
-    static const bool clamp = !(getenv("RSQ_RESIDENT_GRID") && atoi(getenv("RSQ_RESIDENT_GRID")) == 0);
+    const bool clamp = true;
     if (clamp && !p.maxGrid) {
         Kernel* k = lazyForm && p.kernelLazy ? p.kernelLazy : p.kernel;
         grid = std::min<int64_t>(grid, (int64_t)residentWorkgroupsPerCU(k, p.blockThreads) * (int64_t)q.ctx.numCUs);
@@ -482,12 +451,6 @@ static unsigned pipelineGrid(const Query& q, const Pipeline& p, bool lazyForm = 
 static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnlyTable, unsigned grid = 0, unsigned block = 0,
                                  hipEvent_t start = nullptr, hipEvent_t stop = nullptr) {
     p.lastGrid = grid ? grid : pipelineGrid(q, p);
-    if (p.dynamicTiles) {
-        // (the execution's first fill batch zeroed every pipeline's counters; a pipeline launched again within the execution - sizing
-        // pass, second pass of a materialisation, a grown hash table - zeroes its own)
-        if (!p.tileCtrClean) RSQ_HIP(hipMemsetAsync(q.dTileCtr + (size_t)(&p - q.pipelines.data()) * 256 * 32, 0, 256 * 32 * 4, q.ctx.stream));
-        p.tileCtrClean = false;
-    }
     std::vector<uint64_t> args;
     for (auto& a : p.args) args.push_back(argValue(q, p, a, countOnlyTable));
     launch(q.ctx, k, p.lastGrid, block ? block : (unsigned)p.blockThreads, args, start, stop);
@@ -497,7 +460,7 @@ static void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnly
 // The synchronisation at the end of an execution: the stream is queried in a loop for up to 2 ms before the thread blocks
 // (hipStreamSynchronize sleeps on the completion signal's interrupt: 10-20 us of wake-up on a sub-millisecond execution).
 static void waitForStream(Context& ctx) {
-    static const bool spin = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
+    const bool spin = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
     if (spin) {
         const double deadline = nowMs() + 2.0;
         for (;;) {
@@ -554,7 +517,7 @@ static void debugStamps(Query& q, Pipeline& p) {
 static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
     Kernel* k = pass1 ? p.kernelPass1 : (q.flatRun && p.kernelFlat ? p.kernelFlat : p.kernel);
     // late column loads (codegen.cpp compactThen): worth it when the previous execution sent few rows to stage 2
-    static const int64_t lazyDen = getenv("RSQ_LAZY_THRESHOLD") ? std::max(1, atoi(getenv("RSQ_LAZY_THRESHOLD"))) : 32;
+    const int64_t lazyDen = 32;
     if (!pass1 && k == p.kernel && !p.sourceLazy.empty() && p.stage2Rows >= 0 && p.stage2Rows * lazyDen < p.src->nRows) {
         if (!p.kernelLazy) p.kernelLazy = &q.ctx.getKernel(p.sourceLazy, p.entry);
         launchPipelineKernel(q, p, *p.kernelLazy, countOnlyTable, pipelineGrid(q, p, true));
@@ -740,7 +703,7 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
     // A first execution knows the expected selectivity from the column statistics (the estimate behind the late loads): the
     // regions are laid out from it - every partition its even share - without the sampled pass and its two synchronisations
     // (0.3-0.4 ms of a 10 ms shard).  Skewed keys or a wrong estimate overflow a region and take the counted path below.
-    static const bool sampleAlways = getenv("RSQ_STAGED_SAMPLE") && atoi(getenv("RSQ_STAGED_SAMPLE")) != 0;
+    const bool sampleAlways = false;
     if (p.staged && !force && !sampleAlways && !p.stagedExact && p.leadPass >= 0.0) {
         const double passing = (double)rows * p.leadPass;
         const double direct = passing * (double)std::max(1, p.partAtomicsPerRow) / 25e9;
@@ -802,7 +765,7 @@ static void materializePipeline(Query& q, Pipeline& p) {
     RSQ_HIP(hipMemsetAsync(q.dMatCnt, 0, (size_t)slots * 4, ctx.stream));
     q.matLimit = 0;
     launchPipeline(q, p, -1, true);
-    static const bool chainedOk = !(getenv("RSQ_SCAN_CHAINED") && atoi(getenv("RSQ_SCAN_CHAINED")) == 0);
+    const bool chainedOk = !(getenv("RSQ_SCAN_CHAINED") && atoi(getenv("RSQ_SCAN_CHAINED")) == 0);
     // (worth it for many lane slots: 30 M of them 1.43 -> 1.39 ms for TPC-H Q19 at SF10; at SF1 - 3 M slots - the look-back's latency
     // costs more than the two small launches it replaces: 0.210 -> 0.227 ms)
     const bool chained = chainedOk && !q.scanChainedOff && slots >= (8ll << 20);
@@ -868,7 +831,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
             h.capacity = std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);          // (nothing is allocated: the bitmap is the table)
         } else if (h.rank) {
             // a dictionary that carries aggregates scatters them with a multiplicative bijection: power-of-two capacity
-            const int64_t capMul = getenv("RSQ_DEBUG_RANK_CAP") ? std::max(1, atoi(getenv("RSQ_DEBUG_RANK_CAP"))) : 1;      // (measurement only)
+            const int64_t capMul = 1;
             h.capacity = q.aggTable == h.id ? nextPow2(std::max<int64_t>(64, (int64_t)n * capMul)) : std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);
             const int64_t nChunks = (h.bmBlocks + RSQ_RANK_CHUNK_BLOCKS - 1) / RSQ_RANK_CHUNK_BLOCKS;
             // arrival-order buffer: one region per wave of the largest grid this pipeline launches, four times the mean
@@ -907,7 +870,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
         if (!prepared) { prepareTableAsync(ctx, nullptr, 0, 0, h.dTempUsed, (size_t)h.tempWaves, h.dBitmap, bmWords, h.dCount); q.report.num_kernels++; }
         launchPipeline(q, p, -1);
         // the index in one launch (chunk totals chained between the workgroups) when the prologue has zeroed the chain words
-        static const bool chainedOk = !(getenv("RSQ_RANK_CHAINED") && atoi(getenv("RSQ_RANK_CHAINED")) == 0);
+        const bool chainedOk = !(getenv("RSQ_RANK_CHAINED") && atoi(getenv("RSQ_RANK_CHAINED")) == 0);
         if (prepared && chainedOk && !q.chainedIndexOff) { rankTableIndexChained(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase); q.report.num_kernels += 1; }
         else { rankTableIndex(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase); q.report.num_kernels += 2; }
         rankTablePlace(ctx, h.dTemp, h.dTempUsed, (uint32_t)h.tempWaves, (uint32_t)h.tempRegion, h.dCount, (int)std::max<size_t>(1, nWords), h.dBitmap, h.bmMin,
@@ -1143,7 +1106,7 @@ void resolveKernelTime(Query& q) {
 
 // a single register-mode pipeline: its kernel carries the whole step (codegen.cpp, "The step in ONE launch")
 static bool fusedEligible(const Query& q) {
-    static const bool off = getenv("RSQ_FUSED_STEP") && atoi(getenv("RSQ_FUSED_STEP")) == 0;
+    const bool off = getenv("RSQ_FUSED_STEP") && atoi(getenv("RSQ_FUSED_STEP")) == 0;
     return !off && q.aggMode == AggMode::DENSE_REG && q.pipelines.size() == 1 && q.pipelines[0].sink == SinkKind::AGGREGATE &&
            !q.pipelines[0].partitioned && q.dFinTicket != nullptr;
 }
@@ -1259,14 +1222,12 @@ static double runDenseDeviceTail(Query& q) {
 // materialised columns) back, but leaves the tail to the root, which merges all shards' groups first (tail.cpp runTailMerged)
 static void tailUnlessHeld(Query& q) { if (!q.holdTail) runTail(q); }
 
-void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
+void executeQuery(Query& q, bool partialOnly, bool async) {
     Context& ctx = q.ctx;
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(ctx.device));
     const uint64_t epochAtEntry = ctx.execEpoch++;
     q.hRowsView = nullptr;          // (set around a candidate run of the tail only; an execution that did not come back must not leave it)
-    static const bool residentKnob = getenv("RSQ_PERSISTENT_STEP") && atoi(getenv("RSQ_PERSISTENT_STEP")) == 1;
-    if (ctx.residentOwner && (ctx.residentOwner != &q || partialOnly || async)) parkResidentStep(ctx);
     if (async) {
         if (!partialOnly || !denseMode(q)) failUnsupported("asynchronous execution is available for dense partial aggregation only");
         for (auto& p : q.pipelines)
@@ -1335,7 +1296,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         if (hipHostGetDevicePointer(&dv, q.hCandRows, 0) == hipSuccess && dv) q.dHostCandRows = (int64_t*)dv; else (void)hipGetLastError();
     };
     auto fusedSelectOk = [&]() {
-        static const bool off = getenv("RSQ_FUSED_SELECT") && atoi(getenv("RSQ_FUSED_SELECT")) == 0;
+        const bool off = getenv("RSQ_FUSED_SELECT") && atoi(getenv("RSQ_FUSED_SELECT")) == 0;
         const bool publish = q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0);
         if (off || q.fusedSelectOff || !publish || partialOnly || async || getenv("RSQ_TRACE")) return false;
         ensureCandHost();
@@ -1347,25 +1308,17 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         // the kernel leaves its working table, the error word and the ticket at their identities; make them so the first
         // time, after an execution that did not come back (an exception between launch and synchronisation), and whenever
         // another query of this context may have left the shared error word set
-        static const bool pollOk0 = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
-        const bool resident = residentKnob && pollOk0 && !partialOnly && !async && p.persistentForm && q.dPinnedDev && !p.dynamicTiles &&
-                              pipelineGrid(q, p) <= (unsigned)ctx.numCUs && !q.dDebugStamps;
-        if (q.residentRunning && (!resident || nowMs() - q.residentLastRing > RESIDENT_IDLE_MS / 4 || !q.fusedReady || !ctx.errWordClean)) parkResidentStep(ctx);
-        const bool ringOnly = resident && q.residentRunning;      // the kernel is there: this step is a store into the doorbell
         if (!q.fusedReady || !ctx.errWordClean) {
             RSQ_HIP(hipMemcpyAsync(q.dAggWork, q.dAggWorkInit, q.padWords * 8, hipMemcpyDeviceToDevice, ctx.stream));
             RSQ_HIP(hipMemsetAsync(q.dFinTicket, 0, 4, ctx.stream));
             RSQ_HIP(hipMemsetAsync(ctx.dErr, 0, 4, ctx.stream));
-            if (p.dynamicTiles) RSQ_HIP(hipMemsetAsync(q.dTileCtr, 0, q.pipelines.size() * 256 * 32 * 4, ctx.stream));
             ctx.errWordClean = true;
         }
-        p.tileCtrClean = true;                                 // (the kernel's last workgroup puts the tile counters back, like the ticket)
-        static const bool stepTrace0 = getenv("RSQ_STEP_TRACE") != nullptr;
+        static const bool stepTrace0 = getenv("RSQ_TRACE") && atoi(getenv("RSQ_TRACE")) >= 2;
         // a step that runs to its end here takes the next pair of the event ring (read when somebody asks, or when the ring is
         // full); an asynchronous partial step keeps the single pair finalize / settle read
-        const bool ringEvents = !(async && partialOnly) && !resident;      // (no event pair around a step of a resident kernel)
-        if (resident) resolveKernelTime(q);
-        else if (ringEvents) {
+        const bool ringEvents = !(async && partialOnly);
+        if (ringEvents) {
             if (q.evRing.empty()) {
                 q.evRing.resize(256);
                 for (auto& e : q.evRing) { RSQ_HIP(hipEventCreate(&e.first)); RSQ_HIP(hipEventCreate(&e.second)); }
@@ -1374,7 +1327,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         } else resolveKernelTime(q);                           // the previous step's events, before they are recorded again
         q.fusedReady = false;
         q.flatRun = false;                                     // always the padded kernel: the last workgroup unpads
-        static const bool pollOk = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
+        const bool pollOk = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
         const bool poll = pollOk && !partialOnly;
         const uint64_t seq = poll ? ++q.finSeqCounter : 0;
         q.finSeq = seq;
@@ -1385,18 +1338,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         if (ringEvents) { auto& e = q.evRing[q.evTail % q.evRing.size()]; evA = e.first; evB = e.second; }
         // two event records around the launch.  (The extended launch that takes the events itself - RSQ_EXT_EVENTS=1 - costs the
         // host 3 us more per step and the tail another 1.5: measured 16 us of step overhead against 11.5.)
-        static const bool extEvents = getenv("RSQ_EXT_EVENTS") && atoi(getenv("RSQ_EXT_EVENTS")) == 1;
-        if (resident) {
-            // the doorbell carries the step's sequence number; a kernel launched now finds it there and runs this step at once
-            __atomic_store_n(q.hPinned + q.pinnedWords + 5, seq, __ATOMIC_RELEASE);
-            q.residentLastRing = nowMs();
-            if (!ringOnly) {
-                if (!p.kernelPersistent) p.kernelPersistent = &ctx.getKernel("#define RSQ_PERSISTENT 1\n" + p.source, p.entry);
-                RSQ_HIP(hipMemsetAsync(q.dFinTicket + 2, 0, 8, ctx.stream));
-                launchPipelineKernel(q, p, *p.kernelPersistent, -1);
-                q.residentRunning = true; ctx.residentOwner = &q;
-            } else q.report.num_kernels = 0;
-        } else
+        const bool extEvents = false;
         if (extEvents) launchPipelineKernel(q, p, *p.kernel, -1, 0, 0, evA, evB);
         else {
             const double tB = stepTrace0 ? nowMs() : 0;
@@ -1413,8 +1355,8 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         }
         q.finOut = nullptr;
         q.finSeq = 0;
-        if (ringEvents) q.evTail++; else if (!resident) q.kernelTimePending = true;
-        static const bool stepTrace = getenv("RSQ_STEP_TRACE") != nullptr;        // host-side phases of the one-launch step, averaged over 64 steps
+        if (ringEvents) q.evTail++; else q.kernelTimePending = true;
+        static const bool stepTrace = getenv("RSQ_TRACE") && atoi(getenv("RSQ_TRACE")) >= 2;        // host-side phases of the one-launch step, averaged over 64 steps
         const double tLaunched = stepTrace ? nowMs() : 0;
         q.report.bytes_read = (uint64_t)(p.bytesPerRow * p.src->nRows);
         if (async && partialOnly) {
@@ -1433,30 +1375,14 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
                 if ((++spins & 1023u) == 0) {
                     hipError_t e = hipStreamQuery(ctx.stream);
                     if (e != hipSuccess && e != hipErrorNotReady) RSQ_HIP(e);
-                    if (resident) { if (e == hipSuccess) break; }       // (a resident kernel ends only by leaving; its steps take as long as they take)
-                    else if (e == hipSuccess || nowMs() > deadline) { waitForStream(ctx); break; }
+                    if (e == hipSuccess || nowMs() > deadline) { waitForStream(ctx); break; }
                 }
                 __builtin_ia32_pause();
-            }
-            if (resident && *flag != seq) {
-                // the kernel - or some of its workgroups - had left when the doorbell rang (the host was away for longer than it
-                // waits): whatever ran of the step is void; make the identities again and take the step with a fresh launch
-                q.residentRunning = false; ctx.residentOwner = nullptr;
-                q.fusedReady = false;
-                if (residentRetry) failRuntime("internal error: the resident step left twice without publishing its table");
-                executeQuery(q, partialOnly, async, true);
-                return;
             }
             if (*flag != seq) failRuntime("internal error: the fused step finished without publishing its table");
             std::atomic_thread_fence(std::memory_order_acquire);
         } else waitForStream(ctx);
         q.fusedReady = true;
-        if (resident) {
-            // (no event pair around a step of a resident kernel: the last workgroup reports doorbell seen -> table published, 100 MHz ticks)
-            const double ms = (double)q.hPinned[q.pinnedWords + 6] * 1e-5;
-            q.report.kernel_time_ms = ms; q.kernelTimeSumMs += ms; q.kernelTimeLaunches++;
-            q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
-        }
         const double tSeen = stepTrace ? nowMs() : 0;
         if (q.dDebugStamps) {
             static int nPrinted = 0;
@@ -1518,16 +1444,13 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
     std::vector<FillItem> f;                // (kept: an execution that ends on its candidates enqueues the same clears for the next one)
     {
         f.push_back(FillItem{ctx.dErr, 4, 0});
-        bool anyDynamic = false;
-        for (auto& p : q.pipelines) { anyDynamic |= p.dynamicTiles; p.tileCtrClean = p.dynamicTiles; }
-        if (anyDynamic) f.push_back(FillItem{q.dTileCtr, q.pipelines.size() * 256 * 32 * 4, 0});
         if (anyCompaction) f.push_back(FillItem{q.dPipeStats, q.pipelines.size() * 8, 0});
         if (q.dGroupCount) { f.push_back(FillItem{q.dGroupCount, 4, 0}); groupCountCleared = true; }
         if (q.dTopkHists) { f.push_back(FillItem{q.dTopkHists, topkRangeScratchBytes(), 0}); topkScratchCleared = true; }
         // Join tables that have been sized (every execution but a query's first) are readied HERE, all of them in this one launch,
         // instead of one launch in front of every build (TPC-H Q5 builds five tables, Q3 two); likewise the aggregates kept beside
         // a join table's entries.  Nothing touches a table between this fill and its build pipeline.
-        static const bool prologueOk = !(getenv("RSQ_PROLOGUE") && atoi(getenv("RSQ_PROLOGUE")) == 0);
+        const bool prologueOk = true;
         for (auto& hp : q.hashTables) hp->prepared = false;       // (an execution that did not come back must not leave a table marked as readied)
         if (prologueOk && !trace && !interp)
             for (auto& p : q.pipelines) {
@@ -1694,7 +1617,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         if (!groupCountCleared) RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
                        q.dGroupRows, groupRowsAllocated, q.dGroupCount,
-                       h.rank && !(getenv("RSQ_RANK_SCRAMBLE") && atoi(getenv("RSQ_RANK_SCRAMBLE")) == 0),
+                       h.rank,
                        q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr);
         q.report.num_kernels++;
         if (preselect) {
@@ -1794,7 +1717,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
         q.report.execution_time_ms = nowMs() - t0;
         return;
     }
-    static const bool execTraceOn = getenv("RSQ_EXEC_TRACE") != nullptr;       // host-side phases of an execution of the general path, averaged over 8
+    static const bool execTraceOn = getenv("RSQ_TRACE") && atoi(getenv("RSQ_TRACE")) >= 2;       // host-side phases of an execution of the general path, averaged over 8
     const double tEnqueued = execTraceOn ? nowMs() : 0;
     bool sawSequence = false;
     if (selectPublished) {
@@ -1942,7 +1865,7 @@ void executeQuery(Query& q, bool partialOnly, bool async, bool residentRetry) {
             const size_t rowBytes = (size_t)q.groupRowWords * 8;
             q.candidateRun = false;
             if (topkCapacity && nCand <= (int64_t)topkCapacity && nCand < nGroups) {
-                static const bool postClear = !(getenv("RSQ_POST_CLEAR") && atoi(getenv("RSQ_POST_CLEAR")) == 0);
+                const bool postClear = true;
                 if (postClear && candOnHost && !trace && !interp && !q.holdTail) {
                     // the candidates are on the host and decide the answer (or the whole table is read below from buffers the clears
                     // leave alone): ready the next execution now, while the host does its tail
@@ -1981,7 +1904,6 @@ void finalizeQuery(Query& q) {
     Context& ctx = q.ctx;
     if (!denseMode(q)) failUnsupported("partial execution / finalize is available for dense aggregations only");
     RSQ_HIP(hipSetDevice(ctx.device));
-    parkResidentStep(ctx);
     double t1 = nowMs();
     const bool devTail = !q.mergePublishedSeq && denseDeviceTailWanted(q);
     double devTailMs = 0;
@@ -2032,7 +1954,6 @@ void settleAsync(Query& q) {
     Context& ctx = q.ctx;
     if (!q.pendingAsync) return;
     RSQ_HIP(hipSetDevice(ctx.device));
-    parkResidentStep(ctx);
     waitForStream(ctx);
     q.pendingAsync = false;
     float ms = 0;
@@ -2154,7 +2075,7 @@ void mergeGathered(Query& q, const void* gathered, int nRanks) {
     const int64_t G = q.denseGroups;
     if (nRanks > 1) for (auto& p : q.pipelines) if (p.sink == SinkKind::AGGREGATE && p.src->nRowsTotal < 0) q.firstRowsForeign = true;
     // small tables: the merge kernel also publishes the result to host-mapped memory (finalizeQuery polls for it)
-    static const bool pollOk = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
+    const bool pollOk = !(getenv("RSQ_POLL") && atoi(getenv("RSQ_POLL")) == 0);
     const bool publish = pollOk && q.dFinHost && q.tableWords <= 2048;
     q.mergePublishedSeq = publish ? ++q.finSeqCounter : 0;
     mergePartialsAsync(q.ctx, (const int64_t*)gathered, nRanks, (int64_t)q.tableWords, q.nMinBlocks * G, q.nMaxBlocks * G, q.nSumBlocks * G, (int64_t*)q.dAgg,

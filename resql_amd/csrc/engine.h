@@ -90,7 +90,6 @@ struct Context {
     int jitCompiles = 0, jitCacheHits = 0;
     bool errWordClean = false;                 // *dErr is known to be 0 (fused steps reset it themselves and rely on that)
     uint64_t execEpoch = 0;                    // counts executions on this context (a query's "readied for the next execution" state is good for the very next one only)
-    struct Query* residentOwner = nullptr;     // the query whose one-launch step is RESIDENT on this stream (RSQ_PERSISTENT_STEP=1; engine.cpp parkResidentStep)
 
     explicit Context(const rsq_config& c);
     ~Context();
@@ -226,8 +225,7 @@ void parseTblFile(const std::string& path, const std::vector<Type>& types, char 
 // ---- query ------------------------------------------------------------------------------------
 struct Query;
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables);
-void executeQuery(Query& q, bool partialOnly, bool async = false, bool residentRetry = false);
-void parkResidentStep(Context& ctx);          // RSQ_PERSISTENT_STEP=1: end the step kernel that waits on this context's stream (no-op without one)
+void executeQuery(Query& q, bool partialOnly, bool async = false);
 void finalizeQuery(Query& q);
 void finalizeQueryHost(Query& q, const int64_t* words, size_t nWords);
 void settleAsync(Query& q);

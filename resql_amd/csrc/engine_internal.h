@@ -189,8 +189,6 @@ struct Pipeline {
     int partGroups = 0;                  // groups per partition (power of two)
     int partAtomicsPerRow = 0;           // HBM atomics the direct form issues per passing row (sum accumulators)
     // form 3, staged partitioning (rsq_device.h): packed records through LDS rings, regions sized from a sample
-    bool dynamicTiles = false;           // the kernel draws its tiles from per-pool counters (Query::dTileCtr), zeroed before every launch
-    bool tileCtrClean = false;
     bool staged = false;
     double leadPass = -1.0;              // fraction of the rows the selection directly above the scan is expected to pass (column statistics), < 0: none
     bool lateLoads = false;              // the tile loop loads the columns behind the leading selection only for lanes with a passing row
@@ -213,8 +211,6 @@ struct Pipeline {
     std::string sourceLazy;
     Kernel* kernelLazy = nullptr;    // compiled when first chosen
     bool matSkip = false;            // a materialisation whose write pass skips the tiles that counted nothing (codegen.cpp)
-    bool persistentForm = false;     // the source holds the resident form of the one-launch step (RSQ_PERSISTENT 1; engine.cpp "the resident step")
-    Kernel* kernelPersistent = nullptr;      // compiled when RSQ_PERSISTENT_STEP=1 first asks for it
     unsigned lastGrid = 0;           // workgroups of the most recent launch
     int64_t stage2Rows = -1;         // rows the previous execution sent to stage 2 (-1: not known yet)
     int extraLdsBytes = 0;           // LDS a pipeline takes besides the compaction queues (hash aggregation's front table)
@@ -277,7 +273,6 @@ struct Query {
     int64_t partTileStep = 1;              // > 1: the counting pass samples every n-th tile (selectivity estimate)
     // staged partitioning (form 3): region layout [P] base / capacity per workgroup, tracker control block, per-(workgroup, partition) counts
     double kernelTimeSumMs = 0; uint64_t kernelTimeLaunches = 0;      // device time of the executions since the last reset (rsq_query_kernel_time_stats)
-    uint32_t* dTileCtr = nullptr;          // [pipeline][256] tile counters of the dynamically scheduled pipelines
     uint64_t* dDebugStamps = nullptr;      // RSQ_DEBUG_TAIL (measurement only)
     uint64_t* dPinnedDev = nullptr;        // hPinned as the device addresses it (status words are published by a kernel)
     uint64_t* dStageBase = nullptr; uint32_t* dStageCap = nullptr; void* dStageCtl = nullptr; void* hStageLayout = nullptr;
@@ -373,8 +368,6 @@ struct Query {
     std::vector<FillItem> readiedFill;
     bool scanChainedOff = false;         // a look-back of the one-launch offset scan timed out once: three launches from now on
     bool fusedSelectOff = false;         // a meeting point of the one-launch candidate selection timed out once: separate launches from now on
-    bool residentRunning = false;        // RSQ_PERSISTENT_STEP=1: this query's step kernel is on the chip, waiting for the doorbell (hPinned[pinnedWords + 5])
-    double residentLastRing = 0;         // ... when the host last rang it (the kernel leaves by itself after RESIDENT_IDLE_MS without a ring)
     uint64_t mergePublishedSeq = 0;        // > 0: rsq_query_merge_gathered also published the merged table to hPinned; finalize polls for this number
     bool kernelTimePending = false;        // the fused step's events have not been read yet (resolveKernelTime)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> evRing; size_t evHead = 0, evTail = 0;      // event pairs of the one-launch steps not read yet

@@ -192,7 +192,7 @@ void replayLevelByClusters(const uint64_t* h, const uint64_t* ts, size_t cnt, ui
     S.chunkA.assign(nChunks, 0); S.chunkB.assign(nChunks, 0); S.chunkIn.assign(nChunks + 1, 0);
     const uint64_t magic = (uint64_t)((((__uint128_t)1) << 64) / N);
     auto mod = [&](uint64_t x) { uint64_t q = (uint64_t)(((__uint128_t)x * magic) >> 64); uint64_t r = x - q * N; while (r >= N) r -= N; return r; };
-    static const bool traceReplay = getenv("RSQ_TRACE_REPLAY") != nullptr;
+    static const bool traceReplay = getenv("RSQ_TRACE") && atoi(getenv("RSQ_TRACE")) >= 2;
     auto nowUs = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tStep = traceReplay ? nowUs() : 0;
     auto step = [&](const char* what) {

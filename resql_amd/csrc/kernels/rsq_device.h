@@ -327,44 +327,6 @@ RSQ_DEV u32 wave_reserve(u32* ctr) {
     return base + (u32)__popcll(active & ((1ull << lane) - 1ull));
 }
 
-// the next `n` units of a shared counter for the whole wave: one atomic by lane 0, the value broadcast (the caller is wave-uniform)
-RSQ_DEV u32 wave_grab(u32* ctr, u32 n) {
-    u32 v = 0;
-    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, n);
-    return (u32)__builtin_amdgcn_readfirstlane((int)v);
-}
-// ... in two halves, so that the atomic's latency can pass behind other work: issue (the answer lands in lane 0's register), value
-// The resident step (codegen.cpp, RSQ_PERSISTENT): the kernel waits for a sequence number the host stores into mapped pinned memory.
-// ONE thread of the whole grid watches that word (reads of host memory from all 256 workgroups queue up one behind the other on
-// their way out of the chip: 130 us per step, measured); it hands the value on through a word in device memory that one thread of
-// every other workgroup watches.  Returns the new value, or ~0 - "leave" - which workgroup 0 also decides after `idle` ticks of the
-// 100 MHz clock without a ring (the kernel's way out when the host went away; the host launches again when it comes back).
-RSQ_DEV u64 wait_doorbell(const u64* bell_host, u64* bell_dev, u64 seen, u64 idle) {
-    const u64 t0 = (u64)wall_clock64();
-    if (blockIdx.x == 0) {
-        u64 v;
-        for (;;) {
-            v = __hip_atomic_load(bell_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (v != seen) break;
-            if ((u64)wall_clock64() - t0 > idle) { v = ~0ull; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        __hip_atomic_store(bell_dev, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return v;
-    }
-    for (;;) {
-        const u64 v = __hip_atomic_load(bell_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (v == ~0ull || v > seen) return v;                       // (sequence numbers only grow; the word is 0 at launch)
-        if ((u64)wall_clock64() - t0 > 4 * idle) return ~0ull;      // (workgroup 0 never came: not reachable, but every wave has its exit)
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-RSQ_DEV u32 wave_grab_issue(u32* ctr, u32 n) {
-    u32 v = 0;
-    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, n);
-    return v;
-}
-RSQ_DEV u32 wave_grab_value(u32 issued) { return (u32)__builtin_amdgcn_readfirstlane((int)issued); }
 
 // the 32-bit word of a key-domain bitmap that holds `key`'s bit (0 for keys outside the domain)
 RSQ_DEV u32 bm_word(const u32* bm, i64 bmmin, u64 bmbits, i64 key) {
@@ -448,9 +410,6 @@ RSQ_DEV u64 hash64(u64 x) {     // splitmix64 finaliser; the engine's own table 
     x ^= x >> 31;
     return x;
 }
-
-// blocked hash of a join key with a known range: d = key - min, m = (capacity << 32) / range (see codegen.cpp slotOf)
-RSQ_DEV u64 blocked_slot(u64 d, u64 m, u64 mask) { return (hash64(d >> 7) + (((d & 127ull) * m) >> 32)) & mask; }
 
 // ---- staged partitioning (large dense aggregations: codegen.cpp emitDenseAggregation, form 3) ------------------------------
 // One pass over the rows turns every passing row into a packed record in the region of its partition (partition = a

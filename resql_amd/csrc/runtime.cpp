@@ -71,7 +71,6 @@ Context::Context(const rsq_config& c) : cfg(c), device(c.device) {
 Context::~Context() {
     if (device >= 0) {
         (void)hipSetDevice(device);
-        parkResidentStep(*this);
         for (auto& kv : kernels) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
         if (dCompactChain) (void)hipFree(dCompactChain);
         if (spareTailArena.dev) (void)hipFree(spareTailArena.dev);
@@ -116,7 +115,6 @@ void Context::scratchFree(void* p) {
 void Context::setStream(hipStream_t s, bool callers) {
     if (device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(device));
-    parkResidentStep(*this);
     RSQ_HIP(hipStreamSynchronize(stream));     // nothing of ours may still be in flight on the stream we leave
     stream = callers ? s : ownStream;          // a caller's stream may be the null stream (0)
 }
@@ -224,7 +222,7 @@ void Context::compileManyToCache(const std::vector<std::string>& sources) {
         for (auto& t : todo) seen = seen || t.first == key;
         if (!seen) todo.emplace_back(key, &src);
     }
-    static const bool helpersOff = getenv("RSQ_COMPILE_HELPERS") && atoi(getenv("RSQ_COMPILE_HELPERS")) == 0;
+    const bool helpersOff = getenv("RSQ_COMPILE_HELPERS") && atoi(getenv("RSQ_COMPILE_HELPERS")) == 0;
     const std::string helper = libraryDir() + "/rsq_kernel_compiler";
     if (todo.size() > 1 && !helpersOff && access(helper.c_str(), X_OK) == 0) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());

@@ -55,5 +55,5 @@ def test_register_flush_goes_lane_by_lane(compile_ctx):
     li = tpch.lineitem_table(0.01, tpch.Q1_COLUMNS)
     _, src = _explain_and_source(compile_ctx, tpch.q1_plan(li))
     assert "s_lane[" in src and "rsq::wave_reduce_to_lane63<" in src and "rsq::wave_to_lds<" not in src
-    assert "#define RSQ_DYN_TILES 0" in src                                                    # tiles dealt up front (the dynamic hand-out measured slower)
+    assert "tile_ctr" not in src and "for (i64 t = wave * tstep; t < ntiles;" in src            # tiles dealt up front (the dynamic hand-out measured slower and is gone)
     assert "a.fin_out" in src                                                                  # the step in one launch

@@ -205,26 +205,6 @@ def test_plain_c_host_links_and_runs(tmp_path):
     assert out[3].startswith("error") and pr.returncode == 1          # compile-only context: no device to execute on
 
 
-def test_resident_form_of_the_one_launch_step_compiles_for_gfx950(compile_ctx, tmp_path):
-    """RSQ_PERSISTENT_STEP=1 compiles the same source with RSQ_PERSISTENT 1 when it first asks for it - on the GPU box only; here the
-    resident form of TPC-H Q1's and Q6's kernels goes through hipcc so that a change to the generated text cannot break it unseen"""
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("no hipcc")
-    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "resql_amd", "csrc", "kernels")
-    for plan_of, cols in ((tpch.q1_plan, tpch.Q1_COLUMNS), (tpch.q6_plan, tpch.Q6_COLUMNS)):
-        li = tpch.lineitem_table(0.01, cols, n_rows=256)
-        q = compile_ctx.compile(plan_of(li), [compile_ctx.table(li)])
-        assert "#if RSQ_PERSISTENT" in q.source and "rsq::wait_doorbell(a.pers_bell" in q.source
-        src = tmp_path / "step.hip"
-        src.write_text(q.source)
-        p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-DRSQ_PERSISTENT=1", "-include", "hip/hip_runtime.h", "-I", inc,
-                            "--cuda-device-only", "-c", "-o", str(tmp_path / "step.o"), str(src)], capture_output=True, text=True, timeout=300)
-        assert p.returncode == 0, p.stderr[-2000:]
-
-
 def test_config_struct_is_validated_without_a_gpu():
     """rsq_config.struct_size / emission_order / compat_flags are checked by rsq_ctx_create (compile-only context: no device needed)"""
     import ctypes as C
