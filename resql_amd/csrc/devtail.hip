@@ -174,6 +174,97 @@ __global__ void __launch_bounds__(256) k_dense_rows(const u64* __restrict__ tabl
     }
 }
 
+// ---- the same tail over the group rows of a hash / join-entry aggregation -----------------------------------------------------------
+__global__ void __launch_bounds__(256) k_row_first_keys(const i64* __restrict__ rows, int stride, i64 n, u64* __restrict__ keys, u32* __restrict__ idx) {
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) { keys[i] = (u64)rows[(size_t)i * (size_t)stride]; idx[i] = (u32)i; }
+}
+__device__ __forceinline__ int row_str_byte(const i64* w, int i) { return (int)(signed char)(u8)((u64)w[i >> 3] >> (8 * (i & 7))); }
+// Values::hash of the group's values (reference src/ValuesJitFlounder.h:65-162; hashChar / hashVarchar src/qlib/hash.h:116-147), as hostref.cpp refHashValue
+__global__ void __launch_bounds__(256) k_row_hashes(const i64* __restrict__ rows, int stride, const u32* __restrict__ idx, i64 n, RowTailKeys keys, u64* __restrict__ hashes) {
+    const u64 A = 1710227316115945415ull, B = 741332713408129251ull;
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+        const i64* r = rows + (size_t)idx[i] * (size_t)stride;
+        u64 h = 0;
+        for (int k = 0; k < keys.n; k++) {
+            const RowTailKey& key = keys.k[k];
+            const i64 v = r[key.word];
+            switch (key.typeTag) {
+                case RSQ_BIGINT: case RSQ_DECIMAL: h += (u64)v * A + B; break;
+                case RSQ_INT: case RSQ_DATE: h += ((u64)(i64)(int)(u32)v + B) * A; break;
+                case RSQ_BOOL: if ((u8)v == 0) h += 31636373ull; break;
+                case RSQ_CHAR:
+                    if (key.len <= 1) { h += (u64)(u8)v; h += h; break; }
+                    {   // hashChar: the declared length, missing characters count as ' '
+                        bool ended = false;
+                        for (int c = 0; c < key.len; c++) {
+                            int ch = ended ? 0 : row_str_byte(r + key.word, c);
+                            if (ch == 0) { ended = true; ch = ' '; }
+                            const int m = (int)((u32)ch * 31636373u);
+                            h = h + (u64)(i64)m + (u64)(i64)ch;
+                        }
+                    }
+                    break;
+                default:      // VARCHAR: the characters up to the first NUL
+                    for (int c = 0; c < key.len; c++) {
+                        const int ch = row_str_byte(r + key.word, c);
+                        if (ch == 0) break;
+                        const int m = (int)((u32)ch * 31636373u);
+                        h = h + (u64)(i64)m + (u64)(i64)ch;
+                    }
+                    break;
+            }
+        }
+        hashes[i] = h;
+    }
+}
+__global__ void __launch_bounds__(256) k_row_result_rows(const i64* __restrict__ rows, int stride, const u32* __restrict__ idx, const u32* __restrict__ order, i64 nRows,
+                                                         RowTailCols cols, int tupleSize, u8* __restrict__ out, u32* err) {
+    for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < nRows; i += (i64)gridDim.x * blockDim.x) {
+        const u32 at = order ? order[i] : (u32)i;
+        const i64* r = rows + (size_t)(idx ? idx[at] : at) * (size_t)stride;
+        u8* dst = out + (size_t)i * (size_t)tupleSize;
+        for (int c = 0; c < cols.n; c++) {
+            const RowTailCol& col = cols.c[c];
+            u8* p = dst + col.offset;
+            if (col.kind == 0 && col.len > 0) {      // a string by value, NUL terminated / padded to its place in the tuple (ValueMoves::writeString)
+                bool ended = false;
+                for (int b = 0; b < col.width; b++) {
+                    int ch = (ended || b >= col.len) ? 0 : row_str_byte(r + col.a, b);
+                    if (ch == 0) ended = true;
+                    p[b] = (u8)ch;
+                }
+                continue;
+            }
+            i64 v;
+            if (col.kind != 2) v = r[col.a];
+            else {
+                const i64 s = (i64)((u64)r[col.a] * 100ull), n = r[col.b];
+                if (n == 0 || (s == (i64)0x8000000000000000ull && n == -1)) { atomicOr(err, 1u); v = 0; } else v = s / n;
+            }
+            for (int b = 0; b < col.width; b++) p[b] = (u8)((u64)v >> (8 * b));      // packed tuples have no alignment: byte stores
+        }
+    }
+}
+void rowTailFirstKeys(Context& ctx, const int64_t* rows, int stride, int64_t n, uint64_t* keys, uint32_t* idx) {
+    if (n <= 0) return;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (n + 255) / 256));
+    hipLaunchKernelGGL(k_row_first_keys, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, (i64)n, (u64*)keys, idx);
+    RSQ_HIP(hipGetLastError());
+}
+void rowTailHashes(Context& ctx, const int64_t* rows, int stride, const uint32_t* idx, int64_t n, const RowTailKeys& keys, uint64_t* hashes) {
+    if (n <= 0) return;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (n + 255) / 256));
+    hipLaunchKernelGGL(k_row_hashes, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, idx, (i64)n, keys, (u64*)hashes);
+    RSQ_HIP(hipGetLastError());
+}
+void rowTailResultRows(Context& ctx, const int64_t* rows, int stride, const uint32_t* idx, const uint32_t* order, int64_t nRows, const RowTailCols& cols,
+                       int tupleSize, uint8_t* out) {
+    if (nRows <= 0) return;
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8192, (nRows + 255) / 256));
+    hipLaunchKernelGGL(k_row_result_rows, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, idx, order, (i64)nRows, cols, tupleSize, out, ctx.dErr);
+    RSQ_HIP(hipGetLastError());
+}
+
 void densePresentGroups(Context& ctx, const int64_t* firstBlock, int64_t D, uint32_t* flags, uint64_t* offs, void* scanTemp, uint64_t* outFirst, uint32_t* outGid) {
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(4096, (D + 256) / 256));
     hipLaunchKernelGGL(k_present_flags, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstBlock, (i64)D, flags);

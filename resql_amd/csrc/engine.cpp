@@ -120,6 +120,8 @@ Query::~Query() {
         if (!ctx.spareTailArena.dev && !ctx.spareTailArena.pinned) ctx.spareTailArena = dtArena;
         else { if (dtArena.dev) ctx.free(dtArena.dev); if (dtArena.pinned) (void)hipHostFree(dtArena.pinned); }
     }
+    if (rtDev) ctx.free(rtDev);
+    if (rtPinned) (void)hipHostFree(rtPinned);
     if (dGenericCode) ctx.free(dGenericCode);
     for (auto& gp : generic2Progs) { if (gp.dCode) ctx.free(gp.dCode); if (gp.dProbes) ctx.free(gp.dProbes); if (gp.dConstPool) ctx.free(gp.dConstPool); }
     if (dG2Cnt) ctx.free(dG2Cnt);
@@ -1218,6 +1220,102 @@ static double runDenseDeviceTail(Query& q) {
     return nowMs() - tTail0;
 }
 
+// ---- the tail of a hash / join-entry aggregation with many groups on the device (devtail.hip k_row_*) -------------------------------
+// The group rows stay in HBM (q.dGroupRows, n rows of q.groupRowWords words): order by first row (radix sort) -> the reference's hash of
+// every group's values -> the replay of the reference's table (device) -> packed tuples in that order -> [the tuples to the host].
+// With an ORDER BY above, the host then runs the reference's quicksort over the delivered tuples; without, they are the result.
+// The host path this replaces copies all group rows (n x words x 8 bytes over PCIe), decodes them, hashes, replays and builds the
+// rows on the worker pool: 5-30 ms per million groups.
+static bool rowsDeviceTailWanted(Query& q, int64_t n) {
+    const bool off = getenv("RSQ_DEVICE_TAIL") && atoi(getenv("RSQ_DEVICE_TAIL")) == 0;
+    const int64_t minGroups = getenv("RSQ_DEVICE_TAIL_MIN") ? atoll(getenv("RSQ_DEVICE_TAIL_MIN")) : 65536;
+    if (off || q.holdTail || n < minGroups || n >= (1ll << 31) || !q.dGroupRows) return false;
+    if (q.aggMode == AggMode::HASH && q.charGroupsNeedMerge) return false;      // groups equal up to trailing spaces: the host merges them first
+    if (q.rowTail < 0) q.rowTail = planRowsDeviceTail(q, q.rtKeys, q.rtCols, q.rtTupleSize, q.rtLimitRows, q.rtSorts) ? 1 : 0;
+    return q.rowTail == 1;
+}
+
+static double runRowsDeviceTail(Query& q, int64_t n) {
+    Context& ctx = q.ctx;
+    const bool trace = getenv("RSQ_TRACE") != nullptr;
+    const double t0 = nowMs();
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    if (q.rtCapacity < n) {
+        if (q.rtDev) ctx.free(q.rtDev);
+        q.rtDev = nullptr; q.rtCapacity = 0;
+        const int64_t cap = std::max<int64_t>(n + n / 8, 65536);
+        const size_t bytes = up((size_t)cap * 8) * 3 + up((size_t)cap * 4) * 3 + up(radixSortTempBytes(cap)) + up((size_t)cap * (size_t)q.rtTupleSize) +
+                             up(replayDeviceBytes((uint64_t)cap, (uint64_t)cap * 4 + 1024));
+        q.rtDev = ctx.alloc(bytes);
+        q.rtCapacity = cap;
+    }
+    const int64_t cap = q.rtCapacity;
+    char* d = (char*)q.rtDev; size_t at = 0;
+    auto take = [&](size_t b) { void* r = d + at; at += up(b); return r; };
+    uint64_t* keysA = (uint64_t*)take((size_t)cap * 8); uint64_t* keysB = (uint64_t*)take((size_t)cap * 8); uint64_t* hashes = (uint64_t*)take((size_t)cap * 8);
+    uint32_t* idxA = (uint32_t*)take((size_t)cap * 4); uint32_t* idxB = (uint32_t*)take((size_t)cap * 4); uint32_t* order = (uint32_t*)take((size_t)cap * 4);
+    void* sortTemp = take(radixSortTempBytes(cap));
+    uint8_t* rows = (uint8_t*)take((size_t)cap * (size_t)q.rtTupleSize);
+    void* replayWork = d + at;
+    const size_t replayBytes = replayDeviceBytes((uint64_t)cap, (uint64_t)cap * 4 + 1024);
+    int64_t emit = n;
+    const bool limitHere = q.rtLimitRows >= 0 && !q.rtSorts;      // (with an ORDER BY the materialisation's own limit cuts the EMISSION order first, as materialize.h:197-206 does)
+    if (q.rtLimitRows >= 0) emit = std::min(emit, q.rtLimitRows);
+    (void)limitHere;
+    const uint32_t* dIdx = nullptr;
+    const uint32_t* dOrder = nullptr;
+    const int stride = q.groupRowWords;
+    if (ctx.cfg.emission_order != RSQ_EMIT_ANY && n > 1) {
+        int64_t maxRow = 1;
+        for (auto& p : q.pipelines) if (p.sink == SinkKind::AGGREGATE) maxRow = std::max<int64_t>(maxRow, std::max(p.src->row0 + p.src->nRows, p.src->totalRows()));
+        int bits = 1; while (bits < 63 && (maxRow >> bits) != 0) bits++;
+        rowTailFirstKeys(ctx, q.dGroupRows, stride, n, keysA, idxA);
+        const bool inB = radixSortPairs(ctx, keysA, idxA, keysB, idxB, n, bits, sortTemp, radixSortTempBytes(cap));
+        dIdx = inB ? idxB : idxA;
+        rowTailHashes(ctx, q.dGroupRows, stride, dIdx, n, q.rtKeys, hashes);
+        std::vector<std::pair<uint64_t, uint64_t>> levels;
+        if (replayLevels((uint64_t)n, opSize(q.agg), levels) && replayDeviceBytes((uint64_t)n, levels.back().first) <= replayBytes) {
+            replayEmissionOrderDevice(ctx, hashes, (uint64_t)n, levels, replayWork, order);
+            q.report.num_kernels += (uint64_t)((bits + 7) / 8) * 5 + 2 + levels.size() * 12;
+        } else {
+            // (a table beyond the device replay's range: the hashes go to the host, the slot order comes back)
+            std::vector<uint64_t> hh((size_t)n);
+            RSQ_HIP(hipMemcpyAsync(hh.data(), hashes, (size_t)n * 8, hipMemcpyDeviceToHost, ctx.stream));
+            waitForStream(ctx);
+            std::vector<uint32_t>& ord = ctx.replayOrder;
+            refEmissionOrderParallel(hh.data(), (size_t)n, opSize(q.agg), ord, ctx.replayScratch);
+            RSQ_HIP(hipMemcpyAsync(order, ord.data(), (size_t)emit * 4, hipMemcpyHostToDevice, ctx.stream));
+            RSQ_HIP(hipStreamSynchronize(ctx.stream));      // (ord is the context's scratch: keep it until the copy has read it)
+        }
+        dOrder = order;
+    }
+    rowTailResultRows(ctx, q.dGroupRows, stride, dIdx, dOrder, emit, q.rtCols, q.rtTupleSize, rows);
+    const size_t outBytes = std::max<size_t>((size_t)emit * (size_t)q.rtTupleSize, 8);
+    if (q.rtPinnedBytes < outBytes) {
+        if (q.rtPinned) (void)hipHostFree(q.rtPinned);
+        q.rtPinned = nullptr; q.rtPinnedBytes = 0;
+        RSQ_HIP(hipHostMalloc(&q.rtPinned, outBytes + outBytes / 8, hipHostMallocDefault));
+        q.rtPinnedBytes = outBytes + outBytes / 8;
+    }
+    if (emit > 0) RSQ_HIP(hipMemcpyAsync(q.rtPinned, rows, (size_t)emit * (size_t)q.rtTupleSize, hipMemcpyDeviceToHost, ctx.stream));
+    uint32_t err = 0;
+    RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
+    waitForStream(ctx);
+    q.report.num_kernels += 1;
+    if (err) { ctx.errWordClean = false; checkDeviceError(err); }
+    if (trace) fprintf(stderr, "[rsq trace]     device tail over %lld group rows: %.3f ms (ordered, hashed, replayed, %lld tuples built and read back)\n", (long long)n, nowMs() - t0, (long long)emit);
+    int64_t rowsOut = emit;
+    if (q.rtSorts) {
+        const double t1 = nowMs();
+        runRowsTailSort(q, (uint8_t*)q.rtPinned, rowsOut);
+        if (trace) fprintf(stderr, "[rsq trace]     order by over the delivered tuples (the reference's quicksort, host): %.3f ms\n", nowMs() - t1);
+    }
+    q.resultRows = rowsOut;
+    q.resultPinned = (uint8_t*)q.rtPinned;
+    q.resultInPinned = true;
+    return nowMs() - t0;
+}
+
 // a shard of a multi-GPU plan that does not end in a dense partial table runs its pipelines and reads the group rows (or the
 // materialised columns) back, but leaves the tail to the root, which merges all shards' groups first (tail.cpp runTailMerged)
 static void tailUnlessHeld(Query& q) { if (!q.holdTail) runTail(q); }
@@ -1885,8 +1983,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             }
             if (!topkCapacity || q.tailNeedsAllGroups || !(nCand <= (int64_t)topkCapacity && nCand < nGroups)) {
                 q.nGroupRows = nGroups;
-                if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * rowBytes, hipMemcpyDeviceToHost));
-                tailUnlessHeld(q);
+                if (rowsDeviceTailWanted(q, nGroups)) runRowsDeviceTail(q, nGroups);      // many groups: the rows are made on the device
+                else {
+                    if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * rowBytes, hipMemcpyDeviceToHost));
+                    tailUnlessHeld(q);
+                }
             }
             q.report.finalize_time_ms = nowMs() - t1;
             q.report.execution_time_ms = nowMs() - t0;

@@ -213,6 +213,18 @@ void denseGroupHashes(Context& ctx, const uint32_t* gids, int64_t n, const Dense
 void denseResultRows(Context& ctx, const uint64_t* table, int64_t D, const uint32_t* gids, const uint32_t* order, int64_t nRows, const DenseTailKeys& keys,
                      const DenseTailCols& cols, int tupleSize, uint8_t* out);
 
+// ... and the same tail for the GROUP ROWS of a hash / join-entry aggregation ([first row | table words | accumulator blocks], as
+// compactEntries leaves them): order by first row, the reference's hashes from the group values, the replay, packed tuples.
+// tail.cpp planRowsDeviceTail describes where the group values and output columns sit in a row.
+struct RowTailKey { int32_t word, typeTag, len, pad; };      // group value k: row word `word`; strings: `len` bytes in consecutive words (little-endian words = the bytes in order)
+struct RowTailKeys { int32_t n; RowTailKey k[16]; };
+struct RowTailCol { int32_t kind, a, b, width, offset, len; };      // kind 0: the value at row word a (len > 0: a string); 1: row word a; 2: AVG = word a * 100 / word b
+struct RowTailCols { int32_t n; RowTailCol c[24]; };
+void rowTailFirstKeys(Context& ctx, const int64_t* rows, int stride, int64_t n, uint64_t* keys, uint32_t* idx);
+void rowTailHashes(Context& ctx, const int64_t* rows, int stride, const uint32_t* idx, int64_t n, const RowTailKeys& keys, uint64_t* hashes);
+void rowTailResultRows(Context& ctx, const int64_t* rows, int stride, const uint32_t* idx, const uint32_t* order, int64_t nRows, const RowTailCols& cols,
+                       int tupleSize, uint8_t* out);
+
 // the replay of the reference's aggregation hash table on the device (devtail.hip): level sizes on the host, everything else enqueued
 bool replayLevels(uint64_t n, uint64_t minSize, std::vector<std::pair<uint64_t, uint64_t>>& levels);
 size_t replayDeviceBytes(uint64_t n, uint64_t nMax);

@@ -333,6 +333,11 @@ struct Query {
     void* dtReplayWork = nullptr; size_t dtReplayBytes = 0;           // work area of the replay on the device (0: host replay)
     uint64_t* hDtHashes = nullptr; uint32_t* hDtOrder = nullptr;      // pinned
     uint8_t* resultPinned = nullptr;       // pinned copy of the result tuples (device tail)
+    // ... of the group rows of a hash / join-entry aggregation (engine.cpp runRowsDeviceTail): buffers sized for rtCapacity rows
+    int rowTail = -1;                      // -1 not analysed yet, 0 no, 1 yes
+    RowTailKeys rtKeys{}; RowTailCols rtCols{}; int rtTupleSize = 0; int64_t rtLimitRows = -1; bool rtSorts = false;
+    int64_t rtCapacity = 0;
+    void* rtDev = nullptr; void* rtPinned = nullptr; size_t rtPinnedBytes = 0;
     bool resultInPinned = false;
 
     // result
@@ -416,6 +421,9 @@ std::vector<uint32_t>& tailOrderBuffer(Query& q);
 ReplayScratch& tailReplayScratch(Query& q);
 // tail.cpp: can the rows of this dense aggregation be produced on the device (devtail.hip)?  fills the kernels' descriptions
 bool planDenseDeviceTail(Query& q, DenseTailKeys& keys, DenseTailCols& cols, int& tupleSize, int64_t& limitRows);
+// tail.cpp: the same for the group rows of a hash / join-entry aggregation; `sorts`: an ORDER BY follows (the host sorts the delivered tuples)
+bool planRowsDeviceTail(Query& q, RowTailKeys& keys, RowTailCols& cols, int& tupleSize, int64_t& limitRows, bool& sorts);
+void runRowsTailSort(Query& q, uint8_t* tuples, int64_t& rows);
 // tail.cpp: is the first ORDER BY key of an `ORDER BY ... LIMIT k` above the aggregation one word of the group rows?
 void planDeviceTopK(Query& q);
 

@@ -737,6 +737,54 @@ bool planDenseDeviceTail(Query& q, DenseTailKeys& keys, DenseTailCols& cols, int
     return true;
 }
 
+// The same question for the group rows of a hash / join-entry aggregation ([first row | table words | accumulator blocks]): yes when every
+// output column is a group value (strings too: their bytes sit in consecutive words of the row), an accumulator or an AVG.  An ORDER BY
+// above does not prevent it: the device then delivers the tuples in the reference's EMISSION order and the host only runs the
+// reference's quicksort over them (runRowsTailSort) - group decoding, hashing, the replay and the row building stay on the device.
+bool planRowsDeviceTail(Query& q, RowTailKeys& keys, RowTailCols& cols, int& tupleSize, int64_t& limitRows, bool& sorts) {
+    if (!q.agg || (q.aggMode != AggMode::HASH && q.aggMode != AggMode::AT_JOIN_ENTRY) || q.agg->exprs2.empty() || q.agg->exprs2.size() > 16) return false;
+    TailShape sh = buildTailShape(q);
+    if (sh.cur.size() > 24) return false;
+    const HashTable& ht = *q.hashTables[(size_t)q.aggTable];
+    const int nTab = (int)(ht.keys.size() + ht.payload.size());
+    keys.n = (int32_t)q.agg->exprs2.size();
+    for (size_t k = 0; k < q.agg->exprs2.size(); k++) {
+        const Type& t = q.agg->exprs2[k]->type;
+        keys.k[k] = RowTailKey{1 + q.groupSource[k], (int32_t)t.tag, t.isString() ? t.len : (t.tag == RSQ_CHAR ? 1 : 0), 0};
+    }
+    cols.n = (int32_t)sh.cur.size();
+    for (size_t c = 0; c < sh.cur.size(); c++) {
+        const Src& s = sh.colSrc[c];
+        RowTailCol& o = cols.c[c];
+        const Type& t = sh.cur[c].type;
+        o.kind = s.kind; o.offset = sh.offs[c]; o.width = sizeInTuple(t, true); o.len = 0; o.b = 0;
+        if (s.kind == 3) return false;                                    // a computed projection: the host's expression interpreter
+        if (s.kind == 0) {
+            if (s.a < 0 || (size_t)s.a >= q.agg->exprs2.size()) return false;
+            o.a = 1 + q.groupSource[(size_t)s.a];
+            if (t.isString()) { o.len = t.len; if (o.width != t.len + 1) return false; }
+        } else {
+            if (t.isString()) return false;
+            o.a = 1 + nTab + q.accumSlot[(size_t)s.a];
+            if (s.kind == 2) o.b = 1 + nTab + q.accumSlot[(size_t)s.b];
+        }
+        if (!t.isString() && o.width != 8 && o.width != 4 && o.width != 2 && o.width != 1) return false;
+    }
+    tupleSize = (int)sh.ts;
+    limitRows = sh.mat->hasLimit ? std::max<int64_t>(sh.mat->limit, 1) : -1;      // materialize.h:197-206
+    sorts = sh.orderBy != nullptr;
+    q.resultSchema = sh.cur;
+    return true;
+}
+
+// ... and the ORDER BY over the tuples the device delivered in emission order: the reference's quicksort, then its LIMIT (orderby.h:87-93)
+void runRowsTailSort(Query& q, uint8_t* tuples, int64_t& rows) {
+    TailShape sh = buildTailShape(q);
+    if (!sh.orderBy) return;
+    refQuicksort(tuples, rows, sh.ts, sh.reqs);
+    if (sh.orderBy->hasLimit && rows > sh.orderBy->limit) rows = std::max<int64_t>(sh.orderBy->limit, 0);
+}
+
 static void runTailOn(Query& q, Groups& G) {
     OpNode* agg = q.agg;
     const bool trace = getenv("RSQ_TRACE") != nullptr;

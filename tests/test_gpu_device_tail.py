@@ -111,3 +111,67 @@ def test_emission_order_any_gives_the_same_rows(monkeypatch):
             assert b == sorted(b)            # ... in group-id order: deterministic, not the reference's
     finally:
         ctx.close()
+
+
+# ---- the same tail over the GROUP ROWS of a hash / join-entry aggregation (engine.cpp runRowsDeviceTail, devtail.hip k_row_*) -------
+def _hash_plan(t, order=False, limit=None, strings=False):
+    """computed group key (generic hash aggregation), sums / count / min / max / avg; optionally ORDER BY over the result"""
+    p = P.Plan([t])
+    key = p.add(p.mul(p.attr("b"), p.constant("3", P.BIGINT)), p.constant("1", P.BIGINT))
+    sc, cnt, lo, hi, av = p.sum(p.attr("c")), p.count(p.star()), p.min(p.attr("d")), p.max(p.attr("c")), p.avg(p.attr("d"))
+    node = p.selection(p.lt(p.attr("a"), p.constant(str(1 << 30), P.BIGINT)), p.scan("t"))
+    node = p.aggregation([sc, cnt, lo, hi, av], [key], node)
+    node = p.projection([p.as_("k", key), p.as_("s", sc), p.as_("n", cnt), p.as_("lo", lo), p.as_("hi", hi), p.as_("av", av)], node)
+    if order:
+        return p.set_root(p.orderby([p.desc(p.attr("n")), p.asc(p.attr("lo"))], node), limit=limit)
+    return p.set_root(p.materialize(node), limit=limit)
+
+
+@pytest.mark.parametrize("order,limit", [(False, None), (False, 777), (True, None)])
+def test_group_rows_of_a_hash_aggregation_are_finished_on_the_device(gpu_ctx, monkeypatch, capfd, order, limit):
+    """100 000 groups of a computed key: no ORDER BY -> the text IS the reference's emission order (aggregation.h:298-343), made by the
+    device replay; with ORDER BY the device delivers the tuples in that order and the host runs the reference's quicksort over them
+    (ties on both sort keys keep the order that quicksort leaves them in).  Same bytes as the host tail and the oracle."""
+    t = tpch.synthetic_table(700_001, 100_000)
+    plan = _hash_plan(t, order, limit)
+    want = orc.execute(plan)
+    monkeypatch.setenv("RSQ_TRACE", "1")
+    got, _ = _run(gpu_ctx, plan)
+    assert "device tail over" in capfd.readouterr().err
+    assert got.n_rows == want.n_rows and got.text == want.text and got.tuples == want.tuples
+    monkeypatch.setenv("RSQ_DEVICE_TAIL", "0")
+    host, _ = _run(gpu_ctx, plan)
+    assert "device tail over" not in capfd.readouterr().err
+    assert host.tuples == want.tuples
+
+
+def test_group_rows_with_string_group_values(gpu_ctx, monkeypatch, capfd):
+    """VARCHAR and CHAR(1) group values next to an integer one: hashVarchar / the CHAR(1) rule / the integer rule summed as Values::hash
+    does (ValuesJitFlounder.h:65-162), strings written into the tuples NUL-terminated (values.h:136)"""
+    n = 300_000
+    rng = np.random.default_rng(11)
+    names = np.array([f"name{(i * 7919) % 70_000:06d}".encode() for i in range(n)], dtype="S12")
+    t = P.Table("t", [P.Column("s", T.VARCHAR(12), names), P.Column("f", T.CHAR(1), rng.integers(65, 68, n).astype(np.uint8)),
+                      P.Column("x", T.BIGINT(), rng.integers(0, 1000, n).astype(np.int64))], n)
+    p = P.Plan([t])
+    sx, cnt = p.sum(p.attr("x")), p.count(p.star())
+    node = p.aggregation([sx, cnt], [p.attr("s"), p.attr("f")], p.scan("t"))
+    plan = p.set_root(p.materialize(p.projection([p.attr("f"), p.as_("total", sx), p.attr("s"), p.as_("n", cnt)], node)))
+    want = orc.execute(plan)
+    monkeypatch.setenv("RSQ_TRACE", "1")
+    got, _ = _run(gpu_ctx, plan)
+    assert "device tail over" in capfd.readouterr().err
+    assert got.n_rows == want.n_rows > 65536 and got.text == want.text and got.tuples == want.tuples
+
+
+def test_q3_without_limit_takes_the_device_tail(gpu_ctx, monkeypatch, capfd):
+    """aggregation at the join entry (TPC-H Q3's groups hang off the orders entry), ORDER BY revenue desc, o_orderdate, no LIMIT: the
+    device orders, hashes, replays and builds the tuples, the host runs the reference's quicksort - byte for byte the oracle's rows"""
+    sf = 0.2
+    plan = tpch.q3_plan(tpch.customer_table(sf), tpch.orders_table(sf), tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS), limit=None)
+    want = orc.execute(plan)
+    monkeypatch.setenv("RSQ_TRACE", "1")
+    monkeypatch.setenv("RSQ_DEVICE_TAIL_MIN", "1000")
+    got, _ = _run(gpu_ctx, plan)
+    assert "device tail over" in capfd.readouterr().err
+    assert got.n_rows == want.n_rows > 1000 and got.text == want.text

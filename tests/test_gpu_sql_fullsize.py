@@ -48,3 +48,48 @@ def test_join_statements_equal_the_reference_at_full_size(gpu_ctx, sf):
     finally:
         for t in tabs:
             t.close()
+
+
+def test_q3_and_q10_without_limit_equal_the_reference_at_sf1(gpu_ctx, monkeypatch, capfd):
+    """Every group of the aggregation leaves: 11 336 rows (Q3: aggregation at the join entry) and 38 051 rows (Q10: hash aggregation, 7 group
+    values, strings among them), in the reference's emission order sorted by its quicksort.  The UNMODIFIED reference's answers
+    (tests/golden/make_nolimit_golden.py: row count, SHA-256 of the serialised relation, first and last rows).  With
+    RSQ_DEVICE_TAIL_MIN lowered the rows are made by the device tail (engine.cpp runRowsDeviceTail); both ways must give these bytes."""
+    import hashlib
+    from resql_amd import tpch
+    with open(os.path.join(GOLDEN, "ref_nolimit_sf1.json")) as f:
+        gold = json.load(f)
+    sf = gold["sf"]
+
+    def check(text, g):
+        lines = text.splitlines()
+        assert len(lines) - 1 == g["rows"] and lines[:6] == g["head"] and lines[-5:] == g["tail"]
+        assert hashlib.sha256(text.encode("latin1")).hexdigest() == g["sha256"]
+
+    cu, od, li = tpch.customer_table(sf), tpch.orders_table(sf), tpch.lineitem_table(sf, tpch.Q3_LINEITEM_COLUMNS)
+    q3tabs = [gpu_ctx.table(t) for t in (cu, od, li)]
+    db = tpch_full.database(sf, fill_unused=False)
+    host = [db[k] for k in sorted(db)]
+    tabs = [gpu_ctx.table(t) for t in host]
+    try:
+        for min_groups, expect_device in (("1000", True), (None, False)):
+            if min_groups:
+                monkeypatch.setenv("RSQ_DEVICE_TAIL_MIN", min_groups)
+            else:
+                monkeypatch.delenv("RSQ_DEVICE_TAIL_MIN", raising=False)
+            monkeypatch.setenv("RSQ_TRACE", "1")
+            capfd.readouterr()
+            q = gpu_ctx.compile(tpch.q3_plan(cu, od, li, limit=None), q3tabs)
+            q.execute(); q.execute()
+            check(q.result().text, gold["q3_nolimit"])
+            q.close()
+            assert ("device tail over" in capfd.readouterr().err) == expect_device
+            sql = tpch_full.QUERIES["q10"].replace("limit 20", "")
+            q = gpu_ctx.sql_compile(sql, tabs)
+            q.execute(); q.execute()
+            check(q.result().text, gold["q10_nolimit"])
+            q.close()
+            assert ("device tail over" in capfd.readouterr().err) == expect_device
+    finally:
+        for t in tabs + q3tabs:
+            t.close()
