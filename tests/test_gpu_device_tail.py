@@ -148,9 +148,12 @@ def test_group_rows_of_a_hash_aggregation_are_finished_on_the_device(gpu_ctx, mo
 def test_group_rows_with_string_group_values(gpu_ctx, monkeypatch, capfd):
     """VARCHAR and CHAR(1) group values next to an integer one: hashVarchar / the CHAR(1) rule / the integer rule summed as Values::hash
     does (ValuesJitFlounder.h:65-162), strings written into the tuples NUL-terminated (values.h:136)"""
-    n = 300_000
+    # (hashVarchar sums its characters' images, so strings that are permutations of one another collide - qlib/hash.h:131-147 - and the
+    # reference's table, which the oracle restates, degrades to long probe chains: a few thousand groups, not hundreds of thousands)
+    n = 60_000
     rng = np.random.default_rng(11)
-    names = np.array([f"name{(i * 7919) % 70_000:06d}".encode() for i in range(n)], dtype="S12")
+    names = np.array([f"name{(i * 7919) % 4_000:06d}".encode() for i in range(n)], dtype="S12")
+    monkeypatch.setenv("RSQ_DEVICE_TAIL_MIN", "1000")
     t = P.Table("t", [P.Column("s", T.VARCHAR(12), names), P.Column("f", T.CHAR(1), rng.integers(65, 68, n).astype(np.uint8)),
                       P.Column("x", T.BIGINT(), rng.integers(0, 1000, n).astype(np.int64))], n)
     p = P.Plan([t])
@@ -161,7 +164,7 @@ def test_group_rows_with_string_group_values(gpu_ctx, monkeypatch, capfd):
     monkeypatch.setenv("RSQ_TRACE", "1")
     got, _ = _run(gpu_ctx, plan)
     assert "device tail over" in capfd.readouterr().err
-    assert got.n_rows == want.n_rows > 65536 and got.text == want.text and got.tuples == want.tuples
+    assert got.n_rows == want.n_rows > 4000 and got.text == want.text and got.tuples == want.tuples
 
 
 def test_q3_without_limit_takes_the_device_tail(gpu_ctx, monkeypatch, capfd):
