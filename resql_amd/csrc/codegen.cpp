@@ -2200,7 +2200,10 @@ struct Walker {
         closeScope();
         line("#endif");
         closeScope();
-        addArg("cnt", "u32*", 0); addArg("offs", "const u64*", 0); addArg("out_limit", "u64", 0);
+        // cnt[tile * 64 + lane]: tuples the lane's two rows emit; tcnt[tile]: their sum, by the wave; toffs = exclusive scan of tcnt.  The
+        // write pass finds a lane's first position as toffs[tile] + the wave's exclusive prefix over cnt: the scan runs over one count
+        // per 128 ROWS, not per lane (TPC-H Q19 at SF10: 30 M lane counts, 0.27 ms of scan kernels behind a 1.13 ms count pass).
+        addArg("cnt", "u32*", 0); addArg("tcnt", "u32*", 0); addArg("toffs", "const u64*", 0); addArg("out_limit", "u64", 0);
         stateDecl += "    u32 cnt = 0;\n    u64 pos = 0;\n";
         pipe.sink = SinkKind::MATERIALIZE;
         explainSteps.push_back("materialize " + std::to_string(o->schema.size()) + " column(s) in scan order (count / scan / write)");
@@ -2529,7 +2532,7 @@ struct Walker {
                     for (int w = 0; w * 8 < sp.second; w++) s << "        u64 s" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
             // The write pass of a materialisation skips every tile whose 64 lane slots counted nothing in the count pass: a selective
             // statement (TPC-H Q19: 1107 rows out of 60 M) then reads its columns once, not twice.
-            if (matSkip) s << "#if RSQ_PASS == 2\n        const bool live" << u << " = tt" << u << " < tend && __ballot(a.cnt[tt" << u << " * 64 + lane] != 0u) != 0ull;\n#else\n"
+            if (matSkip) s << "#if RSQ_PASS == 2\n        const bool live" << u << " = tt" << u << " < tend && a.tcnt[tt" << u << "] != 0u;\n#else\n"
                            << "        const bool live" << u << " = tt" << u << " < tend;\n#endif\n";
             s << "        if (" << tileLive(u) << ") {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
             for (auto& sp : strPrefetch)
@@ -2559,7 +2562,7 @@ struct Walker {
             }
         for (int u = 0; u < U; u++) {
             s << "        if (" << tileLive(u) << ") {\n";
-            if (mat) s << "            const i64 slot = tt" << u << " * 64 + lane;\n#if RSQ_PASS == 2\n            st.pos = a.offs[slot];\n#endif\n";
+            if (mat) s << "            const i64 slot = tt" << u << " * 64 + lane;\n#if RSQ_PASS == 2\n            st.pos = a.toffs[tt" << u << "] + (u64)rsq::wave_excl_sum_u32(a.cnt[slot]);\n#endif\n";
             for (int j = 0; j < 2; j++) {
                 s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");
                 for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
@@ -2568,7 +2571,7 @@ struct Walker {
                 s << ");\n";
                 if (cq && (QCAP < 192 || j == 1)) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";
             }
-            if (mat) s << "#if RSQ_PASS == 1\n            a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
+            if (mat) s << "#if RSQ_PASS == 1\n            a.cnt[slot] = st.cnt;\n            { const u32 ts = (u32)rsq::wave_sum((u64)st.cnt); if (lane == 0) a.tcnt[tt" << u << "] = ts; }\n            st.cnt = 0;\n#endif\n";
             s << "        }\n";
         }
         s << "    }\n";
@@ -2599,11 +2602,20 @@ struct Walker {
             s << "        while (st.cq_n >= 64) cq_drain(a, st, 64);\n    }\n";
             s << "    while (st.cq_n > 0) cq_drain(a, st, st.cq_n < 64 ? st.cq_n : 64);\n";
         } else {
+            if (mat) {
+                // the rows behind the last whole tile, 64 to a wave: pseudo-tiles ntiles and ntiles + 1 of the count arrays (wave-uniform trip count)
+                s << "    for (i64 rb = (ntiles << 7) + (i64)blockIdx.x * blockDim.x + (i64)(threadIdx.x & ~63u); rb < a.n_rows; rb += (i64)gridDim.x * blockDim.x) {\n";
+                s << "        const i64 r = rb + lane;\n        const bool valid = r < a.n_rows;\n";
+                s << "        const i64 ttile = ntiles + ((rb - (ntiles << 7)) >> 6);\n        const i64 slot = ttile * 64 + lane;\n";
+                s << "#if RSQ_PASS == 2\n        st.pos = a.toffs[ttile] + (u64)rsq::wave_excl_sum_u32(valid ? a.cnt[slot] : 0u);\n#endif\n";
+                s << "        if (valid) row_fn(a, st, r" << rowArgsTail << ");\n";
+                s << "#if RSQ_PASS == 1\n        a.cnt[slot] = st.cnt;\n        { const u32 ts = (u32)rsq::wave_sum((u64)st.cnt); if (lane == 0) a.tcnt[ttile] = ts; }\n        st.cnt = 0;\n#endif\n";
+                s << "    }\n";
+            } else {
             s << "    for (i64 r = (ntiles << 7) + (i64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_rows; r += (i64)gridDim.x * blockDim.x) {\n";
-            if (mat) s << "        const i64 slot = ntiles * 64 + (r - (ntiles << 7));\n#if RSQ_PASS == 2\n        st.pos = a.offs[slot];\n#endif\n";
             s << "        row_fn(a, st, r" << rowArgsTail << ");\n";
-            if (mat) s << "#if RSQ_PASS == 1\n        a.cnt[slot] = st.cnt; st.cnt = 0;\n#endif\n";
             s << "    }\n";
+            }
         }
         if (pipe.staged) s << "#endif\n";
         if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 2] = (u64)wall_clock64();\n";

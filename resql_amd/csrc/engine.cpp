@@ -140,6 +140,7 @@ Query::~Query() {
     for (auto& e : evRing) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (dMatCnt) ctx.free(dMatCnt);
     if (dMatOffs) ctx.free(dMatOffs);
+    if (dMatTileCnt) ctx.free(dMatTileCnt);
     if (dScanTemp) ctx.free(dScanTemp);
     for (void* p : dMatCols) if (p) ctx.free(p);
     if (dGroupRows) ctx.free(dGroupRows);
@@ -396,7 +397,8 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
     (void)p;
     if (a.name == "cq_total") return (uint64_t)(uintptr_t)(q.dPipeStats + (&p - q.pipelines.data()));
     if (a.name == "cnt") return (uint64_t)(uintptr_t)q.dMatCnt;
-    if (a.name == "offs") return (uint64_t)(uintptr_t)q.dMatOffs;
+    if (a.name == "tcnt") return (uint64_t)(uintptr_t)q.dMatTileCnt;
+    if (a.name == "toffs") return (uint64_t)(uintptr_t)q.dMatOffs;
     if (a.name == "out_limit") return (uint64_t)q.matLimit;
     if (a.name.size() >= 2 && a.name[0] == 'o' && isdigit((unsigned char)a.name[1])) {
         size_t k = (size_t)atoi(a.name.c_str() + 1);
@@ -752,31 +754,36 @@ static void runLargeDenseAggregation(Query& q, Pipeline& p) {
 static void materializePipeline(Query& q, Pipeline& p) {
     Context& ctx = q.ctx;
     const int64_t n = p.src->nRows;
-    const int64_t slots = (n >> 7) * 64 + (n & 127) + 1;          // + one trailing zero slot: its offset is the total
-    if (slots > 0x7fffffff) failUnsupported("materialisation over more than 4 G rows in one table (the offset scan is 32-bit)");
+    // lane counts for every tile (and the two pseudo-tiles of the rows behind the last whole one), ONE count per tile for the scan
+    const int64_t tiles = (n >> 7) + 2;
+    const int64_t slots = tiles * 64;
+    if (tiles + 1 > 0x7fffffff) failUnsupported("materialisation over more than 2^38 rows in one table");
     if (q.matSlots < slots) {
         if (q.dMatCnt) ctx.free(q.dMatCnt);
         if (q.dMatOffs) ctx.free(q.dMatOffs);
+        if (q.dMatTileCnt) ctx.free(q.dMatTileCnt);
         if (q.dScanTemp) ctx.free(q.dScanTemp);
         q.dMatCnt = (uint32_t*)ctx.alloc((size_t)slots * 4);
-        q.dMatOffs = (uint64_t*)ctx.alloc((size_t)slots * 8);
-        q.scanTempBytes = scanTempBytes(slots);
+        q.dMatTileCnt = (uint32_t*)ctx.alloc((size_t)(tiles + 1) * 4);
+        q.dMatOffs = (uint64_t*)ctx.alloc((size_t)(tiles + 1) * 8);
+        q.scanTempBytes = scanTempBytes(tiles + 1);
         q.dScanTemp = ctx.alloc(q.scanTempBytes);
         q.matSlots = slots;
     }
-    RSQ_HIP(hipMemsetAsync(q.dMatCnt, 0, (size_t)slots * 4, ctx.stream));
+    // (the count pass writes every lane count it will read back and every whole tile's total: only the pseudo-tiles and the trailing
+    // slot - whose offset is the total - need their zero)
+    RSQ_HIP(hipMemsetAsync(q.dMatTileCnt + (tiles - 2), 0, 3 * 4, ctx.stream));
     q.matLimit = 0;
     launchPipeline(q, p, -1, true);
     const bool chainedOk = !(getenv("RSQ_SCAN_CHAINED") && atoi(getenv("RSQ_SCAN_CHAINED")) == 0);
-    // (worth it for many lane slots: 30 M of them 1.43 -> 1.39 ms for TPC-H Q19 at SF10; at SF1 - 3 M slots - the look-back's latency
-    // costs more than the two small launches it replaces: 0.210 -> 0.227 ms)
-    const bool chained = chainedOk && !q.scanChainedOff && slots >= (8ll << 20);
-    if (chained) exclusiveScanCountsChained(ctx, q.dMatCnt, q.dMatOffs, slots, q.dScanTemp, q.scanTempBytes);
-    else exclusiveScanCounts(ctx, q.dMatCnt, q.dMatOffs, slots, q.dScanTemp, q.scanTempBytes);
+    // (the one-launch scan pays from ~8 M counts on; one count per 128 rows means tables beyond a billion rows)
+    const bool chained = chainedOk && !q.scanChainedOff && tiles + 1 >= (8ll << 20);
+    if (chained) exclusiveScanCountsChained(ctx, q.dMatTileCnt, q.dMatOffs, tiles + 1, q.dScanTemp, q.scanTempBytes);
+    else exclusiveScanCounts(ctx, q.dMatTileCnt, q.dMatOffs, tiles + 1, q.dScanTemp, q.scanTempBytes);
     q.report.num_kernels++;
     uint64_t total = 0;
     uint32_t scanErr = 0;
-    RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + (slots - 1), 8, hipMemcpyDeviceToHost, ctx.stream));
+    RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + tiles, 8, hipMemcpyDeviceToHost, ctx.stream));
     if (chained) RSQ_HIP(hipMemcpyAsync(&scanErr, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
     waitForStream(ctx);
     if (scanErr & 512u) {
@@ -784,8 +791,8 @@ static void materializePipeline(Query& q, Pipeline& p) {
         q.scanChainedOff = true;
         scanErr &= ~512u;
         RSQ_HIP(hipMemcpyAsync(ctx.dErr, &scanErr, 4, hipMemcpyHostToDevice, ctx.stream));
-        exclusiveScanCounts(ctx, q.dMatCnt, q.dMatOffs, slots, q.dScanTemp, q.scanTempBytes);
-        RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + (slots - 1), 8, hipMemcpyDeviceToHost, ctx.stream));
+        exclusiveScanCounts(ctx, q.dMatTileCnt, q.dMatOffs, tiles + 1, q.dScanTemp, q.scanTempBytes);
+        RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + tiles, 8, hipMemcpyDeviceToHost, ctx.stream));
         waitForStream(ctx);
     }
     // MaterializeOp with a LIMIT leaves the pipeline once count >= limit, i.e. after max(limit, 1) tuples (materialize.h:197-206)
@@ -802,7 +809,7 @@ static void materializePipeline(Query& q, Pipeline& p) {
     launchPipeline(q, p, -1, false);
     // (bytes the passes ask for: both read every row - unless the write pass skips the tiles that counted nothing; then it is the
     // count pass, the counts, and whatever tiles do hold result rows, which the host cannot know: not counted)
-    q.report.bytes_read += p.matSkip ? (uint64_t)(p.bytesPerRow * p.src->nRows) + (uint64_t)slots * 4 : 2 * (uint64_t)(p.bytesPerRow * p.src->nRows);
+    q.report.bytes_read += p.matSkip ? (uint64_t)(p.bytesPerRow * p.src->nRows) + (uint64_t)tiles * 4 : 2 * (uint64_t)(p.bytesPerRow * p.src->nRows);
 }
 
 // size (by a counting pass of the same pipeline), allocate and clear a join table, then build it

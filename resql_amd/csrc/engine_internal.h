@@ -286,7 +286,8 @@ struct Query {
     OpNode* matOp = nullptr;
     Schema matSchema;
     uint32_t* dMatCnt = nullptr;           // per lane-tile slot: tuples emitted
-    uint64_t* dMatOffs = nullptr;          // exclusive scan of dMatCnt (+ total at the end)
+    uint32_t* dMatTileCnt = nullptr;       // per 128-row tile: tuples emitted (the sum of its 64 lane counts)
+    uint64_t* dMatOffs = nullptr;          // exclusive scan of dMatTileCnt (+ total at the end)
     void* dScanTemp = nullptr; size_t scanTempBytes = 0;
     int64_t matSlots = 0;
     std::vector<void*> dMatCols;           // output columns (struct of arrays)

@@ -79,6 +79,13 @@ RSQ_DEV u64 wave_sum(u64 v) {
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
     return v;
 }
+// exclusive prefix sum over the lanes of the wave (all 64 lanes must be here)
+RSQ_DEV u32 wave_excl_sum_u32(u32 v) {
+    u32 x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 y = (u32)__shfl_up((int)x, d, 64); if ((int)(threadIdx.x & 63) >= d) x += y; }
+    return x - v;
+}
 RSQ_DEV u64 wave_min_u64(u64 v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { u64 o = shfl_xor_u64(v, m); v = o < v ? o : v; }
