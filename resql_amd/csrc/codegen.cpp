@@ -283,6 +283,10 @@ struct Walker {
     // the selection directly above the scan: its text over the row's column variables, the columns it reads and the fraction of
     // rows it is expected to pass (column statistics, values taken as uniform) - the late-load form of the tile loop (below)
     std::string leadCond; std::vector<int> leadCols; double leadPass = 1.0;
+    std::string stage2Prefix;               // necessary conditions of later joins, tested at the top of stage 2 (consumeProbe: component bitmaps)
+    struct CompFilter { std::string table, symbol, stage2Var; int64_t bits; };
+    std::vector<CompFilter> compFilters;    // ... as consumeProbe found them while stage 2 was generated
+    bool inStage2 = false;                  // the walk is generating the code behind the wave compaction
     bool leadPassComplete = true;       // every part of the predicate was understood (else the estimate is an upper bound only)
     std::string stage2Body;
     std::vector<std::pair<std::string, Sym>> cqLive;     // carried symbols: name -> stage-1 variable and type
@@ -628,11 +632,44 @@ struct Walker {
         // ---- everything downstream goes into stage 2, which sees the carried values under the names q_<k> ----
         const std::string stage1 = body; const int stage1Indent = indent;
         body.clear(); indent = 1;
+        stage2Prefix.clear(); compFilters.clear(); inStage2 = true;
         for (size_t k = 0; k < cqLive.size(); k++) eg.symbols[cqLive[k].first] = Sym{"q_" + std::to_string(k), cqLive[k].second.type};
         explainSteps.push_back("wave compaction");
         downstream();
         while (indent > 1) closeScope();
+        inStage2 = false;
         const std::string down = body;
+        // Component bitmaps of later joins (consumeProbe): the value is a column of this scan, so the test belongs in STAGE 1 - the column
+        // then streams with the tiles instead of being gathered row by row by every survivor, and the rows it rejects never enter the
+        // queue (TPC-H Q5: 9.1 M of 60 M lineitem rows find their order, 1.8 M of those a supplier in ASIA).  A column the test reads
+        // is not loaded late.  Where the stage-1 name of the value is not at hand the test stands at the top of stage 2.
+        std::string stage1Cond;
+        for (auto& cf : compFilters) {
+            std::string v1;
+            for (size_t k = 0; k < cqLive.size(); k++)
+                if (cqLive[k].first == cf.symbol && cqLive[k].second.var.compare(0, 2, "v_") == 0) {
+                    v1 = cqLive[k].second.var;
+                    if (lazyOf[k] >= 0) { pipe.lazyCols.erase(std::remove(pipe.lazyCols.begin(), pipe.lazyCols.end(), lazyOf[k]), pipe.lazyCols.end()); lazyOf[k] = -1; }
+                }
+            const std::string C = cf.table + "_c";
+            std::string test = "rsq::bit_in(a." + C + "_bm, (u64)((i64)(" + (v1.empty() ? cf.stage2Var : v1) + ") - a." + C + "_bmmin), a." + C + "_bmbits)";
+            // A small bitmap (the supplier keys of TPC-H Q5: 12 KB) is read for BOTH rows of the lane and every tile in flight with the
+            // tile loads, like the first probe's key bitmap: tested inside the row function, the eight rows a lane handles per iteration
+            // each wait for their own load (measured: the pipeline 323 us; the loads hit the L1, their latency does not overlap).
+            bool already = false;
+            for (auto& pf : bitmapPrefetch) already = already || pf.first == C;
+            if (!v1.empty() && cf.bits <= (1 << 20) && !already) {
+                const int col = atoi(v1.c_str() + 2);
+                bitmapPrefetch.push_back({C, col, false});
+                const std::string call = "rsq::bm_word(a." + C + "_bm, a." + C + "_bmmin, a." + C + "_bmbits, (i64)";
+                rowParams += ", const u32 pf_" + C;
+                rowArgsTail += ", " + call + "a.c" + std::to_string(col) + "[r])";
+                rowArgsTailGuarded += ", (valid ? " + call + "a.c" + std::to_string(col) + "[r]) : 0u)";
+                test = "rsq::bit_of_word(pf_" + C + ", (u64)((i64)(" + v1 + ") - a." + C + "_bmmin), a." + C + "_bmbits)";
+            }
+            if (!v1.empty()) stage1Cond += (stage1Cond.empty() ? "" : " && ") + test;
+            else stage2Prefix += "    if (!" + test + ") return;      // no build row of " + cf.table + " has this key component: the row cannot reach the sink\n";
+        }
         // only the values stage 2 really reads travel through the queue (a date that was only filtered on does not); the
         // late-loaded ones take the LAST slots, which exist in the RSQ_LAZY 0 form only: the lazy form's queues are
         // smaller, more workgroups fit a CU, and a latency-bound pipeline (tile load, then the key bitmap's L2 load) gets
@@ -670,8 +707,9 @@ struct Walker {
                 body += "#endif\n";
             }
         }
-        stage2Body = body + down;
+        stage2Body = body + stage2Prefix + down;
         body = stage1; indent = stage1Indent;
+        if (!stage1Cond.empty()) openScope("if (" + stage1Cond + ") {");
         line("cq_pass = true;");
         for (size_t k = 0; k < cqLive.size(); k++) {
             if (slot[k] < 0) continue;
@@ -679,6 +717,7 @@ struct Walker {
             if (lazyOf[k] < 0) line(push);
             else { body += "#if !RSQ_LAZY\n"; line(push); body += "#endif\n"; }
         }
+        if (!stage1Cond.empty()) closeScope();
         pipe.compactWords = nSlots;
         pipe.compactWordsLazy = pipe.lazyCols.empty() ? nSlots : nLazySlots;
         return true;
@@ -856,6 +895,19 @@ struct Walker {
                 }
             }
         }
+        // ... or, for a table with several key words, a bitmap over ONE integer component (HashTable::hasCompBitmap)
+        if (!ht->hasBitmap && keyVars.size() > 1 && envInt("RSQ_JOIN_BITMAP", 1, 0, 1))
+            for (size_t ki = 0; ki < o->exprs.size() && !ht->hasCompBitmap; ki++) {
+                Expr* l = o->exprs[ki]->child;
+                auto org = symbolOrigin.find(l->symbol);
+                if (l->tag != RSQ_E_ATTRIBUTE || l->type.isString() || org == symbolOrigin.end() || org->second != -1 || keyFirstWord[ki] < 0) continue;
+                const int ci = pipe.src->findCol(l->symbol);
+                if (ci < 0 || !pipe.src->cols[(size_t)ci].stats.valid || pipe.src->nRows == 0) continue;
+                const ColumnStats& st = pipe.src->cols[(size_t)ci].stats;
+                const unsigned __int128 range = (unsigned __int128)((__int128)st.max - (__int128)st.min) + 1;
+                if (range > ((unsigned __int128)1 << 26)) continue;
+                ht->hasCompBitmap = true; ht->compWord = keyFirstWord[ki]; ht->cbMin = st.min; ht->cbBits = (int64_t)range;
+            }
         // capacity: the reference sizes its table lChild.getSize() * 5 / 3 and grows it; ours cannot grow
         // inside a kernel, so it is sized for twice the rows the build pipeline can deliver and re-run
         // at double size if it still overflows (engine.cpp).
@@ -906,6 +958,12 @@ struct Walker {
         addArg(T + "_state", "u32*", 0); addArg(T + "_words", "i64*", 0); addArg(T + "_cap", "u64", 0); addArg(T + "_count", "u32*", 0);
         addArg(T + "_countonly", "u64", 0);
         if (ht->hasBitmap) { addArg(T + "_bm", "u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht->bmMin); addArg(T + "_bmbits", "u64", (uint64_t)ht->bmBits); }
+        if (ht->hasCompBitmap) {
+            // every build row sets its component's bit, in the sizing pass and in the build alike (a value outside the range the statistics promised raises ERR_GROUP_OVERFLOW)
+            addArg(T + "_c_bm", "u32*", 0); addArg(T + "_c_bmmin", "i64", (uint64_t)ht->cbMin); addArg(T + "_c_bmbits", "u64", (uint64_t)ht->cbBits);
+            line("{ const u64 cd = (u64)(" + keyVars[(size_t)ht->compWord] + " - a." + T + "_c_bmmin); if (cd < a." + T + "_c_bmbits) { const u32 cb = 1u << (cd & 31); if (!(a." + T +
+                 "_c_bm[cd >> 5] & cb)) atomicOr(&a." + T + "_c_bm[cd >> 5], cb); } else atomicOr(a.err, (u32)rsq::ERR_GROUP_OVERFLOW); }");
+        }
         // sizing pass: the same pipeline run once with countonly = 1 tells the host how many entries to expect — and, for a
         // table that could be a rank dictionary, whether two build rows share a key (a bit that is already set)
         countPerThread(T);
@@ -1037,6 +1095,25 @@ struct Walker {
         probeKeys(o, T, keyVars, probeKeyNames);
         if (keyVars.size() != ht.keys.size()) failUnsupported("string join keys of different declared lengths");
         addArg(T + "_state", "const u32*", 0); addArg(T + "_words", "const i64*", 0); addArg(T + "_cap", "u64", 0);
+        if (ht.hasCompBitmap && compacted && inStage2) {
+            // the component's value on the probe side, if it is a column of this pipeline's scan: known at the top of stage 2, where the test goes
+            int ki = -1, w = 0;
+            for (size_t k = 0; k < o->exprs.size(); k++) {
+                if (w == ht.compWord) { ki = (int)k; break; }
+                Expr* r = o->exprs[k]->child->next;
+                w += r->type.isString() ? (r->type.len + 7) / 8 : 1;
+            }
+            if (ki >= 0) {
+                Expr* r = o->exprs[(size_t)ki]->child->next;
+                auto org = r->tag == RSQ_E_ATTRIBUTE ? symbolOrigin.find(r->symbol) : symbolOrigin.end();
+                auto sym = r->tag == RSQ_E_ATTRIBUTE ? eg.symbols.find(r->symbol) : eg.symbols.end();
+                if (org != symbolOrigin.end() && org->second == -1 && sym != eg.symbols.end() && sym->second.var.compare(0, 2, "q_") == 0 && !r->type.isString()) {
+                    addArg(T + "_c_bm", "const u32*", 0); addArg(T + "_c_bmmin", "i64", (uint64_t)ht.cbMin); addArg(T + "_c_bmbits", "u64", (uint64_t)ht.cbBits);
+                    compFilters.push_back({T, r->symbol, sym->second.var, ht.cbBits});      // (compactThen places the test: in stage 1 if it can, else at the top of stage 2)
+                    explainSteps.push_back("component bitmap of " + T + " tested in front of the compaction");
+                }
+            }
+        }
         if (ht.hasBitmap) {
             // keys outside the build side's [min, max] or with a clear bit cannot match: skip the table altogether
             addArg(T + "_bm", "const u32*", 0); addArg(T + "_bmmin", "i64", (uint64_t)ht.bmMin); addArg(T + "_bmbits", "u64", (uint64_t)ht.bmBits);

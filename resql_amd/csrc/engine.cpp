@@ -165,6 +165,7 @@ Query::~Query() {
         if (h->dAcc) ctx.free(h->dAcc);
         if (h->dCount) ctx.free(h->dCount);
         if (h->dBitmap) ctx.free(h->dBitmap);
+        if (h->dCompBitmap) ctx.free(h->dCompBitmap);
         if (h->dTemp) ctx.free(h->dTemp);
         if (h->dTempUsed) ctx.free(h->dTempUsed);
         if (h->dChunkTotal) ctx.free(h->dChunkTotal);
@@ -416,6 +417,7 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
         if (f == "acc") return (uint64_t)(uintptr_t)h.dAcc;
         if (f == "countonly") return id == countOnlyTable ? 1ull : 0ull;
         if (f == "bm") return (uint64_t)(uintptr_t)h.dBitmap;
+        if (f == "c_bm") return (uint64_t)(uintptr_t)h.dCompBitmap;
         if (f == "rank") return h.rank ? 1ull : 0ull;
         if (f == "temp") return (uint64_t)(uintptr_t)h.dTemp;
         if (f == "treg") return (uint64_t)h.tempRegion;
@@ -823,6 +825,11 @@ static void buildHashTable(Query& q, Pipeline& p) {
         h.bmBlocks = h.bmInterleaved ? (h.bmBits + 223) / 224 : (h.bmBits + 255) / 256;
         bmWords = (size_t)h.bmBlocks * 8;
         if (!h.dBitmap) h.dBitmap = (uint32_t*)ctx.alloc(bmWords * 4);
+    }
+    if (h.hasCompBitmap && !h.dCompBitmap) {      // zeroed once: bits are only ever set (HashTable::hasCompBitmap)
+        const size_t cbWords = (size_t)((h.cbBits + 31) / 32) + 1;
+        h.dCompBitmap = (uint32_t*)ctx.alloc(cbWords * 4);
+        RSQ_HIP(hipMemsetAsync(h.dCompBitmap, 0, cbWords * 4, ctx.stream));
     }
     if (h.capacity == 0) {
         // sizing pass.  For a table that could be a rank dictionary the pass also sets the key bits and notes a bit that was

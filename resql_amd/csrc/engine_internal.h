@@ -68,6 +68,15 @@ struct HashTable {
     // arrival order (dTemp), two tiny kernels turn the bitmap into rank prefixes and a placement kernel writes every record to
     // entry number rank(key): no CAS, no scattered read-modify-writes, nearly sequential stores for input clustered by the key.
     // `capacity` is then the number of entries; words[entry][k] and acc[block][entry] as for the hash form.
+    // Component bitmap of a table with SEVERAL key words: one bit per possible value of one integer key component (a plain column of
+    // the build pipeline's scan with a modest range).  A probe whose value for that component is a column of ITS scan tests the bit at
+    // the top of stage 2, before any other table is touched: a necessary condition of the match (TPC-H Q5: four of five lineitem rows
+    // that found their order have a supplier outside ASIA).  Bits are only ever set - the build side's columns are immutable and a
+    // stale bit merely lets a row through to the real probe -, so the bitmap is zeroed once, when it is made.
+    bool hasCompBitmap = false;
+    int compWord = 0;                // which key word
+    int64_t cbMin = 0, cbBits = 0;
+    uint32_t* dCompBitmap = nullptr;
     bool rankCapable = false;
     bool setOnly = false;            // ... probed for all matches and carrying nothing but its key: in the rank form the bitmap alone (no entries)
     bool bmInterleaved = false;      // the bitmap's layout: 32-byte blocks of [rank word | 7 words = 224 bits] (rank-capable tables)

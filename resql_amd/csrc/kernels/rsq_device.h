@@ -79,6 +79,10 @@ RSQ_DEV u64 wave_sum(u64 v) {
     for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
     return v;
 }
+// bit d of a plain bitmap, 0 outside [0, bits)
+RSQ_DEV bool bit_in(const u32* bm, u64 d, u64 bits) { return d < bits && ((bm[d >> 5] >> (d & 31)) & 1u) != 0u; }
+// ... of the bitmap word that holds it, fetched earlier (bm_word)
+RSQ_DEV bool bit_of_word(u32 word, u64 d, u64 bits) { return d < bits && ((word >> (d & 31)) & 1u) != 0u; }
 // exclusive prefix sum over the lanes of the wave (all 64 lanes must be here)
 RSQ_DEV u32 wave_excl_sum_u32(u32 v) {
     u32 x = v;
