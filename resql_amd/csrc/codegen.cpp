@@ -1095,6 +1095,38 @@ struct Walker {
         probeKeys(o, T, keyVars, probeKeyNames);
         if (keyVars.size() != ht.keys.size()) failUnsupported("string join keys of different declared lengths");
         addArg(T + "_state", "const u32*", 0); addArg(T + "_words", "const i64*", 0); addArg(T + "_cap", "u64", 0);
+        bool compScope = false;
+        if (ht.hasCompBitmap && !compacted) {
+            // the probe in front of which the compaction is cut (or a pipeline without one): the component's bit is tested right here
+            int ki = -1, w = 0;
+            for (size_t k = 0; k < o->exprs.size(); k++) {
+                if (w == ht.compWord) { ki = (int)k; break; }
+                Expr* r = o->exprs[k]->child->next;
+                w += r->type.isString() ? (r->type.len + 7) / 8 : 1;
+            }
+            if (ki >= 0 && !o->exprs[(size_t)ki]->child->next->type.isString()) {
+                Expr* r = o->exprs[(size_t)ki]->child->next;
+                const std::string C = T + "_c";
+                addArg(C + "_bm", "const u32*", 0); addArg(C + "_bmmin", "i64", (uint64_t)ht.cbMin); addArg(C + "_bmbits", "u64", (uint64_t)ht.cbBits);
+                auto org = r->tag == RSQ_E_ATTRIBUTE ? symbolOrigin.find(r->symbol) : symbolOrigin.end();
+                auto sym = r->tag == RSQ_E_ATTRIBUTE ? eg.symbols.find(r->symbol) : eg.symbols.end();
+                bool already = false;
+                for (auto& pf : bitmapPrefetch) already = already || pf.first == C;
+                const std::string d = "(u64)(" + keyVars[(size_t)ht.compWord] + " - a." + C + "_bmmin)";
+                if (!already && ht.cbBits <= (1 << 20) && org != symbolOrigin.end() && org->second == -1 && sym != eg.symbols.end() && sym->second.var.compare(0, 2, "v_") == 0) {
+                    const int col = atoi(sym->second.var.c_str() + 2);      // (a small bitmap: the word arrives with the tile, for both rows of the lane)
+                    bitmapPrefetch.push_back({C, col, false});
+                    const std::string call = "rsq::bm_word(a." + C + "_bm, a." + C + "_bmmin, a." + C + "_bmbits, (i64)";
+                    rowParams += ", const u32 pf_" + C;
+                    rowArgsTail += ", " + call + "a.c" + std::to_string(col) + "[r])";
+                    rowArgsTailGuarded += ", (valid ? " + call + "a.c" + std::to_string(col) + "[r]) : 0u)";
+                    openScope("if (rsq::bit_of_word(pf_" + C + ", " + d + ", a." + C + "_bmbits)) {");
+                } else openScope("if (rsq::bit_in(a." + C + "_bm, " + d + ", a." + C + "_bmbits)) {");
+                compScope = true;
+                selective = true;
+                explainSteps.push_back("component bitmap of " + T + " tested in front of the probe");
+            }
+        }
         if (ht.hasCompBitmap && compacted && inStage2) {
             // the component's value on the probe side, if it is a column of this pipeline's scan: known at the top of stage 2, where the test goes
             int ki = -1, w = 0;
@@ -1164,6 +1196,7 @@ struct Walker {
         });
         if (!cut) probeTable(o, ht, T, keyVars, probeKeyNames);
         if (ht.hasBitmap) closeScope();
+        if (compScope) closeScope();
         closeScope();
     }
 
@@ -1588,11 +1621,27 @@ struct Walker {
                 // (with the dependencies certain the words go from their loads straight into the table, value by value: staged in
                 // the array first, 31 words of TPC-H Q10's group values were 62 more live VGPRs - the kernel held 163 and ran three
                 // waves per SIMD)
-                for (size_t ci = 0; ci < carriedVals.size(); ci++) {
-                    const Carried& c = carriedVals[ci];
-                    openScope("{");
-                    std::vector<std::string> words = keyWords(c.g, T + "_n" + std::to_string(ci), false);
-                    for (int w = 0; w < c.nWords; w++) line("rsq::st_agent(&" + aggWord(c.firstWord + w) + ", " + words[(size_t)w] + ");");
+                // While the dependencies hold (T_fd) nobody READS the carried words inside this kernel - they are not compared, and the group
+                // rows are gathered by the next kernel -, so they are PLAIN stores: the compiler merges neighbouring words into 16-byte
+                // stores and nothing waits for a write-through to be acknowledged word by word.  Agent-scope stores only in the full form,
+                // where other lanes compare them.  TPC-H Q10 at SF10 (380 K new groups of 31 carried words): the pipeline 559 -> 419 us.
+                auto storeCarried = [&](bool plain, const std::string& tag) {
+                    for (size_t ci = 0; ci < carriedVals.size(); ci++) {
+                        const Carried& c = carriedVals[ci];
+                        openScope("{");
+                        std::vector<std::string> words = keyWords(c.g, T + "_n" + tag + std::to_string(ci), false);
+                        for (int w = 0; w < c.nWords; w++)
+                            line(plain ? aggWord(c.firstWord + w) + " = " + words[(size_t)w] + ";" : "rsq::st_agent(&" + aggWord(c.firstWord + w) + ", " + words[(size_t)w] + ");");
+                        closeScope();
+                    }
+                };
+                if (fdCond.empty()) storeCarried(true, "");
+                else {
+                    openScope("if (" + T + "_fd) {");
+                    storeCarried(true, "p");
+                    closeScope();
+                    openScope("else {");
+                    storeCarried(false, "");
                     closeScope();
                 }
             }

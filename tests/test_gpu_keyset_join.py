@@ -98,7 +98,7 @@ def test_component_bitmap_of_a_two_key_join_is_tested_in_front_of_the_compaction
     want = orc.execute(plan)
     tabs = [gpu_ctx.table(d), gpu_ctx.table(f)]
     q = gpu_ctx.compile(plan, tabs)
-    assert "component bitmap of ht0 tested in front of the compaction" in q.explain
+    assert "component bitmap of ht0 tested in front of the probe" in q.explain
     assert "pf_ht0_c" in q.source and "ht0_c_bm" in q.source
     q.await_kernels()
     for _ in range(3):
