@@ -936,6 +936,15 @@ struct Walker {
         ht->rankCapable = (ht->unique || 1) && ht->hasBitmap && ht->keyCas && ht->aos && keyVars.size() == 1 &&
                           envInt("RSQ_JOIN_RANK", 1, 0, 1) != 0;
         ht->setOnly = ht->rankCapable && !ht->unique && ht->payload.empty();
+        // IDENTITY: the build pipeline is the bare scan of a table in the order of its (engine-owned, hence immutable) key column.  If the
+        // sizing pass then finds the keys unique and every row inserted, entry number rank(key) IS the row's number: the build writes
+        // its record straight to words[row] - coalesced, streaming - and the arrival buffer and the placement kernel are not needed
+        // (TPC-H Q12 builds on all 15 M orders: 240 MB appended, read again and scattered to entries 16 bytes at a time).
+        {
+            const int ci = o->exprs[0]->child->tag == RSQ_E_ATTRIBUTE ? pipe.src->findCol(o->exprs[0]->child->symbol) : -1;
+            ht->identityCapable = ht->rankCapable && !ht->setOnly && from->tag == RSQ_OP_SCAN && ci >= 0 && pipe.src->cols[(size_t)ci].owned &&
+                                  pipe.src->cols[(size_t)ci].stats.valid && pipe.src->cols[(size_t)ci].stats.ascending;
+        }
         // (a table that may become a rank dictionary keeps its bitmap in the interleaved layout, rsq_device.h bmi_word)
         ht->bmInterleaved = ht->rankCapable;
         const std::string bmw = ht->bmInterleaved ? "rsq::bmi_word(d)" : "d >> 5";
@@ -990,6 +999,16 @@ struct Walker {
             // a.<T>_tused[wave] at the end, where the placement kernel finds it.  A wave that overflows its region says so
             // (the host then keeps the hash form).
             line("{ " + bitSet + setBit + " }");
+            if (ht->identityCapable) {
+                addArg(T + "_ident", "u64", 0);
+                openScope("if (a." + T + "_ident) {");
+                line("i64* rec = a." + T + "_words + (u64)(row - a.row0) * " + std::to_string(1 + (int)ht->payload.size()) + "ull;");
+                line("rec[0] = " + keyVars[0] + ";");
+                int iw = 1;
+                for (auto& p : ht->payload) line("rec[" + std::to_string(iw++) + "] = " + toWord(eg.symbols[p.name].var, p.type) + ";");
+                closeScope();
+                openScope("else {");
+            }
             addArg(T + "_treg", "u64", 0); addArg(T + "_tused", "u32*", 0);
             stateDecl += "    u32* tch_" + T + ";\n";
             prologue += "    __shared__ u32 s_tch_" + T + "[RSQ_BLOCK_THREADS / 64];\n    st.tch_" + T + " = s_tch_" + T + " + (threadIdx.x >> 6);\n" +
@@ -1014,6 +1033,7 @@ struct Walker {
                 closeScope();
                 line("else atomicOr(a.err, (u32)rsq::NOTE_BUILD_KEYS_NOT_UNIQUE);      // the region is full: this table is not for the dictionary");
             }
+            if (ht->identityCapable) closeScope();
             epilogue += "    if (a." + T + "_rank && !a." + T + "_countonly && (threadIdx.x & 63) == 0) {\n        const u32 used = st.tch_" + T + "[0];\n" +
                         "        a." + T + "_tused[(u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = used < a." + T + "_treg ? used : (u32)a." + T + "_treg;\n    }\n";
             line("st.n_" + T + "++;");

@@ -419,6 +419,7 @@ static uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int coun
         if (f == "bm") return (uint64_t)(uintptr_t)h.dBitmap;
         if (f == "c_bm") return (uint64_t)(uintptr_t)h.dCompBitmap;
         if (f == "rank") return h.rank ? 1ull : 0ull;
+        if (f == "ident") return h.identity ? 1ull : 0ull;
         if (f == "temp") return (uint64_t)(uintptr_t)h.dTemp;
         if (f == "treg") return (uint64_t)h.tempRegion;
         if (f == "tused") return (uint64_t)(uintptr_t)h.dTempUsed;
@@ -842,6 +843,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
         RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
         waitForStream(ctx);
         h.rank = h.rankCapable && !(err & 64u);
+        h.identity = h.rank && h.identityCapable && (int64_t)n == p.src->nRows && n > 0;
         if (err & 64u) { err &= ~64u; RSQ_HIP(hipMemcpy(ctx.dErr, &err, 4, hipMemcpyHostToDevice)); }
         if (h.rank && h.setOnly) {
             h.capacity = std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);          // (nothing is allocated: the bitmap is the table)
@@ -857,7 +859,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
             const int64_t wavesMax = (int64_t)std::max(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
             const int64_t wavesMin = (int64_t)std::min(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
             h.tempWaves = wavesMax;
-            h.tempRegion = ((4 * (int64_t)n / std::max<int64_t>(1, wavesMin) + 64 + 63) / 64) * 64;
+            h.tempRegion = h.identity ? 64 : ((4 * (int64_t)n / std::max<int64_t>(1, wavesMin) + 64 + 63) / 64) * 64;      // (identity: nothing is appended)
             h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
             h.dTemp = (int64_t*)ctx.alloc((size_t)h.tempWaves * (size_t)h.tempRegion * 8 * std::max<size_t>(1, nWords));
             h.dTempUsed = (uint32_t*)ctx.alloc((size_t)h.tempWaves * 4);
@@ -869,7 +871,7 @@ static void buildHashTable(Query& q, Pipeline& p) {
             h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
         }
         if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
-        if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.rank ? "bitmap-rank dictionary" : "hash table", n);
+        if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.identity ? "bitmap-rank dictionary, entries in row order" : h.rank ? "bitmap-rank dictionary" : "hash table", n);
     }
     // (an execution whose tables are all sized readies them in its first fill launch — prologueFills below — and h.prepared says so)
     const bool prepared = h.prepared;
@@ -889,9 +891,11 @@ static void buildHashTable(Query& q, Pipeline& p) {
         const bool chainedOk = !(getenv("RSQ_RANK_CHAINED") && atoi(getenv("RSQ_RANK_CHAINED")) == 0);
         if (prepared && chainedOk && !q.chainedIndexOff) { rankTableIndexChained(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase); q.report.num_kernels += 1; }
         else { rankTableIndex(ctx, h.dBitmap, h.bmBlocks, h.dChunkTotal, h.dChunkBase); q.report.num_kernels += 2; }
-        rankTablePlace(ctx, h.dTemp, h.dTempUsed, (uint32_t)h.tempWaves, (uint32_t)h.tempRegion, h.dCount, (int)std::max<size_t>(1, nWords), h.dBitmap, h.bmMin,
-                       h.bmBits, h.dChunkBase, h.bmBlocks, h.dWords, h.capacity);
-        q.report.num_kernels += 1;
+        if (!h.identity) {      // (identity: the build wrote every record to the entry with its row's number)
+            rankTablePlace(ctx, h.dTemp, h.dTempUsed, (uint32_t)h.tempWaves, (uint32_t)h.tempRegion, h.dCount, (int)std::max<size_t>(1, nWords), h.dBitmap, h.bmMin,
+                           h.bmBits, h.dChunkBase, h.bmBlocks, h.dWords, h.capacity);
+            q.report.num_kernels += 1;
+        }
         q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
         return;
     }
@@ -1895,7 +1899,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             ctx.free(h.dWords); ctx.free(h.dTemp); ctx.free(h.dTempUsed); ctx.free(h.dChunkTotal); ctx.free(h.dChunkBase);
             if (h.dAcc) ctx.free(h.dAcc);
             h.dWords = h.dTemp = nullptr; h.dAcc = nullptr; h.dTempUsed = h.dChunkTotal = h.dChunkBase = nullptr;
-            h.rank = false; h.rankCapable = false; h.capacity = 0; h.lastCount = 0;
+            h.rank = false; h.rankCapable = false; h.identity = false; h.capacity = 0; h.lastCount = 0;
         }
         if (any) { executeQuery(q, partialOnly, async); return; }
     }

@@ -77,6 +77,8 @@ struct HashTable {
     int compWord = 0;                // which key word
     int64_t cbMin = 0, cbBits = 0;
     uint32_t* dCompBitmap = nullptr;
+    bool identityCapable = false;    // rank dictionary over a bare scan in key order: entry number == row number when every row is inserted (codegen.cpp consumeBuild)
+    bool identity = false;           // ... and this is so in this query (the sizing pass saw unique keys and as many entries as rows)
     bool rankCapable = false;
     bool setOnly = false;            // ... probed for all matches and carrying nothing but its key: in the rank form the bitmap alone (no entries)
     bool bmInterleaved = false;      // the bitmap's layout: 32-byte blocks of [rank word | 7 words = 224 bits] (rank-capable tables)
