@@ -1590,16 +1590,20 @@ struct Walker {
         const bool lds = 1 && LS >= 64 && slotBytes * LS <= 48 * 1024 && !anyCarried;     // (a front-table slot holds no carried values to create its group with)
         if (lds) {
             stateDecl += "    u32* lc_state;\n    i64* lc_key;\n    u64* lc_acc;\n";
-            prologue += "    __shared__ u32 s_lc_state[" + std::to_string(LS) + "];\n    __shared__ i64 s_lc_key[" + std::to_string(K * LS) +
-                        "];\n    __shared__ u64 s_lc_acc[" + std::to_string(W * LS) + "];\n";
+            prologue += "    __shared__ u32 s_lc_state[" + std::string("RSQ_LC_SLOTS") + "];\n    __shared__ i64 s_lc_key[" + std::to_string(K) + " * RSQ_LC_SLOTS" +
+                        "];\n    __shared__ u64 s_lc_acc[" + std::to_string(W) + " * RSQ_LC_SLOTS];\n";
             prologue += "    st.lc_state = s_lc_state; st.lc_key = s_lc_key; st.lc_acc = s_lc_acc;\n";
-            prologue += "    for (int i = threadIdx.x; i < " + std::to_string(LS) + "; i += blockDim.x) s_lc_state[i] = 0u;\n    __syncthreads();\n";
+            prologue += "    for (int i = threadIdx.x; i < RSQ_LC_SLOTS; i += blockDim.x) s_lc_state[i] = 0u;\n    __syncthreads();\n";
             pipe.extraLdsBytes += (8 * (K + W) + 4) * LS;
+            pipe.ldsSlots = LS; pipe.ldsSlotBytes = 8 * (K + W) + 4;
+            // (the slot count is a macro: the engine compiles the same text with a handful of slots once it knows that the query has a handful of
+            // groups - TPC-H Q12: 2, Q5: 5 -, and the table no longer costs the scan its occupancy: engine.cpp launchPipeline)
+            fileScope += "#ifndef RSQ_LC_SLOTS\n#define RSQ_LC_SLOTS " + std::to_string(LS) + "\n#endif\n";
             // flush (before the entry counter's flush below: the upserts count new entries)
-            std::string f = "    __syncthreads();\n    for (int i = threadIdx.x; i < " + std::to_string(LS) + "; i += blockDim.x) {\n";
+            std::string f = "    __syncthreads();\n    for (int i = threadIdx.x; i < RSQ_LC_SLOTS; i += blockDim.x) {\n";
             f += "        if (st.lc_state[i] == 2u) " + T + "_upsert(a, st, (i64)st.lc_acc[i]";
-            for (int i = 0; i < K; i++) f += ", st.lc_key[" + std::to_string(i * LS) + " + i]";
-            for (int w = 1; w < W; w++) f += ", (i64)st.lc_acc[" + std::to_string(w * LS) + " + i]";
+            for (int i = 0; i < K; i++) f += ", st.lc_key[" + std::to_string(i) + " * RSQ_LC_SLOTS + i]";
+            for (int w = 1; w < W; w++) f += ", (i64)st.lc_acc[" + std::to_string(w) + " * RSQ_LC_SLOTS + i]";
             f += ");\n    }\n";
             epilogue += f;
         }
@@ -1778,24 +1782,24 @@ struct Walker {
             // up to four consecutive slots: two groups that map to the same slot would otherwise send one of them to the
             // HBM table for good — with few groups that is a handful of HBM words taking every update of a hot group
             // (64 groups, 1024 slots: 5.1 ms per 100 M rows against 2.9 ms for 1024 groups, before the probing)
-            line("u32 ls = (u32)(" + hashOf(keyVars) + " >> 44) & " + std::to_string(LS - 1) + "u;");
-            openScope("for (int lt = 0; lt < 4; lt++, ls = (ls + 1u) & " + std::to_string(LS - 1) + "u) {");
+            line("u32 ls = (u32)(" + hashOf(keyVars) + " >> 44) & (u32)(RSQ_LC_SLOTS - 1);");
+            openScope("for (int lt = 0; lt < 4; lt++, ls = (ls + 1u) & (u32)(RSQ_LC_SLOTS - 1)) {");
             line("u32 lst = __hip_atomic_load(&st.lc_state[ls], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);");
             openScope("if (lst == 0u && atomicCAS(&st.lc_state[ls], 0u, 1u) == 0u) {");
-            for (int i = 0; i < K; i++) line("st.lc_key[" + std::to_string(i * LS) + " + ls] = " + keyVars[(size_t)i] + ";");
+            for (int i = 0; i < K; i++) line("st.lc_key[" + std::to_string(i) + " * RSQ_LC_SLOTS + ls] = " + keyVars[(size_t)i] + ";");
             for (int w = 0; w < W; w++) {
                 const int m = q.accums[(size_t)w].merge;
-                line("st.lc_acc[" + std::to_string(w * LS) + " + ls] = " + (m == 0 ? "0ull" : m == 2 ? "0x7fffffffffffffffull" : m == 3 ? "0x8000000000000000ull" : "~0ull") + ";");
+                line("st.lc_acc[" + std::to_string(w) + " * RSQ_LC_SLOTS + ls] = " + (m == 0 ? "0ull" : m == 2 ? "0x7fffffffffffffffull" : m == 3 ? "0x8000000000000000ull" : "~0ull") + ";");
             }
             line("__hip_atomic_store(&st.lc_state[ls], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);");
             line("lst = 2u;");
             closeScope();
             line("if (lst != 2u) break;           // another lane is writing this slot: do not wait, take the HBM table");
             std::string eq;
-            for (int i = 0; i < K; i++) eq += std::string(i ? " && " : "") + "st.lc_key[" + std::to_string(i * LS) + " + ls] == " + keyVars[(size_t)i];
+            for (int i = 0; i < K; i++) eq += std::string(i ? " && " : "") + "st.lc_key[" + std::to_string(i) + " * RSQ_LC_SLOTS + ls] == " + keyVars[(size_t)i];
             openScope("if (" + eq + ") {");
             for (int w = 0; w < W; w++)
-                line("rsq::lds_merge<" + std::to_string(q.accums[(size_t)w].merge) + ">(&st.lc_acc[" + std::to_string(w * LS) + " + ls], (u64)(" +
+                line("rsq::lds_merge<" + std::to_string(q.accums[(size_t)w].merge) + ">(&st.lc_acc[" + std::to_string(w) + " * RSQ_LC_SLOTS + ls], (u64)(" +
                      (w == 0 ? std::string("row") : "in" + std::to_string(w)) + "));");
             line(T + "_done = true;");
             line("break;");

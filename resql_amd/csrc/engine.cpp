@@ -521,17 +521,42 @@ static void debugStamps(Query& q, Pipeline& p) {
             p.entry.c_str(), p.lastGrid, early, dist(0).c_str(), dist(1).c_str(), dist(2).c_str(), dist(3).c_str());
 }
 
+// A hash aggregation that turned out to have a handful of groups (TPC-H Q12: 2, Q5: 5) does not need a front table of 512 or 1024
+// slots per workgroup - 28 to 45 KB of LDS that leave the scan two or three workgroups per CU.  The same source with RSQ_LC_SLOTS 64
+// (3 KB) is compiled when first wanted and launched with the grid its own occupancy allows.
+// Taken only where the large table leaves fewer than three workgroups per CU (Q12 at SF10: 0.566 -> 0.532 ms); where three fit already the
+// smaller table gains nothing and twice the workgroups flush twice the tables (Q5: 0.566 -> 0.61 ms, measured).
+static Kernel* fewGroupsKernel(Query& q, Pipeline& p, const std::string& source, const char* form, Kernel* large) {
+    if (p.ldsSlots <= 64 || q.aggMode != AggMode::HASH || p.sink != SinkKind::AGGREGATE || q.aggTable < 0) return nullptr;
+    const HashTable& h = *q.hashTables[(size_t)q.aggTable];
+    if (h.lastCount == 0 || h.lastCount > 16) return nullptr;
+    if (residentWorkgroupsPerCU(large, p.blockThreads) >= 3) return nullptr;
+    auto it = p.fewGroupKernels.find(form);
+    if (it == p.fewGroupKernels.end()) it = p.fewGroupKernels.emplace(form, &q.ctx.getKernel("#define RSQ_LC_SLOTS 64\n" + source, p.entry)).first;
+    return it->second;
+}
+static unsigned fewGroupsGrid(Query& q, Pipeline& p, Kernel* k) {
+    const int64_t tiles = p.src->nRows >> 7;
+    const int wavesPerBlock = p.blockThreads / 64;
+    const int64_t want = std::max<int64_t>(1, (tiles + (int64_t)wavesPerBlock * p.unroll - 1) / ((int64_t)wavesPerBlock * p.unroll));
+    return (unsigned)std::min<int64_t>(want, (int64_t)std::min(p.unroll >= 3 ? 6 : 8, residentWorkgroupsPerCU(k, p.blockThreads)) * q.ctx.numCUs);
+}
+
 static void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false) {
     Kernel* k = pass1 ? p.kernelPass1 : (q.flatRun && p.kernelFlat ? p.kernelFlat : p.kernel);
     // late column loads (codegen.cpp compactThen): worth it when the previous execution sent few rows to stage 2
     const int64_t lazyDen = 32;
     if (!pass1 && k == p.kernel && !p.sourceLazy.empty() && p.stage2Rows >= 0 && p.stage2Rows * lazyDen < p.src->nRows) {
         if (!p.kernelLazy) p.kernelLazy = &q.ctx.getKernel(p.sourceLazy, p.entry);
+        if (Kernel* few = fewGroupsKernel(q, p, p.sourceLazy, "lazy", p.kernelLazy)) launchPipelineKernel(q, p, *few, countOnlyTable, fewGroupsGrid(q, p, few));
+        else
         launchPipelineKernel(q, p, *p.kernelLazy, countOnlyTable, pipelineGrid(q, p, true));
         debugStamps(q, p);
         if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     %s: late-load form, %u workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(), p.lastGrid, (long long)p.stage2Rows);
         return;
     }
+    if (Kernel* few = (!pass1 && k == p.kernel) ? fewGroupsKernel(q, p, p.source, "eager", k) : nullptr) launchPipelineKernel(q, p, *few, countOnlyTable, fewGroupsGrid(q, p, few));
+    else
     launchPipelineKernel(q, p, *k, countOnlyTable);
     if (getenv("RSQ_TRACE") && p.compact) fprintf(stderr, "[rsq trace]     %s: %u workgroups (%lld rows reached stage 2 last time)\n", p.entry.c_str(), p.lastGrid, (long long)p.stage2Rows);
     debugStamps(q, p);

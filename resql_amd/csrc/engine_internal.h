@@ -224,6 +224,8 @@ struct Pipeline {
     bool matSkip = false;            // a materialisation whose write pass skips the tiles that counted nothing (codegen.cpp)
     unsigned lastGrid = 0;           // workgroups of the most recent launch
     int64_t stage2Rows = -1;         // rows the previous execution sent to stage 2 (-1: not known yet)
+    int ldsSlots = 0, ldsSlotBytes = 0;   // hash aggregation: slots of the LDS front table (the macro RSQ_LC_SLOTS) and bytes per slot
+    std::map<std::string, Kernel*> fewGroupKernels;      // ... the same source compiled with 64 slots, per form (engine.cpp launchPipeline)
     int extraLdsBytes = 0;           // LDS a pipeline takes besides the compaction queues (hash aggregation's front table)
     int blockThreads = 256;
     int unroll = 2;
