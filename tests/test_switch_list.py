@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_the_switch_list_is_complete():
     """the switches read by the library == the ones flipped in tests/test_gpu_knobs.py (plus RSQ_DEVICE_TAIL_MIN / RSQ_FORCE_GENERIC /
-    RSQ_MULTI_GENERAL_MERGE, which other test files flip, and the macro RSQ_CQ_NV, which is not an environment variable); at most 30"""
+    RSQ_MULTI_GENERAL_MERGE, which other test files flip, and the macros RSQ_CQ_NV / RSQ_LC_SLOTS, which are not environment variables); at most 30"""
     text = open(os.path.join(ROOT, "tests", "test_gpu_knobs.py")).read()
     flipped = set(re.findall(r'^    \("(RSQ_[A-Z0-9_]+)", "', text, re.M))
     found = set()
@@ -15,6 +15,6 @@ def test_the_switch_list_is_complete():
     for f in os.listdir(src):
         if f.endswith((".cpp", ".hip")):
             found |= set(re.findall(r'"(RSQ_[A-Z0-9_]+)"', open(os.path.join(src, f)).read()))
-    elsewhere = {"RSQ_DEVICE_TAIL_MIN", "RSQ_FORCE_GENERIC", "RSQ_MULTI_GENERAL_MERGE", "RSQ_CQ_NV"}
+    elsewhere = {"RSQ_DEVICE_TAIL_MIN", "RSQ_FORCE_GENERIC", "RSQ_MULTI_GENERAL_MERGE", "RSQ_CQ_NV", "RSQ_LC_SLOTS"}
     assert found - elsewhere == flipped, sorted((found - elsewhere) ^ flipped)
     assert len(found) <= 30
