@@ -546,32 +546,47 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                         if (keyWord >= 0) { const u64 u = topk_image(kv, keyIs32, keyDesc); imgMax = u > imgMax ? u : imgMax; imgMaxInv = ~u > imgMaxInv ? ~u : imgMaxInv; }
                     }
                 }
-            } else
-            for (unsigned i = (unsigned)t; i < total; i += 256u) {
-                const unsigned pos = base + i;
-                if (pos >= maxRows) continue;
-                const i64 s = lo + (i64)s_list[i];
-                i64* o = out + (size_t)pos * stride;
-                i64 e = s;
-                if (unmix) e = (i64)rank_unmix((u64)s, (u64)cap);
-                // wide rows (string group values): eight words at a time, their loads first (word by word: one round trip each -
-                // 154 us for TPC-H Q10's 380 K groups of 40 words)
-                i64 kv = 0;
-                for (int k0 = 0; k0 < stride; k0 += 8) {
-                    i64 v[8];
+            } else {
+                // wide rows (string group values: TPC-H Q10's 380 K groups of 40 words): EIGHT LANES per row, lane j of the eight copies words
+                // j, j + 8, ... - four of them at a time, their loads first.  A load instruction of the wave then covers 8 rows x 64
+                // contiguous bytes; one thread per row asked for 8 bytes at a stride of 320 (64 memory lines per instruction: 133 us at SF10).
+                const int sub = t & 7;
+                for (unsigned i0 = (unsigned)t >> 3; i0 < total; i0 += 64u) {          // two rows per eight lanes at a time
+                    i64 s2[2], e2[2];
+                    bool ok[2];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const int k = k0 + j;
-                        v[j] = 0;
-                        if (k >= stride) continue;
-                        if (k == 0) v[j] = first[s];
-                        else if (k - 1 < nWords) v[j] = !words ? s : wordsAos ? words[(size_t)e * nWords + (k - 1)] : words[(size_t)(k - 1) * cap + e];
-                        else v[j] = acc[(size_t)(k - 1 - nWords) * cap + s];
+                    for (int r = 0; r < 2; r++) {
+                        const unsigned i = i0 + 32u * (unsigned)r;
+                        ok[r] = i < total && base + i < maxRows;
+                        s2[r] = lo + (i64)s_list[ok[r] ? i : 0u];
+                        e2[r] = unmix ? (i64)rank_unmix((u64)s2[r], (u64)cap) : s2[r];
                     }
+                    for (int k0 = 0; k0 < stride; k0 += 32) {
+                        i64 v[2][4];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) { if (k0 + j < stride) o[k0 + j] = v[j]; if (k0 + j == keyWord) kv = v[j]; }
+                        for (int r = 0; r < 2; r++)
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int k = k0 + j * 8 + sub;
+                                v[r][j] = 0;
+                                if (k >= stride || !ok[r]) continue;
+                                if (k == 0) v[r][j] = first[s2[r]];
+                                else if (k - 1 < nWords) v[r][j] = !words ? s2[r] : wordsAos ? words[(size_t)e2[r] * nWords + (k - 1)] : words[(size_t)(k - 1) * cap + e2[r]];
+                                else v[r][j] = acc[(size_t)(k - 1 - nWords) * cap + s2[r]];
+                            }
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            i64* o = out + (size_t)(base + i0 + 32u * (unsigned)r) * stride;
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int k = k0 + j * 8 + sub;
+                                if (k >= stride || !ok[r]) continue;
+                                o[k] = v[r][j];
+                                if (k == keyWord) { const u64 u = topk_image(v[r][j], keyIs32, keyDesc); imgMax = u > imgMax ? u : imgMax; imgMaxInv = ~u > imgMaxInv ? ~u : imgMaxInv; }
+                            }
+                        }
+                    }
                 }
-                if (keyWord >= 0) { const u64 u = topk_image(kv, keyIs32, keyDesc); imgMax = u > imgMax ? u : imgMax; imgMaxInv = ~u > imgMaxInv ? ~u : imgMaxInv; }
             }
         }
         __syncthreads();          // s_wave / s_base are rewritten by the next chunk
@@ -599,7 +614,9 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
     // large chunks; swept on the box for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us.  (Row positions by look-back through
     // a chain of chunk totals instead of the reservation atomics were tried and measured no gain - TPC-H Q3 at SF10 0.305 against
     // 0.300 ms, Q10 0.939 either way: the 177 / 256 same-word atomics are not what these 19 / 119 us kernels wait for.)
-    const int perThread = capacity >= (1 << 22) ? 64 : capacity >= (1 << 20) ? 32 : 16;
+    // (wide rows - more than eight words - are copied by eight lanes each: their kernel wants waves, not long chunks; TPC-H Q10 at SF10,
+    // 380 K rows of 40 words out of 4 M slots: 133 us with one thread per row and 64 slots per thread - one workgroup per CU)
+    const int perThread = 1 + nWords + nAcc > 8 ? 16 : capacity >= (1 << 22) ? 64 : capacity >= (1 << 20) ? 32 : 16;
     const int64_t chunkSlots = 256 * (int64_t)perThread;
     const int64_t nChunks = std::max<int64_t>(1, (capacity + chunkSlots - 1) / chunkSlots);
     unsigned grid = (unsigned)std::min<int64_t>(8 * (int64_t)ctx.numCUs, nChunks);

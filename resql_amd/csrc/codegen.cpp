@@ -375,7 +375,7 @@ struct Walker {
         multiMatchAbove = false;
         selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
         leadCond.clear(); leadCols.clear(); leadPass = 1.0; leadPassComplete = true;
-        strPrefetch.clear(); strPrefetchWidth.clear(); eg.strWordVars.clear();
+        strPrefetch.clear(); strPrefetchWidth.clear(); strStaged.clear(); strStagedBytes = 0; eg.strWordVars.clear();
         eg.symbols.clear();
         o->schema.clear();
         for (size_t ci = 0; ci < t->cols.size(); ci++) {
@@ -496,6 +496,14 @@ struct Walker {
     // c_mktsegment = 'BUILDING').  RSQ_STRING_PREFETCH=0: never.
     std::vector<std::pair<int, int>> strPrefetch;         // (scanned column, bytes of it that arrive with the tile), in the order of the row function's parameters
     std::map<int, int> strPrefetchWidth;                   // scanned column -> its width (the row stride)
+    // Staged string tiles.  A lane that fetches ITS two rows of a CHAR(25) column asks for 8 bytes at a stride of 50: the wave's one load
+    // instruction touches 25 memory lines, the next word's the same 25 again, and the texture unit, not the memory, bounds the kernel (TPC-H
+    // Q19 at SF10: 63 B rows at 3.5 TB/s, against 6.8 for Q1's plain columns).  A column of at most 32 bytes is therefore fetched as what it
+    // is - 128 rows x W contiguous bytes per tile, 16 bytes per lane and load, every line once - and passed through the wave's own LDS
+    // region, from which each lane reads its rows' words (ds_read_b64 takes any address on gfx950).  All words of the value then arrive
+    // as row-function parameters.
+    std::map<int, int> strStaged;                          // scanned column -> byte offset of its tile in the wave's LDS region
+    int strStagedBytes = 0;                                // bytes of that region (128 x the staged widths)
     void prefetchComparedStrings(const Expr* e) {
         if (1 == 0 || 1 == 0) return;
         if ((e->tag == RSQ_E_EQ || e->tag == RSQ_E_NEQ) && e->child && e->child->next) {
@@ -511,7 +519,9 @@ struct Walker {
             for (auto& sp : strPrefetch) if (sp.first == k) return;
             // (up to 16 bytes: the whole value; longer: its first word - most values differ there, and the line it sits in is on its
             // way when the row function asks for the rest)
-            const int PW = W <= 16 ? W : 8;
+            const bool stage = W <= 32 && strStagedBytes + 128 * W <= 128 * 40;
+            if (stage) { strStaged[k] = strStagedBytes; strStagedBytes += 128 * W; }
+            const int PW = stage || W <= 16 ? W : 8;
             strPrefetch.push_back({k, PW});
             strPrefetchWidth[k] = W;
             eg.strWordVars[sy->second.var] = (PW + 7) / 8;
@@ -2360,6 +2370,39 @@ struct Walker {
     }
 
     // -------------------------------------------------------------------------------------------
+    // staged string tiles (see strStaged): chunk c = 64 * round + lane of the tile's 8 * W 16-byte chunks
+    int stagedRounds(int col) { return (8 * strPrefetchWidth[col] + 63) / 64; }
+    void stagedChunkDecls(std::ostringstream& s, const std::string& ind, const char* pre, int col, int u) {
+        for (int r = 0; r < stagedRounds(col); r++) s << ind << "rsq::u32v4 " << pre << col << "_" << u << "_" << r << " = {0u, 0u, 0u, 0u};\n";
+    }
+    void stagedChunkLoads(std::ostringstream& s, const std::string& ind, const char* pre, int col, int u) {     // (`b` = the lane's first row of the tile)
+        const int W = strPrefetchWidth[col];
+        for (int r = 0; r < stagedRounds(col); r++)
+            s << ind << pre << col << "_" << u << "_" << r << " = rsq::ld_str_chunk<" << W << ", " << r << ">(a.c" << col << " + (b - lane * 2) * " << W << ", lane);\n";
+    }
+    // ... through the wave's LDS region into the words the row function takes (same-wave LDS operations execute in order)
+    void stagedUnstage(std::ostringstream& s, const std::string& ind, int u) {
+        for (auto& sp : strPrefetch) {
+            auto it = strStaged.find(sp.first);
+            if (it == strStaged.end()) continue;
+            const int W = strPrefetchWidth[sp.first];
+            for (int r = 0; r < stagedRounds(sp.first); r++)
+                s << ind << "rsq::st_str_chunk<" << W << ", " << r << ">(strt + " << it->second << ", lane, q" << sp.first << "_" << u << "_" << r << ");\n";
+        }
+        if (!strStaged.empty()) s << ind << "rsq::wave_lds_order();\n";
+        for (auto& sp : strPrefetch) {
+            auto it = strStaged.find(sp.first);
+            if (it == strStaged.end()) continue;
+            const int W = strPrefetchWidth[sp.first];
+            for (int j = 0; j < 2; j++)
+                for (int w = 0; w * 8 < sp.second; w++)
+                    s << ind << "const u64 s" << sp.first << "_" << u << "_" << j << "_" << w << " = rsq::ld_bytes<" << std::min(8, sp.second - w * 8) << ">(strt + " << it->second
+                      << " + (lane * 2 + " << j << ") * " << W << " + " << w * 8 << ");\n";
+        }
+        if (!strStaged.empty()) s << ind << "rsq::wave_lds_order();\n";
+    }
+
+    // -------------------------------------------------------------------------------------------
     // second round of loads of tile `tile` (unrolled copy u): the late columns, by the lanes that hold a row the leading selection passes
     void emitLateLoads(std::ostringstream& s, const std::string& tile, int u, const std::vector<char>& lateCol, const std::string& tileEnd = "ntiles") {
         s << "        if (" << tile << " < " << tileEnd << ") {\n";
@@ -2443,6 +2486,11 @@ struct Walker {
         }
         pipe.leadPass = leadCond.empty() || !leadPassComplete ? -1.0 : leadPass;      // (for the engine's first layout of staged regions: only a complete estimate)
         const int U = pipe.unroll;
+        if (strStagedBytes > 0) {
+            pipe.extraLdsBytes += (pipe.blockThreads / 64) * strStagedBytes;
+            prologue += "    __shared__ __attribute__((aligned(16))) char s_strt[(RSQ_BLOCK_THREADS / 64) * " + std::to_string(strStagedBytes) + "];\n    char* const strt = s_strt + (threadIdx.x >> 6) * " +
+                        std::to_string(strStagedBytes) + ";\n";
+        }
         // 63 left over + 128 pushed by one tile, rounded up.  (RSQ_QCAP=128 drains after every row_fn call instead: smaller
         // queues, 7 instead of 4 workgroups of a five-word pipeline per CU — measured slower: Q3's orders pipeline 0.24 ->
         // 0.31 ms, its inserts do not want more waves.)
@@ -2489,7 +2537,7 @@ struct Walker {
             for (int k = 0; k < pipe.compactWords; k++) s << ", const i64 qw_" << k;
             s << ") {\n" << stage2Body << "}\n";
             s << "static RSQ_DEV void cq_drain(const Args& a, State& st, const int count) {\n";
-            s << "    const int lane = threadIdx.x & 63;\n    const int i = st.cq_n - count + lane;\n";
+            s << "    const int lane = threadIdx.x & 63;\n    const int i = st.cq_n - count + lane;\n    rsq::wave_lds_order();      // (the entries were pushed by other lanes)\n";
             s << "    if (lane < count) {\n        stage2(a, st, st.cq[i]";
             for (int k = 0; k < pipe.compactWordsLazy; k++) s << ", st.cq[" << (k + 1) * QCAP << " + i]";
             if (pipe.compactWords > pipe.compactWordsLazy) {
@@ -2606,11 +2654,13 @@ struct Walker {
             auto isLazy = [&](int k) { return std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) != pipe.lazyCols.end(); };
             auto tileLoads = [&](const std::string& ind, const char* pre, int u) {      // pre: "t" / "s" (this iteration's) or "n" / "ns" (the next one's)
                 const std::string spre = pre[0] == 'n' ? "ns" : "s";
-                for (auto& sp : strPrefetch)
+                for (auto& sp : strPrefetch) {
+                    if (strStaged.count(sp.first)) { stagedChunkLoads(s, ind, pre[0] == 'n' ? "nq" : "q", sp.first, u); continue; }
                     for (int j = 0; j < 2; j++)
                         for (int w = 0; w * 8 < sp.second; w++)
                             s << ind << spre << sp.first << "_" << u << "_" << j << "_" << w << " = rsq::ld_bytes<" << std::min(8, sp.second - w * 8) << ">(a.c" << sp.first
                               << " + (b + " << j << ") * " << strPrefetchWidth[sp.first] << " + " << w * 8 << ");\n";
+                }
                 for (int k : tileCols) {
                     if (isLazy(k)) s << "#if !RSQ_LAZY\n";
                     s << ind << "rsq::ld2(a.c" << k << " + b, " << pre << k << "_" << u << ");\n";
@@ -2620,7 +2670,10 @@ struct Walker {
             s << "    const i64 tend = ntiles;\n";
             for (int u = 0; u < U; u++) {
                 for (int k : tileCols) s << "    " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2] = {0, 0};\n";
-                for (auto& sp : strPrefetch) for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++) s << "    u64 s" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
+                for (auto& sp : strPrefetch) {
+                    if (strStaged.count(sp.first)) { stagedChunkDecls(s, "    ", "q", sp.first, u); continue; }
+                    for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++) s << "    u64 s" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
+                }
             }
             for (int u = 0; u < U; u++) {
                 s << "    {\n        const i64 p = wave * tstep + " << u << " * nwaves * tstep;\n        if (p < tend) {\n            const i64 b = (p << 7) + lane * 2;\n";
@@ -2644,13 +2697,17 @@ struct Walker {
                 }
             for (int u = 0; u < U; u++) {
                 for (int k : tileCols) s << "        " << colTypes[(size_t)k] << " n" << k << "_" << u << "[2] = {0, 0};\n";
-                for (auto& sp : strPrefetch) for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++) s << "        u64 ns" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
+                for (auto& sp : strPrefetch) {
+                    if (strStaged.count(sp.first)) { stagedChunkDecls(s, "        ", "nq", sp.first, u); continue; }
+                    for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++) s << "        u64 ns" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
+                }
                 s << "        {\n            const i64 nt = tt" << u << " + nwaves * tstep * " << U << ";\n            const i64 b = ((nt < tend ? nt : tend - 1) << 7) + lane * 2;\n";
                 tileLoads("            ", "n", u);
                 s << "        }\n";
             }
             for (int u = 0; u < U; u++) {
                 s << "        if (tt" << u << " < tend) {\n";
+                stagedUnstage(s, "            ", u);
                 for (int j = 0; j < 2; j++) {
                     s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");
                     for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << ", t" << k << "_" << u << "[" << j << "]";
@@ -2663,8 +2720,14 @@ struct Walker {
             }
             for (int u = 0; u < U; u++) {
                 for (int k : tileCols) s << "        t" << k << "_" << u << "[0] = n" << k << "_" << u << "[0]; t" << k << "_" << u << "[1] = n" << k << "_" << u << "[1];\n";
-                for (auto& sp : strPrefetch) for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++)
-                    s << "        s" << sp.first << "_" << u << "_" << j << "_" << w << " = ns" << sp.first << "_" << u << "_" << j << "_" << w << ";\n";
+                for (auto& sp : strPrefetch) {
+                    if (strStaged.count(sp.first)) {
+                        for (int r = 0; r < stagedRounds(sp.first); r++) s << "        q" << sp.first << "_" << u << "_" << r << " = nq" << sp.first << "_" << u << "_" << r << ";\n";
+                        continue;
+                    }
+                    for (int j = 0; j < 2; j++) for (int w = 0; w * 8 < sp.second; w++)
+                        s << "        s" << sp.first << "_" << u << "_" << j << "_" << w << " = ns" << sp.first << "_" << u << "_" << j << "_" << w << ";\n";
+                }
             }
             s << "    }\n";
         };
@@ -2677,19 +2740,23 @@ struct Walker {
         for (int u = 0; u < U; u++) {
             s << "        const i64 tt" << u << " = t + " << u << " * nwaves * tstep;\n";
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k]) s << "        " << colTypes[(size_t)k] << " t" << k << "_" << u << "[2]" << (lateCol[(size_t)k] ? " = {0, 0}" : "") << ";\n";
-            for (auto& sp : strPrefetch)
+            for (auto& sp : strPrefetch) {
+                if (strStaged.count(sp.first)) { stagedChunkDecls(s, "        ", "q", sp.first, u); continue; }
                 for (int j = 0; j < 2; j++)
                     for (int w = 0; w * 8 < sp.second; w++) s << "        u64 s" << sp.first << "_" << u << "_" << j << "_" << w << " = 0;\n";
+            }
             // The write pass of a materialisation skips every tile whose 64 lane slots counted nothing in the count pass: a selective
             // statement (TPC-H Q19: 1107 rows out of 60 M) then reads its columns once, not twice.
             if (matSkip) s << "#if RSQ_PASS == 2\n        const bool live" << u << " = tt" << u << " < tend && a.tcnt[tt" << u << "] != 0u;\n#else\n"
                            << "        const bool live" << u << " = tt" << u << " < tend;\n#endif\n";
             s << "        if (" << tileLive(u) << ") {\n            const i64 b = (tt" << u << " << 7) + lane * 2;\n";
-            for (auto& sp : strPrefetch)
+            for (auto& sp : strPrefetch) {
+                if (strStaged.count(sp.first)) { stagedChunkLoads(s, "            ", "q", sp.first, u); continue; }
                 for (int j = 0; j < 2; j++)
                     for (int w = 0; w * 8 < sp.second; w++)
                         s << "            s" << sp.first << "_" << u << "_" << j << "_" << w << " = rsq::ld_bytes<" << std::min(8, sp.second - w * 8) << ">(a.c" << sp.first
                           << " + (b + " << j << ") * " << strPrefetchWidth[sp.first] << " + " << w * 8 << ");\n";
+            }
             for (int k = 0; k < ncols; k++) if (!colIsString[(size_t)k] && !lateCol[(size_t)k]) {
                 const bool lazy = std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) != pipe.lazyCols.end();
                 if (lazy) s << "#if !RSQ_LAZY\n";
@@ -2712,6 +2779,7 @@ struct Walker {
             }
         for (int u = 0; u < U; u++) {
             s << "        if (" << tileLive(u) << ") {\n";
+            stagedUnstage(s, "            ", u);
             if (mat) s << "            const i64 slot = tt" << u << " * 64 + lane;\n#if RSQ_PASS == 2\n            st.pos = a.toffs[tt" << u << "] + (u64)rsq::wave_excl_sum_u32(a.cnt[slot]);\n#endif\n";
             for (int j = 0; j < 2; j++) {
                 s << "            row_fn(a, st, (tt" << u << " << 7) + lane * 2 + " << j << (cq ? ", true" : "");
@@ -2736,7 +2804,7 @@ struct Walker {
                 eagerRegs += r;
                 if (std::find(pipe.lazyCols.begin(), pipe.lazyCols.end(), k) == pipe.lazyCols.end()) lazyRegs += r;
             }
-            for (auto& sp : strPrefetch) { eagerRegs += 4 * ((sp.second + 7) / 8); lazyRegs += 4 * ((sp.second + 7) / 8); }
+            for (auto& sp : strPrefetch) { const int r = strStaged.count(sp.first) ? 4 * stagedRounds(sp.first) : 4 * ((sp.second + 7) / 8); eagerRegs += r; lazyRegs += r; }
             const int budget = 24;      // (64: TPC-H Q5 0.69 -> 0.78 ms, the eager form's 133 -> 183 VGPRs)
             const bool eagerOk = cqPipelined && eagerRegs * U <= budget, lazyOk = cqPipelined && lazyRegs * U <= budget;
             if (latePipelined || (eagerOk && (lazyOk || pipe.lazyCols.empty()))) emitPipelinedLoop();

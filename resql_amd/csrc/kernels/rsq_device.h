@@ -67,6 +67,27 @@ RSQ_DEV void ld2(const i32* p, i32 (&v)[2]) { i32x2 t = *reinterpret_cast<const 
 RSQ_DEV void ld2(const u8* p, u8 (&v)[2]) { u8x2 t = *reinterpret_cast<const u8x2*>(p); v[0] = t.x; v[1] = t.y; }
 #endif
 
+// One 128-row tile of a W-byte string column = 8 * W chunks of 16 bytes; chunk 64 * R + lane is the lane's load number R (the lanes past the
+// last chunk repeat it: an unconditional load, which the compiler's wait counting needs of every load of the tile).  Tiles start at
+// multiples of 128 rows, so the chunks are 16-byte aligned wherever the column base is.
+typedef u32 u32v4 __attribute__((ext_vector_type(4)));
+template <int W, int R>
+RSQ_DEV u32v4 ld_str_chunk(const char* tile, int lane) {
+    int c = R * 64 + lane;
+    if ((R + 1) * 64 > 8 * W) c = c < 8 * W ? c : 8 * W - 1;
+    return __builtin_nontemporal_load(reinterpret_cast<const u32v4*>(tile) + c);
+}
+template <int W, int R>
+RSQ_DEV void st_str_chunk(char* ldsTile, int lane, u32v4 v) {
+    const int c = R * 64 + lane;
+    if ((R + 1) * 64 <= 8 * W || c < 8 * W) reinterpret_cast<u32v4*>(ldsTile)[c] = v;
+}
+
+// Between the chunk stores and the word loads, and behind the loads: the compiler reasons per thread, proves that a lane's own chunk stores
+// never touch the bytes it reads back (they are other lanes' chunks) and would keep the previous tile's words in registers.  The hardware
+// needs nothing here - the LDS operations of one wave execute in order.
+RSQ_DEV void wave_lds_order() { asm volatile("" ::: "memory"); }
+
 // ---- wave64 reductions ----------------------------------------------------------------------
 RSQ_DEV u64 shfl_xor_u64(u64 v, int mask) {
     u32 lo = (u32)v, hi = (u32)(v >> 32);
