@@ -422,11 +422,21 @@ __device__ inline u64 rank_unmix(u64 x, u64 cap) {
     return (L << lo) | R;
 }
 
+// where the words of a table entry live (the packed group row [first row | table words | accumulator blocks] read in place)
+struct EntrySource {
+    const i64* first; i64 cap; const i64* words; int nWords; int wordsAos; const i64* acc; int nAcc; int unmix;
+};
+__device__ __forceinline__ i64 entry_word(const EntrySource& es, i64 s, i64 e, int k) {
+    if (k == 0) return es.first[s];
+    if (k - 1 < es.nWords) return !es.words ? s : es.wordsAos ? es.words[(size_t)e * es.nWords + (k - 1)] : es.words[(size_t)(k - 1) * es.cap + e];
+    return es.acc[(size_t)(k - 1 - es.nWords) * es.cap + s];
+}
+
 template <int COMPACT_PER_THREAD>
 __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__ first, i64 cap, const i64* __restrict__ words, int nWords,
                                                          int wordsAos, const i64* __restrict__ acc, int nAcc, i64* __restrict__ out,
                                                          unsigned maxRows, unsigned* count, int unmix, int keyWord, int keyIs32, int keyDesc,
-                                                         u64* __restrict__ imageRange, u64* __restrict__ chain, unsigned launchNo) {
+                                                         u64* __restrict__ imageRange, u64* __restrict__ chain, unsigned launchNo, int narrow) {
     const int stride = 1 + nWords + nAcc;
     u64 imgMax = 0, imgMaxInv = 0;      // range of the sort-key images of the rows written (keyWord >= 0): max(u), max(~u)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -510,6 +520,21 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                 if (f[r] != 0x7fffffffffffffffll) s_list[lp++] = (unsigned)(r * 256 + t);
             __syncthreads();
             const unsigned base = s_base;
+            if (narrow) {
+                // rows [slot | sort key] only: the candidate selection reads the keys and fetches the few rows it takes from the table itself
+                // (k_topk_range_select).  TPC-H Q10 at SF10: 380 K groups of 40 words, 20 of them wanted - 108 us of row copies.
+                const EntrySource es{first, cap, words, nWords, wordsAos, acc, nAcc, unmix};
+                for (unsigned i = (unsigned)t; i < total; i += 256u) {
+                    const unsigned pos = base + i;
+                    if (pos >= maxRows) continue;
+                    const i64 s = lo + (i64)s_list[i];
+                    const i64 e = unmix ? (i64)rank_unmix((u64)s, (u64)cap) : s;
+                    const i64 kv = entry_word(es, s, e, keyWord);
+                    out[(size_t)pos * 2] = s;
+                    out[(size_t)pos * 2 + 1] = kv;
+                    const u64 u = topk_image(kv, keyIs32, keyDesc); imgMax = u > imgMax ? u : imgMax; imgMaxInv = ~u > imgMaxInv ? ~u : imgMaxInv;
+                }
+            } else
             if (stride <= 8) {
                 // three rows per thread at a time, all their loads first, then their stores.  (Word by word, every load waited for
                 // its predecessor's store, and the sort key's image was read back from the row just written: chains of up to ten
@@ -609,21 +634,22 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
 
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix, int keyWord, bool keyIs32,
-                    bool keyDesc, uint64_t* imageRange) {
+                    bool keyDesc, uint64_t* imageRange, bool narrow) {
+    if (narrow && (!imageRange || keyWord < 0)) throw Error(RSQ_ERR_DEVICE, "compactEntries: narrow rows carry the sort key");
     // slots per thread: every chunk costs one reservation atomic on the same word (they serialise), so large tables take
     // large chunks; swept on the box for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us.  (Row positions by look-back through
     // a chain of chunk totals instead of the reservation atomics were tried and measured no gain - TPC-H Q3 at SF10 0.305 against
     // 0.300 ms, Q10 0.939 either way: the 177 / 256 same-word atomics are not what these 19 / 119 us kernels wait for.)
     // (wide rows - more than eight words - are copied by eight lanes each: their kernel wants waves, not long chunks; TPC-H Q10 at SF10,
     // 380 K rows of 40 words out of 4 M slots: 133 us with one thread per row and 64 slots per thread - one workgroup per CU)
-    const int perThread = 1 + nWords + nAcc > 8 ? 16 : capacity >= (1 << 22) ? 64 : capacity >= (1 << 20) ? 32 : 16;
+    const int perThread = 1 + nWords + nAcc > 8 && !narrow ? 16 : capacity >= (1 << 22) ? 64 : capacity >= (1 << 20) ? 32 : 16;
     const int64_t chunkSlots = 256 * (int64_t)perThread;
     const int64_t nChunks = std::max<int64_t>(1, (capacity + chunkSlots - 1) / chunkSlots);
     unsigned grid = (unsigned)std::min<int64_t>(8 * (int64_t)ctx.numCUs, nChunks);
     u64* chain = nullptr;
     unsigned launchNo = 0;
 #define RSQ_LAUNCH_COMPACT(PT) hipLaunchKernelGGL(k_compact_entries<PT>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, \
-                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0, imageRange ? keyWord : -1, keyIs32 ? 1 : 0, keyDesc ? 1 : 0, (u64*)imageRange, chain, launchNo)
+                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0, imageRange ? keyWord : -1, keyIs32 ? 1 : 0, keyDesc ? 1 : 0, (u64*)imageRange, chain, launchNo, narrow ? 1 : 0)
     if (perThread >= 64) RSQ_LAUNCH_COMPACT(64); else if (perThread >= 32) RSQ_LAUNCH_COMPACT(32); else RSQ_LAUNCH_COMPACT(16);
 #undef RSQ_LAUNCH_COMPACT
     RSQ_HIP(hipGetLastError());
@@ -820,7 +846,8 @@ __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict
                                                            const unsigned* __restrict__ nRows, unsigned maxRows, const u64* __restrict__ imageRange,
                                                            unsigned* __restrict__ hist, unsigned want, i64* __restrict__ cand, unsigned capacity,
                                                            unsigned* candCount, unsigned* ticket1, unsigned* ticket2, unsigned* err, u64* __restrict__ host, u64 seq,
-                                                           const unsigned* __restrict__ groupCount, const u64* __restrict__ pipeStats, int nPipelines) {
+                                                           const unsigned* __restrict__ groupCount, const u64* __restrict__ pipeStats, int nPipelines,
+                                                           EntrySource es, int fullStride) {
     __shared__ unsigned s_hist[TOPK_BINS];
     __shared__ unsigned s_above[256];
     __shared__ unsigned s_bin, s_flag;
@@ -902,9 +929,22 @@ __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict
         const unsigned pos = base + (unsigned)__popcll(vote & ((1ull << lane) - 1ull));
         if (pos >= capacity) return;
         const i64* src = rows + (size_t)i * stride;
-        i64* dst = cand + (size_t)pos * stride;
         // (host-mapped memory, read by the host as soon as the sequence number arrives: system-scope stores, waited for before this
         // workgroup takes its second ticket)
+        if (es.first) {          // narrow rows [slot | key] (k_compact_entries): the candidate's words come from the table entry
+            const i64 s = src[0];
+            const i64 e = es.unmix ? (i64)rank_unmix((u64)s, (u64)es.cap) : s;
+            i64* dst = cand + (size_t)pos * fullStride;
+            for (int w0 = 0; w0 < fullStride; w0 += 8) {
+                i64 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = w0 + j < fullStride ? entry_word(es, s, e, w0 + j) : 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (w0 + j < fullStride) __hip_atomic_store(dst + w0 + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        i64* dst = cand + (size_t)pos * stride;
         for (int w = 0; w < stride; w++) __hip_atomic_store(dst + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
 #pragma unroll
@@ -955,16 +995,25 @@ void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int
 
 void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                                      uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* candHostMapped, uint32_t capacity,
-                                     uint64_t* hostWords, uint64_t seq, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines) {
+                                     uint64_t* hostWords, uint64_t seq, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines,
+                                     const TableEntries* entries) {
     if (nPipelines > 56) throw Error(RSQ_ERR_UNSUPPORTED, "more than 56 pipelines in one query");
     const u64* range = (const u64*)scratch;
     unsigned* candCount = (unsigned*)((char*)scratch + 16);
     unsigned* hist = (unsigned*)((char*)scratch + 24);
+    EntrySource es{};
+    int fullStride = stride;
+    if (entries) {
+        if (stride != 2 || keyWord != 1) throw Error(RSQ_ERR_DEVICE, "selectTopCandidatesRangePublish: narrow rows are [slot | key]");
+        es = EntrySource{(const i64*)entries->firstRow, (i64)entries->capacity, (const i64*)entries->words, entries->nWords, entries->wordsAos ? 1 : 0,
+                         (const i64*)entries->acc, entries->nAcc, entries->unmix ? 1 : 0};
+        fullStride = 1 + entries->nWords + entries->nAcc;
+    }
     // (the grid must be on the chip as a whole: at most one workgroup per CU)
     const unsigned grid = (unsigned)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)ctx.numCUs, (rowsUpperBound + 1023) / 1024));
     hipLaunchKernelGGL(k_topk_range_select, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)rows, stride, keyWord, is32 ? 1 : 0, desc ? 1 : 0,
                        (const unsigned*)nRows, (unsigned)rowsUpperBound, range, hist, (unsigned)want, (i64*)candHostMapped, (unsigned)capacity, candCount,
-                       (unsigned*)((char*)scratch + 20), (unsigned*)((char*)scratch + 24 + TOPK_BINS * sizeof(unsigned)), err, (u64*)hostWords, (u64)seq, (const unsigned*)groupCount, (const u64*)pipeStats, nPipelines);
+                       (unsigned*)((char*)scratch + 20), (unsigned*)((char*)scratch + 24 + TOPK_BINS * sizeof(unsigned)), err, (u64*)hostWords, (u64)seq, (const unsigned*)groupCount, (const u64*)pipeStats, nPipelines, es, fullStride);
     RSQ_HIP(hipGetLastError());
 }
 

@@ -144,6 +144,7 @@ Query::~Query() {
     if (dScanTemp) ctx.free(dScanTemp);
     for (void* p : dMatCols) if (p) ctx.free(p);
     if (dGroupRows) ctx.free(dGroupRows);
+    if (dNarrowRows) ctx.free(dNarrowRows);
     if (dPipeStats) ctx.free(dPipeStats);
     if (dGroupCount) ctx.free(dGroupCount);
     if (dTopkImages) ctx.free(dTopkImages);
@@ -1426,6 +1427,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     uint32_t groupRowsAllocated = 0;              // rows the group-row buffers of this execution can take
     uint64_t selectSeq = 0;                       // ... announced by this sequence number in pinned word 4
     bool selectPublished = false;                 // ... and the selection's launch has delivered candidates and status words to the host
+    bool narrowRows = false;                      // ... from narrow group rows [slot | sort key]: q.dGroupRows was NOT written by this execution
     auto ensureCandHost = [&]() {        // coherent pinned rows for topkCapacity candidates, and the device's view of them
         const size_t need = (size_t)topkCapacity * (size_t)q.groupRowWords;
         if (q.hCandRowsWords >= need && q.dHostCandRows) return;
@@ -1756,11 +1758,31 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (!topkScratchCleared) prepareTopCandidatesRange(ctx, q.dTopkHists);
         }
         if (!groupCountCleared) RSQ_HIP(hipMemsetAsync(q.dGroupCount, 0, 4, ctx.stream));
+        // Wide group rows of which the statement wants a few (TPC-H Q10: 380 K groups of 40 words - string group values -, LIMIT 20): the
+        // compaction writes [slot | sort key] per group, the one-launch selection fetches its candidates' rows from the table.  Whatever
+        // then turns out to need every row (candidates that overflow or do not decide the answer) starts the execution over with full rows.
+        narrowRows = preselect && q.groupRowWords > 8 && !q.narrowRowsOff && fusedSelectOk();
+        if (narrowRows && q.narrowRowsCap < groupRowsAllocated) {
+            if (q.dNarrowRows) ctx.free(q.dNarrowRows);
+            q.dNarrowRows = nullptr; q.narrowRowsCap = 0;
+            q.dNarrowRows = (int64_t*)ctx.alloc((size_t)groupRowsAllocated * 16);
+            q.narrowRowsCap = groupRowsAllocated;
+        }
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
-                       q.dGroupRows, groupRowsAllocated, q.dGroupCount,
+                       narrowRows ? q.dNarrowRows : q.dGroupRows, groupRowsAllocated, q.dGroupCount,
                        h.rank,
-                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr);
+                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr, narrowRows);
         q.report.num_kernels++;
+        if (narrowRows) {
+            topkRange = true;
+            const TableEntries te{(const int64_t*)h.dAcc, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks, h.rank};
+            selectTopCandidatesRangePublish(ctx, q.dNarrowRows, 2, 1, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated,
+                                            q.topkWant, q.dTopkHists, q.dHostCandRows, topkCapacity, q.dPinnedDev + words, selectSeq = ++q.finSeqCounter, ctx.dErr, q.dGroupCount,
+                                            anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size(), &te);
+            q.report.num_kernels += 1;
+            selectPublished = true;
+            topkSpec = topkCapacity;
+        } else
         if (preselect) {
             // the short form: the compaction collected the range of the sort key's images, ONE histogram over that range finds
             // the candidates (aot_kernels.hip); the exact radix select runs only if they overflow the buffer (below)
@@ -2002,6 +2024,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 return;
             }
             int64_t nCand = topkCapacity ? (int64_t)(uint32_t)q.hPinned[words + 2] : 0;
+            if (narrowRows && nCand > (int64_t)topkCapacity) { q.narrowRowsOff = true; executeQuery(q, partialOnly, async); return; }      // (the exact selection reads full rows)
             if (topkRange && nCand > (int64_t)topkCapacity) { nCand = exactCandidates(groupRowsAllocated); topkSpec = topkCapacity; }
             const size_t rowBytes = (size_t)q.groupRowWords * 8;
             q.candidateRun = false;
@@ -2025,6 +2048,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 q.candidateRun = false;
             }
             if (!topkCapacity || q.tailNeedsAllGroups || !(nCand <= (int64_t)topkCapacity && nCand < nGroups)) {
+                if (narrowRows) { q.narrowRowsOff = true; executeQuery(q, partialOnly, async); return; }      // (every row is needed: none was written)
                 q.nGroupRows = nGroups;
                 if (rowsDeviceTailWanted(q, nGroups)) runRowsDeviceTail(q, nGroups);      // many groups: the rows are made on the device
                 else {

@@ -177,7 +177,13 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix = false,
                     // optional: while writing the rows, collect the range of the images of row word `keyWord` (a sort key) into
                     // imageRange[0] = max(image), imageRange[1] = max(~image) — both must be 0 before the launch
-                    int keyWord = -1, bool keyIs32 = false, bool keyDesc = false, uint64_t* imageRange = nullptr);
+                    int keyWord = -1, bool keyIs32 = false, bool keyDesc = false, uint64_t* imageRange = nullptr,
+                    // narrow: rows of TWO words [slot | word `keyWord` of the packed row] instead (wide rows of which an ORDER BY ... LIMIT
+                    // wants a few: selectTopCandidatesRangePublish fetches those from the table, TableEntries)
+                    bool narrow = false);
+struct TableEntries {
+    const int64_t* firstRow; int64_t capacity; const int64_t* words; int nWords; bool wordsAos; const int64_t* acc; int nAcc; bool unmix;
+};
 // ORDER BY ... LIMIT pre-selection: the rows of `rows` ([*nRows][stride] words) whose word `keyWord` is among the `want`
 // leading values of the requested order (ties of the last one included) are copied to `cand`.  `scratch` (topkHistBytes() bytes)
 // holds [image range: 2 x u64][candidate count: u32][pad][histograms]; the candidate count is read from scratch + 16.
@@ -197,7 +203,9 @@ void selectTopCandidatesRange(Context& ctx, const int64_t* rows, int stride, int
 // A meeting point that timed out sets bit 256 of *err.
 void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stride, int keyWord, bool is32, bool desc, const uint32_t* nRows,
                                      uint32_t rowsUpperBound, uint32_t want, void* scratch, int64_t* candHostMapped, uint32_t capacity,
-                                     uint64_t* hostWords, uint64_t seq, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines);
+                                     uint64_t* hostWords, uint64_t seq, uint32_t* err, const uint32_t* groupCount, const uint64_t* pipeStats, int nPipelines,
+                                     // rows are compactEntries' narrow rows (stride 2, keyWord 1): the candidates are written as full packed rows read from these entries
+                                     const TableEntries* entries = nullptr);
 
 // devtail.hip: the tail of a large dense aggregation on the device (present groups, order by first row, the reference's hashes,
 // packed result tuples); tail.cpp planDenseDeviceTail says whether a plan qualifies and describes keys and columns

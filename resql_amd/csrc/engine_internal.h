@@ -386,6 +386,9 @@ struct Query {
     uint64_t readiedEpoch = 0;
     std::vector<FillItem> readiedFill;
     bool scanChainedOff = false;         // a look-back of the one-launch offset scan timed out once: three launches from now on
+    int64_t* dNarrowRows = nullptr;      // group rows as [slot | sort key] for the candidate selection over wide rows (executeQuery)
+    uint32_t narrowRowsCap = 0;
+    bool narrowRowsOff = false;          // an execution needed every group row after all: full rows from now on
     bool fusedSelectOff = false;         // a meeting point of the one-launch candidate selection timed out once: separate launches from now on
     uint64_t mergePublishedSeq = 0;        // > 0: rsq_query_merge_gathered also published the merged table to hPinned; finalize polls for this number
     bool kernelTimePending = false;        // the fused step's events have not been read yet (resolveKernelTime)

@@ -150,3 +150,35 @@ def test_large_dense_tables_take_the_candidate_path(gpu_ctx):
                          (lambda p: [p.desc(p.attr("n"))], 5)):
         want = run_both_ways(gpu_ctx, dense_plan(t, order, limit))
         assert want.n_rows == limit
+
+
+def test_wide_group_rows_select_from_slot_and_key_rows(gpu_ctx):
+    """group rows of more than eight words (two CHAR(40) group values) above 6 000 groups: the compaction writes [slot | sort key] rows
+    and the selection fetches its candidates from the table (engine.cpp narrowRows).  ORDER BY a sum decides from the candidates;
+    ORDER BY count(*) ties every group - the candidates overflow, the execution starts over with full rows; both must agree with the
+    oracle, executed twice (the second execution remembers which way it went)."""
+    import numpy as np
+    n, g = 90_000, 6_000
+    r = np.arange(n)
+    a = np.array([b"customer-name-%06d-of-the-first-kind" % (i % g) for i in range(n)], dtype="S40")
+    b = np.array([b"address-%06d-somewhere-far-away" % ((i % g) * 7 % g) for i in range(n)], dtype="S40")
+    v = ((r * 2654435761) % 1000 - 300).astype(np.int64)
+    t = P.Table("t", [P.Column("a", P.TypeInit.CHAR(40), a), P.Column("b", P.TypeInit.CHAR(40), b), P.Column("v", P.TypeInit.BIGINT(), v)], n)
+    for order in (lambda p, s, c: [p.desc(p.attr("s")), p.attr("a")], lambda p, s, c: [p.desc(p.attr("c")), p.attr("a")], lambda p, s, c: [p.attr("s")]):
+        p = P.Plan([t])
+        s, c = p.sum(p.attr("v")), p.count(p.star())
+        node = p.aggregation([s, c], [p.attr("a"), p.attr("b")], p.scan("t"))
+        node = p.projection([p.attr("a"), p.attr("b"), p.as_("s", s), p.as_("c", c)], node)
+        node = p.orderby(order(p, s, c), node)
+        plan = p.set_root(node, limit=12)
+        want = orc.execute(plan)
+        tabs = [gpu_ctx.table(t)]
+        q = gpu_ctx.compile(plan, tabs)
+        try:
+            for _ in range(3):
+                q.execute()
+                got = q.result()
+                assert got.text == want.text and got.tuples == want.tuples
+        finally:
+            q.close(); tabs[0].close()
+    run_both_ways(gpu_ctx, plan)
