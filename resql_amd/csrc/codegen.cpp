@@ -375,7 +375,7 @@ struct Walker {
         multiMatchAbove = false;
         selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
         leadCond.clear(); leadCols.clear(); leadPass = 1.0; leadPassComplete = true;
-        strPrefetch.clear(); strPrefetchWidth.clear(); strStaged.clear(); strStagedBytes = 0; eg.strWordVars.clear();
+        strPrefetch.clear(); strPrefetchWidth.clear(); strStaged.clear(); strStagedBytes = 0; postTile.clear(); eg.strWordVars.clear();
         eg.symbols.clear();
         o->schema.clear();
         for (size_t ci = 0; ci < t->cols.size(); ci++) {
@@ -502,6 +502,7 @@ struct Walker {
     // is - 128 rows x W contiguous bytes per tile, 16 bytes per lane and load, every line once - and passed through the wave's own LDS
     // region, from which each lane reads its rows' words (ds_read_b64 takes any address on gfx950).  All words of the value then arrive
     // as row-function parameters.
+    std::string postTile;                                  // code behind the two row_fn calls of a tile in the tile loops ($TILE = the tile's number; wave-uniform)
     std::map<int, int> strStaged;                          // scanned column -> byte offset of its tile in the wave's LDS region
     int strStagedBytes = 0;                                // bytes of that region (128 x the staged widths)
     void prefetchComparedStrings(const Expr* e) {
@@ -1011,8 +1012,19 @@ struct Walker {
             line("{ " + bitSet + setBit + " }");
             if (ht->identityCapable) {
                 addArg(T + "_ident", "u64", 0);
+                // Records at the row's number: the 128 rows of a tile are 128 x NW consecutive words of the table.  A lane storing ITS rows' words
+                // writes 8 bytes at a stride of 16 x NW per instruction (TPC-H Q12's orders table: 240 MB of records in 94 us, Q10's customers:
+                // seven words per row in 48 us); the records go through the wave's LDS region instead and leave as the wave's 16-byte stores,
+                // every line whole (the flush behind the tile's rows, finishPipeline).  The rows behind the last tile store directly.
+                const std::string NWI = std::to_string(1 + (int)ht->payload.size());
+                stateDecl += "    i64* rec_" + T + ";\n    bool in_tile = true;\n";
+                prologue += "    __shared__ __attribute__((aligned(16))) i64 s_rec_" + T + "[(RSQ_BLOCK_THREADS / 64) * 128 * " + NWI + "];\n    st.rec_" + T + " = s_rec_" + T +
+                            " + (threadIdx.x >> 6) * 128 * " + NWI + ";\n";
+                pipe.extraLdsBytes += (pipe.blockThreads / 64) * 128 * 8 * (1 + (int)ht->payload.size());
+                postTile += "            if (a." + T + "_ident && a." + T + "_rank && !a." + T + "_countonly) rsq::flush_tile_records<" + NWI + ">(st.rec_" + T + ", a." + T + "_words + (u64)(($TILE) << 7) * " + NWI +
+                            "ull, lane);\n";
                 openScope("if (a." + T + "_ident) {");
-                line("i64* rec = a." + T + "_words + (u64)(row - a.row0) * " + std::to_string(1 + (int)ht->payload.size()) + "ull;");
+                line("i64* rec = st.in_tile ? st.rec_" + T + " + (u32)(lr & 127) * " + NWI + "u : a." + T + "_words + (u64)(row - a.row0) * " + NWI + "ull;");
                 line("rec[0] = " + keyVars[0] + ";");
                 int iw = 1;
                 for (auto& p : ht->payload) line("rec[" + std::to_string(iw++) + "] = " + toWord(eg.symbols[p.name].var, p.type) + ";");
@@ -2371,6 +2383,11 @@ struct Walker {
 
     // -------------------------------------------------------------------------------------------
     // staged string tiles (see strStaged): chunk c = 64 * round + lane of the tile's 8 * W 16-byte chunks
+    std::string postTileFor(const std::string& tile) {
+        std::string out = postTile;
+        for (size_t at; (at = out.find("$TILE")) != std::string::npos;) out.replace(at, 5, tile);
+        return out;
+    }
     int stagedRounds(int col) { return (8 * strPrefetchWidth[col] + 63) / 64; }
     void stagedChunkDecls(std::ostringstream& s, const std::string& ind, const char* pre, int col, int u) {
         for (int r = 0; r < stagedRounds(col); r++) s << ind << "rsq::u32v4 " << pre << col << "_" << u << "_" << r << " = {0u, 0u, 0u, 0u};\n";
@@ -2716,6 +2733,7 @@ struct Walker {
                     s << ");\n";
                     if (cq && (QCAP < 192 || j == 1)) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";
                 }
+                s << postTileFor("tt" + std::to_string(u));
                 s << "        }\n";
             }
             for (int u = 0; u < U; u++) {
@@ -2790,6 +2808,7 @@ struct Walker {
                 if (cq && (QCAP < 192 || j == 1)) s << "            while (st.cq_n >= 64) cq_drain(a, st, 64);\n";
             }
             if (mat) s << "#if RSQ_PASS == 1\n            a.cnt[slot] = st.cnt;\n            { const u32 ts = (u32)rsq::wave_sum((u64)st.cnt); if (lane == 0) a.tcnt[tt" << u << "] = ts; }\n            st.cnt = 0;\n#endif\n";
+            s << postTileFor("tt" + std::to_string(u));
             s << "        }\n";
         }
         s << "    }\n";
@@ -2812,6 +2831,7 @@ struct Walker {
             else emitPlainLoop();
         }
         if (dbgStamps) s << "    if (a.dbg && threadIdx.x == 0) a.dbg[(u64)blockIdx.x * 8 + 1] = (u64)wall_clock64();\n";
+        if (!postTile.empty()) s << "    st.in_tile = false;\n";
         if (cq) {
             // tail rows with a wave-uniform trip count (the push votes across the wave)
             s << "    for (i64 rb = (ntiles << 7) + (i64)blockIdx.x * blockDim.x; rb < a.n_rows; rb += (i64)gridDim.x * blockDim.x) {\n";

@@ -88,6 +88,17 @@ RSQ_DEV void st_str_chunk(char* ldsTile, int lane, u32v4 v) {
 // needs nothing here - the LDS operations of one wave execute in order.
 RSQ_DEV void wave_lds_order() { asm volatile("" ::: "memory"); }
 
+// The records of one tile (128 rows x NW words, written by the lanes into the wave's LDS region) leave as the wave's 16-byte stores.
+template <int NW>
+RSQ_DEV void flush_tile_records(i64* ldsTile, i64* dst, int lane) {
+    wave_lds_order();
+    const u32v4* src = reinterpret_cast<const u32v4*>(ldsTile);
+    u32v4* out = reinterpret_cast<u32v4*>(dst);
+#pragma unroll
+    for (int r = 0; r < NW; r++) out[r * 64 + lane] = src[r * 64 + lane];
+    wave_lds_order();
+}
+
 // ---- wave64 reductions ----------------------------------------------------------------------
 RSQ_DEV u64 shfl_xor_u64(u64 v, int mask) {
     u32 lo = (u32)v, hi = (u32)(v >> 32);
