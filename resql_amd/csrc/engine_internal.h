@@ -444,4 +444,37 @@ void runRowsTailSort(Query& q, uint8_t* tuples, int64_t& rows);
 // tail.cpp: is the first ORDER BY key of an `ORDER BY ... LIMIT k` above the aggregation one word of the group rows?
 void planDeviceTopK(Query& q);
 
+// ---- engine_pipelines.cpp: one pipeline on the device, by sink (called from executeQuery) --------------------------------------
+inline int64_t nextPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
+bool denseMode(const Query& q);
+uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTable);
+int residentWorkgroupsPerCU(Kernel* k, int blockThreads);
+unsigned pipelineGrid(const Query& q, const Pipeline& p, bool lazyForm = false);
+void launchPipelineKernel(Query& q, Pipeline& p, Kernel& k, int countOnlyTable, unsigned grid = 0, unsigned block = 0,
+                                 hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+void waitForStream(Context& ctx);
+void debugStamps(Query& q, Pipeline& p);
+Kernel* fewGroupsKernel(Query& q, Pipeline& p, const std::string& source, const char* form, Kernel* large);
+unsigned fewGroupsGrid(Query& q, Pipeline& p, Kernel* k);
+void launchPipeline(Query& q, Pipeline& p, int countOnlyTable, bool pass1 = false);
+void prepareStageBuffers(Query& q, const Pipeline& p);
+bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64_t>& estimate, bool tentative = false);
+void runLargeDenseAggregation(Query& q, Pipeline& p);
+void materializePipeline(Query& q, Pipeline& p);
+void buildHashTable(Query& q, Pipeline& p);
+void checkDeviceError(uint32_t err);
+void checkAsyncDeviceError(uint32_t err);
+void enqueueTableInit(Query& q);
+void enqueueTableReadback(Query& q);
+void tableFromPinned(Query& q);
+void dropTable(Context& ctx, HashTable& h);
+void leaveGeneric2(Query& q);
+void generic2Launch(Query& q, size_t pi, int matPass);
+void runGeneric2Pipeline(Query& q, size_t pi);
+// ---- engine_devtail.cpp: the tails that stay on the device ----------------------------------------------------------------------
+bool denseDeviceTailWanted(Query& q);
+double runDenseDeviceTail(Query& q);
+bool rowsDeviceTailWanted(Query& q, int64_t n);
+double runRowsDeviceTail(Query& q, int64_t n);
+
 }  // namespace rsq
