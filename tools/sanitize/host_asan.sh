@@ -12,7 +12,7 @@ for SAN in address undefined; do
     B=${TMPDIR:-/tmp}/rsq_host_$SAN; mkdir -p $B
     EXTRA=""; [ $SAN = undefined ] && EXTRA="-fno-sanitize=vptr"
     cd $ROOT/resql_amd/csrc
-    for f in expr.cpp hostref.cpp hostpar.cpp runtime.cpp codegen.cpp tail.cpp engine.cpp engine_pipelines.cpp engine_devtail.cpp generic.cpp generic2.cpp tbl.cpp sqlfront.cpp api.cpp multi.cpp aot_kernels.hip devtail.hip generic_kernels.hip; do
+    for f in expr.cpp hostref.cpp hostpar.cpp runtime.cpp codegen.cpp codegen_join.cpp codegen_agg.cpp codegen_loop.cpp tail.cpp engine.cpp engine_pipelines.cpp engine_devtail.cpp generic.cpp generic2.cpp tbl.cpp sqlfront.cpp api.cpp multi.cpp aot_kernels.hip devtail.hip generic_kernels.hip; do
         /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC -fsanitize=$SAN $EXTRA -fno-gpu-sanitize -fno-omit-frame-pointer --offload-arch=gfx950 -I../../include -I. -x hip -c $f -o $B/$f.o
     done
     /opt/rocm/bin/hipcc -shared -fPIC -fsanitize=$SAN $EXTRA -fno-gpu-sanitize --offload-arch=gfx950 -o $B/libresql_hip.so $B/*.o -lhiprtc -ldl -lpthread

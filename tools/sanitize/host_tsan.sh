@@ -13,7 +13,7 @@ cp $ROOT/resql_amd/libresql_hip.so ${TMPDIR:-/tmp}/libresql_hip.good.so
 trap 'cp ${TMPDIR:-/tmp}/libresql_hip.good.so $ROOT/resql_amd/libresql_hip.so' EXIT
 B=${TMPDIR:-/tmp}/rsq_host_thread; mkdir -p $B
 cd $ROOT/resql_amd/csrc
-for f in expr.cpp hostref.cpp hostpar.cpp runtime.cpp codegen.cpp tail.cpp engine.cpp engine_pipelines.cpp engine_devtail.cpp generic.cpp generic2.cpp tbl.cpp sqlfront.cpp api.cpp multi.cpp aot_kernels.hip devtail.hip generic_kernels.hip; do
+for f in expr.cpp hostref.cpp hostpar.cpp runtime.cpp codegen.cpp codegen_join.cpp codegen_agg.cpp codegen_loop.cpp tail.cpp engine.cpp engine_pipelines.cpp engine_devtail.cpp generic.cpp generic2.cpp tbl.cpp sqlfront.cpp api.cpp multi.cpp aot_kernels.hip devtail.hip generic_kernels.hip; do
     /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC -fsanitize=thread -fno-gpu-sanitize -fno-omit-frame-pointer --offload-arch=gfx950 -I../../include -I. -x hip -c $f -o $B/$f.o &
     while [ $(jobs -r | wc -l) -ge 8 ]; do sleep 0.2; done
 done
