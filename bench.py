@@ -65,7 +65,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
-PMC_PROFILES = ("profiles/r03_q1_sf10_pmc.json", "profiles/r02_q1_sf10_pmc.json", "profiles/r01_q1_sf10_pmc.json")
+PMC_PROFILES = ("profiles/r04_q1_sf10_pmc.json", "profiles/r03_q1_sf10_pmc.json", "profiles/r02_q1_sf10_pmc.json", "profiles/r01_q1_sf10_pmc.json")
 INIT_TIMEOUT_S = 120        # rendezvous of the ranks (a rank that never arrives must not hold the others for minutes)
 
 

@@ -331,7 +331,7 @@ struct Walker {
     bool downstreamMaterializes(OpNode* o);
     bool compactThen(OpNode* o, const std::function<void()>& downstream);
 
-    void countPerThread(const std::string& T);
+    void countPerThread(const std::string& T, bool identityCapable = false);
 
     std::vector<std::string> keyWords(Expr* e, const std::string& prefix, bool stripChar, std::vector<std::string>* endsWithSpace = nullptr, int stripMode = -1);
 

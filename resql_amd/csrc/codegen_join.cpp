@@ -9,8 +9,12 @@ namespace cg {
 // the kernel.  (One atomic per inserted entry on a single word serialises: 1.45 M of them cost 4.6 ms on
 // MI355X, more than the rest of TPC-H Q3 together; inside a divergent probe loop neither the compiler nor a
 // ballot folds them, the matching lanes arrive one at a time.)
-void Walker::countPerThread(const std::string& T) {
+void Walker::countPerThread(const std::string& T, bool identityCapable) {
     stateDecl += "    u32 n_" + T + " = 0;\n";
+    // (a dictionary whose entry numbers are the row numbers holds n_rows entries: one store says so.  The workgroups of a build finish
+    // together, and their 1 792 adds to the one counter word were the last ~20 us of TPC-H Q10's 48 us customer build.)
+    if (identityCapable)
+        epilogue += "    if (a." + T + "_ident && a." + T + "_rank && !a." + T + "_countonly) { if (blockIdx.x == 0 && threadIdx.x == 0) *a." + T + "_count = (u32)a.n_rows; }\n    else\n";
     // wave sum -> LDS -> ONE global atomic per workgroup: atomics on a single word serialise (~11 ns each), and a
     // random-access pipeline launches 8 workgroups per CU
     epilogue += "    {\n        __shared__ u32 s_n_" + T + ";\n        if (threadIdx.x == 0) s_n_" + T + " = 0;\n        __syncthreads();\n";
@@ -249,7 +253,7 @@ void Walker::consumeBuildBody(OpNode* o, OpNode* from) {
     }
     // sizing pass: the same pipeline run once with countonly = 1 tells the host how many entries to expect — and, for a
     // table that could be a rank dictionary, whether two build rows share a key (a bit that is already set)
-    countPerThread(T);
+    countPerThread(T, ht->identityCapable);
     if (ht->rankCapable) {
         addArg(T + "_rank", "u64", 0); addArg(T + "_temp", "i64*", 0);
         openScope("if (a." + T + "_countonly) {");

@@ -12,6 +12,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 
 step() { echo "== $*"; }
+# the commit the files were collected at goes INTO every file (HEAD_SHA from the caller: the GPU box has no .git)
+stamp_all() { [ -n "${HEAD_SHA:-}" ] && python3 "$ROOT/tools/stamp_profiles.py" "$OUT" "$R" "$HEAD_SHA"; }
 found() {   # found DIR PATTERN -> path of the first match, or empty (and a message)
     local f; f=$(find "$1" -name "$2" 2>/dev/null | head -n 1)
     if [ -z "$f" ]; then echo "   (no $2 under $1: step skipped)" >&2; fi
@@ -19,8 +21,50 @@ found() {   # found DIR PATTERN -> path of the first match, or empty (and a mess
 }
 
 # PART=a (default): bench, Q1 / Q3 / large-group kernel statistics and PMC passes; PART=b: end-to-end tables (config 5, SQL at SF1 / SF10,
-# cold compile latencies, shard tails, late-load traffic, the C-ABI path).  Each part fits one gpurun call.
+# cold compile latencies, shard tails, late-load traffic, the C-ABI path); PART=c: the join statements one by one (kernel statistics + a FETCH_SIZE
+# pass each).  Each part fits one gpurun call.  HEAD_SHA=<commit> in the environment is written into every file collected.
 PART=${PART:-a}
+if [ "$PART" = "c" ]; then
+step "the join statements at SF10, one by one: kernel statistics and one FETCH_SIZE pass each"
+for qn in q5 q10 q12 q19; do
+    rm -rf /tmp/prof_j_$qn /tmp/prof_jp_$qn
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_j_$qn -- python3 "$ROOT/tools/sql_bench.py" 10 --repeat 6 --only $qn > /tmp/j_$qn.log 2>&1
+    f=$(found /tmp/prof_j_$qn '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_${qn}_sf10_kernel_stats.csv"
+    timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_jp_$qn -- python3 "$ROOT/tools/sql_bench.py" 10 --repeat 3 --only $qn > /tmp/jp_$qn.log 2>&1
+done
+python3 - "$OUT/${R}_joins_sf10_pmc.json" <<'PY'
+import csv, glob, json, sys
+out = {"note": "FETCH_SIZE per dispatch (KB as rocprofv3 reports them; gfx950 counts 1/2 of the bytes of wide coalesced streaming reads, MI355X_MICROARCH.md): "
+               "the LARGEST dispatch of each kernel name per statement (sizing passes share a name with the build they size); average duration from the "
+               "separate --kernel-trace --stats run of the same command", "statements": {}}
+for qn in ("q5", "q10", "q12", "q19"):
+    fs = glob.glob(f"/tmp/prof_jp_{qn}/*/*counter_collection.csv"); ks = glob.glob(f"/tmp/prof_j_{qn}/*/*kernel_stats.csv")
+    e = {}
+    if fs:
+        per = {}
+        for r in csv.DictReader(open(fs[0])):
+            k = r["Kernel_Name"].split("(")[0]
+            if r["Counter_Name"] != "FETCH_SIZE" or not (k.startswith("rsq_p") or "k_rank" in k or "k_compact" in k or "k_topk" in k or "k_scan" in k): continue
+            per.setdefault(k, {}); per[k][r["Dispatch_Id"]] = per[k].get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+        for k, d in per.items(): e.setdefault(k, {})["FETCH_SIZE_KB"] = round(max(d.values()), 1)
+    if ks:
+        for r in csv.DictReader(open(ks[0])):
+            k = r["Name"].split("(")[0]
+            if k in e: e[k]["avg_us"] = round(float(r["AverageNs"]) / 1e3, 1); e[k]["calls"] = int(r["Calls"])
+    out["statements"][qn] = e
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print("   join statements:", {q: len(v) for q, v in out["statements"].items()})
+PY
+step "compile latency with the kernels compiled in process, and at SF10 with the interpreter's execution time beside the specialised one"
+RSQ_GENERIC=1 RSQ_COMPILE_HELPERS=0 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_in_process.jsonl"
+RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 10 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_sf10.jsonl"
+step "group rows of a hash aggregation: the tail on the device against the host's"
+timeout -k 10 200 python3 "$ROOT/tools/hash_tail_bench.py" > "$OUT/${R}_hash_tail_device_vs_host.txt" 2>/dev/null
+timeout -k 10 200 python3 "$ROOT/tools/hash_tail_bench.py" 100000000 262144 >> "$OUT/${R}_hash_tail_device_vs_host.txt" 2>/dev/null
+ls -la "$OUT" | tail -n 12
+stamp_all
+exit 0
+fi
 if [ "$PART" = "b" ]; then
 step "TPC-H Q3 at SF10 WITHOUT the profiler (what README / DESIGN quote)"
 timeout -k 10 200 python3 "$ROOT/tools/profile_case.py" q3 10 16 2>/dev/null | grep '^q3 ' > "$OUT/${R}_q3_sf10_runs_noprofiler.txt"
@@ -70,6 +114,7 @@ RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/de
 step "the same Q1 step through the C ABI's one-process path: 8 shards on this one GPU"
 timeout -k 10 200 python3 "$ROOT/bench.py" --path capi --capi-devices 0,0,0,0,0,0,0,0 --steps 20 2>/dev/null | grep '^{' > "$OUT/${R}_bench_capi_8shards_1gpu.json"
 ls -la "$OUT" | tail -n 20
+stamp_all
 exit 0
 fi
 
@@ -180,4 +225,5 @@ PY
 [ -f "$OUT/${R}_q1_sf10_kernel_stats.csv" ] && head -n 3 "$OUT/${R}_q1_sf10_kernel_stats.csv" | cut -c1-150
 [ -f "$OUT/${R}_q3_sf10_kernel_stats.csv" ] && head -n 5 "$OUT/${R}_q3_sf10_kernel_stats.csv" | cut -c1-150
 [ -f "$OUT/${R}_bench_n1.json" ] && cut -c1-600 "$OUT/${R}_bench_n1.json"
+stamp_all
 exit 0

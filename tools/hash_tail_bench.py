@@ -22,6 +22,10 @@ def plan_of(t):
     return p.set_root(p.materialize(p.projection([p.as_("k", key), p.as_("s", sc), p.as_("n", cnt), p.as_("lo", lo), p.as_("hi", hi), p.as_("av", av)], node)))
 
 
+print("# tools/hash_tail_bench.py on one MI355X: the tail of a hash aggregation (computed group key, 6 output columns of 8 bytes, no ORDER BY: rows in\n"
+      "# the reference's emission order), device (engine_devtail.cpp runRowsDeviceTail, devtail.hip k_row_*) against the host's worker pool.\n"
+      "# \"tail\" includes the copy of the finished tuples to the host (1 M x 48 B = 50 MB over PCIe is ~2 ms of it).\n"
+      f"{rows // 1000000} M rows, {groups} groups:", flush=True)
 ctx = engine.Context(device=0)
 t = ctx.generate(engine.GEN_SYNTHETIC, rows, 1.0, param=groups)
 import hashlib
