@@ -506,7 +506,9 @@ void buildHashTable(Query& q, Pipeline& p) {
         RSQ_HIP(hipMemcpyAsync(&n, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
         waitForStream(ctx);
-        h.rank = h.rankCapable && !(err & 64u);
+        // (a table of a few hundred rows stays a hash table: the dictionary's index and placement are two launches of 3-4 us each for
+        // entries that sit in one cache line either way - TPC-H Q5's region and nation tables)
+        h.rank = h.rankCapable && !(err & 64u) && (n > 1024 || h.setOnly);
         h.identity = h.rank && h.identityCapable && (int64_t)n == p.src->nRows && n > 0;
         if (err & 64u) { err &= ~64u; RSQ_HIP(hipMemcpy(ctx.dErr, &err, 4, hipMemcpyHostToDevice)); }
         if (h.rank && h.setOnly) {
