@@ -92,3 +92,33 @@ def test_dictionary_records_in_row_order_leave_as_whole_lines(gpu_ctx, n_payload
     node = p.aggregation(sums + [p.count(p.star())], [p.attr("g")], j)
     proj = [p.attr("g")] + [p.as_(f"s{k}", sums[k]) for k in range(n_payload)]
     _run_twice(gpu_ctx, p.set_root(p.materialize(p.projection(proj, node))))
+
+
+def test_staged_tiles_in_front_of_a_large_dense_aggregation(gpu_ctx, monkeypatch):
+    """the count / scatter kernels of a partitioned aggregation run as 1024-thread workgroups (16 waves, 16 LDS regions) from the same source:
+    6 M rows, 2^17 dense groups, a CHAR(10) equality in front; every form of the large aggregation (RSQ_PARTITION 0 / default / 2)"""
+    n, g = 6_000_000, 1 << 17
+    rng = np.random.default_rng(3)
+    s = _strings(n, 10, 9)
+    b = rng.integers(0, g, n).astype(np.int64)
+    c = rng.integers(0, 1000, n).astype(np.int64)
+    t = P.Table("t", [P.Column("s", T.CHAR(10), s), P.Column("b", T.BIGINT(), b), P.Column("c", T.BIGINT(), c)], n)
+    p = P.Plan([t])
+    node = p.selection(p.eq(p.attr("s"), p.constant("MAIL", P.VARCHAR)), p.scan("t"))
+    sm, cnt = p.sum(p.attr("c")), p.count(p.star())
+    node = p.aggregation([sm, cnt], [p.attr("b")], node)
+    plan = p.set_root(p.materialize(p.projection([p.attr("b"), p.as_("sv", sm), p.as_("cn", cnt)], node)))
+    want = orc.execute(plan)
+    for mode in (None, "0", "2"):
+        if mode is None: monkeypatch.delenv("RSQ_PARTITION", raising=False)
+        else: monkeypatch.setenv("RSQ_PARTITION", mode)
+        tabs = [gpu_ctx.table(t)]
+        q = gpu_ctx.compile(plan, tabs)
+        try:
+            q.await_kernels()
+            for _ in range(2):
+                q.execute()
+                got = q.result()
+                assert got.n_rows == want.n_rows and sorted(got.text.splitlines()) == sorted(want.text.splitlines()), mode
+        finally:
+            q.close(); tabs[0].close()
