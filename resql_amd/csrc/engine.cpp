@@ -636,6 +636,12 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     // row counters, the group counter and the candidate selection's scratch of a compaction behind the last pipeline
     bool groupCountCleared = false, topkScratchCleared = false;
     bool accumulatorsCleared = false;       // the aggregates beside a join table's entries are at their identities (AT_JOIN_ENTRY)
+    // A hash aggregation that has run before: its table is readied with everything else in the first fill (or behind the previous
+    // execution's last kernel), the group count is the remembered one, and whether the table overflowed or CHAR groups need merging
+    // is read from the FINAL status words - no synchronisation between the pipelines and the group rows.  (TPC-H Q10 at SF10: two 4-byte
+    // read-backs with a stream synchronisation each and three clearing launches, ~40 of 590 us.)  Whatever turns out different from the
+    // remembered state starts the execution over on the careful path (lastCount = 0).
+    bool hashWarm = false;
     std::vector<FillItem> f;                // (kept: an execution that ends on its candidates enqueues the same clears for the next one)
     {
         f.push_back(FillItem{ctx.dErr, 4, 0});
@@ -679,6 +685,18 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                     f.push_back(FillItem{(uint64_t*)h.dAcc + (size_t)b * (size_t)h.capacity, (size_t)h.capacity * 8, idv});
                 }
                 accumulatorsCleared = true;
+            }
+        }
+        if (!trace && !interp && q.aggMode == AggMode::HASH && !partialOnly && !async && !q.holdTail && q.aggTable >= 0) {
+            HashTable& h = *q.hashTables[(size_t)q.aggTable];
+            if (h.capacity > 0 && h.dState && h.dAcc && h.lastCount > 0 && (int64_t)h.lastCount * 2 <= h.capacity) {
+                f.push_back(FillItem{h.dState, (size_t)h.capacity * 4, 0});
+                f.push_back(FillItem{h.dCount, 4, 0});
+                for (int b = 0; b < h.nAccBlocks; b++) {
+                    const uint64_t idv = b < q.nMinBlocks ? 0x7fffffffffffffffull : b < q.nMinBlocks + q.nMaxBlocks ? 0x8000000000000000ull : 0ull;
+                    f.push_back(FillItem{(uint64_t*)h.dAcc + (size_t)b * (size_t)h.capacity, (size_t)h.capacity * 8, idv});
+                }
+                hashWarm = true;
             }
         }
         // ... unless the previous execution of this query has already enqueued exactly these clears behind its last kernel and
@@ -728,6 +746,12 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             fillBatchAsync(ctx, f.data(), (int)f.size());
         };
         if (q.aggMode == AggMode::AT_JOIN_ENTRY && !accumulatorsCleared) { resetAccumulators(*q.hashTables[(size_t)q.aggTable]); q.report.num_kernels++; }
+        if (q.aggMode == AggMode::HASH && hashWarm) {
+            launchPipeline(q, p, -1);
+            q.report.bytes_read += (uint64_t)(p.bytesPerRow * p.src->nRows);
+            tracePoint(p);
+            continue;
+        }
         if (q.aggMode == AggMode::HASH) {
             // The number of groups is not known before the scan: start from the reference's own estimate
             // (AggregationOp::getSize, aggregation.h:81-92) and re-run the pipeline with a 4x larger table while
@@ -775,11 +799,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         const int nTab = (int)(h.keys.size() + h.payload.size());
         q.groupRowWords = 1 + nTab + h.nAccBlocks;
         // Rows to provide for: the number of occupied entries.  It is read back (one synchronisation) on the first
-        // execution; later executions of a join-entry aggregation reuse it — the build reads the same table — and the
+        // execution; later executions reuse it — the build reads the same table (hash aggregation: hashWarm above) — and the
         // compaction never writes beyond the buffer: a larger count is noticed after the final synchronisation and
         // the execution is repeated with a fresh count.
         uint32_t nEntries = h.lastCount;
-        if (q.aggMode != AggMode::AT_JOIN_ENTRY || nEntries == 0 || getenv("RSQ_TRACE")) {
+        if ((q.aggMode != AggMode::AT_JOIN_ENTRY && !hashWarm) || nEntries == 0 || getenv("RSQ_TRACE")) {
             RSQ_HIP(hipMemcpyAsync(&nEntries, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
             waitForStream(ctx);
             h.lastCount = nEntries;
@@ -1002,6 +1026,19 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
         if (any) { executeQuery(q, partialOnly, async); return; }
     }
+    if (hashWarm) {
+        HashTable& h = *q.hashTables[(size_t)q.aggTable];
+        const uint32_t e = (uint32_t)q.hPinned[words];
+        if (e & 2u) {               // the table overflowed (more groups than last time): four times the slots, on the careful path
+            ctx.free(h.dState); ctx.free(h.dWords); ctx.free(h.dAcc);
+            h.dState = nullptr; h.dWords = nullptr; h.dAcc = nullptr;
+            if (h.capacity >= ((int64_t)1 << 31)) failRuntime("Hash table full");
+            h.capacity *= 4; h.lastCount = 0;
+            executeQuery(q, partialOnly, async);
+            return;
+        }
+        if (((e & 32u) != 0) != q.charGroupsNeedMerge) { h.lastCount = 0; executeQuery(q, partialOnly, async); return; }      // (the careful path reads the note before it plans the tail)
+    }
     checkDeviceError((uint32_t)q.hPinned[words]);
     // the short candidate selection overflowed its buffer (many rows share the leading bin): the exact radix select, now
     bool candOnHost = selectPublished;      // the candidates are in hCandRows (else: in hGroupRows, copied)
@@ -1071,10 +1108,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (nGroups > (int64_t)groupRowsAllocated) {
                 // more groups than the remembered entry count provided for (the build side changed under us): start over
                 q.hashTables[(size_t)q.aggTable]->lastCount = 0;
-                if (q.aggMode != AggMode::AT_JOIN_ENTRY) failRuntime("internal error: more groups than hash-table entries");
+                if (q.aggMode != AggMode::AT_JOIN_ENTRY && !hashWarm) failRuntime("internal error: more groups than hash-table entries");
                 executeQuery(q, partialOnly, async);
                 return;
             }
+            if (q.aggMode == AggMode::HASH) q.hashTables[(size_t)q.aggTable]->lastCount = (uint32_t)nGroups;      // (what the next execution provides for)
             int64_t nCand = topkCapacity ? (int64_t)(uint32_t)q.hPinned[words + 2] : 0;
             if (narrowRows && nCand > (int64_t)topkCapacity) { q.narrowRowsOff = true; executeQuery(q, partialOnly, async); return; }      // (the exact selection reads full rows)
             if (topkRange && nCand > (int64_t)topkCapacity) { nCand = exactCandidates(groupRowsAllocated); topkSpec = topkCapacity; }
