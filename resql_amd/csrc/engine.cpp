@@ -144,6 +144,7 @@ Query::~Query() {
     for (void* p : dMatCols) if (p) ctx.free(p);
     if (dGroupRows) ctx.free(dGroupRows);
     if (dNarrowRows) ctx.free(dNarrowRows);
+    if (hInlineRows) (void)hipHostFree(hInlineRows);
     if (dPipeStats) ctx.free(dPipeStats);
     if (dGroupCount) ctx.free(dGroupCount);
     if (dTopkImages) ctx.free(dTopkImages);
@@ -932,12 +933,27 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
     q.kernelTimePending = true;
     bool devTail = false;                   // the rows of a large dense aggregation are made on the device (runDenseDeviceTail)
+    bool inlineRows = false;                // up to kInlineRows group rows arrive with the status words
+    constexpr uint32_t kInlineRows = 64;
     if (!selectPublished) {
         const bool wantGroups = !partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH || denseTopk);
         if (q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0)) {
             // error word, group count, candidate count and the pipelines' row counters: one kernel writes them into the pinned words
+            if (wantGroups && !denseTopk && !topkCapacity && !q.holdTail && !trace && q.dGroupRows && q.groupRowWords > 0) {
+                const size_t need = (size_t)kInlineRows * (size_t)q.groupRowWords;
+                if (q.inlineRowsWords < need) {
+                    if (q.hInlineRows) (void)hipHostFree(q.hInlineRows);
+                    q.hInlineRows = nullptr; q.dHostInlineRows = nullptr; q.inlineRowsWords = 0;
+                    RSQ_HIP(hipHostMalloc((void**)&q.hInlineRows, need * 8, hipHostMallocDefault));
+                    void* dv = nullptr;
+                    if (hipHostGetDevicePointer(&dv, q.hInlineRows, 0) == hipSuccess && dv) { q.dHostInlineRows = (int64_t*)dv; q.inlineRowsWords = need; }
+                    else (void)hipGetLastError();
+                }
+                inlineRows = q.dHostInlineRows != nullptr;
+            }
             publishStatusAsync(ctx, q.dPinnedDev + words, ctx.dErr, wantGroups ? q.dGroupCount : nullptr, topkCapacity ? q.dCandCount : nullptr,
-                               anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size());
+                               anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size(),
+                               inlineRows ? q.dGroupRows : nullptr, q.groupRowWords, std::min<uint32_t>(kInlineRows, groupRowsAllocated), q.dHostInlineRows);
             q.report.num_kernels++;
         } else {
             RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
@@ -1141,6 +1157,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                 if (narrowRows) { q.narrowRowsOff = true; executeQuery(q, partialOnly, async); return; }      // (every row is needed: none was written)
                 q.nGroupRows = nGroups;
                 if (rowsDeviceTailWanted(q, nGroups)) runRowsDeviceTail(q, nGroups);      // many groups: the rows are made on the device
+                else if (inlineRows && nGroups <= (int64_t)std::min<uint32_t>(kInlineRows, groupRowsAllocated)) {      // (the rows came with the status words)
+                    q.hRowsView = q.hInlineRows;
+                    tailUnlessHeld(q);
+                    q.hRowsView = nullptr;
+                }
                 else {
                     if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * rowBytes, hipMemcpyDeviceToHost));
                     tailUnlessHeld(q);

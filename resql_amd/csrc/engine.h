@@ -147,8 +147,11 @@ void fillU64Async(Context& ctx, uint64_t* dptr, size_t n, uint64_t value);
 struct FillItem { void* p; size_t bytes; uint64_t value; };
 // the words an execution's host side reads first, written into host-mapped pinned memory by one kernel: [0] error word, [1] group count,
 // [2] candidate count, [8 + i] row counter of pipeline i (null sources are skipped)
+// ... and, when `rows` is given and the group count is at most maxInline, the first group-count rows of `rowWords` words into hostRows
+// (host-mapped too): a handful of group rows travel with the status words
 void publishStatusAsync(Context& ctx, uint64_t* hostWords, const uint32_t* err, const uint32_t* groupCount, const uint32_t* candCount,
-                        const uint64_t* pipeStats, int nPipelines);
+                        const uint64_t* pipeStats, int nPipelines, const int64_t* rows = nullptr, int rowWords = 0, uint32_t maxInline = 0,
+                        int64_t* hostRows = nullptr);
 void fillBatchAsync(Context& ctx, const FillItem* items, int count);
 // bitmap-rank dictionary (aot_kernels.hip): the rank words of a bitmap laid out in nBlocks 32-byte blocks [rank | 224 bits]
 // (chunkTotal / chunkBase[ceil(nBlocks / RSQ_RANK_CHUNK_BLOCKS) (+ 1)] are scratch), and the placement of appended build records at the rank of

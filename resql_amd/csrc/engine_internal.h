@@ -386,6 +386,9 @@ struct Query {
     uint64_t readiedEpoch = 0;
     std::vector<FillItem> readiedFill;
     bool scanChainedOff = false;         // a look-back of the one-launch offset scan timed out once: three launches from now on
+    int64_t* hInlineRows = nullptr;      // a handful of group rows delivered with the status words (publishStatusAsync): host-mapped, and the device's view
+    int64_t* dHostInlineRows = nullptr;
+    size_t inlineRowsWords = 0;
     int64_t* dNarrowRows = nullptr;      // group rows as [slot | sort key] for the candidate selection over wide rows (executeQuery)
     uint32_t narrowRowsCap = 0;
     bool narrowRowsOff = false;          // an execution needed every group row after all: full rows from now on
