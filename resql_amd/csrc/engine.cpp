@@ -141,7 +141,7 @@ Query::~Query() {
     if (dMatOffs) ctx.free(dMatOffs);
     if (dMatTileCnt) ctx.free(dMatTileCnt);
     if (dScanTemp) ctx.free(dScanTemp);
-    for (void* p : dMatCols) if (p) ctx.free(p);
+    freeMatCols(*this);
     if (dGroupRows) ctx.free(dGroupRows);
     if (dNarrowRows) ctx.free(dNarrowRows);
     if (hInlineRows) (void)hipHostFree(hInlineRows);
@@ -1116,7 +1116,8 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             for (size_t c = 0; c < q.matSchema.size(); c++) {
                 size_t bytes = (size_t)q.matRows * (size_t)columnWidth(q.matSchema[c].type);
                 q.hMatCols[c].resize(bytes);
-                if (bytes) RSQ_HIP(hipMemcpy(q.hMatCols[c].data(), q.dMatCols[c], bytes, hipMemcpyDeviceToHost));
+                if (bytes && c < q.hMatMapped.size() && q.hMatMapped[c]) memcpy(q.hMatCols[c].data(), q.hMatMapped[c], bytes);      // (written by the device, complete with the stream)
+                else if (bytes) RSQ_HIP(hipMemcpy(q.hMatCols[c].data(), q.dMatCols[c], bytes, hipMemcpyDeviceToHost));
             }
         } else {
             const int64_t nGroups = (int64_t)(uint32_t)q.hPinned[words + 1];

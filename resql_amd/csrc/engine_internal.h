@@ -304,6 +304,7 @@ struct Query {
     void* dScanTemp = nullptr; size_t scanTempBytes = 0;
     int64_t matSlots = 0;
     std::vector<void*> dMatCols;           // output columns (struct of arrays)
+    std::vector<void*> hMatMapped;         // ... a small result's columns are host-mapped pinned memory (the write pass stores over PCIe; these are the host's pointers): no copy after the final wait
     int64_t matCapacity = 0;               // rows the output columns can hold
     uint64_t matLimit = 0;                 // rows pass 2 may write
     int64_t matRows = 0;
@@ -450,6 +451,8 @@ void planDeviceTopK(Query& q);
 // ---- engine_pipelines.cpp: one pipeline on the device, by sink (called from executeQuery) --------------------------------------
 inline int64_t nextPow2(int64_t v) { int64_t p = 1; while (p < v) p <<= 1; return p; }
 bool denseMode(const Query& q);
+void allocMatCols(Query& q, int64_t capacity);
+void freeMatCols(Query& q);
 uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTable);
 int residentWorkgroupsPerCU(Kernel* k, int blockThreads);
 unsigned pipelineGrid(const Query& q, const Pipeline& p, bool lazyForm = false);

@@ -418,6 +418,34 @@ void runLargeDenseAggregation(Query& q, Pipeline& p) {
 }
 
 // count / scan / write (see consumeMaterialize in codegen.cpp)
+// Output columns of a materialisation.  A result of up to 256 KB lives in host-mapped pinned memory: the write pass stores its few rows over
+// PCIe and the host has them when the stream reports completion (TPC-H Q19: 1107 rows; the blocking copy afterwards cost ~15 us).
+void freeMatCols(Query& q) {
+    for (size_t c = 0; c < q.dMatCols.size(); c++) {
+        if (c < q.hMatMapped.size() && q.hMatMapped[c]) (void)hipHostFree(q.hMatMapped[c]);
+        else if (q.dMatCols[c]) q.ctx.free(q.dMatCols[c]);
+    }
+    q.dMatCols.clear(); q.hMatMapped.clear();
+}
+void allocMatCols(Query& q, int64_t capacity) {
+    freeMatCols(q);
+    q.matCapacity = capacity;
+    size_t total = 0;
+    for (auto& a : q.matSchema) total += (size_t)capacity * (size_t)columnWidth(a.type);
+    bool mapped = total <= (256u << 10) && q.ctx.device >= 0;
+    for (auto& a : q.matSchema) {
+        const size_t bytes = std::max<size_t>(8, (size_t)capacity * (size_t)columnWidth(a.type));
+        void* h = nullptr; void* d = nullptr;
+        if (mapped && (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d)) {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+            h = nullptr; mapped = false;            // (this column and the ones behind it: device memory)
+        }
+        if (h) { q.dMatCols.push_back(d); q.hMatMapped.push_back(h); }
+        else { q.dMatCols.push_back(q.ctx.alloc(bytes)); q.hMatMapped.push_back(nullptr); }
+    }
+}
+
 void materializePipeline(Query& q, Pipeline& p) {
     Context& ctx = q.ctx;
     const int64_t n = p.src->nRows;
@@ -467,10 +495,7 @@ void materializePipeline(Query& q, Pipeline& p) {
     if (q.matOp->hasLimit) keep = std::min<uint64_t>(total, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));
     q.matRows = (int64_t)keep;
     if ((int64_t)keep > q.matCapacity || q.dMatCols.empty()) {
-        for (void* c : q.dMatCols) if (c) ctx.free(c);
-        q.dMatCols.clear();
-        q.matCapacity = std::max<int64_t>((int64_t)keep, 1);
-        for (auto& a : q.matSchema) q.dMatCols.push_back(ctx.alloc((size_t)q.matCapacity * (size_t)columnWidth(a.type)));
+        allocMatCols(q, std::max<int64_t>((int64_t)keep, 1));
     }
     q.matLimit = keep;
     launchPipeline(q, p, -1, false);
@@ -742,10 +767,7 @@ void runGeneric2Pipeline(Query& q, size_t pi) {
             if (q.matOp->hasLimit) keep = std::min<uint64_t>(total, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));      // materialize.h:197-206
             q.matRows = (int64_t)keep;
             if ((int64_t)keep > q.matCapacity || q.dMatCols.empty()) {
-                for (void* c : q.dMatCols) if (c) ctx.free(c);
-                q.dMatCols.clear();
-                q.matCapacity = std::max<int64_t>((int64_t)keep, 1);
-                for (auto& a : q.matSchema) q.dMatCols.push_back(ctx.alloc((size_t)q.matCapacity * (size_t)columnWidth(a.type)));
+                allocMatCols(q, std::max<int64_t>((int64_t)keep, 1));
             }
             q.matLimit = keep;
             generic2Launch(q, pi, 2);
