@@ -930,7 +930,10 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             denseTopk = true;
         }
     }
-    RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
+    // The execution's end event.  Where a status kernel follows, the event stands BEHIND it: an event between two kernels is a barrier
+    // packet of its own and kept the status kernel waiting ~6 us (per-dispatch trace); behind the last kernel it delays nobody.
+    const bool statusKernelFollows = !selectPublished && q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0);
+    if (!statusKernelFollows) RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
     q.kernelTimePending = true;
     bool devTail = false;                   // the rows of a large dense aggregation are made on the device (runDenseDeviceTail)
     bool inlineRows = false;                // up to kInlineRows group rows arrive with the status words
@@ -953,7 +956,9 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             }
             publishStatusAsync(ctx, q.dPinnedDev + words, ctx.dErr, wantGroups ? q.dGroupCount : nullptr, topkCapacity ? q.dCandCount : nullptr,
                                anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size(),
-                               inlineRows ? q.dGroupRows : nullptr, q.groupRowWords, std::min<uint32_t>(kInlineRows, groupRowsAllocated), q.dHostInlineRows);
+                               inlineRows ? q.dGroupRows : nullptr, q.groupRowWords, std::min<uint32_t>(kInlineRows, groupRowsAllocated), q.dHostInlineRows,
+                               q.matWarmRun ? q.dMatTotal : nullptr);
+            RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
             q.report.num_kernels++;
         } else {
             RSQ_HIP(hipMemcpyAsync(q.hPinned + words, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
@@ -1041,6 +1046,10 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             h.rank = false; h.rankCapable = false; h.identity = false; h.capacity = 0; h.lastCount = 0;
         }
         if (any) { executeQuery(q, partialOnly, async); return; }
+    }
+    if (q.matWarmRun) {             // the write pass ran with the remembered total: it must be this execution's
+        q.matWarmRun = false;
+        if ((int64_t)q.hPinned[words + 3] != q.matLastTotal) { q.matLastTotal = -1; executeQuery(q, partialOnly, async); return; }
     }
     if (hashWarm) {
         HashTable& h = *q.hashTables[(size_t)q.aggTable];

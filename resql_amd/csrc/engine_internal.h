@@ -308,6 +308,9 @@ struct Query {
     int64_t matCapacity = 0;               // rows the output columns can hold
     uint64_t matLimit = 0;                 // rows pass 2 may write
     int64_t matRows = 0;
+    int64_t matLastTotal = -1;             // rows the previous execution's count pass found (-1: unknown): a warm execution runs its write pass without
+    bool matWarmRun = false;               // waiting for the total; the total then arrives with the status words and must equal the remembered one
+    const uint64_t* dMatTotal = nullptr;   // (where it stands: the last offset of the scan)
     std::vector<std::vector<uint8_t>> hMatCols;
 
     // compacted group rows read back from a join-entry aggregation: [nGroups][groupWords]

@@ -476,6 +476,23 @@ void materializePipeline(Query& q, Pipeline& p) {
     if (chained) exclusiveScanCountsChained(ctx, q.dMatTileCnt, q.dMatOffs, tiles + 1, q.dScanTemp, q.scanTempBytes);
     else exclusiveScanCounts(ctx, q.dMatTileCnt, q.dMatOffs, tiles + 1, q.dScanTemp, q.scanTempBytes);
     q.report.num_kernels++;
+    // A materialisation that has run before does not wait for the total: the write pass runs with the remembered one, the total arrives
+    // with the status words (publishStatusAsync word 3) and executeQuery starts over on this careful path if it differs.
+    q.dMatTotal = q.dMatOffs + tiles;
+    q.matWarmRun = false;
+    {
+        const bool publish = q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0);
+        uint64_t keepWarm = (uint64_t)std::max<int64_t>(q.matLastTotal, 0);
+        if (q.matOp->hasLimit) keepWarm = std::min<uint64_t>(keepWarm, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));
+        if (q.matLastTotal >= 0 && publish && !chained && !getenv("RSQ_TRACE") && !q.holdTail && !q.dMatCols.empty() && (int64_t)keepWarm <= q.matCapacity) {
+            q.matRows = (int64_t)keepWarm;
+            q.matLimit = keepWarm;
+            q.matWarmRun = true;
+            launchPipeline(q, p, -1, false);
+            q.report.bytes_read += p.matSkip ? (uint64_t)(p.bytesPerRow * p.src->nRows) + (uint64_t)tiles * 4 : 2 * (uint64_t)(p.bytesPerRow * p.src->nRows);
+            return;
+        }
+    }
     uint64_t total = 0;
     uint32_t scanErr = 0;
     RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + tiles, 8, hipMemcpyDeviceToHost, ctx.stream));
@@ -490,6 +507,7 @@ void materializePipeline(Query& q, Pipeline& p) {
         RSQ_HIP(hipMemcpyAsync(&total, q.dMatOffs + tiles, 8, hipMemcpyDeviceToHost, ctx.stream));
         waitForStream(ctx);
     }
+    q.matLastTotal = (int64_t)total;
     // MaterializeOp with a LIMIT leaves the pipeline once count >= limit, i.e. after max(limit, 1) tuples (materialize.h:197-206)
     uint64_t keep = total;
     if (q.matOp->hasLimit) keep = std::min<uint64_t>(total, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));
