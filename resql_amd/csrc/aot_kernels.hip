@@ -342,9 +342,11 @@ void fillBatchAsync(Context& ctx, const FillItem* items, int count) {
 
 __global__ void k_publish_status(u64* __restrict__ host, const unsigned* __restrict__ err, const unsigned* __restrict__ groupCount,
                                  const unsigned* __restrict__ candCount, const u64* __restrict__ pipeStats, int nPipelines,
-                                 const i64* __restrict__ rows, int rowWords, unsigned maxInline, i64* __restrict__ hostRows, const u64* __restrict__ word3) {
+                                 const i64* __restrict__ rows, int rowWords, unsigned maxInline, i64* __restrict__ hostRows, const u64* __restrict__ word3,
+                                 const u64* __restrict__ copySrc, u64* __restrict__ copyDst, unsigned copyWords) {
     const int t = threadIdx.x;
     if (t == 3 && word3) host[3] = *word3;
+    for (unsigned i = (unsigned)t; i < copyWords; i += blockDim.x) copyDst[i] = copySrc[i];      // (a small dense aggregate table: no read-back copy of its own)
     // a handful of group rows travel with the status words (TPC-H Q5: five, Q12: two): the host then has them when the stream reports
     // completion, instead of asking for them with a blocking copy afterwards (a blit kernel and another round trip, ~20 us)
     if (rows && groupCount) {
@@ -357,10 +359,11 @@ __global__ void k_publish_status(u64* __restrict__ host, const unsigned* __restr
     if (pipeStats && t >= 8 && t < 8 + nPipelines) host[t] = pipeStats[t - 8];
 }
 void publishStatusAsync(Context& ctx, uint64_t* hostWords, const uint32_t* err, const uint32_t* groupCount, const uint32_t* candCount,
-                        const uint64_t* pipeStats, int nPipelines, const int64_t* rows, int rowWords, uint32_t maxInline, int64_t* hostRows, const uint64_t* word3) {
+                        const uint64_t* pipeStats, int nPipelines, const int64_t* rows, int rowWords, uint32_t maxInline, int64_t* hostRows, const uint64_t* word3,
+                        const uint64_t* copySrc, uint64_t* copyDst, uint32_t copyWords) {
     if (nPipelines > 56) throw Error(RSQ_ERR_UNSUPPORTED, "more than 56 pipelines in one query");
     hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(64), 0, ctx.stream, (u64*)hostWords, (const unsigned*)err, (const unsigned*)groupCount,
-                       (const unsigned*)candCount, (const u64*)pipeStats, nPipelines, (const i64*)rows, rowWords, (unsigned)maxInline, (i64*)hostRows, (const u64*)word3);
+                       (const unsigned*)candCount, (const u64*)pipeStats, nPipelines, (const i64*)rows, rowWords, (unsigned)maxInline, (i64*)hostRows, (const u64*)word3, (const u64*)copySrc, (u64*)copyDst, (unsigned)copyWords);
     RSQ_HIP(hipGetLastError());
 }
 

@@ -938,8 +938,12 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     bool devTail = false;                   // the rows of a large dense aggregation are made on the device (runDenseDeviceTail)
     bool inlineRows = false;                // up to kInlineRows group rows arrive with the status words
     constexpr uint32_t kInlineRows = 64;
+    // a small dense aggregate table (TPC-H Q14: one group behind a join) travels with the status words instead of a copy of its own
+    const size_t tableInlineWords = q.aggPad > 1 && !q.flatRun ? (size_t)q.padWords : (size_t)q.tableWords;
+    bool tableInline = false;
     if (!selectPublished) {
         const bool wantGroups = !partialOnly && (q.aggMode == AggMode::AT_JOIN_ENTRY || q.aggMode == AggMode::HASH || denseTopk);
+        tableInline = statusKernelFollows && !partialOnly && denseMode(q) && !denseTopk && !trace && tableInlineWords > 0 && tableInlineWords <= 1024 && !(!async && denseDeviceTailWanted(q));
         if (q.dPinnedDev && !(getenv("RSQ_PUBLISH_STATUS") && atoi(getenv("RSQ_PUBLISH_STATUS")) == 0)) {
             // error word, group count, candidate count and the pipelines' row counters: one kernel writes them into the pinned words
             if (wantGroups && !denseTopk && !topkCapacity && !q.holdTail && !trace && q.dGroupRows && q.groupRowWords > 0) {
@@ -957,7 +961,8 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             publishStatusAsync(ctx, q.dPinnedDev + words, ctx.dErr, wantGroups ? q.dGroupCount : nullptr, topkCapacity ? q.dCandCount : nullptr,
                                anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size(),
                                inlineRows ? q.dGroupRows : nullptr, q.groupRowWords, std::min<uint32_t>(kInlineRows, groupRowsAllocated), q.dHostInlineRows,
-                               q.matWarmRun ? q.dMatTotal : nullptr);
+                               q.matWarmRun ? q.dMatTotal : nullptr,
+                               tableInline ? (const uint64_t*)(q.aggPad > 1 && !q.flatRun ? q.dAggWork : q.dAgg) : nullptr, q.dPinnedDev, tableInline ? (uint32_t)tableInlineWords : 0u);
             RSQ_HIP(hipEventRecord(q.gev1, ctx.stream));
             q.report.num_kernels++;
         } else {
@@ -967,7 +972,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (topkCapacity) RSQ_HIP(hipMemcpyAsync(q.hPinned + words + 2, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         }
         devTail = !partialOnly && !async && denseMode(q) && !denseTopk && denseDeviceTailWanted(q);
-        if (!partialOnly && denseMode(q) && !denseTopk && !devTail) enqueueTableReadback(q);
+        if (!partialOnly && denseMode(q) && !denseTopk && !devTail && !tableInline) enqueueTableReadback(q);
         if (topkCapacity) RSQ_HIP(hipMemcpyAsync(q.hGroupRows, q.dCandRows, (size_t)topkSpec * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost, ctx.stream));
     }
     if (async && partialOnly) {

@@ -152,7 +152,8 @@ struct FillItem { void* p; size_t bytes; uint64_t value; };
 void publishStatusAsync(Context& ctx, uint64_t* hostWords, const uint32_t* err, const uint32_t* groupCount, const uint32_t* candCount,
                         const uint64_t* pipeStats, int nPipelines, const int64_t* rows = nullptr, int rowWords = 0, uint32_t maxInline = 0,
                         int64_t* hostRows = nullptr,
-                        const uint64_t* word3 = nullptr);      // ... and *word3 into word [3] (a warm materialisation's row total)
+                        const uint64_t* word3 = nullptr,       // ... and *word3 into word [3] (a warm materialisation's row total)
+                        const uint64_t* copySrc = nullptr, uint64_t* copyDst = nullptr, uint32_t copyWords = 0);      // ... and copyWords words besides (a small dense table)
 void fillBatchAsync(Context& ctx, const FillItem* items, int count);
 // bitmap-rank dictionary (aot_kernels.hip): the rank words of a bitmap laid out in nBlocks 32-byte blocks [rank | 224 bits]
 // (chunkTotal / chunkBase[ceil(nBlocks / RSQ_RANK_CHUNK_BLOCKS) (+ 1)] are scratch), and the placement of appended build records at the rank of
