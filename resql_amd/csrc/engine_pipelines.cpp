@@ -76,6 +76,10 @@ int residentWorkgroupsPerCU(Kernel* k, int blockThreads) {
     if (it != k->residentPerCU.end()) return it->second;
     int n = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, k->fn, blockThreads, 0) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 1 << 20; }
+    // ... and never more than 24 waves per CU: that is what the boxes of this pool hold of these kernels whatever the query above says
+    // (workgroup timestamps, RSQ_DEBUG_TAIL=1: of 1 792 256-thread workgroups - 7 per CU, 32-36 VGPRs, 9-17 KB of LDS - 1 536 start at once
+    // and 256 when the first ones leave; TPC-H Q12's orders build then ends at 70 us with its median workgroup done at 41).
+    n = std::min(n, std::max(1, 1536 / std::max(64, blockThreads)));
     k->residentPerCU[blockThreads] = n;
     return n;
 }
