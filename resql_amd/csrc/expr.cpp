@@ -442,6 +442,9 @@ struct Deriver {
                 break;
             case UNARY: {
                 Expr* child = e->child;
+                // (a node that lost an operand: the SQL planner shares ONE node between identical expressions - as the reference's does, which
+                // dies on such statements, e.g. two equal aggregates over the group column - and linking it below a second parent cut its chain)
+                if (!child) failType(std::string("malformed expression: ") + exprTagNames[e->tag] + " without its operand (one expression node used in two places)");
                 derive(child);
                 switch (e->tag) {
                     case RSQ_E_TYPECAST: break;
@@ -456,6 +459,7 @@ struct Deriver {
                 break;
             }
             case BINARY: {
+                if (!e->child || !e->child->next) failType(std::string("malformed expression: ") + exprTagNames[e->tag] + " without both operands (one expression node used in two places)");
                 Expr* left = e->child; Expr* right = e->child->next;
                 derive(left); derive(right);
                 switch (e->tag) {
