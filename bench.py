@@ -65,7 +65,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec); ~6.3 TB/s achievable
-PMC_PROFILES = ("profiles/r04_q1_sf10_pmc.json", "profiles/r03_q1_sf10_pmc.json", "profiles/r02_q1_sf10_pmc.json", "profiles/r01_q1_sf10_pmc.json")
+PMC_PROFILES = ("profiles/r05_q1_sf10_pmc.json", "profiles/r04_q1_sf10_pmc.json", "profiles/r03_q1_sf10_pmc.json", "profiles/r02_q1_sf10_pmc.json",
+                "profiles/r01_q1_sf10_pmc.json")
+TRAFFIC_PLAUSIBLE = (0.98, 1.5)      # counter bytes / algorithmic bytes of a full scan: below 0.98 the pass did not measure this kernel
 INIT_TIMEOUT_S = 120        # rendezvous of the ranks (a rank that never arrives must not hold the others for minutes)
 
 
@@ -202,16 +204,31 @@ def cpu_baseline(sample_sf: float, device_table=None, repeat: int = 3):
 def committed_traffic(bytes_per_launch: int):
     """HBM bytes per launch of the Q1 kernel from the rocprofv3 --pmc pass committed under profiles/ (FETCH_SIZE,
     collected in its own run and corrected as MI355X_MICROARCH.md prescribes for gfx950) — only for the configuration
-    it was measured on.  Returns (traffic, source)."""
+    it was measured on, and only if the figure can be one: a full scan cannot fetch less than its algorithmic bytes
+    (round 4's file averaged SF1 and SF10 dispatches of the same kernel name and said 0.22 x).  Returns (traffic, source);
+    a file that is refused is named in the source with the reason, and the next older one is tried."""
+    refused = []
     for rel in PMC_PROFILES:
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 pmc = json.load(f)
-            if pmc.get("algorithmic_bytes_per_launch") == bytes_per_launch:
-                return pmc["hbm_read_bytes_per_launch_corrected"], f"{rel} (committed rocprofv3 --pmc FETCH_SIZE pass; not measured by this run)"
         except Exception:
             continue
-    return None, None
+        if pmc.get("algorithmic_bytes_per_launch") != bytes_per_launch:
+            continue
+        if pmc.get("invalid"):
+            refused.append(f"{rel}: {pmc['invalid']}")
+            continue
+        got = pmc.get("hbm_read_bytes_per_launch_corrected")
+        ratio = (got / bytes_per_launch) if got else 0.0
+        if not (TRAFFIC_PLAUSIBLE[0] <= ratio <= TRAFFIC_PLAUSIBLE[1]):
+            refused.append(f"{rel}: {ratio:.3f} x the algorithmic bytes over {pmc.get('launches')} launches is not a measurement of this kernel")
+            continue
+        src = f"{rel} (committed rocprofv3 --pmc FETCH_SIZE pass over {pmc.get('launches')} launches; not measured by this run)"
+        if refused:
+            src += "; refused: " + "; ".join(refused)
+        return got, src
+    return None, ("refused: " + "; ".join(refused)) if refused else None
 
 
 def golden_answer(sf: float):

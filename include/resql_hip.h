@@ -66,7 +66,24 @@ typedef struct rsq_config {
     const char* kernel_cache_dir;/* directory with pre-built code objects (NULL: <library dir>/../_kcache) */
     int32_t emission_order;      /* rsq_emission_order: order of an aggregation's rows when the plan does not sort them */
     uint32_t compat_flags;       /* rsq_compat bits: where "as the reference's source says" and "as its JIT executes" differ */
+    uint32_t engine_flags;       /* rsq_engine_flags bits (0: the defaults) */
+    uint32_t reserved0;
+    int64_t  arena_reserve_bytes;/* device memory the context takes from the driver when it is created, for the tables and buffers of its
+                                  * queries (0: 2 GiB, and 40 MiB of pinned host memory; < 0: nothing up front - slabs are taken when first needed) */
+    int64_t  arena_keep_bytes;   /* free arena memory the context keeps between queries before slabs go back to the driver (0: 1/8 of the
+                                  * device's memory) */
 } rsq_config;
+
+/* A ReSQL host compiles a statement, executes it ONCE and deletes the plan (reference src/execute.h:213-247).  Two things make that one
+ * execution cost what a repeated one costs, both owned by the context and both on by default:
+ *   - memory arenas: join / aggregation tables, group rows and pinned read-back buffers of a query are ranges of slabs the context took
+ *     from the driver once (hipMalloc / hipFree / hipHostMalloc cost more than a whole TPC-H Q3 at SF10).  RSQ_ENGINE_DRIVER_ALLOC takes
+ *     every buffer from the driver instead;
+ *   - the plan memo: what an execution learns about a plan over a table version - build cardinalities, whether build keys are unique
+ *     (rank dictionary or hash form), group counts, region layouts of a staged aggregation, result sizes, which kernel form ran - is
+ *     kept by (kernel texts, table ids + versions) and a later query of the same shape starts with it; everything in it is re-checked by
+ *     the execution (a stale entry costs a repeated execution, never a wrong answer).  RSQ_ENGINE_NO_PLAN_MEMO starts every query cold. */
+enum rsq_engine_flags { RSQ_ENGINE_DRIVER_ALLOC = 1u, RSQ_ENGINE_NO_PLAN_MEMO = 2u };
 
 /* Semantics switches.  The default (0) computes what the reference's SOURCE specifies; a bit selects what its asmjit back end
  * actually executes where the two differ, for a drop-in host that must return the JIT's own answers:
@@ -105,18 +122,44 @@ int  rsq_ctx_create(const rsq_config* cfg, rsq_ctx** out);
 void rsq_ctx_destroy(rsq_ctx* ctx);
 /* Message of the last failing call on this context (or of rsq_ctx_create when ctx == NULL). */
 const char* rsq_last_error(const rsq_ctx* ctx);
+/* What the context holds (its arenas, see rsq_engine_flags) and how often it went to the driver: a host that runs statement after
+ * statement sees driver calls stop growing once the slabs cover its working set.  struct_size = sizeof(rsq_memory_stats), as in rsq_config. */
+typedef struct rsq_memory_stats {
+    uint32_t struct_size;
+    uint32_t reserved0;
+    uint64_t device_slab_bytes;      /* device memory held by the arena */
+    uint64_t device_used_bytes;      /* ... of it handed out to live queries */
+    uint64_t device_slab_allocs;     /* hipMalloc calls made for slabs since the context was created */
+    uint64_t pinned_slab_bytes;      /* pinned host memory held (coherent + non-coherent arenas) */
+    uint64_t pinned_used_bytes;
+    uint64_t pinned_slab_allocs;     /* hipHostMalloc calls made for slabs */
+    uint64_t raw_driver_calls;       /* hipMalloc / hipFree calls outside the arenas (table columns; every buffer with RSQ_ENGINE_DRIVER_ALLOC) */
+    uint64_t arena_requests;         /* buffers handed out by the arenas */
+    double   driver_ms;              /* host time spent inside those driver calls */
+    uint64_t plan_memo_entries;      /* plans the context remembers */
+    uint64_t plan_memo_hits;         /* queries that were compiled with a remembered entry */
+} rsq_memory_stats;
+int  rsq_ctx_memory_stats(const rsq_ctx* ctx, rsq_memory_stats* out);
 
 /* ---- tables ------------------------------------------------------------------------------ */
 /* Copy host columns to the device (H2D is outside every timed region). Column statistics the
  * planner uses (row count as Relation::tupleNum(), min/max, byte-value sets) are gathered here. */
 int  rsq_table_create(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out);
 /* Adopt columns that already live in this GPU's memory (e.g. torch tensors): `data` pointers are
- * device pointers, not copied, and must outlive the table.  Their CONTENT must not change while the table exists: the
- * column statistics gathered here (min / max, byte-value sets) shape the kernels compiled against the table (dense group
- * ids, key bitmaps).  Kernels range-check what they derive from the statistics — a value outside them makes the
- * execution fail with RSQ_ERR_RUNTIME instead of touching memory it should not — but an in-range change goes unnoticed
- * where a byte-set or a uniqueness assumption was baked in: create a new table after changing the data. */
+ * device pointers, not copied, and must outlive the table.  The column statistics gathered here (min / max, byte-value sets,
+ * whether a column ascends) shape the kernels compiled against the table (dense group ids, key bitmaps, rank dictionaries), so
+ * the CONTENT of adopted columns should not change while queries compiled over the table are in use.  If it does, nothing is
+ * answered wrongly in silence: kernels over adopted columns check every value they derive from the statistics - a key outside
+ * [min, max], a CHAR(1) / BOOL value that is not in the byte-value set (also one INSIDE the range: 'B' where the set was
+ * {A, N, R}), two build rows with one key where the keys were unique - and the execution fails with RSQ_ERR_RUNTIME ("column
+ * statistics"), or falls back to the general form of the table, instead of touching memory it should not or counting a row into a
+ * neighbouring group.  (Columns the engine owns - uploaded, generated, loaded from '.tbl' - cannot change and skip those checks.)
+ * After changing adopted data call rsq_table_refresh_stats and compile the statements anew. */
 int  rsq_table_create_device(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out);
+/* Gather the column statistics of `t` again (adopted columns whose content the host changed in place; the reference has no
+ * counterpart - its operators take whatever values arrive, operators/aggregation.h:240-295).  Queries compiled BEFORE the call keep the
+ * statistics they were compiled with (and their checks); compile the statement again to plan with the new ones. */
+int  rsq_table_refresh_stats(rsq_table* t);
 /* Transpose a ReSQL row store (reference src/dbdata.h: DataBlocks of packed tuples, strings by
  * value) into device columns: the bridge for a host that keeps ReSQL's own Relation objects. */
 int  rsq_table_from_rowstore(rsq_ctx* ctx, const rsq_table_desc* schema /* data pointers ignored */,
@@ -311,10 +354,13 @@ void rsq_db_destroy(rsq_db* db);
  * the root and reduce them with the engine's merge kernel. */
 enum rsq_merge_mode { RSQ_MERGE_AUTO = 0, RSQ_MERGE_RCCL = 1, RSQ_MERGE_PEER_COPY = 2 };
 typedef struct rsq_multi_config {
-    rsq_config base;            /* per-GPU context settings; base.device is ignored */
-    const int32_t* devices;     /* HIP device ordinals, one shard each; devices[0] is the root */
+    uint32_t struct_size;       /* sizeof(rsq_multi_config) of the header the host was compiled against (as rsq_config.struct_size) */
     int32_t n_devices;
+    const rsq_config* base;     /* per-GPU context settings (NULL: the defaults); base->device is ignored.  A pointer, not a member: rsq_config
+                                 * grows behind its own struct_size without moving the fields of this struct */
+    const int32_t* devices;     /* HIP device ordinals, one shard each; devices[0] is the root */
     int32_t merge;              /* rsq_merge_mode; AUTO = RCCL when the devices are distinct */
+    int32_t reserved0;
 } rsq_multi_config;
 typedef struct rsq_multi rsq_multi;
 typedef struct rsq_multi_query rsq_multi_query;

@@ -85,6 +85,7 @@ void computeColumnStats(Context& ctx, Table& t) {
     unsigned* dset = (unsigned*)ctx.alloc(8 * sizeof(unsigned));
     const unsigned grid = 1024;
     for (auto& c : t.cols) {
+        c.stats = ColumnStats();                // (a table that grew or was refreshed: nothing of the old statistics stays)
         if (!c.dptr) continue;
         if (c.type.tag == RSQ_BOOL || (c.type.tag == RSQ_CHAR && c.type.len == 1)) {
             RSQ_HIP(hipMemsetAsync(dset, 0, 32, ctx.stream));
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(256) k_gen_synth(i64* a, i64* b, i64* c, i64* 
 
 static void addCol(Context& ctx, Table& t, const char* name, Type type, bool withData) {
     TableColumn c; c.name = name; c.type = type;
-    if (withData) { c.dptr = ctx.alloc((size_t)t.nRows * (size_t)columnWidth(type)); c.owned = true; }
+    if (withData) { c.dptr = ctx.allocRaw((size_t)t.nRows * (size_t)columnWidth(type)); c.owned = true; }
     t.cols.push_back(c);
 }
 static void* colPtr(Table& t, const char* n) { int i = t.findCol(n); return i < 0 ? nullptr : t.cols[i].dptr; }
@@ -1729,7 +1730,7 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters) {
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "bandwidth probe needs a device context");
     RSQ_HIP(hipSetDevice(ctx.device));
     bytes &= ~(size_t)1023;
-    void* buf = ctx.alloc(bytes);
+    void* buf = ctx.allocRaw(bytes);      // (gigabytes, once: not through the arena)
     u64* out = (u64*)ctx.alloc(8);
     RSQ_HIP(hipMemsetAsync(buf, 1, bytes, ctx.stream));
     RSQ_HIP(hipMemsetAsync(out, 0, 8, ctx.stream));
@@ -1741,7 +1742,7 @@ double measureReadBandwidth(Context& ctx, size_t bytes, int iters) {
     RSQ_HIP(hipEventRecord(ctx.ev1, ctx.stream));
     RSQ_HIP(hipEventSynchronize(ctx.ev1));
     float ms = 0; RSQ_HIP(hipEventElapsedTime(&ms, ctx.ev0, ctx.ev1));
-    ctx.free(buf); ctx.free(out);
+    ctx.freeRaw(buf); ctx.free(out);
     return (double)bytes * iters / (ms * 1e-3) / 1e9;
 }
 

@@ -43,7 +43,7 @@ Table* makeTable(Context& ctx, const rsq_table_desc& d, bool adopt) {
         if (c.data) {
             if (adopt) { tc.dptr = const_cast<void*>(c.data); tc.owned = false; }
             else if (ctx.device >= 0) {
-                tc.dptr = ctx.alloc(bytes); tc.owned = true;
+                tc.dptr = ctx.allocRaw(bytes); tc.owned = true;
                 if (bytes) RSQ_HIP(hipMemcpy(tc.dptr, c.data, bytes, hipMemcpyHostToDevice));
             } else {   // compile-only context: keep a host copy for the statistics
                 tc.dptr = malloc(bytes ? bytes : 1); tc.owned = true;
@@ -71,6 +71,7 @@ rsq_config readConfig(const rsq_config* cfg) {
     c.struct_size = (uint32_t)sizeof(rsq_config);
     if (c.emission_order != RSQ_EMIT_REFERENCE && c.emission_order != RSQ_EMIT_ANY) failInvalid("rsq_config.emission_order must be RSQ_EMIT_REFERENCE (0) or RSQ_EMIT_ANY (1)");
     if (c.compat_flags & ~(uint32_t)RSQ_COMPAT_JIT_INT16_CAST) failInvalid("rsq_config.compat_flags has bits this library does not know");
+    if (c.engine_flags & ~(uint32_t)(RSQ_ENGINE_DRIVER_ALLOC | RSQ_ENGINE_NO_PLAN_MEMO)) failInvalid("rsq_config.engine_flags has bits this library does not know");
     return c;
 }
 }  // namespace rsq
@@ -131,6 +132,7 @@ void unifyShardStats(Table& t, const void* blobs, int nShards, size_t blobBytes)
         t.cols[i].stats = o;
     }
     t.nRowsTotal = total;
+    t.version++;
 }
 }  // namespace rsq
 
@@ -159,6 +161,25 @@ void rsq_ctx_destroy(rsq_ctx* ctx) { delete C(ctx); }
 const char* rsq_last_error(const rsq_ctx* ctx) {
     if (!ctx) return g_createError.c_str();
     return reinterpret_cast<const Context*>(ctx)->lastError.c_str();
+}
+
+int rsq_ctx_memory_stats(const rsq_ctx* ctx, rsq_memory_stats* out) {
+    if (!ctx || !out) return RSQ_ERR_INVALID;
+    const Context& c = *reinterpret_cast<const Context*>(ctx);
+    const uint32_t have = out->struct_size;
+    if (have < offsetof(rsq_memory_stats, device_used_bytes) || have > 4096) return RSQ_ERR_INVALID;
+    rsq_memory_stats m{};
+    m.struct_size = (uint32_t)sizeof m;
+    if (c.devArena) { m.device_slab_bytes = c.devArena->slabBytes(); m.device_used_bytes = c.devArena->usedBytes(); m.device_slab_allocs = c.devArena->nSlabAllocs; m.arena_requests += c.devArena->nAllocs; m.driver_ms += c.devArena->slabAllocMs; }
+    for (const Arena* a : {c.pinArena.get(), c.pinNcArena.get()})
+        if (a) { m.pinned_slab_bytes += a->slabBytes(); m.pinned_used_bytes += a->usedBytes(); m.pinned_slab_allocs += a->nSlabAllocs; m.arena_requests += a->nAllocs; m.driver_ms += a->slabAllocMs; }
+    m.raw_driver_calls = c.allocStats.rawCalls;
+    m.driver_ms += c.allocStats.rawMs;
+    m.plan_memo_entries = c.planMemo.size();
+    m.plan_memo_hits = c.planMemoHits;
+    memcpy(out, &m, std::min<size_t>(have, sizeof m));
+    out->struct_size = have;
+    return RSQ_OK;
 }
 
 int rsq_table_create(rsq_ctx* ctx, const rsq_table_desc* desc, rsq_table** out) {
@@ -247,7 +268,19 @@ int64_t rsq_table_rows(const rsq_table* t) { return t ? reinterpret_cast<const T
 int rsq_table_set_first_row(rsq_table* t, int64_t row0) {
     if (!t || row0 < 0) return RSQ_ERR_INVALID;
     reinterpret_cast<Table*>(t)->row0 = row0;
+    reinterpret_cast<Table*>(t)->version++;
     return RSQ_OK;
+}
+
+int rsq_table_refresh_stats(rsq_table* t) {
+    if (!t) return RSQ_ERR_INVALID;
+    Table& tab = *reinterpret_cast<Table*>(t);
+    if (!tab.ctx) return RSQ_ERR_INVALID;
+    return guarded(tab.ctx, [&] {
+        if (!tab.ownStats.empty()) failInvalid("rsq_table_refresh_stats: the table plans with unified shard statistics; refresh the shards and unify again");
+        computeColumnStats(*tab.ctx, tab);
+        tab.version++;          // (the context's plan memo: what queries learnt over the old content does not describe the new)
+    });
 }
 
 int rsq_table_read_column(rsq_ctx* ctx, const rsq_table* t, const char* name, void* host_dst, size_t bytes) {
@@ -582,10 +615,10 @@ void appendTable(Context& ctx, Table& t, Table& more) {
         TableColumn& a = t.cols[c]; TableColumn& b = more.cols[c];
         const size_t w = (size_t)columnWidth(a.type);
         if (ctx.device >= 0) {
-            char* nu = (char*)ctx.alloc((size_t)(n0 + n1) * w);
+            char* nu = (char*)ctx.allocRaw((size_t)(n0 + n1) * w);
             if (n0 && a.dptr) RSQ_HIP(hipMemcpy(nu, a.dptr, (size_t)n0 * w, hipMemcpyDeviceToDevice));
             if (n1 && b.dptr) RSQ_HIP(hipMemcpy(nu + (size_t)n0 * w, b.dptr, (size_t)n1 * w, hipMemcpyDeviceToDevice));
-            if (a.owned && a.dptr) ctx.free(a.dptr);
+            if (a.owned && a.dptr) ctx.freeRaw(a.dptr);
             a.dptr = nu; a.owned = true;
         } else {
             char* nu = (char*)malloc(std::max<size_t>(1, (size_t)(n0 + n1) * w));
@@ -597,6 +630,7 @@ void appendTable(Context& ctx, Table& t, Table& more) {
         }
     }
     t.nRows = n0 + n1;
+    t.version++;
     computeColumnStats(ctx, t);
 }
 

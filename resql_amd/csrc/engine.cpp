@@ -117,10 +117,10 @@ Query::~Query() {
     if (dtArena.dev || dtArena.pinned) {
         // the arenas go back to the context for the next query, unless it already holds a pair
         if (!ctx.spareTailArena.dev && !ctx.spareTailArena.pinned) ctx.spareTailArena = dtArena;
-        else { if (dtArena.dev) ctx.free(dtArena.dev); if (dtArena.pinned) (void)hipHostFree(dtArena.pinned); }
+        else { if (dtArena.dev) ctx.free(dtArena.dev); if (dtArena.pinned) ctx.freePinned(dtArena.pinned); }
     }
     if (rtDev) ctx.free(rtDev);
-    if (rtPinned) (void)hipHostFree(rtPinned);
+    if (rtPinned) ctx.freePinned(rtPinned);
     if (dGenericCode) ctx.free(dGenericCode);
     for (auto& gp : generic2Progs) { if (gp.dCode) ctx.free(gp.dCode); if (gp.dProbes) ctx.free(gp.dProbes); if (gp.dConstPool) ctx.free(gp.dConstPool); }
     if (dG2Cnt) ctx.free(dG2Cnt);
@@ -130,9 +130,9 @@ Query::~Query() {
     if (dAggInit) ctx.free(dAggInit);
     if (dAggWork) ctx.free(dAggWork);
     if (dAggWorkInit) ctx.free(dAggWorkInit);
-    if (hPinned) (void)hipHostFree(hPinned);
-    if (hGroupRows) (void)hipHostFree(hGroupRows);
-    if (hCandRows) (void)hipHostFree(hCandRows);
+    if (hPinned) ctx.freePinned(hPinned);
+    if (hGroupRows) ctx.freePinned(hGroupRows);
+    if (hCandRows) ctx.freePinned(hCandRows);
     if (dFinTicket) ctx.free(dFinTicket);
     if (gev0) (void)hipEventDestroy(gev0);
     if (gev1) (void)hipEventDestroy(gev1);
@@ -144,7 +144,7 @@ Query::~Query() {
     freeMatCols(*this);
     if (dGroupRows) ctx.free(dGroupRows);
     if (dNarrowRows) ctx.free(dNarrowRows);
-    if (hInlineRows) (void)hipHostFree(hInlineRows);
+    if (hInlineRows) ctx.freePinned(hInlineRows);
     if (dPipeStats) ctx.free(dPipeStats);
     if (dGroupCount) ctx.free(dGroupCount);
     if (dTopkImages) ctx.free(dTopkImages);
@@ -156,7 +156,7 @@ Query::~Query() {
     if (dStageBase) ctx.free(dStageBase);
     if (dStageCap) ctx.free(dStageCap);
     if (dStageCtl) ctx.free(dStageCtl);
-    if (hStageLayout) (void)hipHostFree(hStageLayout);
+    if (hStageLayout) ctx.freePinned(hStageLayout);
     if (dStageCounts) ctx.free(dStageCounts);
     if (dPartTotals) ctx.free(dPartTotals);
     for (void* r : dPartRecords) if (r) ctx.scratchFree(r);
@@ -221,6 +221,12 @@ static std::vector<std::string> kernelSources(const Query& q) {
         if (p.staged) { v.push_back(p.sourceStagedScatter); v.push_back(p.sourceStagedAgg); }
         v.push_back(p.source);
         if (!p.sourceLazy.empty()) v.push_back(p.sourceLazy);      // (chosen at run time; compiled with the others so that choosing it never blocks an execution)
+        // ... and so is the 64-slot front table of a hash aggregation that turns out to have a handful of groups (engine_pipelines.cpp
+        // fewGroupsKernel): compiled when first wanted it cost TPC-H Q12's second query 0.57 s of hiprtc in the middle of an execution
+        if (p.ldsSlots > 64 && q.aggMode == AggMode::HASH && p.sink == SinkKind::AGGREGATE && q.aggTable >= 0) {
+            v.push_back("#define RSQ_LC_SLOTS 64\n" + p.source);
+            if (!p.sourceLazy.empty()) v.push_back("#define RSQ_LC_SLOTS 64\n" + p.sourceLazy);
+        }
     }
     return v;
 }
@@ -243,10 +249,115 @@ static void resolveKernels(Query& q) {
             p.kernelStagedAgg = &ctx.getKernel(p.sourceStagedAgg, "rsq_staged_agg");
         }
         p.kernel = &ctx.getKernel(p.source, p.entry);
-        if (!p.sourceLazy.empty() && ctx.device < 0) (void)ctx.getKernel(p.sourceLazy, p.entry);      // build(): warm the cache with both forms
+        // both forms are loaded now: the first execution that chooses the late-load form must not read and load a code object
+        // (TPC-H Q3 at SF10: 0.86 ms for the execution that first chose it, 0.32 ms after)
+        if (!p.sourceLazy.empty()) p.kernelLazy = &ctx.getKernel(p.sourceLazy, p.entry);
+        if (ctx.device < 0 && p.ldsSlots > 64 && q.aggMode == AggMode::HASH && p.sink == SinkKind::AGGREGATE && q.aggTable >= 0) {      // build(): the few-groups forms too
+            (void)ctx.getKernel("#define RSQ_LC_SLOTS 64\n" + p.source, p.entry);
+            if (!p.sourceLazy.empty()) (void)ctx.getKernel("#define RSQ_LC_SLOTS 64\n" + p.sourceLazy, p.entry);
+        }
     }
 }
 
+
+// ================================================================================================
+// the context's plan memo (engine.h Context::PlanMemo)
+// ================================================================================================
+static uint64_t fnv1a64(const std::string& s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+// (kernel texts - they carry every constant of the plan and everything the planner took from the column statistics -, then identity
+// and version of every table in plan order)
+static std::string planMemoKey(const Query& q) {
+    uint64_t h = 1469598103934665603ull;
+    for (auto& p : q.pipelines) h = fnv1a64(p.source, h) * 0x9E3779B97F4A7C15ull;
+    std::string k = std::to_string(h);
+    for (Table* t : q.tables) k += "|" + std::to_string(t->uid) + "." + std::to_string(t->version) + "." + std::to_string(t->nRows) + "." + std::to_string(t->row0) + "." + std::to_string(t->nRowsTotal);
+    return k;
+}
+
+// a freshly compiled query takes what an earlier one with the same key has learnt: its join tables are sized and allocated (no counting
+// pass, no read-back), its hash aggregation starts with the table that held the groups, late-load / staged / materialisation choices and
+// the forms that timed out once are the earlier query's.  Runs at compile time, where the arenas make the allocations cheap.
+static void applyPlanMemo(Query& q) {
+    Context& ctx = q.ctx;
+    if (ctx.planMemoOff || ctx.device < 0 || q.genericActive) return;
+    q.memoKey = planMemoKey(q);
+    auto it = ctx.planMemo.find(q.memoKey);
+    if (it == ctx.planMemo.end()) return;
+    Context::PlanMemo& m = it->second;
+    if (m.joins.size() != q.hashTables.size() || m.pipes.size() != q.pipelines.size()) return;
+    m.stamp = ++ctx.planMemoClock;
+    for (size_t i = 0; i < q.pipelines.size(); i++) {
+        Pipeline& p = q.pipelines[i];
+        p.stage2Rows = m.pipes[i].stage2Rows;
+        p.stagedExact = m.pipes[i].stagedExact; p.stagedCaps = m.pipes[i].stagedCaps; p.stagedCapsRows = m.pipes[i].stagedCapsRows;
+        if (p.sink != SinkKind::BUILD) continue;
+        HashTable& h = *q.hashTables[(size_t)p.buildTable];
+        const Context::PlanMemo::Join& j = m.joins[(size_t)p.buildTable];
+        if (j.buildRows < 0 || h.capacity != 0) continue;
+        sizeJoinTable(q, p, h, (uint32_t)j.buildRows, j.dupKeys);
+    }
+    for (size_t i = 0; i < q.hashTables.size(); i++) q.hashTables[i]->lastCount = m.joins[i].lastCount;
+    if (q.aggMode == AggMode::HASH && q.aggTable >= 0 && m.hashCapacity > 0) {
+        HashTable& h = *q.hashTables[(size_t)q.aggTable];
+        if (h.capacity == 0 && !h.dState) {
+            h.capacity = m.hashCapacity; h.lastCount = m.hashCount;
+            h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
+            h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (h.keys.size() + h.payload.size()));
+            h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
+        }
+        q.charGroupsNeedMerge = m.charGroupsNeedMerge;
+        for (auto& p : q.pipelines)         // a handful of groups: the 64-slot front table's kernel is loaded now (engine_pipelines.cpp fewGroupsKernel)
+            if (p.sink == SinkKind::AGGREGATE) {
+                const bool lazy = !p.sourceLazy.empty() && p.stage2Rows >= 0 && p.stage2Rows * 32 < p.src->nRows;
+                (void)fewGroupsKernel(q, p, lazy ? p.sourceLazy : p.source, lazy ? "lazy" : "eager", lazy ? p.kernelLazy : p.kernel);
+            }
+    }
+    q.matLastTotal = m.matLastTotal;
+    if (q.matOp && !q.agg && m.matLastTotal >= 0) {
+        uint64_t keep = (uint64_t)m.matLastTotal;
+        if (q.matOp->hasLimit) keep = std::min<uint64_t>(keep, (uint64_t)std::max<int64_t>(q.matOp->limit, 1));
+        if (q.dMatCols.empty()) allocMatCols(q, std::max<int64_t>((int64_t)keep, 1));
+    }
+    q.narrowRowsOff = m.narrowRowsOff; q.fusedSelectOff = m.fusedSelectOff; q.chainedIndexOff = m.chainedIndexOff; q.scanChainedOff = m.scanChainedOff;
+    q.stageWorkgroups = m.stageWorkgroups;
+    q.memoApplied = true;
+    ctx.planMemoHits++;
+}
+
+// after an execution that ran to its end: what it knows now
+static void rememberPlan(Query& q) {
+    Context& ctx = q.ctx;
+    if (ctx.planMemoOff || q.memoKey.empty() || q.genericActive) return;
+    Context::PlanMemo& m = ctx.planMemo[q.memoKey];
+    m.stamp = ++ctx.planMemoClock;
+    m.joins.resize(q.hashTables.size()); m.pipes.resize(q.pipelines.size());
+    for (size_t i = 0; i < q.hashTables.size(); i++) {
+        const HashTable& h = *q.hashTables[i];
+        m.joins[i].buildRows = h.capacity != 0 ? h.buildRows : -1; m.joins[i].dupKeys = h.dupKeys; m.joins[i].lastCount = h.lastCount;
+    }
+    for (size_t i = 0; i < q.pipelines.size(); i++) {
+        const Pipeline& p = q.pipelines[i];
+        Context::PlanMemo::Pipe& mp = m.pipes[i];
+        mp.stage2Rows = p.stage2Rows; mp.stagedExact = p.stagedExact; mp.stagedCapsRows = p.stagedCapsRows;
+        if (mp.stagedCaps != p.stagedCaps) mp.stagedCaps = p.stagedCaps;
+    }
+    if (q.aggMode == AggMode::HASH && q.aggTable >= 0) {
+        const HashTable& h = *q.hashTables[(size_t)q.aggTable];
+        m.hashCapacity = h.dState ? h.capacity : 0; m.hashCount = h.lastCount; m.charGroupsNeedMerge = q.charGroupsNeedMerge;
+    }
+    m.matLastTotal = q.matLastTotal;
+    m.narrowRowsOff = q.narrowRowsOff; m.fusedSelectOff = q.fusedSelectOff; m.chainedIndexOff = q.chainedIndexOff; m.scanChainedOff = q.scanChainedOff;
+    m.stageWorkgroups = q.stageWorkgroups;
+    if (ctx.planMemo.size() > 512) {          // the least recently used half goes
+        std::vector<std::pair<uint64_t, std::string>> byAge;
+        for (auto& kv : ctx.planMemo) byAge.emplace_back(kv.second.stamp, kv.first);
+        std::sort(byAge.begin(), byAge.end());
+        for (size_t i = 0; i < byAge.size() / 2; i++) ctx.planMemo.erase(byAge[i].second);
+    }
+}
 
 Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* tables, int nTables) {
     double t0 = nowMs();
@@ -349,7 +460,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         if (q->aggMode == AggMode::AT_JOIN_ENTRY || q->aggMode == AggMode::HASH) q->dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
         q->dPipeStats = (uint64_t*)ctx.alloc(std::max<size_t>(1, q->pipelines.size()) * 8);
         size_t pw = q->pinnedWords + 8 + q->pipelines.size();
-        RSQ_HIP(hipHostMalloc((void**)&q->hPinned, pw * 8, hipHostMallocDefault));
+        q->hPinned = (uint64_t*)ctx.allocPinned(pw * 8);
         memset(q->hPinned, 0, pw * 8);
         {   // the device's view of the pinned words: status words are published by one kernel instead of one copy each
             void* dv = nullptr;
@@ -364,6 +475,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
             }
         }
     }
+    applyPlanMemo(*q);
     q->report.compilation_time_ms = nowMs() - t0;
     q->report.jit_cache_hits = ctx.jitCacheHits - hits0;
     q->report.jit_compiles = ctx.jitCompiles - comp0;
@@ -380,6 +492,7 @@ void awaitKernels(Query& q) {
     resolveKernels(q);
     q.genericActive = false;
     if (q.generic2) leaveGeneric2(q);
+    applyPlanMemo(q);
     q.report.jit_compiles = (int32_t)kernelSources(q).size();
 }
 
@@ -406,6 +519,18 @@ void resolveKernelTime(Query& q) {
     q.report.hbm_gbps = ms > 0 ? (double)q.report.bytes_read / (ms * 1e-3) / 1e9 : 0;
 }
 
+// The pinned host copy of the group rows, made when rows are first read back and as large as that read-back: a statement that ends on
+// a handful of candidates (TPC-H Q10: 380 K groups of 40 words, LIMIT 20) never pins the 121 MB its full rows would take (7 ms of
+// hipHostMalloc in the first execution on a fresh context).  Non-coherent: cached on the host (the tail reads every word), valid after
+// the copy's synchronisation.
+static void ensureHostGroupRows(Query& q, size_t words) {
+    if (q.hGroupRowsWords >= words && q.hGroupRows) return;
+    if (q.hGroupRows) q.ctx.freePinned(q.hGroupRows);
+    q.hGroupRows = nullptr; q.hGroupRowsWords = 0;
+    q.hGroupRows = (int64_t*)q.ctx.allocPinned(std::max<size_t>(words, 8) * 8, true);
+    q.hGroupRowsWords = words;
+}
+
 // a single register-mode pipeline: its kernel carries the whole step (codegen.cpp, "The step in ONE launch")
 static bool fusedEligible(const Query& q) {
     const bool off = getenv("RSQ_FUSED_STEP") && atoi(getenv("RSQ_FUSED_STEP")) == 0;
@@ -417,7 +542,13 @@ static bool fusedEligible(const Query& q) {
 // materialised columns) back, but leaves the tail to the root, which merges all shards' groups first (tail.cpp runTailMerged)
 static void tailUnlessHeld(Query& q) { if (!q.holdTail) runTail(q); }
 
+static void executeQueryBody(Query& q, bool partialOnly, bool async);
 void executeQuery(Query& q, bool partialOnly, bool async) {
+    executeQueryBody(q, partialOnly, async);
+    rememberPlan(q);
+}
+
+static void executeQueryBody(Query& q, bool partialOnly, bool async) {
     Context& ctx = q.ctx;
     if (ctx.device < 0) throw Error(RSQ_ERR_DEVICE, "this context has no device (compile-only)");
     RSQ_HIP(hipSetDevice(ctx.device));
@@ -439,6 +570,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             resolveKernels(q);
             q.genericActive = false;
             if (q.generic2) leaveGeneric2(q);
+            applyPlanMemo(q);
             q.report.jit_compiles = (int32_t)kernelSources(q).size();       // built by the compiler thread since rsq_query_compile returned
         } else if (!q.generic2) {
             // ---- the generic pipeline: table init, ONE interpreter launch, read-back ----
@@ -484,9 +616,9 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
     auto ensureCandHost = [&]() {        // coherent pinned rows for topkCapacity candidates, and the device's view of them
         const size_t need = (size_t)topkCapacity * (size_t)q.groupRowWords;
         if (q.hCandRowsWords >= need && q.dHostCandRows) return;
-        if (q.hCandRows) (void)hipHostFree(q.hCandRows);
+        if (q.hCandRows) ctx.freePinned(q.hCandRows);
         q.hCandRows = nullptr; q.dHostCandRows = nullptr; q.hCandRowsWords = 0;
-        RSQ_HIP(hipHostMalloc((void**)&q.hCandRows, std::max<size_t>(need, 8) * 8, hipHostMallocDefault));
+        q.hCandRows = (int64_t*)ctx.allocPinned(std::max<size_t>(need, 8) * 8);
         q.hCandRowsWords = need;
         void* dv = nullptr;
         if (hipHostGetDevicePointer(&dv, q.hCandRows, 0) == hipSuccess && dv) q.dHostCandRows = (int64_t*)dv; else (void)hipGetLastError();
@@ -811,15 +943,11 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
         groupRowsAllocated = std::max<uint32_t>(1, nEntries);
         size_t need = (size_t)groupRowsAllocated * (size_t)q.groupRowWords;
-        if (q.hGroupRowsWords < need) {
+        if (q.dGroupRowsWords < need) {
             if (q.dGroupRows) ctx.free(q.dGroupRows);
-            q.dGroupRows = nullptr; q.hGroupRowsWords = 0;          // (nothing dangles if an allocation below throws)
+            q.dGroupRows = nullptr; q.dGroupRowsWords = 0;          // (nothing dangles if the allocation below throws)
             q.dGroupRows = (int64_t*)ctx.alloc(need * 8);
-            if (q.hGroupRows) (void)hipHostFree(q.hGroupRows);
-            q.hGroupRows = nullptr;
-            // non-coherent pinned memory: cached on the host (the tail reads every word), valid after the copy's sync
-            RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
-            q.hGroupRowsWords = need;
+            q.dGroupRowsWords = need;
         }
         // ORDER BY ... LIMIT k over many groups: select the candidate rows on the device and read back only those
         if (q.topkWord == -2) planDeviceTopK(q);
@@ -893,14 +1021,12 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             q.groupRowWords = 2 + W;
             groupRowsAllocated = D;
             const size_t need = (size_t)D * (size_t)q.groupRowWords;
-            if (q.hGroupRowsWords < need) {
+            if (q.dGroupRowsWords < need) {
                 if (q.dGroupRows) ctx.free(q.dGroupRows);
+                q.dGroupRows = nullptr; q.dGroupRowsWords = 0;
                 q.dGroupRows = (int64_t*)ctx.alloc(need * 8);
-                if (q.hGroupRows) (void)hipHostFree(q.hGroupRows);
-                q.hGroupRows = nullptr;
-                RSQ_HIP(hipHostMalloc((void**)&q.hGroupRows, need * 8, hipHostMallocNonCoherent));
-                q.hGroupRowsWords = need;
-                }
+                q.dGroupRowsWords = need;
+            }
             if (!q.dGroupCount) q.dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
             topkCapacity = std::min<uint32_t>(D, std::max<uint32_t>(1024, 4 * q.topkWant));
             if (!q.dTopkHists) { q.dTopkHists = (uint32_t*)ctx.alloc(topkHistBytes()); q.dCandCount = q.dTopkHists + 4; }
@@ -949,9 +1075,9 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (wantGroups && !denseTopk && !topkCapacity && !q.holdTail && !trace && q.dGroupRows && q.groupRowWords > 0) {
                 const size_t need = (size_t)kInlineRows * (size_t)q.groupRowWords;
                 if (q.inlineRowsWords < need) {
-                    if (q.hInlineRows) (void)hipHostFree(q.hInlineRows);
+                    if (q.hInlineRows) ctx.freePinned(q.hInlineRows);
                     q.hInlineRows = nullptr; q.dHostInlineRows = nullptr; q.inlineRowsWords = 0;
-                    RSQ_HIP(hipHostMalloc((void**)&q.hInlineRows, need * 8, hipHostMallocDefault));
+                    q.hInlineRows = (int64_t*)ctx.allocPinned(need * 8);
                     void* dv = nullptr;
                     if (hipHostGetDevicePointer(&dv, q.hInlineRows, 0) == hipSuccess && dv) { q.dHostInlineRows = (int64_t*)dv; q.inlineRowsWords = need; }
                     else (void)hipGetLastError();
@@ -973,7 +1099,10 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         }
         devTail = !partialOnly && !async && denseMode(q) && !denseTopk && denseDeviceTailWanted(q);
         if (!partialOnly && denseMode(q) && !denseTopk && !devTail && !tableInline) enqueueTableReadback(q);
-        if (topkCapacity) RSQ_HIP(hipMemcpyAsync(q.hGroupRows, q.dCandRows, (size_t)topkSpec * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost, ctx.stream));
+        if (topkCapacity) {
+            ensureHostGroupRows(q, (size_t)topkCapacity * (size_t)q.groupRowWords);
+            RSQ_HIP(hipMemcpyAsync(q.hGroupRows, q.dCandRows, (size_t)topkSpec * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost, ctx.stream));
+        }
     }
     if (async && partialOnly) {
         // everything is enqueued; the caller orders its own work (the group-by merge collective) behind it on the same
@@ -1049,6 +1178,7 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
             if (h.dAcc) ctx.free(h.dAcc);
             h.dWords = h.dTemp = nullptr; h.dAcc = nullptr; h.dTempUsed = h.dChunkTotal = h.dChunkBase = nullptr;
             h.rank = false; h.rankCapable = false; h.identity = false; h.capacity = 0; h.lastCount = 0;
+            h.dupKeys = true;                      // (what the plan memo tells the next query of this shape)
         }
         if (any) { executeQuery(q, partialOnly, async); return; }
     }
@@ -1084,7 +1214,10 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
         uint32_t n = 0;
         RSQ_HIP(hipMemcpyAsync(&n, q.dCandCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         waitForStream(ctx);
-        if (n <= topkCapacity) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dCandRows, (size_t)n * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost));
+        if (n <= topkCapacity) {
+            ensureHostGroupRows(q, (size_t)topkCapacity * (size_t)q.groupRowWords);
+            RSQ_HIP(hipMemcpy(q.hGroupRows, q.dCandRows, (size_t)n * (size_t)q.groupRowWords * 8, hipMemcpyDeviceToHost));
+        }
         return (int64_t)n;
     };
     if (!partialOnly) {
@@ -1178,7 +1311,10 @@ void executeQuery(Query& q, bool partialOnly, bool async) {
                     q.hRowsView = nullptr;
                 }
                 else {
-                    if (q.nGroupRows) RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * rowBytes, hipMemcpyDeviceToHost));
+                    if (q.nGroupRows) {
+                        ensureHostGroupRows(q, (size_t)q.nGroupRows * (size_t)q.groupRowWords);
+                        RSQ_HIP(hipMemcpy(q.hGroupRows, q.dGroupRows, (size_t)q.nGroupRows * rowBytes, hipMemcpyDeviceToHost));
+                    }
                     tailUnlessHeld(q);
                 }
             }

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -13,6 +14,7 @@
 
 #include "expr.h"
 #include "hostref.h"
+#include "mempool.h"
 #include "resql_hip.h"
 
 #define RSQ_RANK_CHUNK_BLOCKS 1024       /* 32-byte bitmap blocks one workgroup of the rank index handles (aot_kernels.hip) */
@@ -45,8 +47,14 @@ struct TableColumn {
 
 struct Context;
 
+inline std::atomic<uint64_t> g_nextTableUid{1};
+
 struct Table {
     Context* ctx = nullptr;
+    // identity for the context's plan memo: uid is unique in the process, version counts everything that changes what a query over the
+    // table may have learnt (rows appended, statistics unified / refreshed, first row set)
+    uint64_t uid = g_nextTableUid.fetch_add(1);
+    uint64_t version = 0;
     std::string name;
     int64_t nRows = 0;
     int64_t row0 = 0;                          // global index of the first row (row-range shards)
@@ -104,8 +112,22 @@ struct Context {
     std::set<std::string> freshlyCompiled;      // keys compileManyToCache built and getKernel has not loaded yet
     std::mutex freshMutex;
     std::string cacheKey(const std::string& source);
+    // Buffers of queries (join / aggregation tables, group rows, scratch) come out of the context's arenas (mempool.h): a statement
+    // that is compiled, executed once and destroyed - all a ReSQL host ever does, reference src/execute.h:213-247 - must not pay
+    // hipMalloc / hipFree / hipHostMalloc per execution.  A freed range is handed out again once the stream has drained
+    // (alloc asks hipStreamQuery; waitForStream tells).  RSQ_ENGINE_DRIVER_ALLOC in rsq_config.engine_flags takes every buffer
+    // from the driver as before (measurement, tests).
     void* alloc(size_t bytes);
     void free(void* p);
+    void* allocPinned(size_t bytes, bool nonCoherent = false);      // host memory the device reads / writes (hipHostMalloc)
+    void freePinned(void* p);
+    void* allocRaw(size_t bytes);              // straight from the driver: table columns (large, long-lived)
+    void freeRaw(void* p);
+    void streamDrained();                      // the caller has just seen the stream idle: pending ranges are free
+    std::unique_ptr<Arena> devArena, pinArena, pinNcArena;
+    bool driverAlloc = false;
+    size_t arenaKeepBytes = 0;
+    struct AllocStats { uint64_t devCalls = 0, pinCalls = 0, rawCalls = 0; double devMs = 0, pinMs = 0, rawMs = 0; } allocStats;
     void setStream(hipStream_t s, bool callers);   // callers == false: back to the context's own stream
     // large transient device buffers (partition records): freed buffers are kept and handed out again, because
     // hipMalloc / hipFree of multi-GB buffers costs tens to hundreds of ms
@@ -125,6 +147,24 @@ struct Context {
     TailArena spareTailArena;
     ReplayScratch replayScratch;
     std::vector<uint32_t> replayOrder;
+    // The plan memo (include/resql_hip.h rsq_engine_flags): what executions have learnt, by (kernel texts, table ids + versions).  A ReSQL
+    // host compiles, executes once and deletes (reference src/execute.h:213-247); the reference's operators size their tables from
+    // getSize() estimates and grow them while they run (qlib/hash.h:385-419) - here sizes are found by a counting pass, a read-back and
+    // an allocation, which a second query over the same tables must not repeat.  Every entry is re-checked by the execution it serves.
+    struct PlanMemo {
+        struct Join { int64_t buildRows = -1; bool dupKeys = false; uint32_t lastCount = 0; };
+        struct Pipe { int64_t stage2Rows = -1; bool stagedExact = false; std::vector<uint32_t> stagedCaps; int64_t stagedCapsRows = -1; };
+        std::vector<Join> joins;
+        std::vector<Pipe> pipes;
+        int64_t hashCapacity = 0; uint32_t hashCount = 0; bool charGroupsNeedMerge = false;
+        int64_t matLastTotal = -1;
+        bool narrowRowsOff = false, fusedSelectOff = false, chainedIndexOff = false, scanChainedOff = false;
+        uint32_t stageWorkgroups = 0;
+        uint64_t stamp = 0;
+    };
+    std::map<std::string, PlanMemo> planMemo;
+    uint64_t planMemoClock = 0, planMemoHits = 0;
+    bool planMemoOff = false;
 };
 
 rsq_config readConfig(const rsq_config* cfg);      // api.cpp: the host's struct (struct_size bytes), validated

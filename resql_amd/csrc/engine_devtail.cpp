@@ -50,7 +50,7 @@ double runDenseDeviceTail(Query& q) {
         if (spare.dev && spare.devBytes >= devBytes && spare.pinnedBytes >= pinBytes) { q.dtArena = spare; spare = Context::TailArena(); }
         else {
             q.dtArena.dev = ctx.alloc(devBytes); q.dtArena.devBytes = devBytes;
-            RSQ_HIP(hipHostMalloc(&q.dtArena.pinned, pinBytes, hipHostMallocDefault)); q.dtArena.pinnedBytes = pinBytes;
+            q.dtArena.pinned = ctx.allocPinned(pinBytes); q.dtArena.pinnedBytes = pinBytes;
         }
         char* d = (char*)q.dtArena.dev; size_t at = 0; int k = 0;
         auto take = [&]() { void* r = d + at; at += sz[k++]; return r; };
@@ -189,9 +189,9 @@ double runRowsDeviceTail(Query& q, int64_t n) {
     rowTailResultRows(ctx, q.dGroupRows, stride, dIdx, dOrder, emit, q.rtCols, q.rtTupleSize, rows);
     const size_t outBytes = std::max<size_t>((size_t)emit * (size_t)q.rtTupleSize, 8);
     if (q.rtPinnedBytes < outBytes) {
-        if (q.rtPinned) (void)hipHostFree(q.rtPinned);
+        if (q.rtPinned) ctx.freePinned(q.rtPinned);
         q.rtPinned = nullptr; q.rtPinnedBytes = 0;
-        RSQ_HIP(hipHostMalloc(&q.rtPinned, outBytes + outBytes / 8, hipHostMallocDefault));
+        q.rtPinned = ctx.allocPinned(outBytes + outBytes / 8);
         q.rtPinnedBytes = outBytes + outBytes / 8;
     }
     if (emit > 0) RSQ_HIP(hipMemcpyAsync(q.rtPinned, rows, (size_t)emit * (size_t)q.rtTupleSize, hipMemcpyDeviceToHost, ctx.stream));

@@ -89,6 +89,8 @@ struct HashTable {
     uint32_t* dChunkTotal = nullptr; // [chunks]
     uint32_t* dChunkBase = nullptr;  // [chunks + 1]
     int64_t bmBlocks = 0;            // 32-byte blocks the bitmap is allocated in (256 bits, or 224 bits + the rank word)
+    int64_t buildRows = -1;          // build rows and duplicate keys as the sizing pass saw them (what the plan memo keeps)
+    bool dupKeys = false;
     bool prepared = false;           // this execution's first fill launch has readied the table (engine.cpp: the prologue); buildHashTable then skips its own
 };
 
@@ -317,7 +319,8 @@ struct Query {
     int64_t* dGroupRows = nullptr;
     uint32_t* dGroupCount = nullptr;
     int64_t* hGroupRows = nullptr;         // pinned (a pageable target makes the 6 MB read-back of Q3 SF10 cost ~1 ms)
-    size_t hGroupRowsWords = 0;
+    size_t hGroupRowsWords = 0;            // (allocated when rows are first read back: ensureHostGroupRows)
+    size_t dGroupRowsWords = 0;
     int64_t nGroupRows = 0;
     int groupRowWords = 0;
 
@@ -419,6 +422,8 @@ struct Query {
     bool firstRowsForeign = false;         // the partial table may hold first rows of shards whose size this query's table does not know (bound / gathered partials, table never unified)
     bool holdTail = false;                 // a shard of a multi-GPU plan: execute reads the group rows / materialised columns back and stops (tail.cpp runTailMerged)
     std::string allSource, explainText;
+    std::string memoKey;                   // the context's plan memo entry of this query (empty: none)
+    bool memoApplied = false;              // ... and an earlier query's entry was found when this one was compiled
 
     explicit Query(Context& c) : ctx(c) {}
     ~Query();
@@ -471,6 +476,7 @@ bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64_t>& es
 void runLargeDenseAggregation(Query& q, Pipeline& p);
 void materializePipeline(Query& q, Pipeline& p);
 void buildHashTable(Query& q, Pipeline& p);
+void sizeJoinTable(Query& q, Pipeline& p, HashTable& h, uint32_t n, bool dupKeys);
 void checkDeviceError(uint32_t err);
 void checkAsyncDeviceError(uint32_t err);
 void enqueueTableInit(Query& q);

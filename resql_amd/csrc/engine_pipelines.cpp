@@ -115,13 +115,14 @@ void waitForStream(Context& ctx) {
         const double deadline = nowMs() + 2.0;
         for (;;) {
             const hipError_t e = hipStreamQuery(ctx.stream);
-            if (e == hipSuccess) return;
+            if (e == hipSuccess) { ctx.streamDrained(); return; }
             if (e != hipErrorNotReady) RSQ_HIP(e);
             if (nowMs() > deadline) break;
             __builtin_ia32_pause();
         }
     }
     RSQ_HIP(hipStreamSynchronize(ctx.stream));
+    ctx.streamDrained();
 }
 
 // RSQ_DEBUG_TAIL=1 (measurement only): the device timestamps a pipeline's workgroups left (codegen.cpp finishPipeline)
@@ -225,7 +226,7 @@ void prepareStageBuffers(Query& q, const Pipeline& p) {
         q.dStageBase = (uint64_t*)ctx.alloc((size_t)P * 8);
         q.dStageCap = (uint32_t*)ctx.alloc((size_t)P * 4);
         q.dStageCtl = ctx.alloc(32);
-        RSQ_HIP(hipHostMalloc((void**)&q.hStageLayout, (size_t)P * 12, hipHostMallocDefault));     // the layout travels from pinned memory: no wait for the copy
+        q.hStageLayout = ctx.allocPinned((size_t)P * 12);     // the layout travels from pinned memory: no wait for the copy
     }
     if (q.stageCountsWords < words) {
         if (q.dStageCounts) ctx.free(q.dStageCounts);
@@ -426,7 +427,7 @@ void runLargeDenseAggregation(Query& q, Pipeline& p) {
 // PCIe and the host has them when the stream reports completion (TPC-H Q19: 1107 rows; the blocking copy afterwards cost ~15 us).
 void freeMatCols(Query& q) {
     for (size_t c = 0; c < q.dMatCols.size(); c++) {
-        if (c < q.hMatMapped.size() && q.hMatMapped[c]) (void)hipHostFree(q.hMatMapped[c]);
+        if (c < q.hMatMapped.size() && q.hMatMapped[c]) q.ctx.freePinned(q.hMatMapped[c]);
         else if (q.dMatCols[c]) q.ctx.free(q.dMatCols[c]);
     }
     q.dMatCols.clear(); q.hMatMapped.clear();
@@ -440,10 +441,13 @@ void allocMatCols(Query& q, int64_t capacity) {
     for (auto& a : q.matSchema) {
         const size_t bytes = std::max<size_t>(8, (size_t)capacity * (size_t)columnWidth(a.type));
         void* h = nullptr; void* d = nullptr;
-        if (mapped && (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d)) {
-            (void)hipGetLastError();
-            if (h) (void)hipHostFree(h);
-            h = nullptr; mapped = false;            // (this column and the ones behind it: device memory)
+        if (mapped) {
+            h = q.ctx.allocPinned(bytes);
+            if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) {
+                (void)hipGetLastError();
+                q.ctx.freePinned(h);
+                h = nullptr; mapped = false;            // (this column and the ones behind it: device memory)
+            }
         }
         if (h) { q.dMatCols.push_back(d); q.hMatMapped.push_back(h); }
         else { q.dMatCols.push_back(q.ctx.alloc(bytes)); q.hMatMapped.push_back(nullptr); }
@@ -526,6 +530,51 @@ void materializePipeline(Query& q, Pipeline& p) {
     q.report.bytes_read += p.matSkip ? (uint64_t)(p.bytesPerRow * p.src->nRows) + (uint64_t)tiles * 4 : 2 * (uint64_t)(p.bytesPerRow * p.src->nRows);
 }
 
+// Form and buffers of a join table from the number of its build rows and whether two of them share a key: what the sizing pass of a
+// query's first execution finds out - or what the context's plan memo remembers of an earlier query with the same pipelines over the
+// same table versions (engine.cpp applyPlanMemo).  Either way the build re-checks both (NOTE_BUILD_KEYS_NOT_UNIQUE, table full).
+void sizeJoinTable(Query& q, Pipeline& p, HashTable& h, uint32_t n, bool dupKeys) {
+    Context& ctx = q.ctx;
+    const size_t nWords = h.keys.size() + h.payload.size();
+    if (h.hasBitmap) {
+        h.bmBlocks = h.bmInterleaved ? (h.bmBits + 223) / 224 : (h.bmBits + 255) / 256;
+        if (!h.dBitmap) h.dBitmap = (uint32_t*)ctx.alloc((size_t)h.bmBlocks * 32);
+    }
+    h.buildRows = (int64_t)n; h.dupKeys = h.dupKeys || dupKeys;      // (a dictionary that met duplicates once stays a hash table)
+    dupKeys = h.dupKeys;
+    // (a table of a few hundred rows stays a hash table: the dictionary's index and placement are two launches of 3-4 us each for
+    // entries that sit in one cache line either way - TPC-H Q5's region and nation tables)
+    h.rank = h.rankCapable && !dupKeys && (n > 1024 || h.setOnly);
+    h.identity = h.rank && h.identityCapable && (int64_t)n == p.src->nRows && n > 0;
+    if (h.rank && h.setOnly) {
+        h.capacity = std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);          // (nothing is allocated: the bitmap is the table)
+    } else if (h.rank) {
+        // a dictionary that carries aggregates scatters them with a multiplicative bijection: power-of-two capacity
+        const int64_t capMul = 1;
+        h.capacity = q.aggTable == h.id ? nextPow2(std::max<int64_t>(64, (int64_t)n * capMul)) : std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);
+        const int64_t nChunks = (h.bmBlocks + RSQ_RANK_CHUNK_BLOCKS - 1) / RSQ_RANK_CHUNK_BLOCKS;
+        // arrival-order buffer: one region per wave of the largest grid this pipeline launches, four times the mean
+        // number of records per wave of the smallest one
+        const int64_t wpb = p.blockThreads / 64;
+        if (!p.sourceLazy.empty() && !p.kernelLazy) p.kernelLazy = &ctx.getKernel(p.sourceLazy, p.entry);      // (both forms' grids are final below)
+        const int64_t wavesMax = (int64_t)std::max(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
+        const int64_t wavesMin = (int64_t)std::min(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
+        h.tempWaves = wavesMax;
+        h.tempRegion = h.identity ? 64 : ((4 * (int64_t)n / std::max<int64_t>(1, wavesMin) + 64 + 63) / 64) * 64;      // (identity: nothing is appended)
+        h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
+        h.dTemp = (int64_t*)ctx.alloc((size_t)h.tempWaves * (size_t)h.tempRegion * 8 * std::max<size_t>(1, nWords));
+        h.dTempUsed = (uint32_t*)ctx.alloc((size_t)h.tempWaves * 4);
+        h.dChunkTotal = (uint32_t*)ctx.alloc((size_t)nChunks * 4);
+        h.dChunkBase = (uint32_t*)ctx.alloc((size_t)(nChunks + 1) * 4);
+    } else {
+        h.capacity = nextPow2(std::max<int64_t>(1024, 2 * (int64_t)n));
+        if (!h.keyCas) h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
+        h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
+    }
+    if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
+    if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.identity ? "bitmap-rank dictionary, entries in row order" : h.rank ? "bitmap-rank dictionary" : "hash table", n);
+}
+
 // size (by a counting pass of the same pipeline), allocate and clear a join table, then build it
 void buildHashTable(Query& q, Pipeline& p) {
     Context& ctx = q.ctx;
@@ -553,38 +602,8 @@ void buildHashTable(Query& q, Pipeline& p) {
         RSQ_HIP(hipMemcpyAsync(&n, h.dCount, 4, hipMemcpyDeviceToHost, ctx.stream));
         RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
         waitForStream(ctx);
-        // (a table of a few hundred rows stays a hash table: the dictionary's index and placement are two launches of 3-4 us each for
-        // entries that sit in one cache line either way - TPC-H Q5's region and nation tables)
-        h.rank = h.rankCapable && !(err & 64u) && (n > 1024 || h.setOnly);
-        h.identity = h.rank && h.identityCapable && (int64_t)n == p.src->nRows && n > 0;
-        if (err & 64u) { err &= ~64u; RSQ_HIP(hipMemcpy(ctx.dErr, &err, 4, hipMemcpyHostToDevice)); }
-        if (h.rank && h.setOnly) {
-            h.capacity = std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);          // (nothing is allocated: the bitmap is the table)
-        } else if (h.rank) {
-            // a dictionary that carries aggregates scatters them with a multiplicative bijection: power-of-two capacity
-            const int64_t capMul = 1;
-            h.capacity = q.aggTable == h.id ? nextPow2(std::max<int64_t>(64, (int64_t)n * capMul)) : std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);
-            const int64_t nChunks = (h.bmBlocks + RSQ_RANK_CHUNK_BLOCKS - 1) / RSQ_RANK_CHUNK_BLOCKS;
-            // arrival-order buffer: one region per wave of the largest grid this pipeline launches, four times the mean
-            // number of records per wave of the smallest one
-            const int64_t wpb = p.blockThreads / 64;
-            if (!p.sourceLazy.empty() && !p.kernelLazy) p.kernelLazy = &ctx.getKernel(p.sourceLazy, p.entry);      // (both forms' grids are final below)
-            const int64_t wavesMax = (int64_t)std::max(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
-            const int64_t wavesMin = (int64_t)std::min(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
-            h.tempWaves = wavesMax;
-            h.tempRegion = h.identity ? 64 : ((4 * (int64_t)n / std::max<int64_t>(1, wavesMin) + 64 + 63) / 64) * 64;      // (identity: nothing is appended)
-            h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
-            h.dTemp = (int64_t*)ctx.alloc((size_t)h.tempWaves * (size_t)h.tempRegion * 8 * std::max<size_t>(1, nWords));
-            h.dTempUsed = (uint32_t*)ctx.alloc((size_t)h.tempWaves * 4);
-            h.dChunkTotal = (uint32_t*)ctx.alloc((size_t)nChunks * 4);
-            h.dChunkBase = (uint32_t*)ctx.alloc((size_t)(nChunks + 1) * 4);
-        } else {
-            h.capacity = nextPow2(std::max<int64_t>(1024, 2 * (int64_t)n));
-            if (!h.keyCas) h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
-            h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
-        }
-        if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
-        if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.identity ? "bitmap-rank dictionary, entries in row order" : h.rank ? "bitmap-rank dictionary" : "hash table", n);
+        if (err & 64u) { const uint32_t cleared = err & ~64u; RSQ_HIP(hipMemcpy(ctx.dErr, &cleared, 4, hipMemcpyHostToDevice)); }
+        sizeJoinTable(q, p, h, n, (err & 64u) != 0);
     }
     // (an execution whose tables are all sized readies them in its first fill launch — prologueFills below — and h.prepared says so)
     const bool prepared = h.prepared;

@@ -176,10 +176,18 @@ void enqueueMergeUntimed(rsq_multi_query& mq) {
 
 extern "C" {
 
-int rsq_multi_create(const rsq_multi_config* cfg, rsq_multi** out) {
-    if (!out || !cfg || cfg->n_devices < 1 || !cfg->devices) return RSQ_ERR_INVALID;
+int rsq_multi_create(const rsq_multi_config* hostCfg, rsq_multi** out) {
+    if (!out || !hostCfg) return RSQ_ERR_INVALID;
     *out = nullptr;
     return guardedM(nullptr, [&] {
+        // the host's struct, struct_size bytes of it (every later field reads as 0), like rsq_config (api.cpp readConfig)
+        rsq_multi_config mc{};
+        const uint32_t have = hostCfg->struct_size;
+        if (have < offsetof(rsq_multi_config, merge) || have > 4096)
+            failInvalid("rsq_multi_config.struct_size is " + std::to_string(have) + ": set it to sizeof(rsq_multi_config) (" + std::to_string(sizeof(rsq_multi_config)) + " in this library)");
+        memcpy(&mc, hostCfg, std::min<size_t>(have, sizeof mc));
+        const rsq_multi_config* cfg = &mc;
+        if (cfg->n_devices < 1 || !cfg->devices) failInvalid("rsq_multi_create needs at least one device");
         std::unique_ptr<rsq_multi> m(new rsq_multi());
         std::set<int> distinct;
         for (int i = 0; i < cfg->n_devices; i++) {
@@ -193,7 +201,7 @@ int rsq_multi_create(const rsq_multi_config* cfg, rsq_multi** out) {
         if (m->merge == RSQ_MERGE_RCCL && m->sharedDevice)
             failInvalid("an RCCL communicator cannot hold the same device twice: use RSQ_MERGE_PEER_COPY for shards that share a GPU");
         for (int i = 0; i < cfg->n_devices; i++) {
-            rsq_config c = readConfig(&cfg->base);
+            rsq_config c = readConfig(cfg->base);
             c.device = cfg->devices[i];
             m->ctxs.push_back(new Context(c));
         }

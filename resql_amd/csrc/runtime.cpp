@@ -15,6 +15,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <atomic>
@@ -65,6 +66,24 @@ Context::Context(const rsq_config& c) : cfg(c), device(c.device) {
         RSQ_HIP(hipMemset(dErr, 0, sizeof(uint32_t)));
         RSQ_HIP(hipEventCreate(&ev0));
         RSQ_HIP(hipEventCreate(&ev1));
+        driverAlloc = (c.engine_flags & RSQ_ENGINE_DRIVER_ALLOC) != 0;
+        planMemoOff = (c.engine_flags & RSQ_ENGINE_NO_PLAN_MEMO) != 0;
+        if (!driverAlloc) {
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); totalB = (size_t)64 << 30; freeB = totalB; }
+            arenaKeepBytes = c.arena_keep_bytes > 0 ? (size_t)c.arena_keep_bytes : totalB / 8;
+            const int dev = device;
+            devArena.reset(new Arena([dev](size_t b) -> void* { void* p = nullptr; (void)hipSetDevice(dev); if (hipMalloc(&p, b) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; },
+                                     [](void* p) { (void)hipFree(p); }, (size_t)256 << 20, 256));
+            pinArena.reset(new Arena([](size_t b) -> void* { void* p = nullptr; if (hipHostMalloc(&p, b, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; },
+                                     [](void* p) { (void)hipHostFree(p); }, (size_t)8 << 20, 256));
+            pinNcArena.reset(new Arena([](size_t b) -> void* { void* p = nullptr; if (hipHostMalloc(&p, b, hipHostMallocNonCoherent) != hipSuccess) { (void)hipGetLastError(); return nullptr; } return p; },
+                                       [](void* p) { (void)hipHostFree(p); }, (size_t)32 << 20, 256));
+            // the first slabs now: a query's first execution on a fresh context must not wait for the driver either
+            const size_t want = c.arena_reserve_bytes < 0 ? 0 : c.arena_reserve_bytes > 0 ? (size_t)c.arena_reserve_bytes : std::min<size_t>((size_t)2 << 30, freeB / 4);
+            devArena->reserve(want);
+            if (c.arena_reserve_bytes >= 0) { pinArena->reserve((size_t)8 << 20); pinNcArena->reserve((size_t)32 << 20); }
+        }
     }
 }
 
@@ -72,12 +91,14 @@ Context::~Context() {
     if (device >= 0) {
         (void)hipSetDevice(device);
         for (auto& kv : kernels) if (kv.second.module) (void)hipModuleUnload(kv.second.module);
-        if (dCompactChain) (void)hipFree(dCompactChain);
-        if (spareTailArena.dev) (void)hipFree(spareTailArena.dev);
-        if (spareTailArena.pinned) (void)hipHostFree(spareTailArena.pinned);
-        for (auto& e : scratchFreeList) (void)hipFree(e.first);
-        for (auto& e : scratchLive) (void)hipFree(e.first);
+        (void)hipDeviceSynchronize();
+        if (dCompactChain) free(dCompactChain);
+        if (spareTailArena.dev) free(spareTailArena.dev);
+        if (spareTailArena.pinned) freePinned(spareTailArena.pinned);
+        for (auto& e : scratchFreeList) free(e.first);
+        for (auto& e : scratchLive) free(e.first);
         if (dErr) (void)hipFree(dErr);
+        devArena.reset(); pinArena.reset(); pinNcArena.reset();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ownStream) (void)hipStreamDestroy(ownStream);
@@ -119,17 +140,100 @@ void Context::setStream(hipStream_t s, bool callers) {
     stream = callers ? s : ownStream;          // a caller's stream may be the null stream (0)
 }
 
-void* Context::alloc(size_t bytes) {
+namespace {
+struct StopWatch {
+    double& acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit StopWatch(double& a) : acc(a) {}
+    ~StopWatch() { acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
+void* Context::allocRaw(size_t bytes) {
+    allocStats.rawCalls++;
+    StopWatch sw(allocStats.rawMs);
     void* p = nullptr;
     RSQ_HIP(hipSetDevice(device));
-    RSQ_HIP(hipMalloc(&p, bytes ? bytes : 256));
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 256);
+    if (e != hipSuccess && devArena) {
+        // the arena's free slabs go back to the driver first (what is pending becomes free once the device is idle)
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        devArena->promote(); devArena->trim(0);
+        e = hipMalloc(&p, bytes ? bytes : 256);
+    }
+    RSQ_HIP(e);
     return p;
 }
-void Context::free(void* p) { if (p) (void)hipFree(p); }
+void Context::freeRaw(void* p) { if (p) { allocStats.rawCalls++; StopWatch sw(allocStats.rawMs); (void)hipFree(p); } }
+
+void Context::streamDrained() {
+    if (devArena && devArena->hasPending()) devArena->promote();
+    if (pinArena && pinArena->hasPending()) pinArena->promote();
+    if (pinNcArena && pinNcArena->hasPending()) pinNcArena->promote();
+}
+
+static void* arenaAlloc(Context& ctx, Arena& a, size_t bytes, const char* what) {
+    // ranges freed while kernels were still enqueued become reusable when the stream is idle: ask (1-2 us) before growing
+    if (a.hasPending() && hipStreamQuery(ctx.stream) == hipSuccess) ctx.streamDrained();
+    if (!a.fitsWithoutGrowing(bytes) && a.hasPending()) {      // a new slab costs more than waiting for what is in flight
+        RSQ_HIP(hipStreamSynchronize(ctx.stream));
+        ctx.streamDrained();
+    }
+    void* p = a.alloc(bytes);
+    if (!p) {
+        // the driver refused a new slab: give back what is wholly free (here and in the device arena), then once more
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        ctx.streamDrained();
+        a.trim(0);
+        if (ctx.devArena && &a != ctx.devArena.get()) ctx.devArena->trim(0);
+        p = a.alloc(bytes);
+    }
+    if (!p) throw Error(RSQ_ERR_NOMEM, std::string("out of ") + what + " memory: " + std::to_string(bytes) + " bytes asked for, " +
+                                       std::to_string(a.slabBytes()) + " held by the context's arena (" + std::to_string(a.usedBytes()) + " in use)");
+    return p;
+}
+
+void* Context::alloc(size_t bytes) {
+    if (!devArena) return allocRaw(bytes);
+    allocStats.devCalls++;
+    StopWatch sw(allocStats.devMs);
+    RSQ_HIP(hipSetDevice(device));
+    return arenaAlloc(*this, *devArena, bytes ? bytes : 256, "device");
+}
+void Context::free(void* p) {
+    if (!p) return;
+    if (devArena && devArena->free(p)) {
+        if (devArena->freeBytes() > arenaKeepBytes + ((size_t)1 << 30)) devArena->trim(arenaKeepBytes);
+        return;
+    }
+    freeRaw(p);
+}
+void* Context::allocPinned(size_t bytes, bool nonCoherent) {
+    allocStats.pinCalls++;
+    StopWatch sw(allocStats.pinMs);
+    Arena* a = nonCoherent ? pinNcArena.get() : pinArena.get();
+    if (!a) {
+        void* p = nullptr;
+        allocStats.rawCalls++;
+        StopWatch raw(allocStats.rawMs);
+        RSQ_HIP(hipHostMalloc(&p, bytes ? bytes : 8, nonCoherent ? hipHostMallocNonCoherent : hipHostMallocDefault));
+        return p;
+    }
+    return arenaAlloc(*this, *a, bytes ? bytes : 8, "pinned host");
+}
+void Context::freePinned(void* p) {
+    if (!p) return;
+    if (pinArena && pinArena->free(p)) { if (pinArena->freeBytes() > ((size_t)1 << 30)) pinArena->trim((size_t)256 << 20); return; }
+    if (pinNcArena && pinNcArena->free(p)) { if (pinNcArena->freeBytes() > ((size_t)1 << 30)) pinNcArena->trim((size_t)256 << 20); return; }
+    allocStats.rawCalls++;
+    StopWatch raw(allocStats.rawMs);
+    (void)hipHostFree(p);
+}
 
 Table::~Table() {
     if (ctx && ctx->device >= 0) {
-        for (auto& c : cols) if (c.owned && c.dptr) (void)hipFree(c.dptr);
+        for (auto& c : cols) if (c.owned && c.dptr) ctx->freeRaw(c.dptr);
     } else {
         for (auto& c : cols) if (c.owned && c.dptr) ::free(c.dptr);
     }

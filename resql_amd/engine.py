@@ -26,11 +26,14 @@ class rsq_config(C.Structure):
                 ("print_assembly", C.c_int32), ("print_flounder", C.c_int32), ("print_performance", C.c_int32),
                 ("num_threads", C.c_int32), ("emit_machine_code", C.c_int32), ("optimize", C.c_int32),
                 ("device", C.c_int32), ("kernel_cache_dir", C.c_char_p), ("emission_order", C.c_int32),
-                ("compat_flags", C.c_uint32)]
+                ("compat_flags", C.c_uint32), ("engine_flags", C.c_uint32), ("reserved0", C.c_uint32),
+                ("arena_reserve_bytes", C.c_int64), ("arena_keep_bytes", C.c_int64)]
 
     @classmethod
-    def make(cls, device: int, cache_dir=None, print_source: bool = False, emission_order: int = 0, compat_flags: int = 0):
-        return cls(C.sizeof(cls), 1 if print_source else 0, 0, 0, 1, 1, 0, device, cache_dir, emission_order, compat_flags)
+    def make(cls, device: int, cache_dir=None, print_source: bool = False, emission_order: int = 0, compat_flags: int = 0,
+             engine_flags: int = 0, arena_reserve_bytes: int = 0, arena_keep_bytes: int = 0):
+        return cls(C.sizeof(cls), 1 if print_source else 0, 0, 0, 1, 1, 0, device, cache_dir, emission_order, compat_flags,
+                   engine_flags, 0, arena_reserve_bytes, arena_keep_bytes)
 
 
 class rsq_report(C.Structure):
@@ -40,13 +43,22 @@ class rsq_report(C.Structure):
                 ("jit_cache_hits", C.c_int32), ("jit_compiles", C.c_int32)]
 
 
+class rsq_memory_stats(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("device_slab_bytes", C.c_uint64), ("device_used_bytes", C.c_uint64),
+                ("device_slab_allocs", C.c_uint64), ("pinned_slab_bytes", C.c_uint64), ("pinned_used_bytes", C.c_uint64),
+                ("pinned_slab_allocs", C.c_uint64), ("raw_driver_calls", C.c_uint64), ("arena_requests", C.c_uint64), ("driver_ms", C.c_double),
+                ("plan_memo_entries", C.c_uint64), ("plan_memo_hits", C.c_uint64)]
+
+
 class rsq_multi_config(C.Structure):
-    _fields_ = [("base", rsq_config), ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_int32), ("merge", C.c_int32)]
+    _fields_ = [("struct_size", C.c_uint32), ("n_devices", C.c_int32), ("base", C.POINTER(rsq_config)), ("devices", C.POINTER(C.c_int32)),
+                ("merge", C.c_int32), ("reserved0", C.c_int32)]
 
 
 MERGE_AUTO, MERGE_RCCL, MERGE_PEER_COPY = 0, 1, 2
 EMIT_REFERENCE, EMIT_ANY = 0, 1
 COMPAT_JIT_INT16_CAST = 1      # rsq_compat: TYPECAST INT -> BIGINT as the reference's asmjit JIT executes it (low 16 bits)
+ENGINE_DRIVER_ALLOC, ENGINE_NO_PLAN_MEMO = 1, 2      # rsq_engine_flags
 
 
 class EngineError(RuntimeError):
@@ -80,6 +92,7 @@ def lib():
         L.rsq_ctx_create.argtypes = [C.POINTER(rsq_config), C.POINTER(vp)]
         L.rsq_ctx_destroy.argtypes = [vp]
         L.rsq_last_error.restype = C.c_char_p
+        L.rsq_ctx_memory_stats.argtypes = [vp, C.POINTER(rsq_memory_stats)]
         L.rsq_last_error.argtypes = [vp]
         L.rsq_table_create.argtypes = [vp, C.POINTER(P.rsq_table_desc), C.POINTER(vp)]
         L.rsq_table_create_device.argtypes = [vp, C.POINTER(P.rsq_table_desc), C.POINTER(vp)]
@@ -91,6 +104,7 @@ def lib():
         L.rsq_table_rows.argtypes = [vp]
         L.rsq_table_read_column.argtypes = [vp, vp, C.c_char_p, vp, C.c_size_t]
         L.rsq_table_set_first_row.argtypes = [vp, i64]
+        L.rsq_table_refresh_stats.argtypes = [vp]
         L.rsq_table_stats_bytes.restype = i64
         L.rsq_table_stats_bytes.argtypes = [vp]
         L.rsq_table_stats_export.argtypes = [vp, vp, i64]
@@ -170,7 +184,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
-    "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_set_first_row", "rsq_table_read_column",
+    "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_set_first_row", "rsq_table_refresh_stats", "rsq_ctx_memory_stats", "rsq_table_read_column",
     "rsq_table_stats_bytes", "rsq_table_stats_export", "rsq_table_unify_shard_stats", "rsq_table_total_rows",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_await_kernels", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
@@ -202,12 +216,13 @@ class Context:
         return self
 
     def __init__(self, device: int = 0, cache_dir: Optional[str] = None, print_source: bool = False, emission_order: int = 0,
-                 compat_flags: int = 0):
+                 compat_flags: int = 0, engine_flags: int = 0, arena_reserve_bytes: int = 0, arena_keep_bytes: int = 0):
         """emission_order: EMIT_REFERENCE (0: rows of an unsorted aggregation in the reference's hash-table order) or EMIT_ANY;
-        compat_flags: rsq_compat bits (COMPAT_JIT_INT16_CAST)"""
+        compat_flags: rsq_compat bits (COMPAT_JIT_INT16_CAST); engine_flags: rsq_engine_flags bits (ENGINE_DRIVER_ALLOC,
+        ENGINE_NO_PLAN_MEMO); arena_*: see rsq_config"""
         self._L = lib()
         self._cache = cache_dir.encode() if cache_dir else None
-        cfg = rsq_config.make(device, self._cache, print_source, emission_order, compat_flags)
+        cfg = rsq_config.make(device, self._cache, print_source, emission_order, compat_flags, engine_flags, arena_reserve_bytes, arena_keep_bytes)
         h = C.c_void_p()
         rc = self._L.rsq_ctx_create(C.byref(cfg), C.byref(h))
         if rc != 0:
@@ -218,6 +233,13 @@ class Context:
     def _check(self, rc: int):
         if rc != 0:
             raise EngineError(rc, self._L.rsq_last_error(self.h).decode())
+
+    def memory_stats(self) -> dict:
+        """rsq_ctx_memory_stats as a dict: what the context's arenas hold, driver calls, plan-memo entries / hits"""
+        m = rsq_memory_stats()
+        m.struct_size = C.sizeof(rsq_memory_stats)
+        self._check(self._L.rsq_ctx_memory_stats(self.h, C.byref(m)))
+        return {k: getattr(m, k) for k, _ in rsq_memory_stats._fields_ if k not in ("struct_size", "reserved0")}
 
     def set_stream(self, hip_stream: Optional[int]):
         """launch on the caller's HIP stream (an integer handle, 0 = the null stream; e.g.
@@ -377,6 +399,10 @@ class DeviceTable:
     def set_row0(self, row0: int):
         """this table is rows [row0, row0 + n_rows) of a larger one (a shard); before queries are compiled over it"""
         self.ctx._check(self.ctx._L.rsq_table_set_first_row(self.h, row0))
+
+    def refresh_stats(self):
+        """gather the column statistics again (adopted columns whose content changed); compile statements anew afterwards"""
+        self.ctx._check(self.ctx._L.rsq_table_refresh_stats(self.h))
 
     @property
     def total_rows(self) -> int:
@@ -545,7 +571,8 @@ class MultiContext:
         self._L = lib()
         self._devs = (C.c_int32 * len(devices))(*devices)
         self._cache = cache_dir.encode() if cache_dir else None
-        cfg = rsq_multi_config(rsq_config.make(0, self._cache, False, emission_order, compat_flags), self._devs, len(devices), merge)
+        self._base = rsq_config.make(0, self._cache, False, emission_order, compat_flags)
+        cfg = rsq_multi_config(C.sizeof(rsq_multi_config), len(devices), C.pointer(self._base), self._devs, merge, 0)
         h = C.c_void_p()
         rc = self._L.rsq_multi_create(C.byref(cfg), C.byref(h))
         if rc != 0:
