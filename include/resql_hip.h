@@ -179,6 +179,12 @@ int  rsq_table_load_tbl(rsq_ctx* ctx, const rsq_table_desc* schema, const char* 
 int  rsq_table_generate(rsq_ctx* ctx, int32_t kind, int64_t row0, int64_t n_rows, double scale_factor,
                         int64_t param, uint64_t seed, rsq_table** out);
 int64_t rsq_table_rows(const rsq_table* t);
+/* BULK INSERT appends (executeBulkInsert adds tuples to the Relation it finds, reference src/execute.h:332-388; a Relation also grows
+ * under its AppendIterator, src/dbdata.h:246-330): the rows of `more` - same context, same column types, made by any of the functions
+ * above from the NEW tuples only - go behind the rows of `t`; `more` is consumed (destroyed) on success.  Column statistics are gathered
+ * again; statements compiled before the call still answer over the rows they were compiled for - compile anew, as a ReSQL host does per
+ * statement anyway. */
+int  rsq_table_append(rsq_table* t, rsq_table* more);
 /* A table that is a row range [row0, row0 + n_rows) of a larger one (a shard): rows are numbered from row0 wherever a row number
  * is observable — the order in which groups first occur decides the emission order of an aggregation (operators/aggregation.h:
  * 298-343 scans the hash table the groups entered in input order).  Set before queries are compiled over the table. */

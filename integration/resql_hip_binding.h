@@ -153,9 +153,9 @@ private:
 // One engine context + the device copies of the Relations it has seen.
 class JitContextHip {
 public:
-    // compat: rsq_compat bits — a host that must return exactly what ReSQL's asmjit JIT returns today passes
-    // RSQ_COMPAT_JIT_INT16_CAST; 0 computes what the reference's source specifies
-    explicit JitContextHip(const JitConfig& cfg, int device = 0, uint32_t compat = 0) {
+    // compat: rsq_compat bits.  The drop-in's default is RSQ_COMPAT_JIT_INT16_CAST: the answers ReSQL's asmjit JIT gives TODAY, bit for
+    // bit; 0 computes what the reference's source specifies (what ReSQL answers once its movsx is fixed)
+    explicit JitContextHip(const JitConfig& cfg, int device = 0, uint32_t compat = RSQ_COMPAT_JIT_INT16_CAST) {
         rsq_config c{};
         c.struct_size = sizeof c;
         c.compat_flags = compat;
@@ -167,50 +167,54 @@ public:
         report.config = cfg;
     }
     ~JitContextHip() {
-        for (auto& kv : tables_) rsq_table_destroy(kv.second);
+        for (auto& kv : tables_) rsq_table_destroy(kv.second.t);
         if (ctx_) rsq_ctx_destroy(ctx_);
     }
 
-    // Relation (row store of 2 MiB DataBlocks, dbdata.h:23-102) -> device columns, once per Relation
+    // Relation (row store of 2 MiB DataBlocks, dbdata.h:23-102) -> device columns.  A Relation grows (executeBulkInsert appends,
+    // execute.h:332-388; AppendIterator, dbdata.h:246-330) and never shrinks or rewrites: what was transposed stays valid, and a
+    // Relation that holds more tuples than its device copy gets only the NEW tuples transposed and appended (rsq_table_append) -
+    // the tail of the block that was last in use, then the blocks added since.
     rsq_table* deviceTable(Relation* rel, const std::string& name) {
         auto it = tables_.find(rel);
-        if (it != tables_.end()) return it->second;
-        std::vector<rsq_column> cols;
-        for (auto& a : rel->_schema._attribs) {
-            rsq_column c{};
-            std::strncpy(c.name, a.name.c_str(), RSQ_SYMBOL_MAX - 1);
-            c.type = toRsqType(a.type);
-            cols.push_back(c);
+        if (it == tables_.end()) {
+            Resident r;
+            r.t = fromBlocks(rel, name, 0, 0);
+            noteSynced(rel, r);
+            tables_[rel] = r;
+            return r.t;
         }
-        rsq_table_desc d{};
-        std::strncpy(d.name, name.c_str(), RSQ_SYMBOL_MAX - 1);
-        d.n_cols = (int32_t)cols.size(); d.cols = cols.data();
-        std::vector<const uint8_t*> blocks; std::vector<size_t> sizes;
-        for (auto& b : rel->_dataBlocks) { blocks.push_back(b->begin()); sizes.push_back(b->_contentSize); }
-        rsq_table* t = nullptr;
-        check(rsq_table_from_rowstore(ctx_, &d, blocks.data(), sizes.data(), (int32_t)blocks.size(), &t));
-        tables_[rel] = t;
-        return t;
+        Resident& r = it->second;
+        if (r.deviceOnly || rel->tupleNum() == r.tuples) return r.t;
+        if (rel->tupleNum() < r.tuples) throw ResqlError("Relation " + name + " holds fewer tuples than its device copy.");
+        rsq_table* more = fromBlocks(rel, name, r.blocks ? r.blocks - 1 : 0, r.blocks ? r.lastBlockBytes : 0);
+        int rc = rsq_table_append(r.t, more);
+        if (rc != RSQ_OK) { rsq_table_destroy(more); check(rc); }
+        noteSynced(rel, r);
+        return r.t;
     }
 
     // BULK INSERT (execute.h:332-388) straight into device columns: the Relation object stays the table's identity
-    // (plans scan it), its rows live on the GPU only.  Same field rules as the reference's loop (csrc/tbl.cpp).
+    // (plans scan it), its rows live on the GPU only.  Same field rules as the reference's loop (csrc/tbl.cpp).  A second
+    // BULK INSERT into the same table appends, as the reference's does.
     int64_t bulkInsert(Relation* rel, const std::string& name, const std::string& fileName, char fieldTerminator) {
-        if (tables_.count(rel)) throw ResqlError("Table " + name + " is already resident on the device.");
-        std::vector<rsq_column> cols;
-        for (auto& a : rel->_schema._attribs) {
-            rsq_column c{};
-            std::strncpy(c.name, a.name.c_str(), RSQ_SYMBOL_MAX - 1);
-            c.type = toRsqType(a.type);
-            cols.push_back(c);
-        }
+        std::vector<rsq_column> cols = columnsOf(rel);
         rsq_table_desc d{};
         std::strncpy(d.name, name.c_str(), RSQ_SYMBOL_MAX - 1);
         d.n_cols = (int32_t)cols.size(); d.cols = cols.data();
         rsq_table* t = nullptr;
         check(rsq_table_load_tbl(ctx_, &d, fileName.c_str(), fieldTerminator, 0, &t));
-        tables_[rel] = t;
-        return rsq_table_rows(t);
+        const int64_t inserted = rsq_table_rows(t);
+        auto it = tables_.find(rel);
+        if (it == tables_.end()) {
+            if (rel->tupleNum() != 0) { rsq_table_destroy(t); throw ResqlError("Table " + name + " holds host tuples: BULK INSERT onto the device needs an empty or device-resident table."); }
+            Resident r; r.t = t; r.deviceOnly = true;
+            tables_[rel] = r;
+        } else {
+            int rc = rsq_table_append(it->second.t, t);
+            if (rc != RSQ_OK) { rsq_table_destroy(t); check(rc); }
+        }
+        return inserted;
     }
 
     // describe + compile + execute + retrieve: the body of executeSelectPlan (execute.h:213-247)
@@ -253,8 +257,40 @@ public:
 
 private:
     void check(int rc) { if (rc != RSQ_OK) throw HipError(rc, rsq_last_error(ctx_)); }
+    // the device copy of a Relation and how much of the Relation it holds
+    struct Resident { rsq_table* t = nullptr; size_t tuples = 0, blocks = 0, lastBlockBytes = 0; bool deviceOnly = false; };
+    std::vector<rsq_column> columnsOf(Relation* rel) {
+        std::vector<rsq_column> cols;
+        for (auto& a : rel->_schema._attribs) {
+            rsq_column c{};
+            std::strncpy(c.name, a.name.c_str(), RSQ_SYMBOL_MAX - 1);
+            c.type = toRsqType(a.type);
+            cols.push_back(c);
+        }
+        return cols;
+    }
+    // the tuples from byte `firstOffset` of block `firstBlock` on, transposed into a new device table
+    rsq_table* fromBlocks(Relation* rel, const std::string& name, size_t firstBlock, size_t firstOffset) {
+        std::vector<rsq_column> cols = columnsOf(rel);
+        rsq_table_desc d{};
+        std::strncpy(d.name, name.c_str(), RSQ_SYMBOL_MAX - 1);
+        d.n_cols = (int32_t)cols.size(); d.cols = cols.data();
+        std::vector<const uint8_t*> blocks; std::vector<size_t> sizes;
+        for (size_t b = firstBlock; b < rel->_dataBlocks.size(); b++) {
+            const size_t off = b == firstBlock ? firstOffset : 0;
+            blocks.push_back((const uint8_t*)rel->_dataBlocks[b]->begin() + off);
+            sizes.push_back(rel->_dataBlocks[b]->_contentSize - off);
+        }
+        rsq_table* t = nullptr;
+        check(rsq_table_from_rowstore(ctx_, &d, blocks.data(), sizes.data(), (int32_t)blocks.size(), &t));
+        return t;
+    }
+    void noteSynced(Relation* rel, Resident& r) {
+        r.tuples = rel->tupleNum(); r.blocks = rel->_dataBlocks.size();
+        r.lastBlockBytes = r.blocks ? rel->_dataBlocks.back()->_contentSize : 0;
+    }
     rsq_ctx* ctx_ = nullptr;
-    std::map<Relation*, rsq_table*> tables_;
+    std::map<Relation*, Resident> tables_;
 };
 
 }  // namespace resql_hip

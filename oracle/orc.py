@@ -142,7 +142,7 @@ def write_case(plan: P.Plan, directory: str) -> str:
 
 def run_reference(plan: P.Plan, threads: int = 1, repeat: int = 1, blocksize: Optional[int] = None,
                   workdir: Optional[str] = None, quiet: bool = False, engine: str = "flounder",
-                  device: int = 0) -> Tuple[str, Dict[str, list]]:
+                  device: int = 0, grow: bool = False) -> Tuple[str, Dict[str, list]]:
     """run the UNMODIFIED reference on the plan; returns (serialised result, timings).
     engine="hip": same harness, same ReSQL plan objects, but executed through integration/resql_hip_binding.h
     (the drop-in), i.e. ReSQL's operator tree -> C ABI -> HIP engine."""
@@ -159,6 +159,8 @@ def run_reference(plan: P.Plan, threads: int = 1, repeat: int = 1, blocksize: Op
             cmd += ["--blocksize", str(blocksize)]
         if quiet:
             cmd += ["--quiet"]
+        if grow:          # run, load every table again behind its rows (BULK INSERT appends), run again: "<first>#grown\n<second>"
+            cmd += ["--grow"]
         pr = subprocess.run(cmd, capture_output=True, text=True, errors="replace")
         if pr.returncode < 0 and os.environ.get("RESQL_HARNESS_DEBUGGER"):
             dbg = os.environ["RESQL_HARNESS_DEBUGGER"].split() + cmd

@@ -472,6 +472,7 @@ int main(int argc, char** argv) {
     int threads = 1, repeat = 1; bool quiet = false; std::string outPath;
     std::string engine = "flounder"; int device = 0;
     std::string sqlTokens; bool dumpParse = false, dumpPlan = false;
+    bool grow = false; int compat = -1;
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
         if (a == "--threads") threads = atoi(argv[++i]);
@@ -484,6 +485,9 @@ int main(int argc, char** argv) {
         else if (a == "--sql-tokens") sqlTokens = argv[++i];   // plan from the reference's parser + planner instead of the case's op lines
         else if (a == "--dump-parse") dumpParse = true;
         else if (a == "--dump-plan") dumpPlan = true;
+        else if (a == "--compat") compat = atoi(argv[++i]);    // rsq_compat bits of the HIP context (default: the binding's)
+        else if (a == "--grow") grow = true;                   // run, load every table AGAIN behind its rows (BULK INSERT appends, execute.h:332-388), run again: both results
+
         else die("unknown option " + a);
     }
 
@@ -505,7 +509,7 @@ int main(int argc, char** argv) {
     if (engine == "hip") {
         JitConfig jc; jc.numThreads = threads;
         try {
-            hip = std::make_unique<resql_hip::JitContextHip>(jc, device);
+            hip = compat < 0 ? std::make_unique<resql_hip::JitContextHip>(jc, device) : std::make_unique<resql_hip::JitContextHip>(jc, device, (uint32_t)compat);
             for (auto& t : c.tables)
                 if (!t.tblPath.empty()) hip->bulkInsert(&db.relations[t.name], t.name, resolve(c, t.tblPath), '|');
         }
@@ -514,7 +518,23 @@ int main(int argc, char** argv) {
 #else
     if (engine == "hip") die("built without the HIP binding");
 #endif
+    if (grow) repeat = 2;
+    auto emit = [&](Relation& rel, std::ostream& os) {
+        os << "#schema ";
+        for (auto& a : rel._schema._attribs) os << a.name << ":" << serializeType(a.type) << "|";
+        os << "\n";
+        serializeRelation(rel, os);
+    };
     for (int rep = 0; rep < repeat; rep++) {
+        if (grow && rep == 1) {
+            if (!quiet) { emit(*result, std::cout); std::cout << "#grown\n"; }
+            for (auto& t : c.tables) loadTable(c, t, db, engine == "hip");
+#ifdef RSQ_WITH_HIP_BINDING
+            if (hip)
+                for (auto& t : c.tables)
+                    if (!t.tblPath.empty()) hip->bulkInsert(&db.relations[t.name], t.name, resolve(c, t.tblPath), '|');
+#endif
+        }
         // plans are single use (operators own iterators / hash tables): rebuild per repetition
         PlanBuilder pb{c, db, {}, {}};
         RelOperator* root = nullptr;

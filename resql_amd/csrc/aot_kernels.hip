@@ -18,20 +18,26 @@ typedef unsigned long long u64;
 // statistics
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) k_minmax(const T* __restrict__ p, i64 n, i64* out /* [min, max, descents] */) {
+__global__ void __launch_bounds__(256) k_minmax(const T* __restrict__ p, i64 n, i64* out /* [min, max, descents, repeats] */) {
     i64 mn = 0x7fffffffffffffffll, mx = (i64)0x8000000000000000ull;
     u64 desc = 0;          // rows smaller than the row before them: 0 = the column is in ascending order
+    u64 same = 0;          // rows equal to the row before them: 0 (in an ascending column) = its values are unique
     for (i64 i = blockIdx.x * (i64)blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
         i64 v = (i64)p[i];
         mn = v < mn ? v : mn; mx = v > mx ? v : mx;
-        if (i > 0 && v < (i64)p[i - 1]) desc++;
+        if (i > 0) { const i64 pv = (i64)p[i - 1]; if (v < pv) desc++; if (v == pv) same++; }
     }
     for (int m = 32; m >= 1; m >>= 1) {
         i64 a = __shfl_xor(mn, m, 64), b = __shfl_xor(mx, m, 64);
         mn = a < mn ? a : mn; mx = b > mx ? b : mx;
         desc += (u64)__shfl_xor((long long)desc, m, 64);
+        same += (u64)__shfl_xor((long long)same, m, 64);
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&out[0], mn); atomicMax(&out[1], mx); if (desc) atomicAdd(reinterpret_cast<u64*>(&out[2]), desc); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&out[0], mn); atomicMax(&out[1], mx);
+        if (desc) atomicAdd(reinterpret_cast<u64*>(&out[2]), desc);
+        if (same) atomicAdd(reinterpret_cast<u64*>(&out[3]), same);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_byteset(const unsigned char* __restrict__ p, i64 n, unsigned* out /* 8 words */) {
@@ -52,6 +58,7 @@ __global__ void __launch_bounds__(256) k_byteset(const unsigned char* __restrict
 
 static void hostStats(Table& t) {
     for (auto& c : t.cols) {
+        c.stats = ColumnStats();
         if (!c.dptr || t.nRows == 0) continue;
         int w = columnWidth(c.type);
         if (c.type.tag == RSQ_BOOL || (c.type.tag == RSQ_CHAR && c.type.len == 1)) {
@@ -64,15 +71,16 @@ static void hostStats(Table& t) {
         } else if (w == 4 || w == 8) {
             if (c.type.isString()) continue;
             int64_t mn = INT64_MAX, mx = INT64_MIN, prev = INT64_MIN;
-            bool asc = true;
+            bool asc = true, strict = true;
             for (int64_t i = 0; i < t.nRows; i++) {
                 int64_t v = (w == 8) ? ((const int64_t*)c.dptr)[i]
                           : (c.type.tag == RSQ_DATE ? (int64_t)((const uint32_t*)c.dptr)[i] : (int64_t)((const int32_t*)c.dptr)[i]);
                 mn = std::min(mn, v); mx = std::max(mx, v);
                 if (v < prev) asc = false;
+                if (i > 0 && v <= prev) strict = false;
                 prev = v;
             }
-            c.stats.min = mn; c.stats.max = mx; c.stats.valid = true; c.stats.ascending = asc;
+            c.stats.min = mn; c.stats.max = mx; c.stats.valid = true; c.stats.ascending = asc; c.stats.strictlyAscending = asc && strict;
         }
     }
 }
@@ -81,7 +89,7 @@ void computeColumnStats(Context& ctx, Table& t) {
     if (ctx.device < 0) { hostStats(t); return; }
     if (t.nRows == 0) return;
     RSQ_HIP(hipSetDevice(ctx.device));
-    i64* dmm = (i64*)ctx.alloc(3 * sizeof(i64));
+    i64* dmm = (i64*)ctx.alloc(4 * sizeof(i64));
     unsigned* dset = (unsigned*)ctx.alloc(8 * sizeof(unsigned));
     const unsigned grid = 1024;
     for (auto& c : t.cols) {
@@ -96,15 +104,15 @@ void computeColumnStats(Context& ctx, Table& t) {
             for (int v = 0; v < 256; v++) if (h[v >> 5] & (1u << (v & 31))) c.stats.distinctBytes.push_back((uint8_t)v);
             if (!c.stats.distinctBytes.empty()) { c.stats.min = c.stats.distinctBytes.front(); c.stats.max = c.stats.distinctBytes.back(); c.stats.valid = true; }
         } else if (!c.type.isString()) {
-            i64 init[3] = {0x7fffffffffffffffll, (i64)0x8000000000000000ull, 0};
-            RSQ_HIP(hipMemcpyAsync(dmm, init, 24, hipMemcpyHostToDevice, ctx.stream));
+            i64 init[4] = {0x7fffffffffffffffll, (i64)0x8000000000000000ull, 0, 0};
+            RSQ_HIP(hipMemcpyAsync(dmm, init, 32, hipMemcpyHostToDevice, ctx.stream));
             if (c.type.tag == RSQ_INT) hipLaunchKernelGGL(k_minmax<int>, dim3(grid), dim3(256), 0, ctx.stream, (const int*)c.dptr, (i64)t.nRows, dmm);
             else if (c.type.tag == RSQ_DATE) hipLaunchKernelGGL(k_minmax<unsigned>, dim3(grid), dim3(256), 0, ctx.stream, (const unsigned*)c.dptr, (i64)t.nRows, dmm);
             else hipLaunchKernelGGL(k_minmax<i64>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)c.dptr, (i64)t.nRows, dmm);
-            i64 h[3];
-            RSQ_HIP(hipMemcpyAsync(h, dmm, 24, hipMemcpyDeviceToHost, ctx.stream));
+            i64 h[4];
+            RSQ_HIP(hipMemcpyAsync(h, dmm, 32, hipMemcpyDeviceToHost, ctx.stream));
             RSQ_HIP(hipStreamSynchronize(ctx.stream));
-            c.stats.min = h[0]; c.stats.max = h[1]; c.stats.valid = true; c.stats.ascending = h[2] == 0;
+            c.stats.min = h[0]; c.stats.max = h[1]; c.stats.valid = true; c.stats.ascending = h[2] == 0; c.stats.strictlyAscending = h[2] == 0 && h[3] == 0;
         }
     }
     ctx.free(dmm); ctx.free(dset);

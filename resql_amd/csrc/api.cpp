@@ -83,7 +83,7 @@ namespace rsq {
 namespace {
 const uint64_t STATS_MAGIC = 0x3174617473717372ull;      // "rsqstat1"
 struct StatsHead { uint64_t magic; int64_t nCols, row0, nRows; };
-struct StatsCol { int32_t valid, ascending; int64_t min, max; int32_t nBytes, pad; uint8_t bytes[256]; };
+struct StatsCol { int32_t valid, ascending; int64_t min, max; int32_t nBytes, strict; uint8_t bytes[256]; };
 }  // namespace
 size_t tableStatsBytes(const Table& t) { return sizeof(StatsHead) + t.cols.size() * sizeof(StatsCol); }
 void exportTableStats(const Table& t, void* buf, size_t bytes) {
@@ -93,7 +93,7 @@ void exportTableStats(const Table& t, void* buf, size_t bytes) {
     for (size_t i = 0; i < t.cols.size(); i++) {
         const ColumnStats& st = t.shardStats(i);
         StatsCol c{};
-        c.valid = st.valid; c.ascending = st.ascending; c.min = st.min; c.max = st.max; c.nBytes = (int32_t)st.distinctBytes.size();
+        c.valid = st.valid; c.ascending = st.ascending; c.strict = st.strictlyAscending; c.min = st.min; c.max = st.max; c.nBytes = (int32_t)st.distinctBytes.size();
         for (size_t k = 0; k < st.distinctBytes.size() && k < 256; k++) c.bytes[k] = st.distinctBytes[k];
         memcpy((char*)buf + sizeof h + i * sizeof c, &c, sizeof c);
     }
@@ -116,6 +116,7 @@ void unifyShardStats(Table& t, const void* blobs, int nShards, size_t blobBytes)
             StatsCol c; memcpy(&c, b + sizeof h + i * sizeof c, sizeof c);
             if (!c.valid) { unknown[i] = true; continue; }
             if (c.nBytes < 0 || c.nBytes > 256) failInvalid("shard statistics: malformed byte-value set");
+            if (c.min > c.max) failInvalid("shard statistics: blob " + std::to_string(s) + " has min > max in column " + t.cols[i].name);
             ColumnStats& o = u[i];
             if (!any[i]) { o.min = c.min; o.max = c.max; any[i] = true; }
             else { o.min = std::min(o.min, c.min); o.max = std::max(o.max, c.max); }
@@ -125,10 +126,19 @@ void unifyShardStats(Table& t, const void* blobs, int nShards, size_t blobBytes)
     if (!mine) failInvalid("shard statistics: none of the blobs is this shard's own (rows " + std::to_string(t.row0) + " + " + std::to_string(t.nRows) + " of " + t.name + ")");
     for (size_t i = 0; i < t.cols.size(); i++) {
         ColumnStats& o = u[i];
+        // this shard's OWN statistics are folded in whatever the blobs said about it: device code trusts the union without a range check
+        // for engine-owned columns (codegen_join.cpp checkKey), so a stale or foreign blob must never narrow it below what the rows here hold
+        const ColumnStats& own = t.ownStats[i];
+        if (own.valid && t.nRows > 0) {
+            if (!any[i]) { o.min = own.min; o.max = own.max; any[i] = true; }
+            else { o.min = std::min(o.min, own.min); o.max = std::max(o.max, own.max); }
+            o.distinctBytes.insert(o.distinctBytes.end(), own.distinctBytes.begin(), own.distinctBytes.end());
+        }
         std::sort(o.distinctBytes.begin(), o.distinctBytes.end());
         o.distinctBytes.erase(std::unique(o.distinctBytes.begin(), o.distinctBytes.end()), o.distinctBytes.end());
         o.valid = any[i] && !unknown[i];
-        o.ascending = t.ownStats[i].ascending;           // (a property of this shard's own rows: it shapes kernels, never a layout)
+        o.ascending = t.ownStats[i].ascending;           // (properties of this shard's own rows: they shape kernels, never a layout)
+        o.strictlyAscending = t.ownStats[i].strictlyAscending;
         t.cols[i].stats = o;
     }
     t.nRowsTotal = total;
@@ -610,6 +620,8 @@ std::string reportText(const rsq_db& db, rsq_query* q, const rsq_report& r) {
 // concatenate `more` behind `t` (BULK INSERT appends, execute.h:332-388): new device columns, statistics recomputed
 void appendTable(Context& ctx, Table& t, Table& more) {
     if (t.cols.size() != more.cols.size()) failInvalid("append: different schemas");
+    for (size_t c = 0; c < t.cols.size(); c++)
+        if (t.cols[c].type.tag != more.cols[c].type.tag || columnWidth(t.cols[c].type) != columnWidth(more.cols[c].type)) failInvalid("append: column " + t.cols[c].name + " has another type");
     const int64_t n0 = t.nRows, n1 = more.nRows;
     for (size_t c = 0; c < t.cols.size(); c++) {
         TableColumn& a = t.cols[c]; TableColumn& b = more.cols[c];
@@ -637,6 +649,17 @@ void appendTable(Context& ctx, Table& t, Table& more) {
 }  // namespace
 
 extern "C" {
+
+int rsq_table_append(rsq_table* t, rsq_table* more) {
+    if (!t || !more || t == more) return RSQ_ERR_INVALID;
+    Table& a = *T(t); Table& b = *T(more);
+    if (!a.ctx || a.ctx != b.ctx) return RSQ_ERR_INVALID;
+    return guarded(a.ctx, [&] {
+        if (!a.ownStats.empty() || a.nRowsTotal >= 0) failInvalid("rsq_table_append: the table is a shard that plans with unified statistics");
+        appendTable(*a.ctx, a, b);
+        delete &b;
+    });
+}
 
 int rsq_db_create(rsq_ctx* ctx, rsq_db** out) {
     if (!ctx || !out) return RSQ_ERR_INVALID;

@@ -222,6 +222,7 @@ void Walker::consumeBuildBody(OpNode* o, OpNode* from) {
         const int ci = o->exprs[0]->child->tag == RSQ_E_ATTRIBUTE ? pipe.src->findCol(o->exprs[0]->child->symbol) : -1;
         ht->identityCapable = ht->rankCapable && !ht->setOnly && from->tag == RSQ_OP_SCAN && ci >= 0 && pipe.src->cols[(size_t)ci].owned &&
                               pipe.src->cols[(size_t)ci].stats.valid && pipe.src->cols[(size_t)ci].stats.ascending;
+        ht->uniqueKnown = ht->identityCapable && pipe.src->cols[(size_t)ci].stats.strictlyAscending && pipe.src->nRows < 0xffffffffll;
     }
     // (a table that may become a rank dictionary keeps its bitmap in the interleaved layout, rsq_device.h bmi_word)
     ht->bmInterleaved = ht->rankCapable;

@@ -34,6 +34,7 @@ struct ColumnStats {
     bool valid = false;
     int64_t min = 0, max = 0;                  // numeric / date columns
     bool ascending = false;                    // ... and no row is smaller than the row before it (the table is clustered by this column)
+    bool strictlyAscending = false;            // ... nor equal to it: the column's values are unique
     std::vector<uint8_t> distinctBytes;        // 1-byte columns (CHAR(1), BOOL): sorted distinct values
 };
 

@@ -592,6 +592,9 @@ void buildHashTable(Query& q, Pipeline& p) {
         h.dCompBitmap = (uint32_t*)ctx.alloc(cbWords * 4);
         RSQ_HIP(hipMemsetAsync(h.dCompBitmap, 0, cbWords * 4, ctx.stream));
     }
+    // a bare scan of a table whose key column is known to be unique (strictly ascending, engine-owned): all rows go in, each under its own
+    // key - what the sizing pass would find (TPC-H Q12 builds on all 15 M orders: the pass was a second scan of the table and a host round trip)
+    if (h.capacity == 0 && h.uniqueKnown && !h.dupKeys) sizeJoinTable(q, p, h, (uint32_t)p.src->nRows, false);
     if (h.capacity == 0) {
         // sizing pass.  For a table that could be a rank dictionary the pass also sets the key bits and notes a bit that was
         // already set (two build rows with one key): only then does the table stay a hash table.

@@ -5,10 +5,11 @@
 // for the SUM of its compiles.  The engine starts one of these helpers per kernel instead (runtime.cpp compileManyToCache): fresh
 // processes that load hiprtc, never touch a GPU, and leave their result in the code-object cache.
 //
-//   rsq_kernel_compiler <include dir> <cache dir> <key> [<key> ...]
+//   rsq_kernel_compiler <include dir> <cache dir> <arch option> <optimisation option> <language option> <key> [<key> ...]
 //
-// For every key: reads <cache dir>/<key>.hip, compiles it with the options of runtime.cpp, publishes <cache dir>/<key>.hsaco by
-// rename.  A failed compile leaves <cache dir>/<key>.err with hiprtc's log; the exit code is the number of failed keys.
+// For every key: reads <cache dir>/<key>.hip, compiles it with the three options the LIBRARY passes (they are part of the cache key the
+// library computed: a helper left over from an older build cannot publish code under a key that claims other options), publishes
+// <cache dir>/<key>.hsaco by rename.  A failed compile leaves <cache dir>/<key>.err with hiprtc's log; the exit code is the number of failed keys.
 #include <hip/hiprtc.h>
 #include <unistd.h>
 
@@ -16,8 +17,6 @@
 #include <fstream>
 #include <sstream>
 #include <string>
-
-#include "kernel_compile_options.h"
 
 static bool readFile(const std::string& path, std::string& out) {
     std::ifstream f(path, std::ios::binary);
@@ -38,16 +37,16 @@ static bool publish(const std::string& path, const std::string& bytes) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 4) { fprintf(stderr, "usage: rsq_kernel_compiler <include dir> <cache dir> <key>...\n"); return 64; }
+    if (argc < 7) { fprintf(stderr, "usage: rsq_kernel_compiler <include dir> <cache dir> <arch option> <opt option> <std option> <key>...\n"); return 64; }
     const std::string inc = std::string("-I") + argv[1], cache = argv[2];
     int failed = 0;
-    for (int i = 3; i < argc; i++) {
+    for (int i = 6; i < argc; i++) {
         const std::string base = cache + "/" + argv[i];
         std::string source;
         if (!readFile(base + ".hip", source)) { failed++; continue; }
         hiprtcProgram prog;
         if (hiprtcCreateProgram(&prog, source.c_str(), "rsq_pipeline.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) { failed++; continue; }
-        const char* opts[] = {RSQ_HIPRTC_ARCH, RSQ_HIPRTC_OPT, RSQ_HIPRTC_STD, inc.c_str()};
+        const char* opts[] = {argv[3], argv[4], argv[5], inc.c_str()};
         if (hiprtcCompileProgram(prog, 4, opts) != HIPRTC_SUCCESS) {
             size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
             std::string log(n, '\0');

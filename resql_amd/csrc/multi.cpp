@@ -331,20 +331,28 @@ int rsq_multi_query_compile(rsq_multi* m, const rsq_plan_desc* plan, rsq_table* 
         // table (union of the byte-value sets, min / max over the shards, summed row count): all of them then derive the same dense
         // group layout whatever their own rows hold, or all of them the hash aggregation where the union is not dense.  A table whose
         // instances are the same rows on every shard (a replicated build side: equal row range and statistics) is left as it is.
-        if (n > 1)
+        // (two passes: every table's blobs are made and checked first, and only then is any table changed - a schema that differs on one
+        // shard must not leave some tables unified and others not)
+        if (n > 1) {
+            auto tab = [&](int i, int t) { return reinterpret_cast<Table*>(tables[(size_t)i * (size_t)n_tables + (size_t)t]); };
+            std::vector<std::vector<char>> allBlobs((size_t)n_tables);
+            std::vector<size_t> blobBytes((size_t)n_tables, 0);
             for (int t = 0; t < n_tables; t++) {
-                auto tab = [&](int i) { return reinterpret_cast<Table*>(tables[(size_t)i * (size_t)n_tables + (size_t)t]); };
-                const size_t bb = tableStatsBytes(*tab(0));
-                std::vector<char> blobs((size_t)n * bb);
+                const size_t bb = tableStatsBytes(*tab(0, t));
+                std::vector<char>& blobs = allBlobs[(size_t)t];
+                blobs.resize((size_t)n * bb);
                 bool replicated = true;
                 for (int i = 0; i < n; i++) {
-                    if (tableStatsBytes(*tab(i)) != bb) failInvalid("table " + tab(i)->name + " has another schema on shard " + std::to_string(i));
-                    exportTableStats(*tab(i), blobs.data() + (size_t)i * bb, bb);
+                    if (tableStatsBytes(*tab(i, t)) != bb) failInvalid("table " + tab(i, t)->name + " has another schema on shard " + std::to_string(i));
+                    exportTableStats(*tab(i, t), blobs.data() + (size_t)i * bb, bb);
                     if (memcmp(blobs.data(), blobs.data() + (size_t)i * bb, bb) != 0) replicated = false;
                 }
-                if (replicated) continue;
-                for (int i = 0; i < n; i++) unifyShardStats(*tab(i), blobs.data(), n, bb);
+                blobBytes[(size_t)t] = replicated ? 0 : bb;
             }
+            for (int t = 0; t < n_tables; t++)
+                if (blobBytes[(size_t)t])
+                    for (int i = 0; i < n; i++) unifyShardStats(*tab(i, t), allBlobs[(size_t)t].data(), n, blobBytes[(size_t)t]);
+        }
         for (int i = 0; i < n; i++) mq->qs.push_back(compileQuery(*m->ctxs[(size_t)i], *plan, tables + (size_t)i * (size_t)n_tables, n_tables));
         mq->dense = queryIsDense(*mq->qs[0]);
         if (mq->dense) {

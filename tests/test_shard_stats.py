@@ -189,3 +189,46 @@ def test_two_ranks_whose_shards_miss_different_groups(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     _, _, whole = shardcases.lineitem_shards(drops=("R", "O"))
     assert open(out).read() == orc.execute(tpch.q1_plan(whole)).text
+
+
+def test_unify_never_narrows_below_the_shards_own_rows_and_refuses_inverted_ranges(compile_ctx):
+    """a shard's own statistics are folded into the union whatever the blobs say about it (device code trusts the union
+    without a range check for engine-owned columns), and a blob with min > max is refused."""
+    import struct
+    shards, row0, whole = shardcases.lineitem_shards()
+    tabs = []
+    for c, r0 in zip(shards, row0):
+        t = compile_ctx.table(shardcases.shard_table(c))
+        t.set_row0(r0)
+        tabs.append(t)
+    blobs = [bytearray(t.stats_blob()) for t in tabs]
+    head, col = 32, 4 + 4 + 8 + 8 + 4 + 4 + 256
+    names = [c.name for c in shardcases.shard_table(shards[0]).columns]
+    qi = names.index("l_quantity")
+    off = head + qi * col + 8
+    true_min, true_max = struct.unpack_from("<qq", blobs[0], off)
+    # shard 0's blob lies: a range narrower than its rows hold (a stale blob of an earlier, smaller table)
+    lying = [bytearray(b) for b in blobs]
+    struct.pack_into("<qq", lying[0], off, true_min + 5, true_max - 5)
+    tabs[0].unify_shard_stats([bytes(b) for b in lying])
+    q = compile_ctx.compile(tpch.q1_plan(SCHEMA_ONLY), [tabs[0]])
+    q.close()
+    back = tabs[0].stats_blob()          # (the export shows the shard's OWN statistics: untouched by what the blobs claimed)
+    assert struct.unpack_from("<qq", back, off) == (true_min, true_max)
+    # the union the planner sees covers the own rows: a plan grouped by l_quantity has a cell for every own value
+    from resql_amd import plan as P2
+    host = shardcases.shard_table(shards[0])
+    p = P2.Plan([host])
+    node = p.aggregation([p.count(p.star())], [p.attr("l_quantity")], p.scan(host.name))
+    node = p.projection([p.attr("l_quantity")], node)
+    q = compile_ctx.compile(p.set_root(p.materialize(node)), [tabs[0]])
+    line = [l for l in q.explain.splitlines() if l.startswith("partial table:")][0]
+    assert f"[{true_min}..{true_max}]" in line, line
+    q.close()
+    inverted = [bytearray(b) for b in blobs]
+    struct.pack_into("<qq", inverted[1], off, 10, 3)
+    with pytest.raises(engine.EngineError) as e:
+        tabs[1].unify_shard_stats([bytes(b) for b in inverted])
+    assert "min > max" in str(e.value)
+    for t in tabs:
+        t.close()
