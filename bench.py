@@ -98,6 +98,12 @@ def parse_args(argv=None):
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the group-by merge (nccl = RCCL over xGMI; gloo only with --no-gpu)")
     ap.add_argument("--no-gpu", action="store_true", help="dry mode, see the module docstring")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal of N > 1 on a ONE-GPU box: the N rank processes all drive device 0 (own context, own row-range shard, real "
+                         "kernels), the partial tables are staged through host memory and merged over gloo (RCCL cannot hold one device twice)")
+    ap.add_argument("--workload", choices=["q1", "q3"], default="q1",
+                    help="q3 (with --share-gpu or under a launcher): TPC-H Q3 with replicated build sides, lineitem sharded on an l_orderkey "
+                         "boundary, every rank's own top 10 merged by the sort keys (resql_amd/dist.py merge_ordered_results)")
     return ap.parse_args(argv)
 
 
@@ -583,6 +589,90 @@ def config_extras(ctx, sf10_table, sf: float):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# --workload q3: joins + many groups across ranks (resql_amd/dist.py): replicated build sides, lineitem cut on an
+# l_orderkey boundary, the whole plan per rank, ONE all-gather of every rank's 10 rows merged by the sort keys
+# ------------------------------------------------------------------------------------------------------------------
+def run_q3_sharded(args, dist, world: int, rank: int, local_rank: int, device) -> int:
+    import torch
+    from resql_amd import datagen, engine, tpch
+    from resql_amd.dist import merge_ordered_results, shard_rows_on_key
+    share = bool(args.share_gpu)
+    sf = args.sf
+    nL, nO, nC = datagen.n_lineitem(sf), datagen.n_orders(sf), datagen.n_customer(sf)
+    # the cut needs the clustering key around the equal-shard boundaries only: a window of rows there is generated on the host
+    per = (nL // (128 * world)) * 128
+    def key_at_factory():
+        cache = {}
+        def key_at(i):
+            base = (i // 4096) * 4096
+            if base not in cache:
+                cache[base] = datagen.lineitem_columns(base, min(4096, nL - base), sf, columns={"l_orderkey"})["l_orderkey"]
+            return int(cache[base][i - base])
+        return key_at
+    row0, n_rows = shard_rows_on_key(nL, world, rank, key_at_factory())
+    ctx = engine.Context(device=local_rank)
+    li = ctx.generate(engine.GEN_LINEITEM, n_rows, sf, row0=row0, param=1)
+    od = ctx.generate(engine.GEN_ORDERS, nO, sf)
+    cu = ctx.generate(engine.GEN_CUSTOMER, nC, sf)
+    plan = tpch.q3_plan(tpch.customer_table(0.001), tpch.orders_table(0.001), tpch.lineitem_table(0.001, tpch.Q3_LINEITEM_COLUMNS, n_rows=0))
+    q = ctx.compile(plan, [cu, od, li])
+    q.await_kernels()
+    cdev = None if (share or dist is None) else device
+    order = [("revenue", False), ("o_orderdate", True)]
+
+    def step():
+        q.execute()
+        return merge_ordered_results(dist if world > 1 else None, q.result(text=False), order, 10, world, cdev)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        merged = step()
+    fence()
+    q.kernel_time_stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        merged = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ksum, kn = q.kernel_time_stats()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if share else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    per_kernel = gather_per_rank(dist, world, ksum / max(1, kn), None if share else device)
+    rows_per = gather_per_rank(dist, world, float(n_rows), None if share else device)
+    rc = 0
+    if rank == 0:
+        want = _golden_text(f"q3_sf{sf:g}")
+        out = {"metric": "TPC-H Q3 rows/s", "value": (nL + nO + nC) * args.steps / elapsed, "unit": "rows/s (lineitem + orders + customer rows of the whole job)",
+               "n_gpus": 1 if share else world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+               "config": {"workload": f"TPC-H Q3 at SF{sf:g}: customer {nC} and orders {nO} replicated on every rank, lineitem {nL} rows cut at l_orderkey "
+                                      f"boundaries into {world} shard(s); every rank runs the whole plan, one all-gather of 10 rows per rank, merged by (revenue desc, o_orderdate)",
+                          "ranks": world, "share_gpu": share, "lineitem_rows_per_rank": [int(v) for v in rows_per],
+                          "backend": "none" if dist is None else ("gloo over host memory (--share-gpu)" if share else dist.get_backend() + " (RCCL)"),
+                          "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
+                          "phases": {"kernel_ms_per_rank": per_kernel}},
+               "parity_checked": (merged.text == want) if want is not None else None,
+               "parity_source": f"tests/golden/ref_full_q3_sf{sf:g}.tbl (the unmodified reference's answer on the unsharded tables)" if want is not None else None}
+        if want is not None and merged.text != want:
+            print(f"bench.py: the merged Q3 answer differs from the reference's:\n{merged.text}\nvs\n{want}", file=sys.stderr)
+            rc = 4
+        print(json.dumps(out), flush=True)
+    q.close()
+    for t in (li, od, cu):
+        t.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else list(argv)
     args = parse_args(argv)
@@ -606,6 +696,9 @@ def main(argv=None) -> int:
     import torch
     from resql_amd import datagen, engine, tpch
 
+    share = bool(args.share_gpu)
+    if share:
+        local_rank = 0                                    # every rank process drives the one GPU
     dist = None
     if world > 1 or args.dist_path:
         import datetime
@@ -615,11 +708,16 @@ def main(argv=None) -> int:
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
+        if share:      # RCCL refuses two ranks on one device: the exchange goes through host memory and gloo, and the line says so
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", local_rank if world > 1 else 0)
+    if args.workload == "q3":
+        return run_q3_sharded(args, dist, world, rank, local_rank, device)
 
     # ---- data: this rank's row range of the SF table, generated in HBM ----
     from resql_amd.dist import PartialMerger, shard_rows
@@ -630,7 +728,7 @@ def main(argv=None) -> int:
     # every rank plans its shard as the WHOLE table (union of the shards' column statistics, summed row count): one dense group
     # layout on all ranks whatever their rows hold — the reference has one hash table all workers reach (aggregation.h:240-295)
     from resql_amd.dist import unify_shard_stats
-    unify_shard_stats(dist if world > 1 else None, table, world, device)
+    unify_shard_stats(dist if world > 1 else None, table, world, None if share else device)
     schema_only = tpch.lineitem_table(0.001, tpch.Q1_COLUMNS, n_rows=0)
     q = ctx.compile(tpch.q1_plan(schema_only), [table])
     q.await_kernels()          # the measured path is the specialised kernel, never the generic pipeline a cold cache starts on
@@ -642,9 +740,10 @@ def main(argv=None) -> int:
     multi = dist is not None
     merger = None
     ranks_seen = 1
+    cdev = torch.device("cpu") if share else device      # where the collectives' tensors live (gloo: host memory)
     if multi:
         # how many ranks the collectives of this run really span: one word of ones, all-reduced over RCCL
-        ones = torch.ones(1, dtype=torch.int64, device=device)
+        ones = torch.ones(1, dtype=torch.int64, device=cdev)
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
     if multi and world > 1:
@@ -659,13 +758,25 @@ def main(argv=None) -> int:
         # single host synchronisation (inside finalize) per step on rank 0 and none on the other ranks
         torch.cuda.set_stream(torch.cuda.Stream(device))       # not the null stream: it serialises against every blocking stream
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        merger = PartialMerger(dist, partial, n_min, n_max, n_sum, world, always_collective=args.dist_path, query=q)
+        if share:
+            staged = torch.empty(words, dtype=torch.int64).pin_memory()      # host staging of the partial table (gloo moves host memory)
+            merger = PartialMerger(dist, staged, n_min, n_max, n_sum, world, always_collective=args.dist_path, query=None)
+        else:
+            merger = PartialMerger(dist, partial, n_min, n_max, n_sum, world, always_collective=args.dist_path, query=q)
 
     def step():
         if not multi:
             q.execute()
             return
         q.execute_partial_async()                     # enqueue: identity image -> kernel(s)
+        if share:
+            staged.copy_(partial, non_blocking=True)  # D2H behind the kernel, then the host-side exchange
+            torch.cuda.current_stream().synchronize()
+            merger.merge()
+            if rank == 0:
+                partial.copy_(staged, non_blocking=True)
+                q.finalize()
+            return
         merger.merge()                                # the one exchange step of the path
         if rank == 0:
             q.finalize()                              # D2H of the merged table, sync, AVG / projection / ORDER BY
@@ -691,14 +802,19 @@ def main(argv=None) -> int:
     ksum, kn = q.kernel_time_stats()
     avg_kernel_ms = ksum / max(1, kn)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     _mark(f"timed region done: {elapsed / args.steps * 1e3:.4f} ms per step")
     # ---- where a multi-rank step's time goes: a second, UNTIMED loop of the same steps with an event pair around the merge ----
     phases = None
-    if multi:
+    if multi and share:
+        phases = {"kernel_ms_per_rank": gather_per_rank(dist, world, avg_kernel_ms, None),
+                  "note": "two rank processes share ONE GPU: their kernels run side by side or one after the other as the hardware queues "
+                          "decide, and the exchange is a D2H copy, a gloo all-gather in host memory and an H2D copy - a rehearsal of the code "
+                          "path, not a measurement of xGMI"}
+    if multi and not share:
         probe = max(1, min(args.steps, 20))
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(probe)]
         fin_ms = 0.0
@@ -729,7 +845,7 @@ def main(argv=None) -> int:
     # ---- the weak-scaling extra runs on every rank (its collectives need all of them), after the headline measurement ----
     weak = None
     weak_error = None
-    if not args.no_extras:
+    if not args.no_extras and not share:
         try:
             # (--dist-path takes the multi-rank step here too, with a process group of one: partial execution, merge collective, finalize)
             weak = weak_scaling_extra(args, ctx, dist if (dist is not None and (world > 1 or args.dist_path)) else None, world, rank, device)
@@ -761,9 +877,11 @@ def main(argv=None) -> int:
                   "rows": n_total, "rows_per_gpu": n_rows, "result_groups": result.n_rows, "path": "dist",
                   "world_size": dist.get_world_size() if dist is not None else 1,
                   "rccl_ranks_seen": ranks_seen,
-                  "backend": (dist.get_backend() + " (RCCL)") if dist is not None else "none (single process, single GPU)",
+                  "backend": ("gloo over host memory (--share-gpu: the rank processes share GPU 0, RCCL cannot hold a device twice)" if share else
+                              (dist.get_backend() + " (RCCL)")) if dist is not None else "none (single process, single GPU)",
+                  "share_gpu": share, "ranks": world,
                   "self_launched": os.environ.get("RSQ_BENCH_SELF_LAUNCHED") == "1",
-                  "parallelism": f"row-range shards x{world}, group-by merge over RCCL: {merger.strategy}"
+                  "parallelism": (f"row-range shards x{world}, group-by merge " + ("staged through host memory over gloo" if share else "over RCCL") + f": {merger.strategy}")
                   if multi else "single GPU"}
         if phases is not None:
             config["phases"] = phases
@@ -776,7 +894,7 @@ def main(argv=None) -> int:
             "metric": "TPC-H Q1 rows/s at SF10",
             "value": n_total * args.steps / elapsed,
             "unit": "rows/s",
-            "n_gpus": world,
+            "n_gpus": 1 if share else world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
