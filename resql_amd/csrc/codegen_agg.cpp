@@ -158,6 +158,7 @@ void Walker::emitHashAggregation(OpNode* o) {
     // value as before.
     std::vector<bool> carried(o->exprs2.size(), false);
     std::string fdCond;                      // run-time condition of the dependencies ("" = they always hold)
+    std::vector<int> condTablesOfFd;         // ... the tables that must be rank dictionaries for it
     if (1) {
         std::set<std::string> groupSyms, determined;
         for (Expr* g : o->exprs2) if (g->tag == RSQ_E_ATTRIBUTE) groupSyms.insert(g->symbol);
@@ -200,6 +201,7 @@ void Walker::emitHashAggregation(OpNode* o) {
         }
         if (kept == 0) std::fill(carried.begin(), carried.end(), false);      // (cannot happen: a chain of dependencies ends in a kept value)
         for (int t : condTables) fdCond += (fdCond.empty() ? "" : " && ") + std::string("a.ht") + std::to_string(t) + "_rank != 0";
+        condTablesOfFd.assign(condTables.begin(), condTables.end());
     }
     bool anyCarried = false;
     for (bool c : carried) anyCarried = anyCarried || c;
@@ -298,6 +300,15 @@ void Walker::emitHashAggregation(OpNode* o) {
         // certain (a table of the chain is in its hash form), by every lane for the full comparison
         int nCarriedWords = 0;
         for (auto& c : carriedVals) nCarriedWords += c.nWords;
+        // (strings by address: RSQ_GROUP_VALUES_BY_ADDRESS=0 copies them into the entries as before)
+        const bool byAddress = nCarriedWords > 0 && envInt("RSQ_GROUP_VALUES_BY_ADDRESS", 1, 0, 1) != 0;
+        if (byAddress) {
+            ht->derefCodes.assign((size_t)NWtab, 0);
+            for (auto& c : carriedVals)
+                if (c.g->type.isString() && c.firstWord < 256 && c.g->type.len < 4096)
+                    for (int w = 0; w < c.nWords; w++) ht->derefCodes[(size_t)(c.firstWord + w)] = entryDerefCode(c.firstWord, 8 * w, std::min(8, c.g->type.len - 8 * w));
+            ht->derefCondTables = condTablesOfFd;
+        }
         if (nCarriedWords) {
             line("const bool " + T + "_fd = " + (fdCond.empty() ? std::string("true") : fdCond) + ";");
 
@@ -319,9 +330,17 @@ void Walker::emitHashAggregation(OpNode* o) {
             // rows are gathered by the next kernel -, so they are PLAIN stores: the compiler merges neighbouring words into 16-byte
             // stores and nothing waits for a write-through to be acknowledged word by word.  Agent-scope stores only in the full form,
             // where other lanes compare them.  TPC-H Q10 at SF10 (380 K new groups of 31 carried words): the pipeline 559 -> 419 us.
+            // ... and a STRING among them is not copied at all then: its address goes into the value's first word (the bytes stay in the
+            // column they came from, immutable while the query runs), and the kernels that make group rows for the host rebuild the words
+            // for the rows they deliver (aot_kernels.hip table_word, HashTable::derefCodes) - TPC-H Q10 at SF10 creates 380 K groups of which
+            // the statement wants 20: 31 words gathered from five strings and stored per new group were 100 of the pipeline's 320 us.
             auto storeCarried = [&](bool plain, const std::string& tag) {
                 for (size_t ci = 0; ci < carriedVals.size(); ci++) {
                     const Carried& c = carriedVals[ci];
+                    if (plain && byAddress && c.g->type.isString()) {
+                        line(aggWord(c.firstWord) + " = (i64)(u64)(" + c.var + ").p;");
+                        continue;
+                    }
                     openScope("{");
                     std::vector<std::string> words = keyWords(c.g, T + "_n" + tag + std::to_string(ci), false);
                     for (int w = 0; w < c.nWords; w++)

@@ -167,6 +167,7 @@ Query::~Query() {
         if (h->dCount) ctx.free(h->dCount);
         if (h->dBitmap) ctx.free(h->dBitmap);
         if (h->dCompBitmap) ctx.free(h->dCompBitmap);
+        if (h->dDeref) ctx.free(h->dDeref);
         if (h->dTemp) ctx.free(h->dTemp);
         if (h->dTempUsed) ctx.free(h->dTempUsed);
         if (h->dChunkTotal) ctx.free(h->dChunkTotal);
@@ -456,6 +457,10 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         for (auto& p : q->pipelines) if (p.partitioned) prepareStageBuffers(*q, p);
         for (auto& h : q->hashTables) {
             h->dCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
+            if (!h->derefCodes.empty()) {           // (string group values kept by address: what the row-making kernels rebuild, aot_kernels.hip table_word)
+                h->dDeref = (int*)ctx.alloc(h->derefCodes.size() * sizeof(int));
+                RSQ_HIP(hipMemcpyAsync(h->dDeref, h->derefCodes.data(), h->derefCodes.size() * sizeof(int), hipMemcpyHostToDevice, ctx.stream));
+            }
         }
         if (q->aggMode == AggMode::AT_JOIN_ENTRY || q->aggMode == AggMode::HASH) q->dGroupCount = (uint32_t*)ctx.alloc(sizeof(uint32_t));
         q->dPipeStats = (uint64_t*)ctx.alloc(std::max<size_t>(1, q->pipelines.size()) * 8);
@@ -973,14 +978,22 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
             q.dNarrowRows = (int64_t*)ctx.alloc((size_t)groupRowsAllocated * 16);
             q.narrowRowsCap = groupRowsAllocated;
         }
+        // string group values that stand in the entries by address (this execution's kernels wrote them so: not the interpreter's, and only
+        // while every table of the dependency chain is a rank dictionary - the kernel's own run-time condition, codegen_agg.cpp)
+        const int* deref = nullptr;
+        if (h.dDeref && !interp) {
+            bool holds = true;
+            for (int t : h.derefCondTables) holds = holds && q.hashTables[(size_t)t]->rank;
+            if (holds) deref = h.dDeref;
+        }
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
                        narrowRows ? q.dNarrowRows : q.dGroupRows, groupRowsAllocated, q.dGroupCount,
                        h.rank,
-                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr, narrowRows);
+                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr, narrowRows, deref);
         q.report.num_kernels++;
         if (narrowRows) {
             topkRange = true;
-            const TableEntries te{(const int64_t*)h.dAcc, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks, h.rank};
+            const TableEntries te{(const int64_t*)h.dAcc, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks, h.rank, deref};
             selectTopCandidatesRangePublish(ctx, q.dNarrowRows, 2, 1, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated,
                                             q.topkWant, q.dTopkHists, q.dHostCandRows, topkCapacity, q.dPinnedDev + words, selectSeq = ++q.finSeqCounter, ctx.dErr, q.dGroupCount,
                                             anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size(), &te);

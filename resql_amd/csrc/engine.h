@@ -226,9 +226,14 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
                     int keyWord = -1, bool keyIs32 = false, bool keyDesc = false, uint64_t* imageRange = nullptr,
                     // narrow: rows of TWO words [slot | word `keyWord` of the packed row] instead (wide rows of which an ORDER BY ... LIMIT
                     // wants a few: selectTopCandidatesRangePublish fetches those from the table, TableEntries)
-                    bool narrow = false);
+                    bool narrow = false,
+                    // deref (device memory, nWords ints, or null): table words that are rebuilt from a string kept by address (entryDerefCode)
+                    const int* deref = nullptr);
+// word w of a table entry = bytes [off, off + len) of the string whose address stands in table word src (len 1..8)
+inline int entryDerefCode(int src, int off, int len) { return (int)(0x40000000u | ((unsigned)src << 16) | ((unsigned)off << 4) | (unsigned)len); }
 struct TableEntries {
     const int64_t* firstRow; int64_t capacity; const int64_t* words; int nWords; bool wordsAos; const int64_t* acc; int nAcc; bool unmix;
+    const int* deref = nullptr;
 };
 // ORDER BY ... LIMIT pre-selection: the rows of `rows` ([*nRows][stride] words) whose word `keyWord` is among the `want`
 // leading values of the requested order (ties of the last one included) are copied to `cand`.  `scratch` (topkHistBytes() bytes)

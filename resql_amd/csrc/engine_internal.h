@@ -90,6 +90,12 @@ struct HashTable {
     uint32_t* dChunkTotal = nullptr; // [chunks]
     uint32_t* dChunkBase = nullptr;  // [chunks + 1]
     int64_t bmBlocks = 0;            // 32-byte blocks the bitmap is allocated in (256 bits, or 224 bits + the rank word)
+    // hash aggregation whose string group values are functions of its key: while the dependencies hold (every table of derefCondTables is a
+    // rank dictionary in this execution) the kernel stores the string's ADDRESS in the value's first word and nothing else; the kernels
+    // that make group rows rebuild the words (aot_kernels.hip table_word).  derefCodes[w]: engine.h entryDerefCode, 0 = the word itself.
+    std::vector<int> derefCodes;
+    std::vector<int> derefCondTables;
+    int* dDeref = nullptr;
     int64_t buildRows = -1;          // build rows and duplicate keys as the sizing pass saw them (what the plan memo keeps)
     bool dupKeys = false;
     bool prepared = false;           // this execution's first fill launch has readied the table (engine.cpp: the prologue); buildHashTable then skips its own

@@ -35,6 +35,7 @@ KNOBS = [
     ("RSQ_GENERIC2", "0", ("joins",)),                   # no whole-pipeline interpreter: joins wait for their kernels
     ("RSQ_COMPILE_HELPERS", "0", ("joins",)),            # kernels compiled in process, one after the other
     ("RSQ_DEVICE_TOPK", "0", ("topk", "q3")),
+    ("RSQ_GROUP_VALUES_BY_ADDRESS", "0", ("topk",)),     # string group values that depend on the key are copied into the entries (what a chain in its hash form falls back to)
     ("RSQ_DEVICE_TAIL", "0", ("dense_large",)),
     ("RSQ_DEVICE_REPLAY", "0", ("dense_large",)),
     ("RSQ_TAIL_THREADS", "1", ("dense_large", "q3")),    # (read once per process: only checks that the setting is accepted when it is the first)

@@ -4,6 +4,7 @@
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$1; ONLY=${2:-q10}
+case "$OUT" in /*) ;; *) OUT="$ROOT/$OUT" ;; esac
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
