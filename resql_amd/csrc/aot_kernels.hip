@@ -445,16 +445,19 @@ __device__ inline u64 rank_unmix(u64 x, u64 cap) {
 // where the words of a table entry live (the packed group row [first row | table words | accumulator blocks] read in place)
 struct EntrySource {
     const i64* first; i64 cap; const i64* words; int nWords; int wordsAos; const i64* acc; int nAcc; int unmix;
-    const int* deref;        // per table word: 0 = the word itself, else engine.h entryDerefCode (string group values kept by address)
+    const int* deref;        // per table word of the ROW: 0 = the word itself, else engine.h entryDerefCode / entryPlainCode (group values kept by address)
+    int tabStride;           // words between two entries of `words` (the row's nWords unless the entries keep one word per carried value)
 };
 // Table word w of entry e.  A hash aggregation whose string group values are functions of its key (TPC-H Q10: name, address, phone,
 // comment, nation behind c_custkey) keeps their ADDRESS in the value's first word instead of copying 31 words into every new group
 // (codegen_agg.cpp); whoever makes group rows for the host rebuilds the words here, for the rows that are really delivered.
-__device__ __forceinline__ i64 table_word(const i64* __restrict__ words, int nWords, int aos, i64 cap, i64 e, int w, const int* __restrict__ deref) {
+__device__ __forceinline__ i64 table_word(const i64* __restrict__ words, int stride, int aos, i64 cap, i64 e, int w, const int* __restrict__ deref) {
     const int d = deref ? deref[w] : 0;
-    if (d == 0) return aos ? words[(size_t)e * nWords + w] : words[(size_t)w * cap + e];
+    if (d == 0) return aos ? words[(size_t)e * stride + w] : words[(size_t)w * cap + e];
     const int src = (d >> 16) & 0xff, off = (d >> 4) & 0xfff, len = d & 0xf;
-    const char* p = reinterpret_cast<const char*>((uintptr_t)(aos ? words[(size_t)e * nWords + src] : words[(size_t)src * cap + e])) + off;
+    const i64 sw = aos ? words[(size_t)e * stride + src] : words[(size_t)src * cap + e];
+    if (!(d & 0x40000000)) return sw;          // (entryPlainCode: the value itself, at another word number)
+    const char* p = reinterpret_cast<const char*>((uintptr_t)sw) + off;
     u64 v = 0;
     if (len == 8) __builtin_memcpy(&v, p, 8);
     else for (int i = 0; i < len; i++) v |= (u64)(unsigned char)p[i] << (8 * i);
@@ -462,7 +465,7 @@ __device__ __forceinline__ i64 table_word(const i64* __restrict__ words, int nWo
 }
 __device__ __forceinline__ i64 entry_word(const EntrySource& es, i64 s, i64 e, int k) {
     if (k == 0) return es.first[s];
-    if (k - 1 < es.nWords) return !es.words ? s : table_word(es.words, es.nWords, es.wordsAos, es.cap, e, k - 1, es.deref);
+    if (k - 1 < es.nWords) return !es.words ? s : table_word(es.words, es.tabStride, es.wordsAos, es.cap, e, k - 1, es.deref);
     return es.acc[(size_t)(k - 1 - es.nWords) * es.cap + s];
 }
 
@@ -471,7 +474,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                                                          int wordsAos, const i64* __restrict__ acc, int nAcc, i64* __restrict__ out,
                                                          unsigned maxRows, unsigned* count, int unmix, int keyWord, int keyIs32, int keyDesc,
                                                          u64* __restrict__ imageRange, u64* __restrict__ chain, unsigned launchNo, int narrow,
-                                                         const int* __restrict__ deref) {
+                                                         const int* __restrict__ deref, int tabStride) {
     const int stride = 1 + nWords + nAcc;
     u64 imgMax = 0, imgMaxInv = 0;      // range of the sort-key images of the rows written (keyWord >= 0): max(u), max(~u)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
             if (narrow) {
                 // rows [slot | sort key] only: the candidate selection reads the keys and fetches the few rows it takes from the table itself
                 // (k_topk_range_select).  TPC-H Q10 at SF10: 380 K groups of 40 words, 20 of them wanted - 108 us of row copies.
-                const EntrySource es{first, cap, words, nWords, wordsAos, acc, nAcc, unmix, deref};
+                const EntrySource es{first, cap, words, nWords, wordsAos, acc, nAcc, unmix, deref, tabStride};
                 for (unsigned i = (unsigned)t; i < total; i += 256u) {
                     const unsigned pos = base + i;
                     if (pos >= maxRows) continue;
@@ -592,7 +595,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                             v[r][k] = 0;
                             if (!ok[r]) continue;
                             if (k == 0) v[r][k] = first[s];
-                            else if (k - 1 < nWords) v[r][k] = !words ? s : table_word(words, nWords, wordsAos, cap, e, k - 1, deref);
+                            else if (k - 1 < nWords) v[r][k] = !words ? s : table_word(words, tabStride, wordsAos, cap, e, k - 1, deref);
                             else if (k < stride) v[r][k] = acc[(size_t)(k - 1 - nWords) * cap + s];
                         }
                     }
@@ -631,7 +634,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                                 v[r][j] = 0;
                                 if (k >= stride || !ok[r]) continue;
                                 if (k == 0) v[r][j] = first[s2[r]];
-                                else if (k - 1 < nWords) v[r][j] = !words ? s2[r] : table_word(words, nWords, wordsAos, cap, e2[r], k - 1, deref);
+                                else if (k - 1 < nWords) v[r][j] = !words ? s2[r] : table_word(words, tabStride, wordsAos, cap, e2[r], k - 1, deref);
                                 else v[r][j] = acc[(size_t)(k - 1 - nWords) * cap + s2[r]];
                             }
 #pragma unroll
@@ -669,7 +672,8 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
 
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix, int keyWord, bool keyIs32,
-                    bool keyDesc, uint64_t* imageRange, bool narrow, const int* deref) {
+                    bool keyDesc, uint64_t* imageRange, bool narrow, const int* deref, int tabStride) {
+    if (tabStride <= 0) tabStride = nWords;
     if (narrow && (!imageRange || keyWord < 0)) throw Error(RSQ_ERR_DEVICE, "compactEntries: narrow rows carry the sort key");
     // slots per thread: every chunk costs one reservation atomic on the same word (they serialise), so large tables take
     // large chunks; swept on the box for a 4 M-slot table: 16 -> 26 us, 32 -> 22 us, 64 -> 19 us.  (Row positions by look-back through
@@ -684,7 +688,7 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
     u64* chain = nullptr;
     unsigned launchNo = 0;
 #define RSQ_LAUNCH_COMPACT(PT) hipLaunchKernelGGL(k_compact_entries<PT>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, \
-                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0, imageRange ? keyWord : -1, keyIs32 ? 1 : 0, keyDesc ? 1 : 0, (u64*)imageRange, chain, launchNo, narrow ? 1 : 0, deref)
+                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0, imageRange ? keyWord : -1, keyIs32 ? 1 : 0, keyDesc ? 1 : 0, (u64*)imageRange, chain, launchNo, narrow ? 1 : 0, deref, tabStride)
     if (perThread >= 64) RSQ_LAUNCH_COMPACT(64); else if (perThread >= 32) RSQ_LAUNCH_COMPACT(32); else RSQ_LAUNCH_COMPACT(16);
 #undef RSQ_LAUNCH_COMPACT
     RSQ_HIP(hipGetLastError());
@@ -1041,7 +1045,7 @@ void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stri
     if (entries) {
         if (stride != 2 || keyWord != 1) throw Error(RSQ_ERR_DEVICE, "selectTopCandidatesRangePublish: narrow rows are [slot | key]");
         es = EntrySource{(const i64*)entries->firstRow, (i64)entries->capacity, (const i64*)entries->words, entries->nWords, entries->wordsAos ? 1 : 0,
-                         (const i64*)entries->acc, entries->nAcc, entries->unmix ? 1 : 0, entries->deref};
+                         (const i64*)entries->acc, entries->nAcc, entries->unmix ? 1 : 0, entries->deref, entries->tabStride > 0 ? entries->tabStride : entries->nWords};
         fullStride = 1 + entries->nWords + entries->nAcc;
     }
     // (the grid must be on the chip as a whole: at most one workgroup per CU)

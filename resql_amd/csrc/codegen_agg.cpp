@@ -244,7 +244,13 @@ void Walker::emitHashAggregation(OpNode* o) {
     for (auto& c : carriedVals) NWtab += c.nWords;
     ht->aos = NWtab > 1 && 1 != 0;
     const bool aggAos = ht->aos;
-    auto aggWord = [&, NWtab, aggAos](int w) {
+    // ... and while the group values that depend on the key stand in the entries by address (below), an entry is its key words and ONE word
+    // per carried value: the kernel then addresses the table with that stride (T_nw; TPC-H Q10: 7 words instead of 32 - the million slots
+    // the groups spread over are 56 MB, not 268), and with the full stride when a table of the dependency chain fell back to its hash form
+    const int NWc = K + (int)carriedVals.size();
+    const bool compactLayout = aggAos && NWc < NWtab && !carriedVals.empty() && envInt("RSQ_GROUP_VALUES_BY_ADDRESS", 1, 0, 1) != 0;
+    auto aggWord = [&, NWtab, aggAos, compactLayout](int w) {
+        if (aggAos && compactLayout) return "a." + T + "_words[" + T + "_s * " + T + "_nw + " + std::to_string(w) + "]";
         return aggAos ? "a." + T + "_words[" + T + "_s * " + std::to_string(NWtab) + " + " + std::to_string(w) + "]"
                       : "a." + T + "_words[" + std::to_string(w) + " * a." + T + "_cap + " + T + "_s]";
     };
@@ -301,16 +307,24 @@ void Walker::emitHashAggregation(OpNode* o) {
         int nCarriedWords = 0;
         for (auto& c : carriedVals) nCarriedWords += c.nWords;
         // (strings by address: RSQ_GROUP_VALUES_BY_ADDRESS=0 copies them into the entries as before)
-        const bool byAddress = nCarriedWords > 0 && envInt("RSQ_GROUP_VALUES_BY_ADDRESS", 1, 0, 1) != 0;
+        bool byAddress = nCarriedWords > 0 && envInt("RSQ_GROUP_VALUES_BY_ADDRESS", 1, 0, 1) != 0;
+        for (auto& c : carriedVals) if (c.g->type.isString() && (NWtab > 255 || c.g->type.len >= 4096)) byAddress = false;      // (what entryDerefCode can say)
         if (byAddress) {
+            // row word w of the table part of a group row <- where it stands in the entry (engine.h entryDerefCode / entryPlainCode; 0: word w itself)
             ht->derefCodes.assign((size_t)NWtab, 0);
-            for (auto& c : carriedVals)
-                if (c.g->type.isString() && c.firstWord < 256 && c.g->type.len < 4096)
-                    for (int w = 0; w < c.nWords; w++) ht->derefCodes[(size_t)(c.firstWord + w)] = entryDerefCode(c.firstWord, 8 * w, std::min(8, c.g->type.len - 8 * w));
+            for (size_t ci = 0; ci < carriedVals.size(); ci++) {
+                const Carried& c = carriedVals[ci];
+                const int src = compactLayout ? K + (int)ci : c.firstWord;
+                for (int w = 0; w < c.nWords; w++)
+                    ht->derefCodes[(size_t)(c.firstWord + w)] = c.g->type.isString() ? entryDerefCode(src, 8 * w, std::min(8, c.g->type.len - 8 * w))
+                                                                                       : (src != c.firstWord + w ? entryPlainCode(src) : 0);
+            }
             ht->derefCondTables = condTablesOfFd;
+            ht->compactStride = compactLayout ? NWc : NWtab;
         }
         if (nCarriedWords) {
             line("const bool " + T + "_fd = " + (fdCond.empty() ? std::string("true") : fdCond) + ";");
+            if (compactLayout) line("const u64 " + T + "_nw = " + (byAddress ? T + "_fd ? " + std::to_string(NWc) + "ull : " : std::string()) + std::to_string(NWtab) + "ull;");
 
         }
         line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0; bool " + T + "_found = false;");
@@ -337,9 +351,16 @@ void Walker::emitHashAggregation(OpNode* o) {
             auto storeCarried = [&](bool plain, const std::string& tag) {
                 for (size_t ci = 0; ci < carriedVals.size(); ci++) {
                     const Carried& c = carriedVals[ci];
-                    if (plain && byAddress && c.g->type.isString()) {
-                        line(aggWord(c.firstWord) + " = (i64)(u64)(" + c.var + ").p;");
-                        continue;
+                    if (plain && byAddress) {
+                        const int dst = compactLayout ? K + (int)ci : c.firstWord;
+                        if (c.g->type.isString()) { line(aggWord(dst) + " = (i64)(u64)(" + c.var + ").p;"); continue; }
+                        if (compactLayout) {
+                            openScope("{");
+                            std::vector<std::string> one = keyWords(c.g, T + "_n" + tag + std::to_string(ci), false);
+                            line(aggWord(dst) + " = " + one[0] + ";");
+                            closeScope();
+                            continue;
+                        }
                     }
                     openScope("{");
                     std::vector<std::string> words = keyWords(c.g, T + "_n" + tag + std::to_string(ci), false);

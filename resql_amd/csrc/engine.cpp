@@ -981,19 +981,20 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
         // string group values that stand in the entries by address (this execution's kernels wrote them so: not the interpreter's, and only
         // while every table of the dependency chain is a rank dictionary - the kernel's own run-time condition, codegen_agg.cpp)
         const int* deref = nullptr;
+        int tabStride = nTab;
         if (h.dDeref && !interp) {
             bool holds = true;
             for (int t : h.derefCondTables) holds = holds && q.hashTables[(size_t)t]->rank;
-            if (holds) deref = h.dDeref;
+            if (holds) { deref = h.dDeref; tabStride = h.compactStride > 0 ? h.compactStride : nTab; }
         }
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
                        narrowRows ? q.dNarrowRows : q.dGroupRows, groupRowsAllocated, q.dGroupCount,
                        h.rank,
-                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr, narrowRows, deref);
+                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr, narrowRows, deref, tabStride);
         q.report.num_kernels++;
         if (narrowRows) {
             topkRange = true;
-            const TableEntries te{(const int64_t*)h.dAcc, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks, h.rank, deref};
+            const TableEntries te{(const int64_t*)h.dAcc, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks, h.rank, deref, tabStride};
             selectTopCandidatesRangePublish(ctx, q.dNarrowRows, 2, 1, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated,
                                             q.topkWant, q.dTopkHists, q.dHostCandRows, topkCapacity, q.dPinnedDev + words, selectSeq = ++q.finSeqCounter, ctx.dErr, q.dGroupCount,
                                             anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size(), &te);

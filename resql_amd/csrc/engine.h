@@ -228,12 +228,15 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
                     // wants a few: selectTopCandidatesRangePublish fetches those from the table, TableEntries)
                     bool narrow = false,
                     // deref (device memory, nWords ints, or null): table words that are rebuilt from a string kept by address (entryDerefCode)
-                    const int* deref = nullptr);
+                    const int* deref = nullptr, int tabStride = 0);
 // word w of a table entry = bytes [off, off + len) of the string whose address stands in table word src (len 1..8)
 inline int entryDerefCode(int src, int off, int len) { return (int)(0x40000000u | ((unsigned)src << 16) | ((unsigned)off << 4) | (unsigned)len); }
+// ... or simply table word src (entries that keep one word per carried value: the row's word numbers are not the entry's)
+inline int entryPlainCode(int src) { return (int)(0x20000000u | ((unsigned)src << 16)); }
 struct TableEntries {
     const int64_t* firstRow; int64_t capacity; const int64_t* words; int nWords; bool wordsAos; const int64_t* acc; int nAcc; bool unmix;
     const int* deref = nullptr;
+    int tabStride = 0;       // words between the entries of `words` (0: nWords)
 };
 // ORDER BY ... LIMIT pre-selection: the rows of `rows` ([*nRows][stride] words) whose word `keyWord` is among the `want`
 // leading values of the requested order (ties of the last one included) are copied to `cand`.  `scratch` (topkHistBytes() bytes)
