@@ -487,7 +487,13 @@ def weak_scaling_extra(args, ctx, dist, world: int, rank: int, device, steps: in
             out.append({"groups": groups, "selectivity": 0.10, "rows_per_gpu": rows, "rows": total_rows, "ms_per_step": ms,
                         "rows_per_s": total_rows / (ms * 1e-3), "result_groups": res.n_rows,
                         "algorithmic_gbps": total_rows * 32 / (ms * 1e-3) / 1e9,
-                        "frac_of_peak_end_to_end": total_rows * 32 / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world),
+                        # ALGORITHMIC bytes (32 B/row) over the whole step against N x 8 TB/s.  At 10 % selectivity the late-load form skips most
+                        # lines of c and d, so this can exceed what the bytes really fetched allow: it is a throughput figure, not a roofline
+                        # fraction - traffic_frac (FETCH_SIZE of the committed --pmc pass over the kernel time) is, where a pass exists
+                        "algorithmic_frac": total_rows * 32 / (ms * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world),
+                        "traffic_frac": None,
+                        "traffic_note": "late loads apply (a < tau at 10 %): see profiles/*_late_loads_pmc.json for the fetched-bytes fraction of the 1 % case; "
+                                        "no --pmc pass is committed for this selectivity",
                         "kernel_ms_per_rank": kms, "merge": merger.strategy if merger is not None else "single GPU",
                         "partial_table_words": n_min + n_max + n_sum})
         q.close()

@@ -397,6 +397,10 @@ void Context::compileToCache(const std::string& source) {
 
 Kernel& Context::getKernel(const std::string& source, const std::string& entry) {
     const std::string key = cacheKey(source);
+    // (the build lists the keys it resolves so that it can remove the code objects of older kernel texts afterwards: __graft_entry__.py)
+    if (const char* usedLog = getenv("RSQ_KCACHE_USED_LOG")) {
+        if (FILE* f = fopen(usedLog, "a")) { fprintf(f, "%s\n", key.c_str()); fclose(f); }
+    }
     auto it = kernels.find(key);
     if (it != kernels.end()) { jitCacheHits++; return it->second; }      // (loaded by an earlier query of this context: a cache hit in the report, like one from disk)
 
