@@ -212,47 +212,56 @@ static void prepareDenseBuffers(Query& q) {
     }
 }
 
-// every kernel source a query's execution may need right away (lazily chosen forms are compiled when first chosen)
-static std::vector<std::string> kernelSources(const Query& q) {
+// every kernel source a query's execution may need right away (lazily chosen forms are compiled when first chosen).
+// quick: the tier a statement with a cold code-object cache runs on first - the pipelines that have a stage 2 with RSQ_STAGE2_CALL
+// (stage 2 a real call instead of inlined at every drain site: a third of the compile time, 40-65 % slower to run; codegen_loop.cpp)
+std::string tierSource(const Pipeline& p, const std::string& source, bool quick) {
+    return quick && p.hasStage2 ? "#define RSQ_STAGE2_CALL 1\n" + source : source;
+}
+static std::vector<std::string> kernelSources(const Query& q, bool quick = false) {
     std::vector<std::string> v;
     for (auto& p : q.pipelines) {
-        if (!p.sourcePass1.empty()) v.push_back(p.sourcePass1);
-        if (!p.sourceFlat.empty()) v.push_back(p.sourceFlat);
-        if (p.partitioned) { v.push_back(p.sourcePartCount); v.push_back(p.sourcePartScatter); v.push_back(p.sourcePartAgg); }
-        if (p.staged) { v.push_back(p.sourceStagedScatter); v.push_back(p.sourceStagedAgg); }
-        v.push_back(p.source);
-        if (!p.sourceLazy.empty()) v.push_back(p.sourceLazy);      // (chosen at run time; compiled with the others so that choosing it never blocks an execution)
+        auto T = [&](const std::string& s) { return tierSource(p, s, quick); };
+        if (!p.sourcePass1.empty()) v.push_back(T(p.sourcePass1));
+        if (!p.sourceFlat.empty()) v.push_back(T(p.sourceFlat));
+        if (p.partitioned) { v.push_back(T(p.sourcePartCount)); v.push_back(T(p.sourcePartScatter)); v.push_back(p.sourcePartAgg); }
+        if (p.staged) { v.push_back(T(p.sourceStagedScatter)); v.push_back(p.sourceStagedAgg); }
+        v.push_back(T(p.source));
+        if (!p.sourceLazy.empty()) v.push_back(T(p.sourceLazy));      // (chosen at run time; compiled with the others so that choosing it never blocks an execution)
         // ... and so is the 64-slot front table of a hash aggregation that turns out to have a handful of groups (engine_pipelines.cpp
         // fewGroupsKernel): compiled when first wanted it cost TPC-H Q12's second query 0.57 s of hiprtc in the middle of an execution
         if (p.ldsSlots > 64 && q.aggMode == AggMode::HASH && p.sink == SinkKind::AGGREGATE && q.aggTable >= 0) {
-            v.push_back("#define RSQ_LC_SLOTS 64\n" + p.source);
-            if (!p.sourceLazy.empty()) v.push_back("#define RSQ_LC_SLOTS 64\n" + p.sourceLazy);
+            v.push_back(T("#define RSQ_LC_SLOTS 64\n" + p.source));
+            if (!p.sourceLazy.empty()) v.push_back(T("#define RSQ_LC_SLOTS 64\n" + p.sourceLazy));
         }
     }
     return v;
 }
-static void resolveKernels(Query& q) {
+static void resolveKernels(Query& q, bool quick = false) {
     Context& ctx = q.ctx;
     // (compiling a query's kernels on one host thread each was tried: hiprtc serialises internally, TPC-H Q3's three kernels took
     // 548 ms in parallel against 448 ms one after the other.  What is not in the cache is therefore compiled in helper PROCESSES
     // first, all at once - runtime.cpp compileManyToCache - and the loop below finds it there)
-    ctx.compileManyToCache(kernelSources(q));
+    ctx.compileManyToCache(kernelSources(q, quick));
+    q.quickTier = quick;
     for (auto& p : q.pipelines) {
-        if (!p.sourcePass1.empty()) p.kernelPass1 = &ctx.getKernel(p.sourcePass1, p.entry);
-        if (!p.sourceFlat.empty()) p.kernelFlat = &ctx.getKernel(p.sourceFlat, p.entry);
+        auto T = [&](const std::string& s) { return tierSource(p, s, quick); };
+        p.fewGroupKernels.clear();                // (kernels of the other tier)
+        if (!p.sourcePass1.empty()) p.kernelPass1 = &ctx.getKernel(T(p.sourcePass1), p.entry);
+        if (!p.sourceFlat.empty()) p.kernelFlat = &ctx.getKernel(T(p.sourceFlat), p.entry);
         if (p.partitioned) {
-            p.kernelPartCount = &ctx.getKernel(p.sourcePartCount, p.entry);
-            p.kernelPartScatter = &ctx.getKernel(p.sourcePartScatter, p.entry);
+            p.kernelPartCount = &ctx.getKernel(T(p.sourcePartCount), p.entry);
+            p.kernelPartScatter = &ctx.getKernel(T(p.sourcePartScatter), p.entry);
             p.kernelPartAgg = &ctx.getKernel(p.sourcePartAgg, "rsq_part_agg");
         }
         if (p.staged) {
-            p.kernelStagedScatter = &ctx.getKernel(p.sourceStagedScatter, p.entry);
+            p.kernelStagedScatter = &ctx.getKernel(T(p.sourceStagedScatter), p.entry);
             p.kernelStagedAgg = &ctx.getKernel(p.sourceStagedAgg, "rsq_staged_agg");
         }
-        p.kernel = &ctx.getKernel(p.source, p.entry);
+        p.kernel = &ctx.getKernel(T(p.source), p.entry);
         // both forms are loaded now: the first execution that chooses the late-load form must not read and load a code object
         // (TPC-H Q3 at SF10: 0.86 ms for the execution that first chose it, 0.32 ms after)
-        if (!p.sourceLazy.empty()) p.kernelLazy = &ctx.getKernel(p.sourceLazy, p.entry);
+        if (!p.sourceLazy.empty()) p.kernelLazy = &ctx.getKernel(T(p.sourceLazy), p.entry);
         if (ctx.device < 0 && p.ldsSlots > 64 && q.aggMode == AggMode::HASH && p.sink == SinkKind::AGGREGATE && q.aggTable >= 0) {      // build(): the few-groups forms too
             (void)ctx.getKernel("#define RSQ_LC_SLOTS 64\n" + p.source, p.entry);
             if (!p.sourceLazy.empty()) (void)ctx.getKernel("#define RSQ_LC_SLOTS 64\n" + p.sourceLazy, p.entry);
@@ -417,10 +426,18 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
             if (!cached) {
                 (void)ctx.cacheKey("");            // fills the header text the compiler thread reads
                 const std::vector<std::string> sources = kernelSources(*q);
+                // ... in two tiers where a pipeline has a stage 2: the quick tier's kernels first (ready in a third of the time: the
+                // executions leave the interpreter for them), then the full ones (the executions move on to those when they are ready)
+                bool twoTiers = false;
+                for (auto& p : q->pipelines) twoTiers = twoTiers || p.hasStage2;
+                const std::vector<std::string> quick = twoTiers ? kernelSources(*q, true) : std::vector<std::string>();
                 Query* qp = q.get();
                 q->bgState = 1;
-                q->bgCompiler = std::thread([qp, sources] {
-                    try { qp->ctx.compileManyToCache(sources); qp->bgState = 2; }      // (one helper process per kernel: hiprtc serialises inside a process)
+                q->bgCompiler = std::thread([qp, sources, quick] {
+                    try {
+                        if (!quick.empty()) { qp->ctx.compileManyToCache(quick); qp->bgState = 2; }
+                        qp->ctx.compileManyToCache(sources); qp->bgState = 4;      // (one helper process per kernel: hiprtc serialises inside a process)
+                    }
                     catch (const std::exception& e) { qp->bgError = e.what(); qp->bgState = 3; }
                 });
             }
@@ -491,13 +508,15 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
 
 // blocks until the query runs on its specialised kernels (joins the compiler thread of a query that started on the generic pipeline)
 void awaitKernels(Query& q) {
-    if (!q.genericActive || q.genericForced) return;
+    if ((!q.genericActive && !q.quickTier) || q.genericForced) return;
     if (q.bgCompiler.joinable()) q.bgCompiler.join();
     if (q.bgState.load() == 3) throw Error(RSQ_ERR_DEVICE, q.bgError);
+    const bool wasGeneric = q.genericActive;
     resolveKernels(q);
     q.genericActive = false;
-    if (q.generic2) leaveGeneric2(q);
-    applyPlanMemo(q);
+    if (wasGeneric && q.generic2) leaveGeneric2(q);
+    if (wasGeneric) applyPlanMemo(q);
+    q.explainText += "kernel tier: full (awaited)\n";
     q.report.jit_compiles = (int32_t)kernelSources(q).size();
 }
 
@@ -567,12 +586,22 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
     double t0 = nowMs();
     const size_t words = q.pinnedWords;
     q.report.num_kernels = 0; q.report.bytes_read = 0;
+    if (!q.genericActive && q.quickTier && q.bgState.load() >= 3) {
+        // the full kernels are in the cache now: the quick tier's are replaced (same arguments, same tables - nothing else changes).
+        // (A full tier that failed to compile leaves the query on the quick one.)
+        const int st = q.bgState.load();
+        if (q.bgCompiler.joinable()) q.bgCompiler.join();
+        if (st == 4) { resolveKernels(q); q.explainText += "kernel tier: full\n"; }
+        else q.bgState = 0;
+    }
     if (q.genericActive) {
         if (!q.genericForced && q.bgState.load() >= 2) {
             // the specialised kernels are in the code-object cache now (or their compilation failed): switch over
-            if (q.bgCompiler.joinable()) q.bgCompiler.join();
-            if (q.bgState.load() == 3) throw Error(RSQ_ERR_DEVICE, q.bgError);
-            resolveKernels(q);
+            const int st = q.bgState.load();
+            if (st != 2 && q.bgCompiler.joinable()) q.bgCompiler.join();      // (2: the thread is still compiling the full tier)
+            if (st == 3) throw Error(RSQ_ERR_DEVICE, q.bgError);
+            resolveKernels(q, st == 2);
+            q.explainText += st == 2 ? "kernel tier: quick (stage 2 called) until the inlined kernels are ready\n" : "kernel tier: full\n";
             q.genericActive = false;
             if (q.generic2) leaveGeneric2(q);
             applyPlanMemo(q);

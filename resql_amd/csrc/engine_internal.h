@@ -224,6 +224,7 @@ struct Pipeline {
     std::vector<ArgSlot> args;
     Kernel* kernel = nullptr;
     int64_t bytesPerRow = 0;
+    bool hasStage2 = false;          // its kernel text has a stage 2 that RSQ_STAGE2_CALL turns into a real call (the quick tier of a cold compile)
     bool compact = false;            // wave-level selection compaction (codegen.cpp compactThen): carried 8-byte values
     int compactWords = 0;
     int compactWordsLazy = 0;        // ... in the late-load form (its queues are smaller)
@@ -423,7 +424,8 @@ struct Query {
     std::vector<bool> savedAos;            // the join tables' own layout flags while the interpreter's (words[slot][w]) are in force
     uint32_t* dG2Cnt = nullptr; uint64_t* dG2Offs = nullptr; void* dG2ScanTemp = nullptr; int64_t g2CntRows = 0;
     std::thread bgCompiler;                // builds the specialised kernels into the code-object cache
-    std::atomic<int> bgState{0};           // 0 none, 1 running, 2 done, 3 failed
+    std::atomic<int> bgState{0};           // 0 none, 1 running, 2 the quick tier is in the cache (the full one still compiling), 3 failed, 4 done
+    bool quickTier = false;                // the pipelines run on the quick tier's kernels (stage 2 called, not inlined)
     std::string bgError;
     bool pendingAsync = false;             // rsq_query_execute_partial_async enqueued a step; finalize accounts for it
     bool chainedIndexOff = false;          // the one-launch rank index timed out once on this query: two launches from then on
@@ -483,6 +485,7 @@ void prepareStageBuffers(Query& q, const Pipeline& p);
 bool runStagedAggregation(Query& q, Pipeline& p, const std::vector<uint64_t>& estimate, bool tentative = false);
 void runLargeDenseAggregation(Query& q, Pipeline& p);
 void materializePipeline(Query& q, Pipeline& p);
+std::string tierSource(const Pipeline& p, const std::string& source, bool quick);
 void buildHashTable(Query& q, Pipeline& p);
 void sizeJoinTable(Query& q, Pipeline& p, HashTable& h, uint32_t n, bool dupKeys);
 void checkDeviceError(uint32_t err);

@@ -176,7 +176,7 @@ Kernel* fewGroupsKernel(Query& q, Pipeline& p, const std::string& source, const 
     if (h.lastCount == 0 || h.lastCount > 16) return nullptr;
     if (residentWorkgroupsPerCU(large, p.blockThreads) >= 3) return nullptr;
     auto it = p.fewGroupKernels.find(form);
-    if (it == p.fewGroupKernels.end()) it = p.fewGroupKernels.emplace(form, &q.ctx.getKernel("#define RSQ_LC_SLOTS 64\n" + source, p.entry)).first;
+    if (it == p.fewGroupKernels.end()) it = p.fewGroupKernels.emplace(form, &q.ctx.getKernel(tierSource(p, "#define RSQ_LC_SLOTS 64\n" + source, q.quickTier), p.entry)).first;
     return it->second;
 }
 unsigned fewGroupsGrid(Query& q, Pipeline& p, Kernel* k) {

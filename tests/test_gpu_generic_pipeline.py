@@ -274,3 +274,61 @@ def test_unseen_join_statement_answers_cold_in_milliseconds(tmp_path, name):
             t.close()
     finally:
         ctx.close(); warm.close()
+
+
+@pytest.mark.parametrize("name", ["q5", "q10"])
+def test_cold_join_statement_moves_through_both_kernel_tiers(tmp_path, name):
+    """an EMPTY code-object cache: the statement answers from the interpreter at once, moves to the QUICK tier's kernels (stage 2 a real
+    call: a third of the hiprtc time) as soon as they are in the cache, and on to the inlined kernels when those are ready — the same bytes
+    at every stage.  (The reference compiles in 0.6-3 ms, JitContextFlounder.h:410-456; here the tiers bound how long a new statement
+    shape runs slowly.)"""
+    from resql_amd import tpch_full
+    import os
+    ctx = engine.Context(device=0, cache_dir=str(tmp_path))
+    warm = engine.Context(device=0)
+    try:
+        db = tpch_full.database(1.0, fill_unused=False)
+        host = [db[k] for k in sorted(db)]
+        tabs = [ctx.table(t) for t in host]
+        wtabs = [warm.table(t) for t in host]
+        sql = tpch_full.QUERIES[name]
+        os.environ["RSQ_GENERIC"] = "0"
+        wq = warm.sql_compile(sql, wtabs); wq.execute(); want = wq.result().text; wq.close()
+        os.environ["RSQ_GENERIC"] = "1"
+        t0 = time.perf_counter()
+        q = ctx.sql_compile(sql, tabs)
+        seen, when = [], {}
+        deadline = time.time() + 120
+        while time.time() < deadline:
+            q.execute()
+            assert q.result().text == want
+            ex = q.explain
+            tier = "full" if "kernel tier: full" in ex else "quick" if "kernel tier: quick" in ex else "interpreter"
+            if not seen or seen[-1] != tier:
+                seen.append(tier)
+                when[tier] = time.perf_counter() - t0
+            if tier == "full":
+                break
+            time.sleep(0.01)
+        print(f"{name}: tiers {seen}, reached after " + ", ".join(f"{k} {v * 1e3:.0f} ms" for k, v in when.items()))
+        assert seen[0] == "interpreter" and seen[-1] == "full", seen
+        assert "quick" in seen, seen                        # (these statements have a stage 2: the quick tier exists and is ready first)
+        for _ in range(2):
+            q.execute()
+            assert q.result().text == want
+        q.close()
+        # ... and a query that is awaited on its quick tier ends on the full kernels too
+        ctx2 = engine.Context(device=0, cache_dir=str(tmp_path / "second"))
+        t2 = [ctx2.table(t) for t in host]
+        q2 = ctx2.sql_compile(sql, t2)
+        q2.execute()
+        q2.await_kernels()
+        assert "kernel tier: full" in q2.explain
+        q2.execute()
+        assert q2.result().text == want
+        q2.close()
+        for t in tabs + wtabs + t2:
+            t.close()
+        ctx2.close()
+    finally:
+        ctx.close(); warm.close()
