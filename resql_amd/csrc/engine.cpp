@@ -434,11 +434,20 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
                 Query* qp = q.get();
                 q->bgState = 1;
                 q->bgCompiler = std::thread([qp, sources, quick] {
+                    // (one helper process per kernel: hiprtc serialises inside a process.  Both tiers' helpers start together - the quick
+                    // tier is ready after its own slowest kernel, not after the full tier's)
+                    std::string fullError;
+                    std::thread full([&] {
+                        try { qp->ctx.compileManyToCache(sources); }
+                        catch (const std::exception& e) { fullError = e.what(); if (fullError.empty()) fullError = "kernel compilation failed"; }
+                    });
                     try {
                         if (!quick.empty()) { qp->ctx.compileManyToCache(quick); qp->bgState = 2; }
-                        qp->ctx.compileManyToCache(sources); qp->bgState = 4;      // (one helper process per kernel: hiprtc serialises inside a process)
+                        full.join();
+                        if (!fullError.empty()) throw Error(RSQ_ERR_DEVICE, fullError);
+                        qp->bgState = 4;
                     }
-                    catch (const std::exception& e) { qp->bgError = e.what(); qp->bgState = 3; }
+                    catch (const std::exception& e) { if (full.joinable()) full.join(); qp->bgError = e.what(); qp->bgState = 3; }
                 });
             }
         }
