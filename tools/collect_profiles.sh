@@ -58,6 +58,9 @@ PY
 step "compile latency with the kernels compiled in process, and at SF10 with the interpreter's execution time beside the specialised one"
 RSQ_GENERIC=1 RSQ_COMPILE_HELPERS=0 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_in_process.jsonl"
 RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 10 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_sf10.jsonl"
+step "an empty code-object cache: interpreter -> quick tier -> full kernels, per statement (SF1 and SF10)"
+RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/tier_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_kernel_tiers_sf1.jsonl"
+RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/tier_latency.py" 10 --only q3,q5,q10,q12,q19 2>/dev/null | grep '^{' > "$OUT/${R}_kernel_tiers_sf10.jsonl"
 step "group rows of a hash aggregation: the tail on the device against the host's"
 timeout -k 10 200 python3 "$ROOT/tools/hash_tail_bench.py" > "$OUT/${R}_hash_tail_device_vs_host.txt" 2>/dev/null
 timeout -k 10 200 python3 "$ROOT/tools/hash_tail_bench.py" 100000000 262144 >> "$OUT/${R}_hash_tail_device_vs_host.txt" 2>/dev/null
@@ -111,6 +114,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 f=$(found /tmp/prof_sql '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_sql_sf10_kernel_stats.csv"
 step "compile latency, cold and warm (empty code-object cache)"
 RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency.jsonl"
+step "compile -> ONE execution -> delete, per statement: first-ever, fresh queries (plan memo + arenas), steady; and the same with both switched off"
+timeout -k 10 300 python3 "$ROOT/tools/first_exec.py" 10 2>/dev/null | grep -E '^\{|^# \{' > "$OUT/${R}_first_exec_sf10.jsonl"
+timeout -k 10 300 python3 "$ROOT/tools/first_exec.py" 10 --driver-alloc --no-memo 2>/dev/null | grep -E '^\{|^# \{' > "$OUT/${R}_first_exec_sf10_driver_alloc_no_memo.jsonl"
+step "what 5 GB of line stores cost beside a 40 GB streaming read (the staged partitioning's write side, DESIGN §4)"
+if hipcc -O3 --offload-arch=gfx950 -o /tmp/store_rate "$ROOT/tools/exp/store_rate.hip" 2>/dev/null; then timeout -k 10 200 /tmp/store_rate > "$OUT/${R}_store_rate.txt" 2>&1; fi
+step "two rank PROCESSES on this one GPU (bench.py --gpus 2 --share-gpu): Q1 at SF10, and TPC-H Q3 with key-aligned shards"
+timeout -k 10 300 python3 "$ROOT/bench.py" --gpus 2 --share-gpu --no-cpu-baseline --no-extras --steps 20 2>/dev/null | grep '^{' > "$OUT/${R}_bench_share_gpu_2ranks.json"
+timeout -k 10 300 python3 "$ROOT/bench.py" --gpus 2 --share-gpu --workload q3 --sf 10 --steps 10 --warmup 2 2>/dev/null | grep '^{' > "$OUT/${R}_bench_share_gpu_q3_2ranks.json"
 step "the same Q1 step through the C ABI's one-process path: 8 shards on this one GPU"
 timeout -k 10 200 python3 "$ROOT/bench.py" --path capi --capi-devices 0,0,0,0,0,0,0,0 --steps 20 2>/dev/null | grep '^{' > "$OUT/${R}_bench_capi_8shards_1gpu.json"
 ls -la "$OUT" | tail -n 20
