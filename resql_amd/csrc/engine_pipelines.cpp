@@ -59,6 +59,7 @@ uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTa
         if (f == "c_bm") return (uint64_t)(uintptr_t)h.dCompBitmap;
         if (f == "rank") return h.rank ? 1ull : 0ull;
         if (f == "ident") return h.identity ? 1ull : 0ull;
+        if (f == "dense") return h.dense ? 1ull : 0ull;
         if (f == "temp") return (uint64_t)(uintptr_t)h.dTemp;
         if (f == "treg") return (uint64_t)h.tempRegion;
         if (f == "tused") return (uint64_t)(uintptr_t)h.dTempUsed;
@@ -546,6 +547,8 @@ void sizeJoinTable(Query& q, Pipeline& p, HashTable& h, uint32_t n, bool dupKeys
     // entries that sit in one cache line either way - TPC-H Q5's region and nation tables)
     h.rank = h.rankCapable && !dupKeys && (n > 1024 || h.setOnly);
     h.identity = h.rank && h.identityCapable && (int64_t)n == p.src->nRows && n > 0;
+    // ... and every value of the key range occurs (as many entries as the range has values, all keys different): rank(key) = key - min
+    h.dense = h.identity && !h.setOnly && (int64_t)n == h.bmBits;
     if (h.rank && h.setOnly) {
         h.capacity = std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);          // (nothing is allocated: the bitmap is the table)
     } else if (h.rank) {
