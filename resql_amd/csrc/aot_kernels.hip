@@ -447,8 +447,6 @@ struct EntrySource {
     const i64* first; i64 cap; const i64* words; int nWords; int wordsAos; const i64* acc; int nAcc; int unmix;
     const int* deref;        // per table word of the ROW: 0 = the word itself, else engine.h entryDerefCode / entryPlainCode (group values kept by address)
     int tabStride;           // words between two entries of `words` (the row's nWords unless the entries keep one word per carried value)
-    const unsigned* state;   // accumulators IN the entries (hash aggregation, codegen_agg.cpp accInEntry): slot s is a group iff state[s] == 2,
-    int accOff;              // ... and its accumulator word b is word accOff + b of the entry (first = word accOff + 0); state == null: blocks
 };
 // Table word w of entry e.  A hash aggregation whose string group values are functions of its key (TPC-H Q10: name, address, phone,
 // comment, nation behind c_custkey) keeps their ADDRESS in the value's first word instead of copying 31 words into every new group
@@ -466,11 +464,6 @@ __device__ __forceinline__ i64 table_word(const i64* __restrict__ words, int str
     return (i64)v;
 }
 __device__ __forceinline__ i64 entry_word(const EntrySource& es, i64 s, i64 e, int k) {
-    if (es.state) {
-        if (k == 0) return es.words[(size_t)e * es.tabStride + es.accOff];
-        if (k - 1 < es.nWords) return table_word(es.words, es.tabStride, 1, es.cap, e, k - 1, es.deref);
-        return es.words[(size_t)e * es.tabStride + es.accOff + (k - 1 - es.nWords)];
-    }
     if (k == 0) return es.first[s];
     if (k - 1 < es.nWords) return !es.words ? s : table_word(es.words, es.tabStride, es.wordsAos, es.cap, e, k - 1, es.deref);
     return es.acc[(size_t)(k - 1 - es.nWords) * es.cap + s];
@@ -481,9 +474,8 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                                                          int wordsAos, const i64* __restrict__ acc, int nAcc, i64* __restrict__ out,
                                                          unsigned maxRows, unsigned* count, int unmix, int keyWord, int keyIs32, int keyDesc,
                                                          u64* __restrict__ imageRange, u64* __restrict__ chain, unsigned launchNo, int narrow,
-                                                         const int* __restrict__ deref, int tabStride, const unsigned* __restrict__ state, int accOff) {
+                                                         const int* __restrict__ deref, int tabStride) {
     const int stride = 1 + nWords + nAcc;
-    const EntrySource esAll{first, cap, words, nWords, wordsAos, acc, nAcc, unmix, deref, tabStride, state, accOff};
     u64 imgMax = 0, imgMaxInv = 0;      // range of the sort-key images of the rows written (keyWord >= 0): max(u), max(~u)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     __shared__ unsigned s_wave[4];
@@ -496,7 +488,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
 #pragma unroll
         for (int r = 0; r < COMPACT_PER_THREAD; r++) {
             const i64 s = lo + r * 256 + t;
-            f[r] = s >= cap ? 0x7fffffffffffffffll : state ? (state[s] == 2u ? 0ll : 0x7fffffffffffffffll) : first[s];      // (only "is a group" is read from it)
+            f[r] = s < cap ? first[s] : 0x7fffffffffffffffll;
             mine += f[r] != 0x7fffffffffffffffll ? 1u : 0u;
         }
         // exclusive prefix of `mine` over the workgroup: wave scan (shuffles), then the four wave totals
@@ -569,7 +561,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
             if (narrow) {
                 // rows [slot | sort key] only: the candidate selection reads the keys and fetches the few rows it takes from the table itself
                 // (k_topk_range_select).  TPC-H Q10 at SF10: 380 K groups of 40 words, 20 of them wanted - 108 us of row copies.
-                const EntrySource& es = esAll;
+                const EntrySource es{first, cap, words, nWords, wordsAos, acc, nAcc, unmix, deref, tabStride};
                 for (unsigned i = (unsigned)t; i < total; i += 256u) {
                     const unsigned pos = base + i;
                     if (pos >= maxRows) continue;
@@ -602,8 +594,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                         for (int k = 0; k < 8; k++) {
                             v[r][k] = 0;
                             if (!ok[r]) continue;
-                            if (state) { if (k < stride) v[r][k] = entry_word(esAll, s, e, k); }
-                            else if (k == 0) v[r][k] = first[s];
+                            if (k == 0) v[r][k] = first[s];
                             else if (k - 1 < nWords) v[r][k] = !words ? s : table_word(words, tabStride, wordsAos, cap, e, k - 1, deref);
                             else if (k < stride) v[r][k] = acc[(size_t)(k - 1 - nWords) * cap + s];
                         }
@@ -642,7 +633,6 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
                                 const int k = k0 + j * 8 + sub;
                                 v[r][j] = 0;
                                 if (k >= stride || !ok[r]) continue;
-                                if (state) { v[r][j] = entry_word(esAll, s2[r], e2[r], k); continue; }
                                 if (k == 0) v[r][j] = first[s2[r]];
                                 else if (k - 1 < nWords) v[r][j] = !words ? s2[r] : table_word(words, tabStride, wordsAos, cap, e2[r], k - 1, deref);
                                 else v[r][j] = acc[(size_t)(k - 1 - nWords) * cap + s2[r]];
@@ -682,7 +672,7 @@ __global__ void __launch_bounds__(256) k_compact_entries(const i64* __restrict__
 
 void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, const int64_t* words, int nWords, bool wordsAos,
                     const int64_t* acc, int nAcc, int64_t* outRows, uint32_t maxRows, uint32_t* count, bool unmix, int keyWord, bool keyIs32,
-                    bool keyDesc, uint64_t* imageRange, bool narrow, const int* deref, int tabStride, const uint32_t* state, int accOff) {
+                    bool keyDesc, uint64_t* imageRange, bool narrow, const int* deref, int tabStride) {
     if (tabStride <= 0) tabStride = nWords;
     if (narrow && (!imageRange || keyWord < 0)) throw Error(RSQ_ERR_DEVICE, "compactEntries: narrow rows carry the sort key");
     // slots per thread: every chunk costs one reservation atomic on the same word (they serialise), so large tables take
@@ -698,7 +688,7 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
     u64* chain = nullptr;
     unsigned launchNo = 0;
 #define RSQ_LAUNCH_COMPACT(PT) hipLaunchKernelGGL(k_compact_entries<PT>, dim3(grid), dim3(256), 0, ctx.stream, (const i64*)firstRow, (i64)capacity, \
-                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0, imageRange ? keyWord : -1, keyIs32 ? 1 : 0, keyDesc ? 1 : 0, (u64*)imageRange, chain, launchNo, narrow ? 1 : 0, deref, tabStride, (const unsigned*)state, accOff)
+                       (const i64*)words, nWords, wordsAos ? 1 : 0, (const i64*)acc, nAcc, (i64*)outRows, (unsigned)maxRows, count, unmix ? 1 : 0, imageRange ? keyWord : -1, keyIs32 ? 1 : 0, keyDesc ? 1 : 0, (u64*)imageRange, chain, launchNo, narrow ? 1 : 0, deref, tabStride)
     if (perThread >= 64) RSQ_LAUNCH_COMPACT(64); else if (perThread >= 32) RSQ_LAUNCH_COMPACT(32); else RSQ_LAUNCH_COMPACT(16);
 #undef RSQ_LAUNCH_COMPACT
     RSQ_HIP(hipGetLastError());
@@ -980,7 +970,7 @@ __global__ void __launch_bounds__(256) k_topk_range_select(const i64* __restrict
         const i64* src = rows + (size_t)i * stride;
         // (host-mapped memory, read by the host as soon as the sequence number arrives: system-scope stores, waited for before this
         // workgroup takes its second ticket)
-        if (es.cap) {            // narrow rows [slot | key] (k_compact_entries): the candidate's words come from the table entry
+        if (es.first) {          // narrow rows [slot | key] (k_compact_entries): the candidate's words come from the table entry
             const i64 s = src[0];
             const i64 e = es.unmix ? (i64)rank_unmix((u64)s, (u64)es.cap) : s;
             i64* dst = cand + (size_t)pos * fullStride;
@@ -1055,8 +1045,7 @@ void selectTopCandidatesRangePublish(Context& ctx, const int64_t* rows, int stri
     if (entries) {
         if (stride != 2 || keyWord != 1) throw Error(RSQ_ERR_DEVICE, "selectTopCandidatesRangePublish: narrow rows are [slot | key]");
         es = EntrySource{(const i64*)entries->firstRow, (i64)entries->capacity, (const i64*)entries->words, entries->nWords, entries->wordsAos ? 1 : 0,
-                         (const i64*)entries->acc, entries->nAcc, entries->unmix ? 1 : 0, entries->deref, entries->tabStride > 0 ? entries->tabStride : entries->nWords,
-                         (const unsigned*)entries->state, entries->accOff};
+                         (const i64*)entries->acc, entries->nAcc, entries->unmix ? 1 : 0, entries->deref, entries->tabStride > 0 ? entries->tabStride : entries->nWords};
         fullStride = 1 + entries->nWords + entries->nAcc;
     }
     // (the grid must be on the chip as a whole: at most one workgroup per CU)

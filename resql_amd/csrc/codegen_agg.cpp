@@ -242,31 +242,17 @@ void Walker::emitHashAggregation(OpNode* o) {
     // cache lines instead of 32 stores a table-length apart (TPC-H Q10 at SF10: 380 K new groups per execution).
     int NWtab = K;
     for (auto& c : carriedVals) NWtab += c.nWords;
-    // ... and the group's ACCUMULATORS behind them (accInEntry): a row that finds its group touches the entry's line(s) - key compare and
-    // updates - instead of one line of the words and one of every accumulator block a table-length apart.  The lane that creates a group
-    // writes the accumulators' identities before it publishes the slot, so nothing is cleared in front of an execution but the slot states
-    // (TPC-H Q10 at SF10: 16 MB of identities per execution).  Measured there: the lineitem pipeline's surviving rows cost ~25 G random lines
-    // per second whatever is in them (the stage-2 experiments of round 5): fewer lines per row is what moves it.
-    const bool accIn = envInt("RSQ_AGG_MODE", 0, 0, 6) != 6;       // (RSQ_AGG_MODE=6: accumulators in their own blocks, as before round 5)
-    ht->accInEntry = accIn;
-    ht->aos = accIn || NWtab > 1;
+    ht->aos = NWtab > 1 && 1 != 0;
     const bool aggAos = ht->aos;
     // ... and while the group values that depend on the key stand in the entries by address (below), an entry is its key words and ONE word
-    // per carried value: the kernel then addresses the table with that stride (T_nw; TPC-H Q10: 7 + 2 words instead of 32 + 2 - the million slots
-    // the groups spread over are 72 MB, not 285), and with the full stride when a table of the dependency chain fell back to its hash form
+    // per carried value: the kernel then addresses the table with that stride (T_nw; TPC-H Q10: 7 words instead of 32 - the million slots
+    // the groups spread over are 56 MB, not 268), and with the full stride when a table of the dependency chain fell back to its hash form
     const int NWc = K + (int)carriedVals.size();
-    const int NA = accIn ? W : 0;                  // accumulator words at the end of an entry
     const bool compactLayout = aggAos && NWc < NWtab && !carriedVals.empty() && envInt("RSQ_GROUP_VALUES_BY_ADDRESS", 1, 0, 1) != 0;
-    auto aggWord = [&, NWtab, aggAos, compactLayout, NA](int w) {
+    auto aggWord = [&, NWtab, aggAos, compactLayout](int w) {
         if (aggAos && compactLayout) return "a." + T + "_words[" + T + "_s * " + T + "_nw + " + std::to_string(w) + "]";
-        return aggAos ? "a." + T + "_words[" + T + "_s * " + std::to_string(NWtab + NA) + " + " + std::to_string(w) + "]"
+        return aggAos ? "a." + T + "_words[" + T + "_s * " + std::to_string(NWtab) + " + " + std::to_string(w) + "]"
                       : "a." + T + "_words[" + std::to_string(w) + " * a." + T + "_cap + " + T + "_s]";
-    };
-    // accumulator word of block b at slot `slot` (an expression): in the entry, or in its block
-    auto accAddr = [&, NWtab, compactLayout, NA, accIn](int b, const std::string& slot) {
-        if (!accIn) return "a." + T + "_acc + " + std::to_string(b) + " * a." + T + "_cap + " + slot;
-        if (compactLayout) return "(u64*)a." + T + "_words + (" + slot + " * " + T + "_nw + (" + T + "_nw - " + std::to_string(NA) + ") + " + std::to_string(b) + ")";
-        return "(u64*)a." + T + "_words + (" + slot + " * " + std::to_string(NWtab + NA) + " + " + std::to_string(NWtab + b) + ")";
     };
 
     // ---- LDS front table (per workgroup) ------------------------------------------------------------------------
@@ -334,11 +320,11 @@ void Walker::emitHashAggregation(OpNode* o) {
                                                                                        : (src != c.firstWord + w ? entryPlainCode(src) : 0);
             }
             ht->derefCondTables = condTablesOfFd;
-            ht->compactStride = (compactLayout ? NWc : NWtab) + NA;
+            ht->compactStride = compactLayout ? NWc : NWtab;
         }
         if (nCarriedWords) {
             line("const bool " + T + "_fd = " + (fdCond.empty() ? std::string("true") : fdCond) + ";");
-            if (compactLayout) line("const u64 " + T + "_nw = " + (byAddress ? T + "_fd ? " + std::to_string(NWc + NA) + "ull : " : std::string()) + std::to_string(NWtab + NA) + "ull;");
+            if (compactLayout) line("const u64 " + T + "_nw = " + (byAddress ? T + "_fd ? " + std::to_string(NWc) + "ull : " : std::string()) + std::to_string(NWtab) + "ull;");
 
         }
         line("u64 " + T + "_adv = 0; u32 " + T + "_spin = 0; bool " + T + "_found = false;");
@@ -349,11 +335,6 @@ void Walker::emitHashAggregation(OpNode* o) {
         openScope("if (atomicCAS(&a." + T + "_state[" + T + "_s], 0u, 1u) == 0u) {");
         for (int i = 0; i < K; i++)
             line("rsq::st_agent(&" + aggWord(i) + ", " + kp[(size_t)i] + ");");
-        if (accIn)          // the accumulators' identities: nobody merges into them before the slot is published (state 2, below)
-            for (int w = 0; w < W; w++) {
-                const int m = q.accums[(size_t)w].merge;
-                line("rsq::st_agent((i64*)(" + accAddr(q.accumSlot[(size_t)w], T + "_s") + "), (i64)" + (m == 0 ? "0ull" : m == 2 ? "0x7fffffffffffffffull" : "0x8000000000000000ull") + ");");
-            }
         // the carried group values of the new group (written by the lane that creates it; compared only in the full form)
         if (nCarriedWords) {
             // (with the dependencies certain the words go from their loads straight into the table, value by value: staged in
@@ -463,7 +444,7 @@ void Walker::emitHashAggregation(OpNode* o) {
             for (int w = 0; w < W; w++) {
                 const std::string in = "x" + std::to_string(w);
                 const std::string op = std::to_string(q.accums[(size_t)w].merge);
-                const std::string dst = accAddr(q.accumSlot[(size_t)w], slot);
+                const std::string dst = "a." + T + "_acc + " + std::to_string(q.accumSlot[(size_t)w]) + " * a." + T + "_cap + " + slot;
                 if (members.empty()) line("rsq::global_merge_always<" + op + ">(" + dst + ", (u64)" + in + ");");
                 else line("{ const u64 r = rsq::subset_reduce<" + op + ">((u64)" + in + ", " + members + "); if (wl_lane == wl_leader) rsq::global_merge_always<" +
                           op + ">(" + dst + ", r); }");

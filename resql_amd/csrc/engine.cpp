@@ -315,8 +315,8 @@ static void applyPlanMemo(Query& q) {
         if (h.capacity == 0 && !h.dState) {
             h.capacity = m.hashCapacity; h.lastCount = m.hashCount;
             h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
-            h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (h.keys.size() + h.payload.size() + (h.accInEntry ? (size_t)h.nAccBlocks : 0)));
-            h.dAcc = (int64_t*)ctx.alloc(h.accInEntry ? 256 : (size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
+            h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (h.keys.size() + h.payload.size()));
+            h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
         }
         q.charGroupsNeedMerge = m.charGroupsNeedMerge;
         for (auto& p : q.pipelines)         // a handful of groups: the 64-slot front table's kernel is loaded now (engine_pipelines.cpp fewGroupsKernel)
@@ -868,7 +868,7 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
             if (h.capacity > 0 && h.dState && h.dAcc && h.lastCount > 0 && (int64_t)h.lastCount * 2 <= h.capacity) {
                 f.push_back(FillItem{h.dState, (size_t)h.capacity * 4, 0});
                 f.push_back(FillItem{h.dCount, 4, 0});
-                for (int b = 0; b < h.nAccBlocks && !h.accInEntry; b++) {      // (accumulators in the entries: their identities are written when a group is created)
+                for (int b = 0; b < h.nAccBlocks; b++) {
                     const uint64_t idv = b < q.nMinBlocks ? 0x7fffffffffffffffull : b < q.nMinBlocks + q.nMaxBlocks ? 0x8000000000000000ull : 0ull;
                     f.push_back(FillItem{(uint64_t*)h.dAcc + (size_t)b * (size_t)h.capacity, (size_t)h.capacity * 8, idv});
                 }
@@ -942,13 +942,12 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
             for (;;) {
                 if (!h.dState) {
                     h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
-                    // key words, then carried group values, then (accInEntry) the accumulators; dAcc is a stub then
-                    h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (h.keys.size() + h.payload.size() + (h.accInEntry ? (size_t)h.nAccBlocks : 0)));
-                    h.dAcc = (int64_t*)ctx.alloc(h.accInEntry ? 256 : (size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
+                    h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (h.keys.size() + h.payload.size()));      // key words, then carried group values
+                    h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
                 }
                 RSQ_HIP(hipMemsetAsync(h.dState, 0, (size_t)h.capacity * 4, ctx.stream));
                 RSQ_HIP(hipMemsetAsync(h.dCount, 0, 4, ctx.stream));
-                if (!h.accInEntry) resetAccumulators(h);
+                resetAccumulators(h);
                 launchPipeline(q, p, -1);
                 uint32_t err = 0;
                 RSQ_HIP(hipMemcpyAsync(&err, ctx.dErr, 4, hipMemcpyDeviceToHost, ctx.stream));
@@ -1020,23 +1019,20 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
         // string group values that stand in the entries by address (this execution's kernels wrote them so: not the interpreter's, and only
         // while every table of the dependency chain is a rank dictionary - the kernel's own run-time condition, codegen_agg.cpp)
         const int* deref = nullptr;
-        const bool accIn = h.accInEntry && !interp && q.aggMode == AggMode::HASH;      // (the interpreter keeps its own layout: blocks)
-        int tabStride = nTab + (accIn ? h.nAccBlocks : 0);
+        int tabStride = nTab;
         if (h.dDeref && !interp) {
             bool holds = true;
             for (int t : h.derefCondTables) holds = holds && q.hashTables[(size_t)t]->rank;
-            if (holds) { deref = h.dDeref; tabStride = h.compactStride > 0 ? h.compactStride : tabStride; }
+            if (holds) { deref = h.dDeref; tabStride = h.compactStride > 0 ? h.compactStride : nTab; }
         }
-        const uint32_t* entryState = accIn ? h.dState : nullptr;
-        const int accOff = accIn ? tabStride - h.nAccBlocks : 0;
         compactEntries(ctx, (const int64_t*)h.dAcc /* block 0 = first row */, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks,
                        narrowRows ? q.dNarrowRows : q.dGroupRows, groupRowsAllocated, q.dGroupCount,
                        h.rank,
-                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr, narrowRows, deref, tabStride, entryState, accOff);
+                       q.topkWord, q.topkIs32, q.topkDesc, preselect ? (uint64_t*)q.dTopkHists : nullptr, narrowRows, deref, tabStride);
         q.report.num_kernels++;
         if (narrowRows) {
             topkRange = true;
-            const TableEntries te{(const int64_t*)h.dAcc, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks, h.rank, deref, tabStride, entryState, accOff};
+            const TableEntries te{(const int64_t*)h.dAcc, h.capacity, h.dWords, nTab, h.aos, h.dAcc, h.nAccBlocks, h.rank, deref, tabStride};
             selectTopCandidatesRangePublish(ctx, q.dNarrowRows, 2, 1, q.topkIs32, q.topkDesc, q.dGroupCount, groupRowsAllocated,
                                             q.topkWant, q.dTopkHists, q.dHostCandRows, topkCapacity, q.dPinnedDev + words, selectSeq = ++q.finSeqCounter, ctx.dErr, q.dGroupCount,
                                             anyCompaction ? q.dPipeStats : nullptr, (int)q.pipelines.size(), &te);

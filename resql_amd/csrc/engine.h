@@ -228,10 +228,7 @@ void compactEntries(Context& ctx, const int64_t* firstRow, int64_t capacity, con
                     // wants a few: selectTopCandidatesRangePublish fetches those from the table, TableEntries)
                     bool narrow = false,
                     // deref (device memory, nWords ints, or null): table words that are rebuilt from a string kept by address (entryDerefCode)
-                    const int* deref = nullptr, int tabStride = 0,
-                    // state (or null) + accOff: the accumulators stand IN the entries (hash aggregation): slot s holds a group iff state[s] == 2,
-                    // accumulator word b (b = 0: the first row) is word accOff + b of the entry; firstRow / acc are not read then
-                    const uint32_t* state = nullptr, int accOff = 0);
+                    const int* deref = nullptr, int tabStride = 0);
 // word w of a table entry = bytes [off, off + len) of the string whose address stands in table word src (len 1..8)
 inline int entryDerefCode(int src, int off, int len) { return (int)(0x40000000u | ((unsigned)src << 16) | ((unsigned)off << 4) | (unsigned)len); }
 // ... or simply table word src (entries that keep one word per carried value: the row's word numbers are not the entry's)
@@ -240,7 +237,6 @@ struct TableEntries {
     const int64_t* firstRow; int64_t capacity; const int64_t* words; int nWords; bool wordsAos; const int64_t* acc; int nAcc; bool unmix;
     const int* deref = nullptr;
     int tabStride = 0;       // words between the entries of `words` (0: nWords)
-    const uint32_t* state = nullptr; int accOff = 0;      // accumulators in the entries (see compactEntries)
 };
 // ORDER BY ... LIMIT pre-selection: the rows of `rows` ([*nRows][stride] words) whose word `keyWord` is among the `want`
 // leading values of the requested order (ties of the last one included) are copied to `cand`.  `scratch` (topkHistBytes() bytes)

@@ -96,7 +96,6 @@ struct HashTable {
     // that make group rows rebuild the words (aot_kernels.hip table_word).  derefCodes[w]: engine.h entryDerefCode, 0 = the word itself.
     std::vector<int> derefCodes;
     std::vector<int> derefCondTables;
-    bool accInEntry = false;         // hash aggregation: the accumulator words stand at the end of every entry (dAcc is a stub), not in blocks of their own
     int compactStride = 0;           // words per entry while the values stand by address (< keys + payload: one word per carried value)
     int* dDeref = nullptr;
     int64_t buildRows = -1;          // build rows and duplicate keys as the sizing pass saw them (what the plan memo keeps)

@@ -43,7 +43,6 @@ KNOBS = [
     ("RSQ_PARTITION", "2", ("dense_large",)),
     ("RSQ_STAGED", "0", ("dense_large",)),
     ("RSQ_AGG_MODE", "5", ("fuzz",)),
-    ("RSQ_AGG_MODE", "6", ("fuzz", "topk")),             # ... and with the accumulators in blocks of their own instead of in the entries (the interpreter's layout)
     ("RSQ_TRACE", "2", ("tpch",)),                       # the traced paths synchronise between kernels: another order of the same calls
     ("RSQ_DEBUG_TAIL", "1", ("q3",)),                    # device timestamps of the pipelines' workgroups (a kernel argument more)
 ]
