@@ -47,6 +47,16 @@ Extra objects on the JSON line:
                  launches, fraction of 8 TB/s in algorithmic bytes (for Q3: streaming bytes, an upper bound; for Q6 also the
                  FETCH_SIZE-based traffic_frac of the committed PMC pass), each answer compared with the reference's recorded one.
 
+`--gpus N --share-gpu` is the rehearsal of N > 1 a ONE-GPU box allows: N fresh rank processes that all drive device 0 (own engine context,
+own row-range shard, the real kernels, statistics unified across the processes, asynchronous partial execution), the partial tables staged
+through host memory and merged over gloo (RCCL cannot hold one device twice; the line says so: `config.backend`, `n_gpus` = 1, `config.ranks`
+= N), rank 0 finalises and the answer is compared with the reference's.  `--workload q3` runs TPC-H Q3 the multi-GPU way instead (replicated
+build sides, lineitem cut on an l_orderkey boundary, every rank's top 10 merged by the sort keys: resql_amd/dist.py).
+
+extras.q1_sf10_one_shot / first_exec_ms / first_ever_exec_ms - what a ReSQL host pays per SELECT, compile -> ONE execution -> delete (reference
+src/execute.h:213-247): the first execution of a FRESH query of the same plan on the same context (plan memo + arenas), and the very first
+execution of the plan on the context, beside the steady state of the re-executed query (exec_ms / ms_per_step).
+
 `--backend gloo --no-gpu` is a dry mode for machines without a GPU (the CPU test of the launch path): every rank takes a
 compile-only engine context, a deterministic stand-in partial table goes through the same sharding, layout check, merge
 and finalisation calls, and the line carries "dry_run": true instead of a measurement.
