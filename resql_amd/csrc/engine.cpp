@@ -134,9 +134,10 @@ Query::~Query() {
     if (hGroupRows) ctx.freePinned(hGroupRows);
     if (hCandRows) ctx.freePinned(hCandRows);
     if (dFinTicket) ctx.free(dFinTicket);
-    if (gev0) (void)hipEventDestroy(gev0);
-    if (gev1) (void)hipEventDestroy(gev1);
-    for (auto& e : evRing) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    // (events not read yet belong to work that may still run: they go back to the pool all the same - a record on a recorded event
+    // simply replaces it, and nobody reads the old pair any more)
+    ctx.giveEvent(gev0); ctx.giveEvent(gev1);
+    for (auto& e : evRing) { ctx.giveEvent(e.first); ctx.giveEvent(e.second); }
     if (dMatCnt) ctx.free(dMatCnt);
     if (dMatOffs) ctx.free(dMatOffs);
     if (dMatTileCnt) ctx.free(dMatTileCnt);
@@ -690,11 +691,15 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
         // full); an asynchronous partial step keeps the single pair finalize / settle read
         const bool ringEvents = !(async && partialOnly);
         if (ringEvents) {
-            if (q.evRing.empty()) {
-                q.evRing.resize(256);
-                for (auto& e : q.evRing) { RSQ_HIP(hipEventCreate(&e.first)); RSQ_HIP(hipEventCreate(&e.second)); }
+            // the ring grows with the steps nobody has read yet: 8 pairs, doubled when full, up to 256 (a statement that is executed once
+            // takes 16 events from the context's pool, a loop of steps ends up with the 512 it had from the start before round 5)
+            const bool full = q.evTail - q.evHead == q.evRing.size();      // (an empty ring is full too)
+            if (q.kernelTimePending || full) resolveKernelTime(q);          // everything recorded so far is read: head == tail
+            if (full && q.evRing.size() < 256) {
+                const size_t more = q.evRing.empty() ? 8 : q.evRing.size();
+                q.evHead = q.evTail = 0;
+                for (size_t i = 0; i < more; i++) { hipEvent_t a = ctx.takeEvent(), b = ctx.takeEvent(); q.evRing.emplace_back(a, b); }
             }
-            if (q.kernelTimePending || q.evTail - q.evHead == q.evRing.size()) resolveKernelTime(q);
         } else resolveKernelTime(q);                           // the previous step's events, before they are recorded again
         q.fusedReady = false;
         q.flatRun = false;                                     // always the padded kernel: the last workgroup unpads
@@ -704,7 +709,7 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
         q.finSeq = seq;
         q.finOut = partialOnly ? q.dAgg : q.dFinHost;          // device partial table | host-mapped pinned read-back buffer
         q.finErr = q.dFinHost + q.pinnedWords;
-        if (!q.gev0) { RSQ_HIP(hipEventCreate(&q.gev0)); RSQ_HIP(hipEventCreate(&q.gev1)); }
+        if (!q.gev0) { q.gev0 = ctx.takeEvent(); q.gev1 = ctx.takeEvent(); }
         hipEvent_t evA = q.gev0, evB = q.gev1;
         if (ringEvents) { auto& e = q.evRing[q.evTail % q.evRing.size()]; evA = e.first; evB = e.second; }
         // two event records around the launch.  (The extended launch that takes the events itself - RSQ_EXT_EVENTS=1 - costs the
@@ -892,7 +897,7 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
     // (the execution's event pair is the query's own, read when somebody asks: an execution that ends on the candidate selection's
     // sequence number returns before the stream has reported the second event)
     resolveKernelTime(q);
-    if (!q.gev0) { RSQ_HIP(hipEventCreate(&q.gev0)); RSQ_HIP(hipEventCreate(&q.gev1)); }
+    if (!q.gev0) { q.gev0 = ctx.takeEvent(); q.gev1 = ctx.takeEvent(); }
     RSQ_HIP(hipEventRecord(q.gev0, ctx.stream));
     double tPipe = nowMs();
     auto tracePoint = [&](const Pipeline& p) {

@@ -125,6 +125,11 @@ struct Context {
     void* allocRaw(size_t bytes);              // straight from the driver: table columns (large, long-lived)
     void freeRaw(void* p);
     void streamDrained();                      // the caller has just seen the stream idle: pending ranges are free
+    // timing events of queries: a query takes them here and gives them back when it is destroyed (a fresh query of a one-launch step
+    // created 512 of them in its first execution: 0.12 ms of a 0.35 ms statement)
+    std::vector<hipEvent_t> eventPool;
+    hipEvent_t takeEvent();
+    void giveEvent(hipEvent_t e) { if (e) eventPool.push_back(e); }
     std::unique_ptr<Arena> devArena, pinArena, pinNcArena;
     bool driverAlloc = false;
     size_t arenaKeepBytes = 0;

@@ -100,6 +100,7 @@ Context::~Context() {
         for (auto& e : scratchLive) free(e.first);
         if (dErr) (void)hipFree(dErr);
         devArena.reset(); pinArena.reset(); pinNcArena.reset();
+        for (hipEvent_t e : eventPool) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ownStream) (void)hipStreamDestroy(ownStream);
@@ -166,6 +167,14 @@ void* Context::allocRaw(size_t bytes) {
     return p;
 }
 void Context::freeRaw(void* p) { if (p) { allocStats.rawCalls++; StopWatch sw(allocStats.rawMs); (void)hipFree(p); } }
+
+hipEvent_t Context::takeEvent() {
+    if (!eventPool.empty()) { hipEvent_t e = eventPool.back(); eventPool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    RSQ_HIP(hipSetDevice(device));
+    RSQ_HIP(hipEventCreate(&e));
+    return e;
+}
 
 void Context::streamDrained() {
     if (devArena && devArena->hasPending()) devArena->promote();
