@@ -568,8 +568,11 @@ int main(int argc, char** argv) {
             // NOT root->deletePlan(): HashJoinOp::~HashJoinOp (hashjoin.h:83-85) frees _ht unconditionally and
             // crashes when produceFlounder never allocated it (AggregationOp's destructor has the null check,
             // aggregation.h:66-70).  A ReSQL-side integration adds the same check; the harness leaks the plan.
+            // (every repetition is what a ReSQL host issues per SELECT: a fresh rsq_query, compiled, executed ONCE, destroyed - exec_ms IS
+            // the first execution; from the second repetition on the context's plan memo and arenas serve it)
             std::cerr << "#timing compile_ms " << hip->report.compilationTime << " exec_ms " << hip->report.executionTime
-                      << " instrs " << hip->report.numMachineInstructions << " kernel_ms " << hip->kernelTimeMs << std::endl;
+                      << " instrs " << hip->report.numMachineInstructions << " kernel_ms " << hip->kernelTimeMs
+                      << " first_exec_ms " << hip->report.executionTime << " repetition " << rep << std::endl;
             continue;
         }
 #endif

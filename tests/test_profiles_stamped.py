@@ -90,8 +90,8 @@ def test_the_newest_rounds_counter_files_are_plausible_and_its_kernel_average_fi
         for case in d.get("cases", {}).values():                   # late loads: fetched bytes never exceed what the columns hold by much
             assert 0.0 < case["traffic_frac_of_8TBps"] <= 1.0, (p, case)
             assert case["hbm_read_bytes_corrected"] <= 1.5 * case["algorithmic_bytes"], (p, case)
-        for sel in d.get("selectivity", {}).values():              # staged partitioning: reads + writes at least the input once
-            assert 1.0 <= sel["over_algorithmic"] <= 3.0, (p, sel["over_algorithmic"])
+        for sel in d.get("selectivity", {}).values():              # staged partitioning: the input once (less what late loads skip at 10 %) + records twice
+            assert 0.8 <= sel["over_algorithmic"] <= 3.0, (p, sel["over_algorithmic"])
     # (the line of the PROFILED process itself: the same launches, the same minute of the same box)
     bench_line = os.path.join(prof, tag + "q1_sf10_kernel_stats_run.json")
     stats = os.path.join(prof, tag + "q1_sf10_kernel_stats.csv")

@@ -56,11 +56,13 @@ json.dump(out, open(sys.argv[1], "w"), indent=1)
 print("   join statements:", {q: len(v) for q, v in out["statements"].items()})
 PY
 step "compile latency with the kernels compiled in process, and at SF10 with the interpreter's execution time beside the specialised one"
-RSQ_GENERIC=1 RSQ_COMPILE_HELPERS=0 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_in_process.jsonl"
-RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 10 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_sf10.jsonl"
+AMD_COMGR_CACHE=0 RSQ_GENERIC=1 RSQ_COMPILE_HELPERS=0 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_in_process.jsonl"
+AMD_COMGR_CACHE=0 RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 10 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency_sf10.jsonl"
 step "an empty code-object cache: interpreter -> quick tier -> full kernels, per statement (SF1 and SF10)"
-RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/tier_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_kernel_tiers_sf1.jsonl"
-RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/tier_latency.py" 10 --only q3,q5,q10,q12,q19 2>/dev/null | grep '^{' > "$OUT/${R}_kernel_tiers_sf10.jsonl"
+# (AMD_COMGR_CACHE=0: the compiler's own per-user cache of compiled programs would answer for hiprtc after the first collection step that compiled
+# the same texts - these steps measure a statement NOBODY has compiled before)
+AMD_COMGR_CACHE=0 RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/tier_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_kernel_tiers_sf1.jsonl"
+AMD_COMGR_CACHE=0 RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/tier_latency.py" 10 --only q3,q5,q10,q12,q19 2>/dev/null | grep '^{' > "$OUT/${R}_kernel_tiers_sf10.jsonl"
 step "group rows of a hash aggregation: the tail on the device against the host's"
 timeout -k 10 200 python3 "$ROOT/tools/hash_tail_bench.py" > "$OUT/${R}_hash_tail_device_vs_host.txt" 2>/dev/null
 timeout -k 10 200 python3 "$ROOT/tools/hash_tail_bench.py" 100000000 262144 >> "$OUT/${R}_hash_tail_device_vs_host.txt" 2>/dev/null
@@ -113,7 +115,7 @@ rm -rf /tmp/prof_sql
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_sql -- python3 "$ROOT/tools/sql_bench.py" 10 --repeat 5 --only q5,q10,q12,q14,q19 > /tmp/sqlp.log 2>&1
 f=$(found /tmp/prof_sql '*kernel_stats.csv'); [ -n "$f" ] && cp "$f" "$OUT/${R}_sql_sf10_kernel_stats.csv"
 step "compile latency, cold and warm (empty code-object cache)"
-RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency.jsonl"
+AMD_COMGR_CACHE=0 RSQ_GENERIC=1 timeout -k 10 300 python3 "$ROOT/tools/compile_latency.py" 1 2>/dev/null | grep '^{' > "$OUT/${R}_compile_latency.jsonl"
 step "compile -> ONE execution -> delete, per statement: first-ever, fresh queries (plan memo + arenas), steady; and the same with both switched off"
 timeout -k 10 300 python3 "$ROOT/tools/first_exec.py" 10 2>/dev/null | grep -E '^\{|^# \{' > "$OUT/${R}_first_exec_sf10.jsonl"
 timeout -k 10 300 python3 "$ROOT/tools/first_exec.py" 10 --driver-alloc --no-memo 2>/dev/null | grep -E '^\{|^# \{' > "$OUT/${R}_first_exec_sf10_driver_alloc_no_memo.jsonl"
