@@ -36,6 +36,26 @@ def test_fuzz_engine_matches_oracle(gpu_ctx, block):
     assert not failures, failures
 
 
+def test_seeds_wide_sweeps_found(gpu_ctx):
+    """tests/golden/sweep_finds.json: seeds beyond 0..319 on which a wide sweep once found the engine wrong, pinned by the reference's digests;
+    every plan executed three times (first execution, warm paths)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "sweep_finds.json")) as f:
+        finds = json.load(f)
+    for seed, g in finds.items():
+        plan, kind = fuzzplans.make(int(seed))
+        tabs = [gpu_ctx.table(t) for t in plan.tables]
+        q = gpu_ctx.compile(plan, tabs)
+        for _ in range(3):
+            q.execute()
+            got = q.result()
+            assert got.n_rows == g["rows"] and fuzzplans.digest(kind, got.text) == g["digest"], (seed, g["what"])
+        q.close()
+        for t in tabs:
+            t.close()
+
+
 @pytest.mark.parametrize("groups", [1, 3, 1024])
 def test_hash_aggregation_under_contention(gpu_ctx, monkeypatch, groups):
     """Generic insert-or-find aggregation when every lane of a wave wants the same few slots at once (the case where a

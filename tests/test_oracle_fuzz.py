@@ -38,6 +38,18 @@ def test_fuzz_oracle_matches_reference_digests(block):
     assert not bad, bad
 
 
+def test_oracle_matches_reference_on_the_seeds_sweeps_found():
+    """seeds beyond the suite's range on which a wide GPU sweep once found the engine wrong (tests/golden/sweep_finds.json, written by
+    make_sweep_finds_golden.py from the unmodified reference); tests/test_gpu_fuzz.py runs the engine on them"""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "sweep_finds.json")) as f:
+        finds = json.load(f)
+    assert finds
+    for seed, g in finds.items():
+        plan, kind = fuzzplans.make(int(seed))
+        res = orc.execute(plan)
+        assert kind == g["kind"] and res.n_rows == g["rows"] and fuzzplans.digest(kind, res.text) == g["digest"], seed
+
+
 def test_fuzz_covers_the_shapes():
     kinds = [g["kind"] for g in GOLDEN.values() if not g["refused"]]
     assert kinds.count("exact") > 200 and kinds.count("multiset") > 40
