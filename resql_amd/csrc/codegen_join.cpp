@@ -224,6 +224,18 @@ void Walker::consumeBuildBody(OpNode* o, OpNode* from) {
                               pipe.src->cols[(size_t)ci].stats.valid && pipe.src->cols[(size_t)ci].stats.ascending;
         ht->uniqueKnown = ht->identityCapable && pipe.src->cols[(size_t)ci].stats.strictlyAscending && pipe.src->nRows < 0xffffffffll;
     }
+    // DIRECT (HashTable::directCapable): every payload value is a column of this scan - it is, over a bare scan - and the statistics promise
+    // unique keys: if the keys also fill their range (known when the form is decided), the probes read the table's columns themselves
+    if (ht->uniqueKnown) {
+        ht->directCapable = true;
+        for (auto& p : ht->payload) {
+            const int pc = pipe.src->findCol(p.name);
+            if (pc < 0 || pipe.src->cols[(size_t)pc].type.tag != p.type.tag || pipe.src->cols[(size_t)pc].type.len != p.type.len) { ht->directCapable = false; break; }
+            ht->directCols.push_back(pc);
+        }
+        if (!ht->directCapable) ht->directCols.clear();
+        ht->directSrc = pipe.src;
+    }
     // (a table that may become a rank dictionary keeps its bitmap in the interleaved layout, rsq_device.h bmi_word)
     ht->bmInterleaved = ht->rankCapable;
     const std::string bmw = ht->bmInterleaved ? "rsq::bmi_word(d)" : "d >> 5";
@@ -289,13 +301,18 @@ void Walker::consumeBuildBody(OpNode* o, OpNode* from) {
             prologue += "    __shared__ __attribute__((aligned(16))) i64 s_rec_" + T + "[(RSQ_BLOCK_THREADS / 64) * 128 * " + NWI + "];\n    st.rec_" + T + " = s_rec_" + T +
                         " + (threadIdx.x >> 6) * 128 * " + NWI + ";\n";
             pipe.extraLdsBytes += (pipe.blockThreads / 64) * 128 * 8 * (1 + (int)ht->payload.size());
-            postTile += "            if (a." + T + "_ident && a." + T + "_rank && !a." + T + "_countonly) rsq::flush_tile_records<" + NWI + ">(st.rec_" + T + ", a." + T + "_words + (u64)(($TILE) << 7) * " + NWI +
+            // (a DIRECT table keeps no records at all: the probes read the columns - only the key bits are set, for the index)
+            const std::string keepsRecords = ht->directCapable ? " && !a." + T + "_direct" : "";
+            if (ht->directCapable) addArg(T + "_direct", "u64", 0);
+            postTile += "            if (a." + T + "_ident && a." + T + "_rank && !a." + T + "_countonly" + keepsRecords + ") rsq::flush_tile_records<" + NWI + ">(st.rec_" + T + ", a." + T + "_words + (u64)(($TILE) << 7) * " + NWI +
                         "ull, lane);\n";
             openScope("if (a." + T + "_ident) {");
+            if (ht->directCapable) openScope("if (!a." + T + "_direct) {");
             line("i64* rec = st.in_tile ? st.rec_" + T + " + (u32)(lr & 127) * " + NWI + "u : a." + T + "_words + (u64)(row - a.row0) * " + NWI + "ull;");
             line("rec[0] = " + keyVars[0] + ";");
             int iw = 1;
             for (auto& p : ht->payload) line("rec[" + std::to_string(iw++) + "] = " + toWord(eg.symbols[p.name].var, p.type) + ";");
+            if (ht->directCapable) closeScope();
             closeScope();
             openScope("else {");
         }
@@ -522,7 +539,17 @@ void Walker::consumeMatch(OpNode* o, HashTable& ht, const std::string& T, const 
     int w = (int)ht.keys.size();
     for (auto& p : ht.payload) {
         std::string var = T + "_v" + std::to_string(w);
-        line("const " + ExprGen::ctype(p.type) + " " + var + " = " + fromWord(wordAt(ht, T, w), p.type) + ";");
+        std::string word = wordAt(ht, T, w);
+        if (ht.directCapable) {
+            // (the direct form: the value of the build table's column at row T_s - a string's address is base + T_s * width, no load at all)
+            const std::string src = "a." + T + "_src" + std::to_string(w);
+            addArg(T + "_direct", "u64", 0); addArg(T + "_src" + std::to_string(w), "const char*", 0);
+            const std::string direct = p.type.isString() ? "(i64)(u64)(" + src + " + " + T + "_s * " + std::to_string(p.type.len) + "ull)"
+                                                         : "(i64)(reinterpret_cast<const " + ExprGen::ctype(p.type) + "*>(" + src + ")[" + T + "_s])";
+            line("const i64 " + T + "_w" + std::to_string(w) + " = a." + T + "_direct ? " + direct + " : " + word + ";");
+            word = T + "_w" + std::to_string(w);
+        }
+        line("const " + ExprGen::ctype(p.type) + " " + var + " = " + fromWord(word, p.type) + ";");
         eg.symbols[p.name] = Sym{var, p.type};
         symbolOrigin[p.name] = ht.id; symbolWord[p.name] = w;
         w++;

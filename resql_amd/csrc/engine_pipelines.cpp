@@ -60,6 +60,11 @@ uint64_t argValue(Query& q, const Pipeline& p, const ArgSlot& a, int countOnlyTa
         if (f == "rank") return h.rank ? 1ull : 0ull;
         if (f == "ident") return h.identity ? 1ull : 0ull;
         if (f == "dense") return h.dense ? 1ull : 0ull;
+        if (f == "direct") return h.direct ? 1ull : 0ull;
+        if (f.compare(0, 3, "src") == 0 && isdigit((unsigned char)f[3])) {      // payload word w of a direct table: the build table's column
+            const size_t w = (size_t)atoi(f.c_str() + 3) - h.keys.size();
+            return h.direct && h.directSrc && w < h.directCols.size() ? (uint64_t)(uintptr_t)h.directSrc->cols[(size_t)h.directCols[w]].dptr : 0ull;
+        }
         if (f == "temp") return (uint64_t)(uintptr_t)h.dTemp;
         if (f == "treg") return (uint64_t)h.tempRegion;
         if (f == "tused") return (uint64_t)(uintptr_t)h.dTempUsed;
@@ -549,6 +554,15 @@ void sizeJoinTable(Query& q, Pipeline& p, HashTable& h, uint32_t n, bool dupKeys
     h.identity = h.rank && h.identityCapable && (int64_t)n == p.src->nRows && n > 0;
     // ... and every value of the key range occurs (as many entries as the range has values, all keys different): rank(key) = key - min
     h.dense = h.identity && !h.setOnly && (int64_t)n == h.bmBits;
+    // ... and is the build table itself when the statistics said so beforehand (HashTable::directCapable) - unless the aggregation keeps its
+    // accumulators beside the entries and makes its group rows from them
+    h.direct = h.identity && h.directCapable && h.uniqueKnown && q.aggTable != h.id && h.directSrc == p.src;
+    for (int c : h.directCols) h.direct = h.direct && p.src->cols[(size_t)c].dptr != nullptr;
+    if (h.direct) {
+        const std::string note = "join table ht" + std::to_string(h.id) + ": the build table's own columns (" +
+                                 (h.dense ? "dense keys in row order: nothing is built" : "keys in row order: only the key bitmap and its index are built") + ")\n";
+        if (q.explainText.find(note) == std::string::npos) q.explainText += note;
+    }
     if (h.rank && h.setOnly) {
         h.capacity = std::max<int64_t>(64, ((int64_t)n + 63) & ~(int64_t)63);          // (nothing is allocated: the bitmap is the table)
     } else if (h.rank) {
@@ -564,18 +578,22 @@ void sizeJoinTable(Query& q, Pipeline& p, HashTable& h, uint32_t n, bool dupKeys
         const int64_t wavesMin = (int64_t)std::min(pipelineGrid(q, p, false), pipelineGrid(q, p, true)) * wpb;
         h.tempWaves = wavesMax;
         h.tempRegion = h.identity ? 64 : ((4 * (int64_t)n / std::max<int64_t>(1, wavesMin) + 64 + 63) / 64) * 64;      // (identity: nothing is appended)
-        h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
-        h.dTemp = (int64_t*)ctx.alloc((size_t)h.tempWaves * (size_t)h.tempRegion * 8 * std::max<size_t>(1, nWords));
-        h.dTempUsed = (uint32_t*)ctx.alloc((size_t)h.tempWaves * 4);
-        h.dChunkTotal = (uint32_t*)ctx.alloc((size_t)nChunks * 4);
-        h.dChunkBase = (uint32_t*)ctx.alloc((size_t)(nChunks + 1) * 4);
+        if (!h.direct) {      // (direct: no entries, no arrival buffer ...
+            h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
+            h.dTemp = (int64_t*)ctx.alloc((size_t)h.tempWaves * (size_t)h.tempRegion * 8 * std::max<size_t>(1, nWords));
+        }
+        if (!(h.direct && h.dense)) {      // ... and with dense keys no index either)
+            h.dTempUsed = (uint32_t*)ctx.alloc((size_t)h.tempWaves * 4);
+            h.dChunkTotal = (uint32_t*)ctx.alloc((size_t)nChunks * 4);
+            h.dChunkBase = (uint32_t*)ctx.alloc((size_t)(nChunks + 1) * 4);
+        }
     } else {
         h.capacity = nextPow2(std::max<int64_t>(1024, 2 * (int64_t)n));
         if (!h.keyCas) h.dState = (uint32_t*)ctx.alloc((size_t)h.capacity * 4);
         h.dWords = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * std::max<size_t>(1, nWords));
     }
     if (q.aggTable == h.id) h.dAcc = (int64_t*)ctx.alloc((size_t)h.capacity * 8 * (size_t)h.nAccBlocks);
-    if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.identity ? "bitmap-rank dictionary, entries in row order" : h.rank ? "bitmap-rank dictionary" : "hash table", n);
+    if (getenv("RSQ_TRACE")) fprintf(stderr, "[rsq trace]     ht%d: %s, %u build rows\n", h.id, h.direct ? (h.dense ? "the build table's own columns (dense keys in row order: nothing is built)" : "the build table's own columns (keys in row order: only the key bitmap and its index are built)") : h.identity ? "bitmap-rank dictionary, entries in row order" : h.rank ? "bitmap-rank dictionary" : "hash table", n);
 }
 
 // size (by a counting pass of the same pipeline), allocate and clear a join table, then build it
@@ -614,6 +632,8 @@ void buildHashTable(Query& q, Pipeline& p) {
     // (an execution whose tables are all sized readies them in its first fill launch — prologueFills below — and h.prepared says so)
     const bool prepared = h.prepared;
     h.prepared = false;
+    if (h.direct && h.dense) return;      // the build table's columns are the entries and key - min is the row: nothing to ready, build or index
+    // (direct with gaps in the key range - TPC-H's o_orderkey -: the build below only sets the key bits, the index follows, no records are kept)
     if (h.rank && h.setOnly) {
         if (!prepared) { prepareTableAsync(ctx, nullptr, 0, 0, nullptr, 0, h.dBitmap, bmWords, h.dCount); q.report.num_kernels++; }
         launchPipeline(q, p, -1);

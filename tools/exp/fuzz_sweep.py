@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Seeds beyond the ones the suite pins: fuzz plans and join plans against the oracle, each executed twice (interpreter first, then the
-specialised kernels).  usage: python tools/exp/fuzz_sweep.py FIRST COUNT [joins]"""
+specialised kernels) and once more as a fresh query on the same tables (the plan memo's path).  usage: python tools/exp/fuzz_sweep.py FIRST COUNT [joins]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -33,6 +33,13 @@ for seed in range(first, first + count):
             if not ok:
                 bad.append((seed, what, rep)); print("MISMATCH", seed, what, "execution", rep, flush=True); break
         q.close()
+        if not bad or bad[-1][0] != seed:      # a FRESH query of the same plan on the same tables, executed once: what the plan memo serves
+            q = ctx.compile(plan, tabs); q.await_kernels(); q.execute()
+            got = q.result()
+            ok = fuzzplans.same(kind, got.text, want.text) if kind is not None else sorted(got.text.splitlines()) == sorted(want.text.splitlines())
+            if not ok:
+                bad.append((seed, what, "fresh")); print("MISMATCH", seed, what, "fresh query", flush=True)
+            q.close()
     except engine.EngineError as e:
         print("ENGINE ERROR", seed, what, str(e)[:160], flush=True); bad.append((seed, what, "error"))
     for t in tabs: t.close()
