@@ -138,6 +138,8 @@ typedef struct rsq_memory_stats {
     double   driver_ms;              /* host time spent inside those driver calls */
     uint64_t plan_memo_entries;      /* plans the context remembers */
     uint64_t plan_memo_hits;         /* queries that were compiled with a remembered entry */
+    uint64_t key_index_entries;      /* key bitmaps of engine-owned key columns kept for every query over the same table version (joins whose build side is that table as it stands) */
+    uint64_t key_index_bytes;        /* ... device memory they hold (part of device_used_bytes; freed with the table or when it changes) */
 } rsq_memory_stats;
 int  rsq_ctx_memory_stats(const rsq_ctx* ctx, rsq_memory_stats* out);
 

@@ -142,7 +142,7 @@ void unifyShardStats(Table& t, const void* blobs, int nShards, size_t blobBytes)
         t.cols[i].stats = o;
     }
     t.nRowsTotal = total;
-    t.version++;
+    t.bumpVersion();
 }
 }  // namespace rsq
 
@@ -187,6 +187,8 @@ int rsq_ctx_memory_stats(const rsq_ctx* ctx, rsq_memory_stats* out) {
     m.driver_ms += c.allocStats.rawMs;
     m.plan_memo_entries = c.planMemo.size();
     m.plan_memo_hits = c.planMemoHits;
+    m.key_index_entries = c.keyIndexes.size();
+    for (auto& kv : c.keyIndexes) m.key_index_bytes += (uint64_t)kv.second.bmBlocks * 32;
     memcpy(out, &m, std::min<size_t>(have, sizeof m));
     out->struct_size = have;
     return RSQ_OK;
@@ -278,7 +280,7 @@ int64_t rsq_table_rows(const rsq_table* t) { return t ? reinterpret_cast<const T
 int rsq_table_set_first_row(rsq_table* t, int64_t row0) {
     if (!t || row0 < 0) return RSQ_ERR_INVALID;
     reinterpret_cast<Table*>(t)->row0 = row0;
-    reinterpret_cast<Table*>(t)->version++;
+    reinterpret_cast<Table*>(t)->bumpVersion();
     return RSQ_OK;
 }
 
@@ -289,7 +291,7 @@ int rsq_table_refresh_stats(rsq_table* t) {
     return guarded(tab.ctx, [&] {
         if (!tab.ownStats.empty()) failInvalid("rsq_table_refresh_stats: the table plans with unified shard statistics; refresh the shards and unify again");
         computeColumnStats(*tab.ctx, tab);
-        tab.version++;          // (the context's plan memo: what queries learnt over the old content does not describe the new)
+        tab.bumpVersion();          // (the context's plan memo: what queries learnt over the old content does not describe the new)
     });
 }
 
@@ -642,7 +644,7 @@ void appendTable(Context& ctx, Table& t, Table& more) {
         }
     }
     t.nRows = n0 + n1;
-    t.version++;
+    t.bumpVersion();
     computeColumnStats(ctx, t);
 }
 

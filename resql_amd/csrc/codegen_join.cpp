@@ -235,6 +235,7 @@ void Walker::consumeBuildBody(OpNode* o, OpNode* from) {
         }
         if (!ht->directCapable) ht->directCols.clear();
         ht->directSrc = pipe.src;
+        ht->directKeyCol = pipe.src->findCol(o->exprs[0]->child->symbol);
     }
     // (a table that may become a rank dictionary keeps its bitmap in the interleaved layout, rsq_device.h bmi_word)
     ht->bmInterleaved = ht->rankCapable;

@@ -166,7 +166,8 @@ Query::~Query() {
         if (h->dWords) ctx.free(h->dWords);
         if (h->dAcc) ctx.free(h->dAcc);
         if (h->dCount) ctx.free(h->dCount);
-        if (h->dBitmap) ctx.free(h->dBitmap);
+        if (h->keyIndex) ctx.releaseKeyIndex(h->keyIndex);      // (the bitmap is the context's key index then)
+        else if (h->dBitmap) ctx.free(h->dBitmap);
         if (h->dCompBitmap) ctx.free(h->dCompBitmap);
         if (h->dDeref) ctx.free(h->dDeref);
         if (h->dTemp) ctx.free(h->dTemp);
@@ -336,6 +337,25 @@ static void applyPlanMemo(Query& q) {
     q.stageWorkgroups = m.stageWorkgroups;
     q.memoApplied = true;
     ctx.planMemoHits++;
+}
+
+// after an execution that ran to its end: the key bitmaps of its direct join tables stay as they are for the next execution, and go to the
+// context for every other query over the same table version (Context::keyIndexes)
+static void keepKeyIndexes(Query& q) {
+    Context& ctx = q.ctx;
+    if (q.genericActive) return;
+    for (auto& p : q.pipelines) {
+        if (p.sink != SinkKind::BUILD) continue;
+        HashTable& h = *q.hashTables[(size_t)p.buildTable];
+        if (!h.direct || h.dense || !h.rank || !h.dBitmap || h.directKeyCol < 0 || h.directSrc != p.src) continue;
+        if (!h.keyIndexReady) { h.keyIndexReady = true; h.keyIndexVersion = p.src->version; }
+        if (h.keyIndex || ctx.planMemoOff || h.keyIndexVersion != p.src->version) continue;
+        const Context::KeyIndexKey key{p.src->uid, p.src->version, p.src->nRows, p.src->row0, h.directKeyCol};
+        if (ctx.keyIndexes.count(key)) continue;      // (another query was first: this one keeps its own)
+        Context::KeyIndex& k = ctx.keyIndexes[key];
+        k.dBitmap = h.dBitmap; k.bmBlocks = h.bmBlocks; k.bmMin = h.bmMin; k.bmBits = h.bmBits; k.refs = 1; k.uid = p.src->uid;
+        h.keyIndex = &k;
+    }
 }
 
 // after an execution that ran to its end: what it knows now
@@ -579,6 +599,7 @@ static void tailUnlessHeld(Query& q) { if (!q.holdTail) runTail(q); }
 static void executeQueryBody(Query& q, bool partialOnly, bool async);
 void executeQuery(Query& q, bool partialOnly, bool async) {
     executeQueryBody(q, partialOnly, async);
+    keepKeyIndexes(q);
     rememberPlan(q);
 }
 
@@ -840,6 +861,7 @@ static void executeQueryBody(Query& q, bool partialOnly, bool async) {
                 HashTable& h = *q.hashTables[(size_t)p.buildTable];
                 h.prepared = false;
                 if (h.capacity == 0) continue;
+                if (h.direct && (h.dense || (h.keyIndexReady && h.keyIndexVersion == p.src->version))) continue;      // nothing is built: nothing to ready
                 const size_t nWords = h.keys.size() + h.payload.size();
                 const size_t bmBytes = h.hasBitmap && h.dBitmap ? (size_t)h.bmBlocks * 32 : 0;
                 if (h.rank && h.setOnly) { if (!bmBytes) continue; }

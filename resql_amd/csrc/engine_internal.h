@@ -88,6 +88,10 @@ struct HashTable {
     bool directCapable = false;
     bool direct = false;
     std::vector<int> directCols;     // per payload word: the column of directSrc
+    int directKeyCol = -1;           // the key's column of directSrc
+    Context::KeyIndex* keyIndex = nullptr;      // the context's key index this table probes (dBitmap is then the index's, not the table's: Context::keyIndexes)
+    bool keyIndexReady = false;      // dBitmap holds the bits and rank words of the build table at keyIndexVersion: nothing to build
+    uint64_t keyIndexVersion = 0;
     const Table* directSrc = nullptr;
     bool rankCapable = false;
     bool setOnly = false;            // ... probed for all matches and carrying nothing but its key: in the rank form the bitmap alone (no entries)

@@ -558,6 +558,16 @@ void sizeJoinTable(Query& q, Pipeline& p, HashTable& h, uint32_t n, bool dupKeys
     // accumulators beside the entries and makes its group rows from them
     h.direct = h.identity && h.directCapable && h.uniqueKnown && q.aggTable != h.id && h.directSrc == p.src;
     for (int c : h.directCols) h.direct = h.direct && p.src->cols[(size_t)c].dptr != nullptr;
+    if (h.direct && !h.dense && !h.keyIndex && !ctx.planMemoOff && h.directKeyCol >= 0) {
+        // the context may hold this column's key index already (another query built it, or this statement's previous query did)
+        auto it = ctx.keyIndexes.find(Context::KeyIndexKey{p.src->uid, p.src->version, p.src->nRows, p.src->row0, h.directKeyCol});
+        if (it != ctx.keyIndexes.end() && !it->second.retired && it->second.bmBlocks == h.bmBlocks && it->second.bmMin == h.bmMin && it->second.bmBits == h.bmBits) {
+            if (h.dBitmap) ctx.free(h.dBitmap);
+            h.dBitmap = it->second.dBitmap;
+            h.keyIndex = &it->second; it->second.refs++;
+            h.keyIndexReady = true; h.keyIndexVersion = p.src->version;
+        }
+    }
     if (h.direct) {
         const std::string note = "join table ht" + std::to_string(h.id) + ": the build table's own columns (" +
                                  (h.dense ? "dense keys in row order: nothing is built" : "keys in row order: only the key bitmap and its index are built") + ")\n";
@@ -633,6 +643,12 @@ void buildHashTable(Query& q, Pipeline& p) {
     const bool prepared = h.prepared;
     h.prepared = false;
     if (h.direct && h.dense) return;      // the build table's columns are the entries and key - min is the row: nothing to ready, build or index
+    if (h.direct && h.keyIndexReady) {
+        if (h.keyIndexVersion == p.src->version) return;      // ... or the key bits and their index stand as an earlier execution left them
+        // (the table changed under a compiled query: its own bitmap again, built by every execution as before)
+        if (h.keyIndex) { ctx.releaseKeyIndex(h.keyIndex); h.keyIndex = nullptr; h.dBitmap = (uint32_t*)ctx.alloc(bmWords * 4); }
+        h.keyIndexReady = false;
+    }
     // (direct with gaps in the key range - TPC-H's o_orderkey -: the build below only sets the key bits, the index follows, no records are kept)
     if (h.rank && h.setOnly) {
         if (!prepared) { prepareTableAsync(ctx, nullptr, 0, 0, nullptr, 0, h.dBitmap, bmWords, h.dCount); q.report.num_kernels++; }

@@ -98,6 +98,8 @@ Context::~Context() {
         if (spareTailArena.pinned) freePinned(spareTailArena.pinned);
         for (auto& e : scratchFreeList) free(e.first);
         for (auto& e : scratchLive) free(e.first);
+        for (auto& kv : keyIndexes) if (kv.second.dBitmap) free(kv.second.dBitmap);
+        keyIndexes.clear();
         if (dErr) (void)hipFree(dErr);
         devArena.reset(); pinArena.reset(); pinNcArena.reset();
         for (hipEvent_t e : eventPool) (void)hipEventDestroy(e);
@@ -241,7 +243,25 @@ void Context::freePinned(void* p) {
     (void)hipHostFree(p);
 }
 
+void Table::bumpVersion() {
+    version++;
+    if (ctx) ctx->retireKeyIndexes(uid);
+}
+void Context::retireKeyIndexes(uint64_t uid) {
+    for (auto it = keyIndexes.begin(); it != keyIndexes.end();) {
+        if (it->second.uid != uid) { ++it; continue; }
+        it->second.retired = true;
+        if (it->second.refs <= 0) { if (it->second.dBitmap) free(it->second.dBitmap); it = keyIndexes.erase(it); } else ++it;
+    }
+}
+void Context::releaseKeyIndex(KeyIndex* k) {
+    if (!k || --k->refs > 0 || !k->retired) return;
+    for (auto it = keyIndexes.begin(); it != keyIndexes.end(); ++it)
+        if (&it->second == k) { if (k->dBitmap) free(k->dBitmap); keyIndexes.erase(it); return; }
+}
+
 Table::~Table() {
+    if (ctx) ctx->retireKeyIndexes(uid);
     if (ctx && ctx->device >= 0) {
         for (auto& c : cols) if (c.owned && c.dptr) ctx->freeRaw(c.dptr);
     } else {

@@ -47,7 +47,7 @@ class rsq_memory_stats(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("reserved0", C.c_uint32), ("device_slab_bytes", C.c_uint64), ("device_used_bytes", C.c_uint64),
                 ("device_slab_allocs", C.c_uint64), ("pinned_slab_bytes", C.c_uint64), ("pinned_used_bytes", C.c_uint64),
                 ("pinned_slab_allocs", C.c_uint64), ("raw_driver_calls", C.c_uint64), ("arena_requests", C.c_uint64), ("driver_ms", C.c_double),
-                ("plan_memo_entries", C.c_uint64), ("plan_memo_hits", C.c_uint64)]
+                ("plan_memo_entries", C.c_uint64), ("plan_memo_hits", C.c_uint64), ("key_index_entries", C.c_uint64), ("key_index_bytes", C.c_uint64)]
 
 
 class rsq_multi_config(C.Structure):

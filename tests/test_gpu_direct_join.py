@@ -108,3 +108,41 @@ def test_materialized_join_reads_strings_in_place(gpu_ctx):
         q.close()
         for t in tabs:
             t.close()
+
+
+def test_key_bits_are_built_once_per_table_version(gpu_ctx):
+    """keys with gaps: the key bitmap and its index are a function of the build table's key column alone - the second execution of a query
+    finds them as the first left them, and so does a FRESH query over the same tables (Context::keyIndexes); appended rows are a new version"""
+    dim, dk = _dim(80_000, "gaps", seed=21)
+    fact = _fact(500_000, dk, seed=22)
+    plan = _plan(dim, fact)
+    want = sorted(orc.execute(plan).text.splitlines())
+    tabs = [gpu_ctx.table(t) for t in plan.tables]
+    try:
+        q = gpu_ctx.compile(plan, tabs)
+        q.execute()
+        first = int(q.report().num_kernels)
+        assert sorted(q.result().text.splitlines()) == want
+        q.execute()
+        again = int(q.report().num_kernels)
+        assert sorted(q.result().text.splitlines()) == want
+        assert again <= first - 2, (first, again)          # no build pipeline, no index
+        q.close()
+        q = gpu_ctx.compile(plan, tabs)                    # what a ReSQL host does per statement
+        q.execute()
+        assert int(q.report().num_kernels) == again and sorted(q.result().text.splitlines()) == want
+        # the build table grows: a new version, its own key bits, the right answer (compiled queries are per statement: a fresh one)
+        q.close()
+        tail, tk = _dim(5_000, "gaps", seed=23)
+        tail.columns[0].data[:] = tail.columns[0].data + (int(dk[-1]) + 1)      # keys stay strictly ascending across the seam
+        tabs[0].append(gpu_ctx.table(tail))
+        grown_dim = P.Table("dim", [P.Column(a.name, a.type, np.concatenate([a.data, b.data])) for a, b in zip(dim.columns, tail.columns)], 85_000)
+        grown = _plan(grown_dim, fact)
+        q = gpu_ctx.compile(grown, tabs)
+        for _ in range(2):
+            q.execute()
+            assert sorted(q.result().text.splitlines()) == sorted(orc.execute(grown).text.splitlines())
+        q.close()
+    finally:
+        for t in tabs:
+            t.close()
