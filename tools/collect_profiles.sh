@@ -121,6 +121,8 @@ timeout -k 10 300 python3 "$ROOT/tools/first_exec.py" 10 2>/dev/null | grep -E '
 timeout -k 10 300 python3 "$ROOT/tools/first_exec.py" 10 --driver-alloc --no-memo 2>/dev/null | grep -E '^\{|^# \{' > "$OUT/${R}_first_exec_sf10_driver_alloc_no_memo.jsonl"
 step "what 5 GB of line stores cost beside a 40 GB streaming read (the staged partitioning's write side, DESIGN §4)"
 if hipcc -O3 --offload-arch=gfx950 -o /tmp/store_rate "$ROOT/tools/exp/store_rate.hip" 2>/dev/null; then timeout -k 10 200 /tmp/store_rate > "$OUT/${R}_store_rate.txt" 2>&1; fi
+step "does a shard's tail overlap the next shard's scan?  two 1.25 B-row shards on two contexts of this GPU (DESIGN round-5 item 6)"
+( timeout -k 10 200 python3 "$ROOT/tools/exp/pair_overlap.py" 0.1 2>&1 | grep '^sel'; timeout -k 10 200 python3 "$ROOT/tools/exp/pair_overlap.py" 0.5 2>&1 | grep '^sel' ) > "$OUT/${R}_pair_overlap.txt"
 step "two rank PROCESSES on this one GPU (bench.py --gpus 2 --share-gpu): Q1 at SF10, and TPC-H Q3 with key-aligned shards"
 timeout -k 10 300 python3 "$ROOT/bench.py" --gpus 2 --share-gpu --no-cpu-baseline --no-extras --steps 20 2>/dev/null | grep '^{' > "$OUT/${R}_bench_share_gpu_2ranks.json"
 timeout -k 10 300 python3 "$ROOT/bench.py" --gpus 2 --share-gpu --workload q3 --sf 10 --steps 10 --warmup 2 2>/dev/null | grep '^{' > "$OUT/${R}_bench_share_gpu_q3_2ranks.json"

@@ -5,8 +5,10 @@
 //   read   : every wave streams its 128-row tiles of four int64 columns (16 B per lane and column, non-temporal), sums them
 //   plain  : the same, and every wave writes one 16-byte word per lane for every K-th tile to ITS OWN contiguous output stream
 //            (perfectly coalesced 1 KiB stores, sequential per wave: the friendliest store pattern there is), 1/8 of the bytes read
-//   regions: the same bytes as whole 128-byte lines, every line to another of the wave's 256 region streams (the staged form's shape:
-//            many open write streams, one line at a time)
+//   regions: whole 128-byte lines, every line to another of the wave's 256 region streams (the staged form's shape: many open write streams,
+//            one line at a time).  NOT 5 GB of unique lines: a region's position advances once per 32 stores of the wave whatever region they
+//            went to, so lines are rewritten while they sit in the L2 and far fewer bytes leave the chip - this line shows what write
+//            COMBINING buys, the four forms below it (every line written exactly once) what unique lines cost
 // Prints ms and GB/s per form, and what the stores cost per GB beside the read.
 #include <hip/hip_runtime.h>
 #include <cstdio>
