@@ -85,6 +85,7 @@ void Walker::produceScan(OpNode* o, std::vector<std::string> request) {     // s
     multiMatchAbove = false;
     selective = false; compacted = false; stage2Body.clear(); cqLive.clear();
     leadCond.clear(); leadCols.clear(); leadPass = 1.0; leadPassComplete = true;
+    pairSplit = std::string::npos; pairCond.clear();
     strPrefetch.clear(); strPrefetchWidth.clear(); strStaged.clear(); strStagedBytes = 0; postTile.clear(); eg.strWordVars.clear();
     eg.symbols.clear();
     o->schema.clear();
@@ -258,6 +259,7 @@ void Walker::consume(OpNode* o, OpNode* from) {
                 if (from->tag == RSQ_OP_SCAN || (1 == 2 && !wasSelective)) prefetchComparedStrings(o->exprs[0]);
                 const std::string cond = eg.emit(o->exprs[0]);
                 if (from->tag == RSQ_OP_SCAN && leadCond.empty()) noteLeadingSelection(o->exprs[0], cond);
+                if (from->tag == RSQ_OP_SCAN && indent == 1 && pairCond.empty() && !compacted) { pairSplit = body.size(); pairCond = cond; }
                 openScope("if (" + cond + ") {");
             }
             explainSteps.push_back("selection " + serializeExpr(o->exprs[0]));

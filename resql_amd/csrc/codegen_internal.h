@@ -284,6 +284,9 @@ struct Walker {
     std::vector<CompFilter> compFilters;    // ... as consumeProbe found them while stage 2 was generated
     bool inStage2 = false;                  // the walk is generating the code behind the wave compaction
     bool leadPassComplete = true;       // every part of the predicate was understood (else the estimate is an upper bound only)
+    // the selection directly above the scan, as text: where its scope starts in `body` and its condition (finishPipeline: the count pass of a
+    // materialisation evaluates it for both rows of a lane first, "pairCond")
+    size_t pairSplit = std::string::npos; std::string pairCond;
     std::string stage2Body;
     std::vector<std::pair<std::string, Sym>> cqLive;     // carried symbols: name -> stage-1 variable and type
 
