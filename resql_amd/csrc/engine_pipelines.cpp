@@ -550,7 +550,10 @@ void sizeJoinTable(Query& q, Pipeline& p, HashTable& h, uint32_t n, bool dupKeys
     dupKeys = h.dupKeys;
     // (a table of a few hundred rows stays a hash table: the dictionary's index and placement are two launches of 3-4 us each for
     // entries that sit in one cache line either way - TPC-H Q5's region and nation tables)
-    h.rank = h.rankCapable && !dupKeys && (n > 1024 || h.setOnly);
+    // ... unless it would be a direct table with dense keys (below): that form costs no launch at all (TPC-H's nation: 25 rows, keys 0..24)
+    const bool smallDirect = h.directCapable && h.uniqueKnown && h.identityCapable && !h.setOnly && q.aggTable != h.id && h.directSrc == p.src &&
+                             (int64_t)n == p.src->nRows && n > 0 && (int64_t)n == h.bmBits;
+    h.rank = h.rankCapable && !dupKeys && (n > 1024 || h.setOnly || smallDirect);
     h.identity = h.rank && h.identityCapable && (int64_t)n == p.src->nRows && n > 0;
     // ... and every value of the key range occurs (as many entries as the range has values, all keys different): rank(key) = key - min
     h.dense = h.identity && !h.setOnly && (int64_t)n == h.bmBits;

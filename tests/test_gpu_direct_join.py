@@ -84,9 +84,14 @@ def test_a_selection_in_front_of_the_build_keeps_the_table(gpu_ctx):
     assert NOTE not in _run(gpu_ctx, _plan(dim, _fact(400_000, dk), select_build=True))
 
 
-def test_small_build_tables_stay_hash_tables(gpu_ctx):
-    dim, dk = _dim(900, "dense")
+def test_small_build_tables(gpu_ctx):
+    """up to 1 024 build rows a dictionary's index and placement launches cost more than a hash table - but dense keys need neither"""
+    dim, dk = _dim(900, "gaps")
     assert NOTE not in _run(gpu_ctx, _plan(dim, _fact(200_000, dk)))
+    dim, dk = _dim(900, "dense")
+    assert "nothing is built" in _run(gpu_ctx, _plan(dim, _fact(200_000, dk)))
+    dim, dk = _dim(25, "dense")
+    assert "nothing is built" in _run(gpu_ctx, _plan(dim, _fact(100_000, dk)))
 
 
 def test_materialized_join_reads_strings_in_place(gpu_ctx):
