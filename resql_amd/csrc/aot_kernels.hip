@@ -1621,7 +1621,8 @@ __device__ __forceinline__ void generic_merge_global(u64* p, u64 v, int merge) {
 }
 
 __global__ void __launch_bounds__(256) k_generic_aggregate(GenericArgs a) {
-    __shared__ i64 s_reg[G_REGS * 256];
+    // (the register file: as many registers as the program names, launchGenericAggregate - all 32 were 64 KB of LDS, two workgroups per CU)
+    extern __shared__ __attribute__((aligned(16))) i64 s_reg[];
     __shared__ u64 s_tab[GENERIC_LDS_TABLE_WORDS];
     i64* reg = s_reg + threadIdx.x;            // register r of this thread: reg[r * 256]
     if (a.ldsTable) {
@@ -1728,8 +1729,17 @@ void launchGenericAggregate(Context& ctx, const GenericProgram& prog, const Gene
     a.nRows = nRows; a.row0 = row0; a.groups = denseGroups; a.tableWords = tableWords;
     a.table = (u64*)dTable; a.err = (unsigned*)ctx.dErr;
     a.ldsTable = tableWords <= GENERIC_LDS_TABLE_WORDS ? 1 : 0;
-    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(2 * (int64_t)ctx.numCUs, (nRows + 255) / 256));
-    hipLaunchKernelGGL(k_generic_aggregate, dim3(grid), dim3(256), 0, ctx.stream, a);
+    int nRegs = 2;
+    for (auto& in : prog.code) nRegs = std::max(nRegs, std::max((int)in.dst, std::max((int)in.a, std::max((int)in.b, in.op == G_SELECT ? (int)in.c : 0))) + 1);
+    for (auto& k : prog.keys) nRegs = std::max(nRegs, k.reg + 1);
+    for (auto& w : prog.accs) nRegs = std::max(nRegs, w.reg + 1);
+    nRegs = std::min<int>(nRegs, G_REGS);      // (G_COL / G_CONST name a column or nothing in `a`: an over-estimate at worst)
+    const size_t regBytes = (size_t)nRegs * 256 * 8;
+    // as many workgroups per CU as their LDS leaves room for (register file + the 24 KB partial table), at most 8
+    const int64_t perCU = std::max<int64_t>(2, std::min<int64_t>(8, (int64_t)(150u << 10) / (int64_t)(regBytes + GENERIC_LDS_TABLE_WORDS * 8 + 256)));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(perCU * (int64_t)ctx.numCUs, (nRows + 255) / 256));
+    if (regBytes > (40u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic_aggregate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G_REGS * 256 * 8));
+    hipLaunchKernelGGL(k_generic_aggregate, dim3(grid), dim3(256), regBytes, ctx.stream, a);
     RSQ_HIP(hipGetLastError());
 }
 

@@ -186,6 +186,7 @@ struct GenericProgram2 {
     std::vector<GenericProbeDesc> probes;
     std::vector<char> constPool;
     GenericSinkDesc sink{};
+    int nRegs = 0;                   // registers the program names (the size of the kernel's register file in LDS)
     // device copies (made when the query is compiled)
     GenericInstr* dCode = nullptr; GenericProbeDesc* dProbes = nullptr; char* dConstPool = nullptr;
 };

@@ -32,7 +32,7 @@ struct Builder2 {
 
     [[noreturn]] void no(const std::string& m) { throw Error(RSQ_ERR_UNSUPPORTED, m); }
     int alloc() {
-        for (int r = 0; r < G2_REGS; r++) if (!used[(size_t)r]) { used[(size_t)r] = true; return r; }
+        for (int r = 0; r < G2_REGS; r++) if (!used[(size_t)r]) { used[(size_t)r] = true; p.nRegs = std::max(p.nRegs, r + 1); return r; }
         no("more than " + std::to_string((int)G2_REGS) + " live values");
     }
     void release(const Val2& v) { if (v.temp && v.reg >= 0) used[(size_t)v.reg] = false; }

@@ -54,12 +54,67 @@ __device__ __forceinline__ void g2_merge(u64* p, u64 v, int merge) {
     else { if ((i64)v > peek_i64(p)) atomicMax(reinterpret_cast<i64*>(p), (i64)v); }
 }
 
+// n (1..8) bytes at p as a little-endian word: one load for 8 (global loads take any alignment), the pieces of ld_bytes otherwise
+__device__ __forceinline__ u64 g2_ld_bytes(const char* p, int n) {
+    u64 v = 0;
+    if (n >= 8) { __builtin_memcpy(&v, p, 8); return v; }
+    int o = 0;
+    if (n & 4) { u32 t; __builtin_memcpy(&t, p, 4); v = t; o = 4; }
+    if (n & 2) { u16 t; __builtin_memcpy(&t, p + o, 2); v |= (u64)t << (8 * o); o += 2; }
+    if (n & 1) v |= (u64)(u8)p[o] << (8 * o);
+    return v;
+}
+// compareChar / compareVarchar (rsq_device.h compare_char, compare_varchar; reference src/qlib/scalar.h:16-46) with the strings read a word at a
+// time: the byte-wise forms cost one dependent global load per character and side - TPC-H Q19's three string predicates over 60 M rows were
+// most of the interpreter's 74 ms.  Same walk, byte for byte: while both run they must agree; once one has ended (NUL, or its capacity) the
+// other may only hold spaces (CHAR) or must have ended too (VARCHAR).
+__device__ __noinline__ u8 g2_compare_str(const char* pa, int capA, const char* pb, int capB, bool charSemantics) {
+    {   // most comparisons end at the first character: one byte of each side decides them
+        const u8 a0 = capA > 0 ? (u8)pa[0] : (u8)0, b0 = capB > 0 ? (u8)pb[0] : (u8)0;
+        if (a0 != 0 && b0 != 0 && a0 != b0) return 0;
+    }
+    int state = 0;                              // 0: both running, 1: only a is left, 2: only b is left
+    const int n = capA > capB ? capA : capB;
+    for (int w0 = 0; w0 < n; w0 += 8) {
+        const u64 wa = w0 < capA ? g2_ld_bytes(pa + w0, capA - w0) : 0ull;
+        const u64 wb = w0 < capB ? g2_ld_bytes(pb + w0, capB - w0) : 0ull;
+        if (state == 0 && wa == wb && !((wa - 0x0101010101010101ull) & ~wa & 0x8080808080808080ull)) continue;      // eight equal bytes, none of them NUL
+#pragma unroll 1
+        for (int i = 0; i < 8; i++) {
+            const u8 ca = (u8)(wa >> (8 * i)), cb = (u8)(wb >> (8 * i));
+            if (state == 0) {
+                if (ca != 0 && cb != 0) { if (ca != cb) return 0; continue; }
+                if (!charSemantics) return ca == cb;
+                if (ca == 0 && cb == 0) return 1;
+                state = ca != 0 ? 1 : 2;
+            }
+            if (state == 1) { if (ca == 0) return 1; if (ca != ' ') return 0; }
+            else { if (cb == 0) return 1; if (cb != ' ') return 0; }
+        }
+    }
+    return 1;                                   // (both ran to their capacities)
+}
+
 #define G2_REG(r) reg[(int)(r) * 256]
 
 __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a) {
-    __shared__ i64 s_reg[G2_REGS * 256];
-    i64* reg = s_reg + threadIdx.x;            // register r of this thread: reg[r * 256] (conflict-free across the lanes)
+    // the register file: as many registers as the program uses (launchGenericPipeline sizes it) - with all 40 a workgroup held 80 KB of
+    // LDS and a CU two workgroups: eight waves for chains of dependent loads
+    extern __shared__ __attribute__((aligned(16))) i64 s_reg[];
+    __shared__ GenericInstr s_code[256];       // the program, where every wave reads it with one broadcast
+    for (int i = threadIdx.x; i < a.nInstr && i < 256; i += 256) s_code[i] = a.code[i];
     const GenericSinkDesc& S = a.sink;
+    // a small dense aggregate table is kept per workgroup in LDS and merged into the device table once, at the end: rows that all want the
+    // same few words (TPC-H Q14: ONE group, 720 K rows that pass) otherwise queue up at the memory side, 11-13 ns per atomic on one address
+    __shared__ u64 s_dense[1024];
+    const bool ldsDense = S.kind == G2_SINK_DENSE && a.denseGroups * (i64)S.nAccs <= 1024;
+    if (ldsDense)
+        for (int i = threadIdx.x; i < (int)(a.denseGroups * S.nAccs); i += 256) {
+            const int m = S.accMerge[i / (int)a.denseGroups];
+            s_dense[i] = m == 0 ? 0ull : m == 2 ? 0x7fffffffffffffffull : 0x8000000000000000ull;
+        }
+    __syncthreads();
+    i64* reg = s_reg + threadIdx.x;            // register r of this thread: reg[r * 256] (conflict-free across the lanes)
     u32 created = 0;                           // groups / entries this thread created (one atomic per thread at the end)
     for (i64 base = (i64)blockIdx.x * 256; base < a.nRows; base += (i64)gridDim.x * 256) {
         const i64 r = base + threadIdx.x;
@@ -74,8 +129,10 @@ __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a)
         u64 rsSlot = 0, rsSteps = 0;
         for (;;) {
             bool fail = false;
-            if (pc < a.nInstr) {
-                const GenericInstr in = a.code[pc];
+            // one instruction.  The lanes of a wave are nearly always AT THE SAME instruction (a row that fails a filter leaves the loop; only the
+            // continuations of probes for all matches set lanes apart): the instruction is then fetched once for the wave and the switch over
+            // its operation is a scalar branch - with a per-lane instruction word every case of the switch was tested under an execution mask.
+            auto stepInstr = [&](const GenericInstr in) {
                 if (in.op == G_PROBE) {
                     const GenericProbeDesc& P = a.probes[in.c];
                     const GenericTableDev& T = a.tab[P.table];
@@ -136,9 +193,8 @@ __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a)
                         case G_CAST16: v = (i64)(short)x; break;
                         case G_SELECT: v = x ? y : G2_REG(in.c); break;
                         case G_STREQ: {      // imm: capA | capB << 16 | charSemantics << 32 | negate << 33
-                            const Str sa = str(reinterpret_cast<const char*>((unsigned long long)(u64)x), (int)(in.imm & 0xffff));
-                            const Str sb = str(reinterpret_cast<const char*>((unsigned long long)(u64)y), (int)((in.imm >> 16) & 0xffff));
-                            const u8 e = ((in.imm >> 32) & 1) ? compare_char(sa, sb) : compare_varchar(sa, sb);
+                            const u8 e = g2_compare_str(reinterpret_cast<const char*>((unsigned long long)(u64)x), (int)(in.imm & 0xffff),
+                                                        reinterpret_cast<const char*>((unsigned long long)(u64)y), (int)((in.imm >> 16) & 0xffff), ((in.imm >> 32) & 1) != 0);
                             v = ((in.imm >> 33) & 1) ? 1 - (i64)e : (i64)e;
                             break;
                         }
@@ -151,9 +207,7 @@ __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a)
                         case G_STRWORD: {    // bytes [8w, 8w + n) of the string at x as a little-endian word; imm = offset | n << 16
                             const char* p = reinterpret_cast<const char*>((unsigned long long)(u64)x) + (in.imm & 0xffff);
                             const int n = (int)((in.imm >> 16) & 0xff);
-                            u64 w = 0;
-                            for (int i = 0; i < n; i++) w |= (u64)(u8)p[i] << (8 * i);
-                            v = (i64)w;
+                            v = n > 0 ? (i64)g2_ld_bytes(p, n) : 0;
                             break;
                         }
                         case G_FILTER: if (x == 0) fail = true; break;
@@ -162,6 +216,11 @@ __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a)
                     if (in.op != G_FILTER) G2_REG(in.dst) = v;
                     if (!fail) pc++;
                 }
+            };
+            if (pc < a.nInstr) {
+                const int pcU = __builtin_amdgcn_readfirstlane(pc);
+                if (__ballot(pc != pcU) == 0ull) stepInstr(s_code[pcU]);
+                else stepInstr(s_code[pc]);
             } else {
                 // ---- the sink ----
                 switch (S.kind) {
@@ -197,6 +256,13 @@ __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a)
                         for (int w = 0; w < S.nAccs; w++) {
                             const int rg = S.accReg[w];
                             const u64 v = rg == -1 ? (u64)row : rg == -2 ? 1ull : (u64)G2_REG(rg);
+                            if (ldsDense) {
+                                u64* p = s_dense + (i64)w * a.denseGroups + gid;
+                                if (S.accMerge[w] == 0) { if (v) atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); }
+                                else if (S.accMerge[w] == 2) atomicMin(reinterpret_cast<long long*>(p), (long long)v);
+                                else atomicMax(reinterpret_cast<long long*>(p), (long long)v);
+                                continue;
+                            }
                             u64* p = a.dense + (i64)S.accBlock[w] * a.denseGroups + gid;
                             if (S.accMerge[w] == 0) { if (v) atomicAdd(p, v); } else g2_merge(p, v, S.accMerge[w]);
                         }
@@ -220,9 +286,7 @@ __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a)
                             const i64 v = G2_REG(S.keyReg[i]);
                             if (S.wordStr[i]) {      // a string group value: its bytes where they lie (NUL padded to the column's width)
                                 const char* sp8 = reinterpret_cast<const char*>((unsigned long long)(u64)v) + S.wordOff[i];
-                                u64 w = 0;
-                                for (int bb = 0; bb < (int)S.wordN[i]; bb++) w |= (u64)(u8)sp8[bb] << (8 * bb);
-                                k[i] = (i64)w;
+                                k[i] = S.wordN[i] ? (i64)g2_ld_bytes(sp8, (int)S.wordN[i]) : 0;
                             } else k[i] = v;
                         }
                         const u64 mask = T.cap - 1;
@@ -293,6 +357,16 @@ __global__ void __launch_bounds__(256) k_generic_pipeline(GenericPipelineArgs a)
         if (S.kind == G2_SINK_MATERIALIZE && a.matPass == 1) a.matCnt[r] = emitted;
     }
     if (created && (S.kind == G2_SINK_BUILD || S.kind == G2_SINK_HASH)) atomicAdd(a.tab[S.table].count, created);
+    if (ldsDense) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < (int)(a.denseGroups * S.nAccs); i += 256) {
+            const int w = i / (int)a.denseGroups, m = S.accMerge[w];
+            const u64 v = s_dense[i];
+            if (v == (m == 0 ? 0ull : m == 2 ? 0x7fffffffffffffffull : 0x8000000000000000ull)) continue;      // (nothing arrived)
+            u64* p = a.dense + (i64)S.accBlock[w] * a.denseGroups + (i - w * (int)a.denseGroups);
+            if (m == 0) atomicAdd(p, v); else g2_merge(p, v, m);
+        }
+    }
 }
 
 void launchGenericPipeline(Context& ctx, const GenericPipelineLaunch& L) {
@@ -312,7 +386,10 @@ void launchGenericPipeline(Context& ctx, const GenericPipelineLaunch& L) {
     for (int c = 0; c < G2_MAX_OUT; c++) a.matOut[c] = L.matOut[c];
     a.dense = (u64*)L.dense; a.denseGroups = L.denseGroups;
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(8 * (int64_t)ctx.numCUs, (L.nRows + 255) / 256));
-    hipLaunchKernelGGL(k_generic_pipeline, dim3(grid), dim3(256), 0, ctx.stream, a);
+    // registers the program names: the builder hands out the lowest free one and keeps the high-water mark (generic2.cpp Builder2::alloc)
+    const size_t regBytes = (size_t)std::min<int>(G2_REGS, std::max<int>(p.nRegs, 2)) * 256 * 8;
+    if (regBytes > (48u << 10)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic_pipeline), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(G2_REGS * 256 * 8));
+    hipLaunchKernelGGL(k_generic_pipeline, dim3(grid), dim3(256), regBytes, ctx.stream, a);
     RSQ_HIP(hipGetLastError());
 }
 
