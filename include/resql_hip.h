@@ -184,8 +184,8 @@ int64_t rsq_table_rows(const rsq_table* t);
 /* BULK INSERT appends (executeBulkInsert adds tuples to the Relation it finds, reference src/execute.h:332-388; a Relation also grows
  * under its AppendIterator, src/dbdata.h:246-330): the rows of `more` - same context, same column types, made by any of the functions
  * above from the NEW tuples only - go behind the rows of `t`; `more` is consumed (destroyed) on success.  Column statistics are gathered
- * again; statements compiled before the call still answer over the rows they were compiled for - compile anew, as a ReSQL host does per
- * statement anyway. */
+ * again and the columns move: a statement compiled BEFORE the call is refused afterwards (rsq_query_execute returns RSQ_ERR_INVALID,
+ * "compile it again") - a ReSQL host compiles per statement anyway (execute.h:213-247). */
 int  rsq_table_append(rsq_table* t, rsq_table* more);
 /* A table that is a row range [row0, row0 + n_rows) of a larger one (a shard): rows are numbered from row0 wherever a row number
  * is observable — the order in which groups first occur decides the emission order of an aggregation (operators/aggregation.h:

@@ -644,6 +644,7 @@ void appendTable(Context& ctx, Table& t, Table& more) {
         }
     }
     t.nRows = n0 + n1;
+    t.layoutVersion++;
     t.bumpVersion();
     computeColumnStats(ctx, t);
 }

@@ -398,6 +398,7 @@ Query* compileQuery(Context& ctx, const rsq_plan_desc& plan, rsq_table* const* t
         Table* t = reinterpret_cast<Table*>(tables[i]);
         if (!t) failInvalid("null table");
         q->tables.push_back(t);
+        q->tableLayouts.push_back(t->layoutVersion);
         for (auto& c : t->cols) q->pool.identTypes[c.name] = c.type;
     }
     q->requestAll = plan.request_all != 0;
@@ -598,6 +599,12 @@ static void tailUnlessHeld(Query& q) { if (!q.holdTail) runTail(q); }
 
 static void executeQueryBody(Query& q, bool partialOnly, bool async);
 void executeQuery(Query& q, bool partialOnly, bool async) {
+    // rows appended to a table move its columns (rsq_table_append): the kernels' arguments of a statement compiled before point at memory
+    // that has been given back.  A ReSQL host compiles per statement (execute.h:213-247); whoever keeps a compiled query across a
+    // BULK INSERT is told to compile it again instead of being answered from freed memory.
+    for (size_t i = 0; i < q.tables.size() && i < q.tableLayouts.size(); i++)
+        if (q.tables[i]->layoutVersion != q.tableLayouts[i])
+            throw Error(RSQ_ERR_INVALID, "rows were appended to table " + q.tables[i]->name + " after this statement was compiled: compile it again");
     executeQueryBody(q, partialOnly, async);
     keepKeyIndexes(q);
     rememberPlan(q);

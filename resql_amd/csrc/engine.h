@@ -58,6 +58,8 @@ struct Table {
     uint64_t uid = g_nextTableUid.fetch_add(1);
     uint64_t version = 0;
     void bumpVersion();                        // version++, and the context's key indexes over the old content are retired (runtime.cpp)
+    uint64_t layoutVersion = 0;                // counts the times the columns MOVED (rsq_table_append allocates them anew): a statement compiled
+                                               // before holds the old addresses and is refused (engine.cpp executeQuery)
     std::string name;
     int64_t nRows = 0;
     int64_t row0 = 0;                          // global index of the first row (row-range shards)

@@ -271,6 +271,7 @@ struct Query {
     OpNode* root = nullptr;
     bool requestAll = false;
     std::vector<Table*> tables;
+    std::vector<uint64_t> tableLayouts;    // Table::layoutVersion of each when the statement was compiled
 
     // device side
     std::vector<Pipeline> pipelines;

@@ -136,11 +136,15 @@ def test_key_bits_are_built_once_per_table_version(gpu_ctx):
         q = gpu_ctx.compile(plan, tabs)                    # what a ReSQL host does per statement
         q.execute()
         assert int(q.report().num_kernels) == again and sorted(q.result().text.splitlines()) == want
-        # the build table grows: a new version, its own key bits, the right answer (compiled queries are per statement: a fresh one)
-        q.close()
+        # the build table grows: a new version, its own key bits, the right answer (compiled queries are per statement: a fresh one);
+        # the statement compiled BEFORE the rows came is refused - its kernels' arguments point at the columns' old place
+        stale = q
         tail, tk = _dim(5_000, "gaps", seed=23)
         tail.columns[0].data[:] = tail.columns[0].data + (int(dk[-1]) + 1)      # keys stay strictly ascending across the seam
         tabs[0].append(gpu_ctx.table(tail))
+        with pytest.raises(engine.EngineError, match="compile it again"):
+            stale.execute()
+        stale.close()
         grown_dim = P.Table("dim", [P.Column(a.name, a.type, np.concatenate([a.data, b.data])) for a, b in zip(dim.columns, tail.columns)], 85_000)
         grown = _plan(grown_dim, fact)
         q = gpu_ctx.compile(grown, tabs)
