@@ -515,7 +515,7 @@ def weak_scaling_extra(args, ctx, dist, world: int, rank: int, device, steps: in
 # ------------------------------------------------------------------------------------------------------------------
 # extras.q1_sf1 / q6_sf10 / q3_sf10: the other single-GPU BASELINE configurations, untimed for `value`
 # ------------------------------------------------------------------------------------------------------------------
-LATE_LOAD_PROFILES = ("profiles/r04_late_loads_pmc.json", "profiles/r03_late_loads_pmc.json")
+LATE_LOAD_PROFILES = ("profiles/r05_late_loads_pmc.json", "profiles/r04_late_loads_pmc.json", "profiles/r03_late_loads_pmc.json")
 
 
 def _golden_text(name: str):

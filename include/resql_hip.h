@@ -216,13 +216,14 @@ int  rsq_query_compile(rsq_ctx* ctx, const rsq_plan_desc* plan, rsq_table* const
                        rsq_query** out);
 /* Run all pipelines and finalise the result.  Blocking, like JitContextFlounder::execute(). */
 int  rsq_query_execute(rsq_query* q);
-/* Low compile latency (the reference compiles a query in 0.6-3 ms, src/JitContextFlounder.h:410-456): a plan shape whose
- * specialised kernels are not in the code-object cache — scan -> selection -> dense aggregation over numeric / date / CHAR(1)
- * columns — is served by a pre-compiled generic pipeline (an interpreter kernel) from its first execution on, while hiprtc
- * builds the kernels on a host thread; an execution that finds them ready switches over.  Results are identical either
- * way.  rsq_query_await_kernels blocks until the query runs on its specialised kernels (benchmarks call it before timing);
- * it returns at once for queries that never were on the generic pipeline.  Environment: RSQ_GENERIC=0 compiles blocking as
- * before, RSQ_FORCE_GENERIC=1 keeps eligible plans on the generic pipeline (tests). */
+/* Low compile latency (the reference compiles a query in 0.6-3 ms, src/JitContextFlounder.h:410-456): a plan whose specialised
+ * kernels are not in the code-object cache is served by pre-compiled interpreter kernels from its first execution on - whole
+ * pipelines: scans, selections, projections, join builds and probes, strings, dense / hash / at-the-join-entry aggregation,
+ * materialisation - while hiprtc builds the kernels on host threads in two tiers (a quick one with stage 2 of a compacted
+ * pipeline as a call, then the inlined one); an execution that finds a tier ready switches over.  Results are identical on
+ * every tier.  rsq_query_await_kernels blocks until the query runs on its final kernels (benchmarks call it before timing);
+ * it returns at once for queries that never were on the interpreter.  Environment: RSQ_GENERIC=0 compiles blocking,
+ * RSQ_FORCE_GENERIC=1 keeps eligible plans on the interpreter (tests). */
 int  rsq_query_await_kernels(rsq_query* q);
 /* Multi-GPU (row-range sharded scans): run the pipelines up to the aggregation and stop.  The
  * dense partial aggregate table then sits in device memory at *dev_ptr as int64 words laid out
